@@ -1,0 +1,178 @@
+/*
+ * ws3d_ops.h -- C ABI of libws3d_hip.so: the MI355X (gfx950) replacement for the
+ * three CUDA extension modules of hlesmqh/WS3D's PointNet++ / roipool3d / iou3d
+ * hot path.
+ *
+ * The reference has no C ABI: its boundary is three pybind11 modules
+ * (pointnet2_cuda, iou3d_cuda, roipool3d_cuda) whose functions take pre-allocated
+ * at::Tensor objects.  Every entry point below replaces one of those functions
+ * (cited as file:line relative to the reference checkout), with the tensors
+ * flattened to plain device pointers + sizes + a stream.  INTEGRATION.md shows the
+ * Python (ctypes) binding a reference maintainer adds; ws3d_amd/compat.py is that
+ * binding, exporting modules with the reference's exact function names.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to C-contiguous row-major arrays; data are
+ *     float32, indices int32 (the reference's dtypes), unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All work
+ *     is enqueued asynchronously on it; no entry point synchronises the device,
+ *     allocates, or frees (scratch comes from caller-provided workspaces sized by
+ *     the *_workspace_bytes() queries);
+ *   - return value: 0 on success, a negative WS3D_E_* code on failure (never
+ *     exit()s, unlike the reference: sampling_gpu.cu:39-43, iou3d.cpp:13-21);
+ *     ws3d_last_error() returns a thread-local message for the last failure;
+ *   - arithmetic contract (bit-exact index outputs): DESIGN.md section 4.
+ */
+#ifndef WS3D_OPS_H
+#define WS3D_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WS3D_OK 0
+#define WS3D_E_INVALID (-1)   /* bad size / null pointer                        */
+#define WS3D_E_LAUNCH (-2)    /* hipGetLastError() != hipSuccess after a launch */
+#define WS3D_E_WORKSPACE (-3) /* workspace missing or too small                 */
+#define WS3D_E_UNSUPPORTED (-4)
+
+#if defined(__GNUC__)
+#define WS3D_API __attribute__((visibility("default")))
+#else
+#define WS3D_API
+#endif
+
+typedef void *ws3d_stream_t;
+
+WS3D_API int ws3d_abi_version(void);
+WS3D_API const char *ws3d_last_error(void);
+/* name/CU count/LDS bytes of the current device; any pointer may be NULL */
+WS3D_API int ws3d_device_info(char *name, int name_len, int *cu_count, int *lds_bytes_per_block);
+
+/* ---------------------------------------------------------------- pointnet2_cuda */
+
+/* furthest_point_sampling_wrapper(b,n,m,xyz,temp,idx)   sampling.cpp:36-46 ->
+ * furthest_point_sampling_kernel sampling_gpu.cu:93-253.
+ * xyz (b,n,3); temp (b,n) in/out scratch, pre-filled by the caller (1e10,
+ * pointnet2_utils.py:26) -- may be NULL (then 1e10 is assumed and nothing is written
+ * back); idx (b,m) out.  idx[.,0] = 0.  Tie-break identical to the reference launch
+ * geometry (block = opt_n_threads(n), cuda_utils.h:10-14).                          */
+WS3D_API int ws3d_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
+                                 ws3d_stream_t stream);
+
+/* Fused a1+a2 of SURVEY section 8a: FPS that also emits the sampled coordinates
+ * new_xyz (b,m,3) = xyz[idx]  (replaces furthest_point_sample + gather_operation +
+ * transpose at pointnet2_modules.py:30-35).  new_xyz may be NULL.                  */
+WS3D_API int ws3d_furthest_point_sampling_gather(int b, int n, int m, const float *xyz, float *temp,
+                                        int32_t *idx, float *new_xyz, ws3d_stream_t stream);
+
+/* gather_points_wrapper(b,c,n,npoints,points,idx,out)   sampling.cpp:11-20 ->
+ * sampling_gpu.cu:8-37.  points (b,c,n), idx (b,npoints) -> out (b,c,npoints).     */
+WS3D_API int ws3d_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,
+                       float *out, ws3d_stream_t stream);
+
+/* gather_points_grad_wrapper   sampling.cpp:23-33 -> sampling_gpu.cu:46-76.
+ * grad_points (b,c,n) must be pre-zeroed by the caller (pointnet2_utils.py:67).    */
+WS3D_API int ws3d_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out,
+                            const int32_t *idx, float *grad_points, ws3d_stream_t stream);
+
+/* ball_query_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)   ball_query.cpp:14-25 ->
+ * ball_query_gpu.cu:9-67.  new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample),
+ * pre-zeroed by the caller (pointnet2_utils.py:218); rows without a hit are left
+ * untouched.                                                                        */
+WS3D_API int ws3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                    const float *xyz, int32_t *idx, ws3d_stream_t stream);
+
+/* group_points_wrapper(b,c,n,npoints,nsample,points,idx,out)   group_points.cpp:25-36
+ * -> group_points_gpu.cu:47-86.  points (b,c,n), idx (b,npoints,nsample) ->
+ * out (b,c,npoints,nsample).                                                        */
+WS3D_API int ws3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                      const int32_t *idx, float *out, ws3d_stream_t stream);
+
+/* group_points_grad_wrapper   group_points.cpp:11-22 -> group_points_gpu.cu:8-44.   */
+WS3D_API int ws3d_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                           const int32_t *idx, float *grad_points, ws3d_stream_t stream);
+
+/* Fused QueryAndGroup.forward (pointnet2_utils.py:241-264 = ball_query + 2x
+ * grouping_operation + centre subtraction + cat).  xyz (b,n,3), new_xyz (b,m,3),
+ * features (b,c,n) or NULL (c = 0) -> out (b, (use_xyz?3:0)+c, m, nsample) with
+ * channel order [dx,dy,dz, features...].  idx_out (b,m,nsample) may be NULL; when
+ * given it receives exactly what ws3d_ball_query would write into a zeroed idx.     */
+WS3D_API int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
+                         const float *xyz, const float *new_xyz, const float *features,
+                         int32_t *idx_out, float *out, ws3d_stream_t stream);
+
+/* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   interpolate.cpp:14-23 ->
+ * interpolate_gpu.cu:9-67.  unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3)
+ * SQUARED distances, idx (b,n,3).                                                   */
+WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                  int32_t *idx, ws3d_stream_t stream);
+
+/* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   interpolate.cpp:26-39 ->
+ * interpolate_gpu.cu:77-117.  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n).    */
+WS3D_API int ws3d_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
+                           const float *weight, float *out, ws3d_stream_t stream);
+
+/* three_interpolate_grad_wrapper(b,c,n,m,grad_out,idx,weight,grad_points)
+ * interpolate.cpp:41-53 -> interpolate_gpu.cu:120-160.  grad_points pre-zeroed.     */
+WS3D_API int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                const int32_t *idx, const float *weight, float *grad_points,
+                                ws3d_stream_t stream);
+
+/* -------------------------------------------------------------------- iou3d_cuda */
+
+/* boxes_overlap_bev_gpu(boxes_a,boxes_b,ans)   iou3d.cpp:31-50 -> iou3d_kernel.cu:
+ * 108-234,354-363.  boxes (N,5) [x1,y1,x2,y2,ry] -> ans (num_a,num_b) overlap area. */
+WS3D_API int ws3d_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                           float *ans, ws3d_stream_t stream);
+
+/* boxes_iou_bev_gpu   iou3d.cpp:52-71 -> iou3d_kernel.cu:214-248,365-371.           */
+WS3D_API int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                       float *ans, ws3d_stream_t stream);
+
+/* The K12/K13 mask alone (iou3d_kernel.cu:250-292 / 306-348): mask (n, ceil(n/64))
+ * uint64, bit t of word c of row i = iou(box_i, box_{64c+t}) > thresh (diagonal
+ * block: only t > i%64).  Words of blocks c < i/64 (never read by the sweep,
+ * iou3d.cpp:108) are written as 0 unless full_grid != 0, in which case they are
+ * computed like the reference grid does.  normal != 0 selects the axis-aligned IoU.  */
+WS3D_API int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
+                  uint64_t *mask, ws3d_stream_t stream);
+
+/* nms_gpu / nms_normal_gpu(boxes, keep, thresh) -> num_to_keep   iou3d.cpp:73-170.
+ * boxes (n,5) already score-sorted (iou3d_utils.py:67-69).  The reference copies the
+ * mask to the host and sweeps there; here mask kernel + greedy sweep both run on the
+ * device: keep (n) int64 DEVICE, num_keep (1) int32 DEVICE -- no D2H, no sync.
+ * workspace: ws3d_nms_workspace_bytes(n) bytes of device memory.                     */
+WS3D_API size_t ws3d_nms_workspace_bytes(int boxes_num);
+WS3D_API int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, void *workspace,
+             size_t workspace_bytes, int64_t *keep, int32_t *num_keep, ws3d_stream_t stream);
+
+/* ---------------------------------------------------------------- roipool3d_cuda */
+
+/* forward(xyz,boxes3d,pts_feature,pooled_features,pooled_empty_flag)
+ * roipool3d.cpp:48-79 -> roipool3dLauncher roipool3d_kernel.cu:209-237 (K14-K16);
+ * forward_slow (roipool3d.cpp:15-44) has identical results.
+ * xyz (B,N,3), boxes3d (B,M,7) [x,y_bottom,z,h,w,l,ry] (already enlarged by the
+ * caller, roipool3d_utils.py:19), pts_feature (B,N,C) -> pooled_features
+ * (B,M,S,3+C) and pooled_empty_flag (B,M) int32, BOTH pre-zeroed by the caller
+ * (roipool3d_utils.py:21-23): rows of empty boxes are left untouched.
+ * pts_idx (B,M,S) int32 may be NULL; when given it receives the selected point
+ * indices (the reference's internal pts_idx scratch; zeros for empty boxes).
+ * No B*N*M scratch, no allocation: selection and copy are fused per box.             */
+WS3D_API int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                   int sampled_pts_num, const float *xyz, const float *boxes3d,
+                   const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
+                   int32_t *pts_idx, ws3d_stream_t stream);
+
+/* Device twin of pts_in_boxes3d_cpu (roipool3d.cpp:97-124): pts (N,3), boxes3d (M,7)
+ * -> flag (M,N) int64 in {0,1}.                                                      */
+WS3D_API int ws3d_pts_in_boxes3d(int boxes_num, int pts_num, const float *pts, const float *boxes3d,
+                        int64_t *flag, ws3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WS3D_OPS_H */

@@ -1,0 +1,326 @@
+"""GPU parity: the HIP kernels (through the C ABI of libws3d_hip.so) against the CPU
+oracle on the same seeded inputs.  Bit-exact for every index/mask output and for the
+pure-copy float outputs; 1e-5 for interpolated features (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from ws3d_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from ws3d_amd import compat, iou3d_ops, pn2_modules, pn2_ops, roipool3d_ops
+    import types
+    return types.SimpleNamespace(pn=pn2_ops, mod=pn2_modules, iou=iou3d_ops, roi=roipool3d_ops, c=compat)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------- FPS
+FPS_CASES = [
+    # (B, N, M, kind, dup_frac)
+    (2, 64, 64, "uniform", 0.0), (3, 100, 37, "uniform", 0.0), (2, 256, 64, "lidar", 0.0),
+    (2, 512, 128, "lidar", 0.0), (2, 1000, 250, "lidar", 0.1), (2, 1024, 256, "uniform", 0.0),
+    (2, 1025, 100, "uniform", 0.0), (2, 2048, 256, "lidar", 0.05), (2, 3000, 100, "lidar", 0.0),
+    (2, 4096, 1024, "lidar", 0.02), (1, 5000, 64, "uniform", 0.0), (1, 8192, 128, "lidar", 0.0),
+    (2, 16384, 4096, "lidar", 0.02), (1, 16384, 4096, "uniform", 0.0), (1, 12345, 777, "lidar", 0.3),
+    (1, 20000, 64, "lidar", 0.0), (1, 65536, 48, "uniform", 0.0),
+]
+
+
+@pytest.mark.parametrize("B,N,M,kind,dup", FPS_CASES)
+def test_fps_bit_exact(ops, oracle, B, N, M, kind, dup):
+    pcs = synth.make_batch(kind, B, N, 7, dup_frac=dup)[:, :, :3].copy()
+    ref = oracle.furthest_point_sample(pcs, M)
+    got = ops.pn.furthest_point_sample(dev(pcs), M)
+    assert got.dtype == torch.int32 and tuple(got.shape) == (B, M)
+    np.testing.assert_array_equal(host(got), ref)
+    if N <= 16384:
+        idx2, new_xyz = ops.pn.furthest_point_sample_gather(dev(pcs), M)
+        np.testing.assert_array_equal(host(idx2), ref)
+        np.testing.assert_array_equal(host(new_xyz), np.stack([pcs[b][ref[b]] for b in range(B)]))
+
+
+@pytest.mark.parametrize("case", ["dups", "lattice", "all_same", "two_points", "one_point"])
+def test_fps_ties(ops, oracle, case):
+    rng = np.random.default_rng(5)
+    if case == "dups":
+        base = synth.lidar_cloud(300, 9)[:, :3]
+        xyz, m = base[rng.integers(0, 300, 1500)], 400
+    elif case == "lattice":
+        g = np.stack(np.meshgrid(np.arange(16), np.arange(16), np.arange(16), indexing="ij"), -1)
+        xyz, m = g.reshape(-1, 3).astype(np.float32)[rng.permutation(4096)], 600
+    elif case == "all_same":
+        xyz, m = np.ones((130, 3), dtype=np.float32), 20
+    elif case == "two_points":
+        xyz, m = np.array([[0, 0, 0], [1, 0, 0]], dtype=np.float32), 2
+    else:
+        xyz, m = np.array([[3, 2, 1]], dtype=np.float32), 1
+    xyz = np.ascontiguousarray(xyz[None])
+    np.testing.assert_array_equal(host(ops.pn.furthest_point_sample(dev(xyz), m)),
+                                  oracle.furthest_point_sample(xyz, m))
+
+
+def test_fps_temp_contract(ops, oracle):
+    """the wrapper-level entry point takes the caller's temp (pre-filled 1e10) and leaves the
+    final running min-distance in it, like the reference kernel does (sampling_gpu.cu:134-135)."""
+    pcs = synth.make_batch("lidar", 2, 3000, 11)[:, :, :3].copy()
+    idx_ref, temp_ref = oracle.furthest_point_sample(pcs, 99, return_temp=True)
+    x = dev(pcs)
+    temp = torch.full((2, 3000), 1e10, device="cuda")
+    idx = torch.empty((2, 99), dtype=torch.int32, device="cuda")
+    ops.c.furthest_point_sampling_wrapper(2, 3000, 99, x, temp, idx)
+    np.testing.assert_array_equal(host(idx), idx_ref)
+    np.testing.assert_array_equal(host(temp), temp_ref)
+
+
+# ------------------------------------------------------------------------------- ball query / group
+BQ_CASES = [
+    # (B, N, M, r, ns, kind)
+    (2, 2048, 256, 0.5, 16, "lidar"), (2, 4096, 300, 1.0, 32, "lidar"), (1, 1024, 128, 0.1, 64, "lidar"),
+    (3, 500, 77, 4.0, 8, "uniform"), (2, 16384, 4096, 0.1, 64, "lidar"), (1, 16384, 4096, 0.5, 32, "lidar"),
+    (1, 16384, 4096, 0.1, 16, "uniform"), (1, 4096, 1024, 2.0, 32, "lidar"), (1, 777, 5, 100.0, 64, "lidar"),
+    (1, 300, 129, 1.0, 3, "uniform"),
+]
+
+
+@pytest.mark.parametrize("B,N,M,r,ns,kind", BQ_CASES)
+def test_ball_query_and_group_bit_exact(ops, oracle, B, N, M, r, ns, kind):
+    pc = synth.make_batch(kind, B, N, 21)
+    xyz = pc[:, :, :3].copy()
+    feats = np.ascontiguousarray(np.transpose(
+        np.concatenate([pc[:, :, 3:], np.random.default_rng(1).standard_normal((B, N, 4)).astype(np.float32)], 2),
+        (0, 2, 1)))
+    cidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(B)])
+    ref_idx = oracle.ball_query(r, ns, xyz, new_xyz)
+    got_idx = ops.pn.ball_query(r, ns, dev(xyz), dev(new_xyz))
+    np.testing.assert_array_equal(host(got_idx), ref_idx)
+    # grouping_operation (pure copy)
+    ref_g = oracle.grouping_operation(feats, ref_idx)
+    got_g = ops.pn.grouping_operation(dev(feats), got_idx)
+    np.testing.assert_array_equal(host(got_g), ref_g)
+    # fused QueryAndGroup == reference composition (pointnet2_utils.py:241-264)
+    xyz_t = np.ascontiguousarray(np.transpose(xyz, (0, 2, 1)))
+    ref_xyz = oracle.grouping_operation(xyz_t, ref_idx) - np.transpose(new_xyz, (0, 2, 1))[..., None]
+    ref_fused = np.concatenate([ref_xyz, ref_g], 1)
+    fused, idx_f = ops.pn.query_and_group(r, ns, dev(xyz), dev(new_xyz), dev(feats), True, return_idx=True)
+    np.testing.assert_array_equal(host(idx_f), ref_idx)
+    np.testing.assert_array_equal(host(fused), ref_fused)
+    qg = ops.pn.QueryAndGroup(r, ns, use_xyz=True)
+    np.testing.assert_array_equal(host(qg(dev(xyz), dev(new_xyz), dev(feats))), ref_fused)
+    np.testing.assert_array_equal(host(qg(dev(xyz), dev(new_xyz), None)), ref_xyz)
+    qg2 = ops.pn.QueryAndGroup(r, ns, use_xyz=False)
+    np.testing.assert_array_equal(host(qg2(dev(xyz), dev(new_xyz), dev(feats))), ref_g)
+
+
+def test_ball_query_no_hit_rows_untouched(ops, oracle):
+    xyz = synth.uniform_cloud(300, 5)[None, :, :3].copy()
+    far = (xyz[:, :10] + np.float32(1000.0)).copy()
+    x, f = dev(xyz), dev(far)
+    idx = torch.full((1, 10, 8), 7, dtype=torch.int32, device="cuda")  # NOT zeroed on purpose
+    ops.c.ball_query_wrapper(1, 300, 10, 0.5, 8, f, x, idx)
+    assert (host(idx) == 7).all()
+    assert (host(ops.pn.ball_query(0.5, 8, x, f)) == 0).all()
+    # strict '<' at exactly r; fused path groups index 0 for no-hit rows
+    p = np.array([[[0, 0, 0], [0.5, 0, 0], [0.25, 0, 0]]], dtype=np.float32)
+    got = host(ops.pn.ball_query(0.5, 4, dev(p), dev(p[:, :1])))
+    np.testing.assert_array_equal(got[0, 0], [0, 2, 0, 0])
+    fused = host(ops.pn.query_and_group(0.5, 8, x, f, None, True))
+    np.testing.assert_array_equal(fused, (xyz[0, 0][None, :, None, None] - np.transpose(far, (0, 2, 1))[..., None]) *
+                                  np.ones((1, 3, 10, 8), dtype=np.float32))
+
+
+def test_gather_and_backward_ops(ops, oracle):
+    rng = np.random.default_rng(3)
+    feat = rng.standard_normal((2, 21, 333)).astype(np.float32)
+    gi = rng.integers(0, 333, (2, 50)).astype(np.int32)
+    np.testing.assert_array_equal(host(ops.pn.gather_operation(dev(feat), dev(gi))), oracle.gather_operation(feat, gi))
+    idx = rng.integers(0, 333, (2, 40, 7)).astype(np.int32)
+    f = dev(feat).requires_grad_(True)
+    out = ops.pn.grouping_operation(f, dev(idx))
+    g = rng.standard_normal(tuple(out.shape)).astype(np.float32)
+    out.backward(dev(g))
+    np.testing.assert_allclose(host(f.grad), oracle.grouping_operation_grad(g, idx, 333), rtol=1e-4, atol=1e-5)
+    f2 = dev(feat).requires_grad_(True)
+    o2 = ops.pn.gather_operation(f2, dev(gi))
+    g2 = rng.standard_normal(tuple(o2.shape)).astype(np.float32)
+    o2.backward(dev(g2))
+    np.testing.assert_allclose(host(f2.grad), oracle.gather_operation_grad(g2, gi, 333), rtol=1e-4, atol=1e-5)
+    # fused QueryAndGroup backward == grouping backward on the feature channels
+    xyz = synth.lidar_cloud(333, 4)[None, :, :3].repeat(2, 0).copy()
+    new_xyz = xyz[:, :40].copy()
+    f3 = dev(feat).requires_grad_(True)
+    o3, idx3 = ops.pn.query_and_group(1.0, 7, dev(xyz), dev(new_xyz), f3, True, return_idx=True)
+    g3 = rng.standard_normal(tuple(o3.shape)).astype(np.float32)
+    o3.backward(dev(g3))
+    np.testing.assert_allclose(host(f3.grad), oracle.grouping_operation_grad(g3[:, 3:], host(idx3), 333),
+                               rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- three_nn / interpolate
+@pytest.mark.parametrize("B,n,m,seed", [(2, 700, 64, 1), (1, 1024, 256, 2), (2, 50, 3, 3), (1, 40, 2, 4),
+                                        (1, 10, 1, 5), (1, 16384, 4096, 6), (2, 4096, 1024, 7), (1, 3000, 1500, 8)])
+def test_three_nn_bit_exact(ops, oracle, B, n, m, seed):
+    unk = synth.make_batch("lidar", B, n, seed)[:, :, :3].copy()
+    kidx = oracle.furthest_point_sample(unk, m)
+    kn = np.stack([unk[b][kidx[b]] for b in range(B)])
+    d2_ref, idx_ref = oracle.three_nn_dist2(unk, kn)
+    dist, idx = ops.pn.three_nn(dev(unk), dev(kn))
+    np.testing.assert_array_equal(host(idx), idx_ref)
+    np.testing.assert_allclose(host(dist), np.sqrt(d2_ref), rtol=1e-6, atol=0)
+    d2 = torch.empty((B, n, 3), device="cuda")
+    i2 = torch.empty((B, n, 3), dtype=torch.int32, device="cuda")
+    ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2, i2)
+    np.testing.assert_array_equal(host(d2), d2_ref)  # squared distances: bit-exact
+
+
+def test_three_interpolate_and_grad(ops, oracle):
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((2, 37, 64)).astype(np.float32)
+    idx = rng.integers(0, 64, (2, 600, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (2, 600, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    f = dev(feat).requires_grad_(True)
+    out = ops.pn.three_interpolate(f, dev(idx), dev(w))
+    ref = oracle.three_interpolate(feat, idx, w)
+    np.testing.assert_allclose(host(out), ref, atol=1e-5, rtol=0)
+    np.testing.assert_array_equal(host(out), ref)  # same contraction as the oracle: bit-exact in practice
+    g = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(dev(g))
+    np.testing.assert_allclose(host(f.grad), oracle.three_interpolate_grad(g, idx, w, 64), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- roipool3d
+def _roi_scene(B, n, m, c, cfg):
+    pc = synth.make_batch("lidar", B, n, cfg)
+    boxes = synth.proposal_boxes(B, m, cfg)
+    for b in range(B):  # put some boxes exactly on the synthetic cars
+        cars = synth.random_boxes3d(15, (1000 * cfg + b) * 7919 + 13)
+        k = min(m // 2, 15)
+        boxes[b, :k] = cars[:k]
+    feat = np.random.default_rng(cfg).standard_normal((B, n, c)).astype(np.float32)
+    return pc[:, :, :3].copy(), boxes, feat
+
+
+@pytest.mark.parametrize("B,n,m,c,s,cfg", [(2, 2048, 24, 8, 64, 1), (2, 16384, 100, 128, 512, 3), (1, 4096, 40, 16, 512, 2),
+                                           (1, 512, 8, 3, 16, 4), (1, 65536, 64, 128, 512, 5), (1, 1000, 5, 1, 700, 6)])
+def test_roipool3d_bit_exact(ops, oracle, B, n, m, c, s, cfg):
+    xyz, boxes, feat = _roi_scene(B, n, m, c, cfg)
+    from ws3d_amd import kitti_utils
+    enl = kitti_utils.enlarge_box3d(boxes.reshape(-1, 7), 1.0).reshape(B, m, 7)
+    ref_pooled, ref_empty, ref_sel = oracle.roipool3d(xyz, enl, feat, s, return_idx=True)
+    pooled, empty = ops.roi.roipool3d_gpu(dev(xyz), dev(feat), dev(boxes), 1.0, sampled_pt_num=s)
+    assert empty.dtype == torch.int32
+    np.testing.assert_array_equal(host(empty), ref_empty)
+    np.testing.assert_array_equal(host(pooled), ref_pooled)
+    assert (ref_empty == 0).any()
+    # selected indices (the reference's internal pts_idx)
+    pf = torch.zeros((B, m, s, 3 + c), device="cuda")
+    ef = torch.zeros((B, m), dtype=torch.int32, device="cuda")
+    sel = torch.full((B, m, s), -5, dtype=torch.int32, device="cuda")
+    ops.c.roipool3d_forward(dev(xyz), dev(enl), dev(feat), pf, ef, sel)
+    np.testing.assert_array_equal(host(sel), ref_sel)
+    # ball variant
+    rng = np.zeros_like(boxes)
+    rng[..., 0], rng[..., 2], rng[..., 3:6] = boxes[..., 0], boxes[..., 2], 6.0
+    rp, re = oracle.roipool3d(xyz, rng, feat, s)
+    bp, be = ops.roi.roipool3dball_gpu(dev(xyz), dev(feat), dev(boxes), 1.0, sampled_pt_num=s)
+    np.testing.assert_array_equal(host(be), re)
+    np.testing.assert_array_equal(host(bp), rp)
+
+
+def test_roipool3d_cpu_twins(ops, oracle):
+    xyz, boxes, feat = _roi_scene(1, 3000, 20, 6, 9)
+    flags = ops.roi.pts_in_boxes3d_cpu(torch.from_numpy(xyz[0]), torch.from_numpy(boxes[0]))
+    ref = oracle.pts_in_boxes3d(xyz[0], boxes[0])
+    np.testing.assert_array_equal(np.stack([f.numpy() for f in flags]).astype(np.int64), ref)
+    pp, pf, pe = ops.roi.roipool_pc_cpu(torch.from_numpy(xyz[0]), torch.from_numpy(feat[0]), torch.from_numpy(boxes[0]), 128)
+    rp, rf, re = oracle.roipool3d_cpu(xyz[0], boxes[0], feat[0], 128)
+    np.testing.assert_array_equal(pe.numpy(), re)
+    np.testing.assert_array_equal(pp.numpy(), rp)
+    np.testing.assert_array_equal(pf.numpy(), rf)
+
+
+# ------------------------------------------------------------------------------- iou3d
+def _bev(n, seed, spread):
+    rng = np.random.default_rng(seed)
+    b3 = synth.random_boxes3d(n, seed)
+    b3[:, 0] = rng.uniform(-spread, spread, n)
+    b3[:, 2] = 30 + rng.uniform(-spread, spread, n)
+    return synth.boxes3d_to_bev(b3), b3
+
+
+@pytest.mark.parametrize("na,nb,spread", [(40, 50, 6.0), (130, 77, 10.0), (1, 1, 0.5), (64, 64, 3.0), (300, 5, 30.0)])
+def test_overlap_and_iou(ops, oracle, na, nb, spread):
+    A, A3 = _bev(na, 1, spread)
+    B, B3 = _bev(nb, 2, spread)
+    ov_ref, iou_ref = oracle.boxes_overlap_bev(A, B), oracle.boxes_iou_bev(A, B)
+    ov = torch.zeros((na, nb), device="cuda")
+    ops.c.boxes_overlap_bev_gpu(dev(A), dev(B), ov)
+    np.testing.assert_allclose(host(ov), ov_ref, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(host(ops.iou.boxes_iou_bev(dev(A), dev(B))), iou_ref, atol=1e-5, rtol=0)
+    # same IEEE op sequence + correctly rounded trig on both sides: expect bit equality
+    np.testing.assert_array_equal(host(ov), ov_ref)
+    iou2d, iou3d = ops.iou.boxes_iou3d_gpu(dev(A3), dev(B3))
+    # composition (iou3d_utils.py:21-56) re-derived in numpy from the oracle overlap
+    hmin_a, hmax_a = (A3[:, 1] - A3[:, 3])[:, None], A3[:, 1][:, None]
+    hmin_b, hmax_b = (B3[:, 1] - B3[:, 3])[None], B3[:, 1][None]
+    oh = np.clip(np.minimum(hmax_a, hmax_b) - np.maximum(hmin_a, hmin_b), 0, None)
+    sa, sb = (A3[:, 4] * A3[:, 5])[:, None], (B3[:, 4] * B3[:, 5])[None]
+    np.testing.assert_allclose(host(iou2d), ov_ref / np.clip(sa + sb - ov_ref, 1e-7, None), atol=1e-5)
+    o3 = ov_ref * oh
+    va, vb = (A3[:, 3] * A3[:, 4] * A3[:, 5])[:, None], (B3[:, 3] * B3[:, 4] * B3[:, 5])[None]
+    np.testing.assert_allclose(host(iou3d), o3 / np.clip(va + vb - o3, 1e-7, None), atol=1e-5)
+
+
+@pytest.mark.parametrize("n,thresh,normal,spread", [(64, 0.5, False, 4.0), (65, 0.3, False, 4.0), (300, 0.7, False, 5.0),
+                                                    (200, 0.5, True, 4.0), (1, 0.5, False, 1.0), (129, 0.1, True, 4.0),
+                                                    (2000, 0.8, False, 12.0), (512, 0.7, False, 8.0)])
+def test_nms_mask_and_keep(ops, oracle, n, thresh, normal, spread):
+    boxes, _ = _bev(n, 3, spread)
+    scores = synth.distinct_scores(n, 3)
+    order = np.argsort(-scores, kind="stable")
+    sorted_boxes = np.ascontiguousarray(boxes[order])
+    ref_mask = oracle.nms_mask(sorted_boxes, thresh, normal)
+    got_full = host(ops.c.nms_mask(dev(sorted_boxes), thresh, normal, full_grid=True)).view(np.uint64)
+    np.testing.assert_array_equal(got_full, ref_mask)
+    got_tri = host(ops.c.nms_mask(dev(sorted_boxes), thresh, normal, full_grid=False)).view(np.uint64)
+    cb = (n + 63) // 64
+    upper = (np.arange(cb)[None, :] >= (np.arange(n) // 64)[:, None])
+    np.testing.assert_array_equal(got_tri, np.where(upper, ref_mask, 0))
+    ref_keep = oracle.nms_sorted(sorted_boxes, thresh, normal)
+    keep, num = ops.c.nms_device(dev(sorted_boxes), thresh, normal)
+    assert int(num.item()) == len(ref_keep)
+    np.testing.assert_array_equal(host(keep)[:len(ref_keep)], ref_keep)
+    fn = ops.iou.nms_normal_gpu if normal else ops.iou.nms_gpu
+    np.testing.assert_array_equal(host(fn(dev(boxes), dev(scores), thresh)), oracle.nms(boxes, scores, thresh, normal))
+    # reference ext signature: CPU int64 keep tensor + returned count (iou3d.cpp:73-120)
+    keep_cpu = torch.zeros(n, dtype=torch.int64)
+    cnt = (ops.c.nms_normal_gpu if normal else ops.c.nms_gpu)(dev(sorted_boxes), keep_cpu, thresh)
+    assert cnt == len(ref_keep)
+    np.testing.assert_array_equal(keep_cpu.numpy()[:cnt], ref_keep)
+
+
+# ------------------------------------------------------------------------------- error behaviour
+def test_errors_are_exceptions_not_exit(ops):
+    from ws3d_amd._lib import Ws3dError
+    with pytest.raises(Ws3dError):
+        ops.pn.furthest_point_sample(torch.zeros((1, 16, 3)), 4)  # CPU tensor: no fallback
+    with pytest.raises(Ws3dError):
+        ops.c.ball_query_wrapper(1, 16, 4, 0.5, 0, torch.zeros((1, 4, 3), device="cuda"),
+                                 torch.zeros((1, 16, 3), device="cuda"),
+                                 torch.zeros((1, 4, 1), dtype=torch.int32, device="cuda"))
+    with pytest.raises(AssertionError):
+        ops.pn.furthest_point_sample(torch.zeros((1, 16, 6), device="cuda")[:, :, :3], 4)  # non-contiguous

@@ -1,0 +1,77 @@
+"""ctypes binding of libws3d_hip.so (C ABI: include/ws3d_ops.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, every op
+raises -- the product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libws3d_hip.so")
+
+_vp = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); kept in the order of include/ws3d_ops.h
+SIGNATURES = {
+    "ws3d_abi_version": (_i, []),
+    "ws3d_last_error": (C.c_char_p, []),
+    "ws3d_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "ws3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_furthest_point_sampling_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
+    "ws3d_boxes_iou_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
+    "ws3d_nms_mask": (_i, [_i, _vp, _f, _i, _i, _vp, _vp]),
+    "ws3d_nms_workspace_bytes": (_sz, [_i]),
+    "ws3d_nms": (_i, [_i, _vp, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_pts_in_boxes3d": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
+}
+
+
+class Ws3dError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library (once).  Raises Ws3dError when it is absent -- build it with
+    ``python -m ws3d_amd.build`` (or ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Ws3dError(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
+            "(run `python -m ws3d_amd.build`).  ws3d_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64.so not found
+        raise Ws3dError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().ws3d_last_error()
+        raise Ws3dError(f"{what or 'ws3d'} failed (rc={rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,85 @@
+"""Build libws3d_hip.so (the C-ABI HIP library, include/ws3d_ops.h) for gfx950.
+
+Plain ``hipcc`` per translation unit (parallel), then one link -- no hipify, no
+CUDAExtension, no CMake.  The shared object is written IN-TREE
+(``ws3d_amd/libws3d_hip.so``) so it travels to the GPU box with the snapshot.
+
+    python -m ws3d_amd.build [--force] [--verbose]
+
+Flags that are part of the numerical contract:
+  -ffp-contract=off   the compiler never fuses a*b+c; every contractual FMA is spelled
+                      with __builtin_fmaf in the sources
+  -fno-fast-math      IEEE semantics for min/max/compare/division
+(hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt keeps fp32 '/' and sqrtf
+correctly rounded; fp32 denormals are preserved by default on gfx9.)
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libws3d_hip.so")
+ARCH = "gfx950"
+SOURCES = ["core.hip", "fps.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip"]
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+            "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin)")
+
+
+def _deps(src: str):
+    return [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
+            os.path.abspath(__file__)]
+
+
+def _compile(src: str, force: bool, verbose: bool) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    if not force and os.path.exists(obj) and all(
+            os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(path)):
+        return obj
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "-c", path, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force, verbose), SOURCES))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
+        # export only the extern "C" ws3d_* symbols (-fvisibility=hidden + default below)
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))
+    sys.exit(0)

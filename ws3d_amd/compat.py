@@ -1,0 +1,340 @@
+"""Drop-in replacements for the reference's three pybind11 extension modules.
+
+The reference's Python wrappers do ``import pointnet2_cuda`` / ``import iou3d_cuda`` /
+``import roipool3d_cuda`` and call functions that take PRE-ALLOCATED torch tensors
+(pointnet2_api.cpp:10-24, iou3d.cpp:174-179, roipool3d.cpp:198-203).  The three
+namespaces below export exactly those function names with the same positional
+arguments, forwarding ``tensor.data_ptr()`` + the current torch stream to the C ABI of
+``libws3d_hip.so`` (include/ws3d_ops.h).  ``install()`` registers them in
+``sys.modules`` so that the reference's own ``pointnet2_utils.py`` / ``iou3d_utils.py`` /
+``roipool3d_utils.py`` run unmodified on an MI355X.
+
+Differences from the reference, all deliberate:
+  * errors raise ``Ws3dError`` instead of ``exit(-1)`` (sampling_gpu.cu:39-43);
+  * every launch goes to torch's CURRENT stream (the reference's iou3d/roipool3d use
+    the null stream and cudaMalloc/cudaFree per call);
+  * ``nms_gpu`` sweeps on the device; the only host sync is the copy of the result
+    into the caller's CPU ``keep`` tensor, which the reference signature demands.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import torch
+
+from . import _lib
+from ._lib import Ws3dError, check
+
+
+def _dev(*tensors):
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise Ws3dError("ws3d_amd ops need HIP ('cuda') tensors; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise Ws3dError("ws3d_amd ops need contiguous tensors (the reference asserts the same)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise Ws3dError("tensors live on different devices")
+    return dev
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if t.dtype != torch.float32:
+        raise Ws3dError(f"{name} must be float32, got {t.dtype}")
+
+
+def _i32(t, name):
+    if t.dtype != torch.int32:
+        raise Ws3dError(f"{name} must be int32, got {t.dtype}")
+
+
+# ------------------------------------------------------------------ pointnet2_cuda
+def furthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_tensor):
+    """sampling.cpp:36-46"""
+    dev = _dev(points_tensor, temp_tensor, idx_tensor)
+    _f32(points_tensor, "xyz"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_furthest_point_sampling(b, n, m, _p(points_tensor), _p(temp_tensor),
+                                                        _p(idx_tensor), _stream()), "furthest_point_sampling")
+    return 1
+
+
+def furthest_point_sampling_gather(b, n, m, xyz, temp, idx, new_xyz):
+    """fused a1+a2 (ws3d extension; no reference counterpart)"""
+    dev = _dev(xyz, temp, idx, new_xyz)
+    _f32(xyz, "xyz"); _i32(idx, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_furthest_point_sampling_gather(b, n, m, _p(xyz), _p(temp), _p(idx),
+                                                               _p(new_xyz), _stream()), "fps_gather")
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tensor):
+    """sampling.cpp:11-20"""
+    dev = _dev(points_tensor, idx_tensor, out_tensor)
+    _f32(points_tensor, "points"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gather_points(b, c, n, npoints, _p(points_tensor), _p(idx_tensor),
+                                              _p(out_tensor), _stream()), "gather_points")
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """sampling.cpp:23-33"""
+    dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gather_points_grad(b, c, n, npoints, _p(grad_out_tensor), _p(idx_tensor),
+                                                   _p(grad_points_tensor), _stream()), "gather_points_grad")
+    return 1
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor):
+    """ball_query.cpp:14-25"""
+    dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor)
+    _f32(xyz_tensor, "xyz"); _f32(new_xyz_tensor, "new_xyz"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_ball_query(b, n, m, float(radius), nsample, _p(new_xyz_tensor),
+                                           _p(xyz_tensor), _p(idx_tensor), _stream()), "ball_query")
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
+    """group_points.cpp:25-36"""
+    dev = _dev(points_tensor, idx_tensor, out_tensor)
+    _f32(points_tensor, "points"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_group_points(b, c, n, npoints, nsample, _p(points_tensor), _p(idx_tensor),
+                                             _p(out_tensor), _stream()), "group_points")
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """group_points.cpp:11-22"""
+    dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_group_points_grad(b, c, n, npoints, nsample, _p(grad_out_tensor),
+                                                  _p(idx_tensor), _p(grad_points_tensor), _stream()),
+              "group_points_grad")
+    return 1
+
+
+def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features, idx_out, out):
+    """fused a5 (ws3d extension)"""
+    dev = _dev(xyz, new_xyz, features, idx_out, out)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_query_and_group(b, n, m, c, float(radius), nsample, int(bool(use_xyz)),
+                                                _p(xyz), _p(new_xyz), _p(features), _p(idx_out), _p(out),
+                                                _stream()), "query_and_group")
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
+    """interpolate.cpp:14-23"""
+    dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)
+    _f32(unknown_tensor, "unknown"); _f32(known_tensor, "known"); _i32(idx_tensor, "idx")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_three_nn(b, n, m, _p(unknown_tensor), _p(known_tensor), _p(dist2_tensor),
+                                         _p(idx_tensor), _stream()), "three_nn")
+
+
+def three_interpolate_wrapper(b, c, m, n, points_tensor, idx_tensor, weight_tensor, out_tensor):
+    """interpolate.cpp:26-39"""
+    dev = _dev(points_tensor, idx_tensor, weight_tensor, out_tensor)
+    _f32(points_tensor, "points"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_three_interpolate(b, c, m, n, _p(points_tensor), _p(idx_tensor),
+                                                  _p(weight_tensor), _p(out_tensor), _stream()),
+              "three_interpolate")
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor):
+    """interpolate.cpp:41-53"""
+    dev = _dev(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
+    _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_three_interpolate_grad(b, c, n, m, _p(grad_out_tensor), _p(idx_tensor),
+                                                       _p(weight_tensor), _p(grad_points_tensor), _stream()),
+              "three_interpolate_grad")
+
+
+# ------------------------------------------------------------------ iou3d_cuda
+def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
+    """iou3d.cpp:31-50"""
+    dev = _dev(boxes_a, boxes_b, ans_overlap)
+    _f32(boxes_a, "boxes_a"); _f32(boxes_b, "boxes_b"); _f32(ans_overlap, "ans")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_boxes_overlap_bev(boxes_a.size(0), _p(boxes_a), boxes_b.size(0), _p(boxes_b),
+                                                  _p(ans_overlap), _stream()), "boxes_overlap_bev")
+    return 1
+
+
+def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
+    """iou3d.cpp:52-71"""
+    dev = _dev(boxes_a, boxes_b, ans_iou)
+    _f32(boxes_a, "boxes_a"); _f32(boxes_b, "boxes_b"); _f32(ans_iou, "ans")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_boxes_iou_bev(boxes_a.size(0), _p(boxes_a), boxes_b.size(0), _p(boxes_b),
+                                              _p(ans_iou), _stream()), "boxes_iou_bev")
+    return 1
+
+
+def nms_device(boxes, thresh, normal=False):
+    """Device-resident NMS: boxes (n,5) score-sorted -> (keep int64 (n,) DEVICE, num int32 (1,)
+    DEVICE).  No host synchronisation (ws3d extension used by the Stage-1 pipeline)."""
+    dev = _dev(boxes)
+    _f32(boxes, "boxes")
+    n = boxes.size(0)
+    lib = _lib.load()
+    ws_bytes = lib.ws3d_nms_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    num = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_nms(n, _p(boxes), float(thresh), int(bool(normal)), _p(ws), ws_bytes, _p(keep),
+                           _p(num), _stream()), "nms")
+    return keep, num
+
+
+def _nms_into_cpu_keep(boxes, keep, thresh, normal):
+    if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
+        raise Ws3dError("keep must be a contiguous CPU int64 tensor (iou3d.cpp:73-82)")
+    keep_dev, num = nms_device(boxes, thresh, normal)
+    n_keep = int(num.item())  # the reference's signature returns the count to the host
+    keep[:n_keep] = keep_dev[:n_keep].cpu()
+    return n_keep
+
+
+def nms_gpu(boxes, keep, nms_overlap_thresh):
+    """iou3d.cpp:73-120"""
+    return _nms_into_cpu_keep(boxes, keep, nms_overlap_thresh, False)
+
+
+def nms_normal_gpu(boxes, keep, nms_overlap_thresh):
+    """iou3d.cpp:123-170"""
+    return _nms_into_cpu_keep(boxes, keep, nms_overlap_thresh, True)
+
+
+def nms_mask(boxes, thresh, normal=False, full_grid=False):
+    """K12/K13 mask only -> (n, ceil(n/64)) int64 tensor holding the uint64 words."""
+    dev = _dev(boxes)
+    _f32(boxes, "boxes")
+    n = boxes.size(0)
+    mask = torch.zeros((n, (n + 63) // 64), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_nms_mask(n, _p(boxes), float(thresh), int(bool(normal)), int(bool(full_grid)),
+                                         _p(mask), _stream()), "nms_mask")
+    return mask
+
+
+# ------------------------------------------------------------------ roipool3d_cuda
+def roipool3d_forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx=None):
+    """roipool3d.cpp:48-79 (forward) == :15-44 (forward_slow)"""
+    dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
+    _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
+    _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_roipool3d(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
+                                          pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
+                                          _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
+              "roipool3d")
+    return 1
+
+
+def pts_in_boxes3d_device(pts, boxes3d):
+    """device twin of pts_in_boxes3d_cpu: (N,3),(M,7) -> (M,N) int64 on the device"""
+    dev = _dev(pts, boxes3d)
+    _f32(pts, "pts"); _f32(boxes3d, "boxes3d")
+    flag = torch.empty((boxes3d.size(0), pts.size(0)), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pts_in_boxes3d(boxes3d.size(0), pts.size(0), _p(pts), _p(boxes3d), _p(flag),
+                                               _stream()), "pts_in_boxes3d")
+    return flag
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise Ws3dError("no HIP device: the reference's *_cpu entry points are served by the MI355X "
+                        "kernels here (H2D -> kernel -> D2H); ws3d_amd has no CPU implementation")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def pts_in_boxes3d_cpu(pts_flag, pts, boxes3d):
+    """roipool3d.cpp:97-124 -- CPU tensors in/out, computed on the device."""
+    dev = _default_device()
+    flag = pts_in_boxes3d_device(pts.float().contiguous().to(dev), boxes3d.float().contiguous().to(dev))
+    pts_flag.copy_(flag.cpu())
+    return 1
+
+
+def roipool3d_cpu(pts, boxes3d, pts_feature, pooled_pts, pooled_features, pooled_empty_flag):
+    """roipool3d.cpp:127-195 -- CPU tensors in/out, computed on the device."""
+    dev = _default_device()
+    S, C_ = pooled_pts.size(1), pts_feature.size(1)
+    M = boxes3d.size(0)
+    out = torch.zeros((1, M, S, 3 + C_), dtype=torch.float32, device=dev)
+    empty = torch.zeros((1, M), dtype=torch.int32, device=dev)
+    roipool3d_forward(pts.float().contiguous().to(dev)[None], boxes3d.float().contiguous().to(dev)[None],
+                      pts_feature.float().contiguous().to(dev)[None], out, empty)
+    out = out[0].cpu()
+    pooled_pts.copy_(out[:, :, :3])
+    pooled_features.copy_(out[:, :, 3:])
+    pooled_empty_flag.copy_(empty[0].cpu().to(pooled_empty_flag.dtype))
+    return 1
+
+
+def _namespace(name, **fns):
+    m = types.ModuleType(name)
+    m.__dict__.update(fns)
+    m.__doc__ = f"ws3d_amd drop-in for the reference's `{name}` pybind11 extension"
+    return m
+
+
+pointnet2_cuda = _namespace(
+    "pointnet2_cuda",
+    furthest_point_sampling_wrapper=furthest_point_sampling_wrapper,
+    gather_points_wrapper=gather_points_wrapper,
+    gather_points_grad_wrapper=gather_points_grad_wrapper,
+    ball_query_wrapper=ball_query_wrapper,
+    group_points_wrapper=group_points_wrapper,
+    group_points_grad_wrapper=group_points_grad_wrapper,
+    three_nn_wrapper=three_nn_wrapper,
+    three_interpolate_wrapper=three_interpolate_wrapper,
+    three_interpolate_grad_wrapper=three_interpolate_grad_wrapper,
+)
+iou3d_cuda = _namespace(
+    "iou3d_cuda",
+    boxes_overlap_bev_gpu=boxes_overlap_bev_gpu,
+    boxes_iou_bev_gpu=boxes_iou_bev_gpu,
+    nms_gpu=nms_gpu,
+    nms_normal_gpu=nms_normal_gpu,
+)
+roipool3d_cuda = _namespace(
+    "roipool3d_cuda",
+    forward=roipool3d_forward,
+    forward_slow=roipool3d_forward,
+    pts_in_boxes3d_cpu=pts_in_boxes3d_cpu,
+    roipool3d_cpu=roipool3d_cpu,
+)
+
+
+def install() -> None:
+    """Register the three namespaces under the reference's module names."""
+    sys.modules["pointnet2_cuda"] = pointnet2_cuda
+    sys.modules["iou3d_cuda"] = iou3d_cuda
+    sys.modules["roipool3d_cuda"] = roipool3d_cuda

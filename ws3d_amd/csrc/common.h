@@ -1,0 +1,91 @@
+// common.h -- shared device helpers for the gfx950 kernels (wave64 only).
+//
+// Arithmetic contract.  This library is compiled with
+// -ffp-contract=off, so the compiler never fuses or re-associates; every FMA that
+// is part of the contract is spelled with __builtin_fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ws3d_ops.h"
+
+#define WS3D_WAVE 64
+
+namespace ws3d {
+
+void set_error(const char *fmt, ...);
+int check_launch(const char *what);
+
+static inline hipStream_t as_stream(ws3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Squared distance of the three pointnet2 search kernels: the source expression
+// dx*dx + dy*dy + dz*dz (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36)
+// under nvcc's default FMA contraction: fma(dz,dz, fma(dx,dx, dy*dy)).
+__device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+
+// float trig = double libm result rounded to float (== correctly rounded float
+// function with overwhelming probability).
+__device__ __forceinline__ float cosf_cr(float a) { return (float)cos((double)a); }
+__device__ __forceinline__ float sinf_cr(float a) { return (float)sin((double)a); }
+__device__ __forceinline__ float atan2f_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+// ---- DPP cross-lane (no LDS traffic) ------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+enum : int {
+    DPP_QUAD_XOR1 = 0xB1,      // quad_perm [1,0,3,2]
+    DPP_QUAD_XOR2 = 0x4E,      // quad_perm [2,3,0,1]
+    DPP_ROW_HALF_MIRROR = 0x141,
+    DPP_ROW_MIRROR = 0x140,
+};
+
+// Single-instruction IEEE min/max (v_min_f32 / v_max_f32 return the non-NaN operand for
+// quiet NaNs, exactly like fminf/fmaxf; the builtins would add a canonicalising v_max
+// per operand).
+__device__ __forceinline__ float min_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float max_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// max over each 16-lane DPP row, result replicated in all 16 lanes of the row.
+// One v_max_f32_dpp per stage (s_nop 1 = the VALU-write -> DPP-read wait states).
+__device__ __forceinline__ float row16_max(float v) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
+    return v;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// max over the whole wave, wave-uniform result
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
+    return max_f32(max_f32(a, b), max_f32(c, d));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int mbcnt(uint64_t mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+}  // namespace ws3d

@@ -1,0 +1,49 @@
+// core.hip -- error reporting + device info for libws3d_hip.so
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "common.h"
+
+namespace ws3d {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char *what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return WS3D_E_LAUNCH;
+    }
+    return WS3D_OK;
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_abi_version(void) { return 1; }
+
+extern "C" const char *ws3d_last_error(void) { return ws3d::g_err; }
+
+extern "C" int ws3d_device_info(char *name, int name_len, int *cu_count, int *lds_bytes_per_block) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) {
+        ws3d::set_error("ws3d_device_info: %s", hipGetErrorString(e));
+        return WS3D_E_LAUNCH;
+    }
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (lds_bytes_per_block) *lds_bytes_per_block = (int)p.sharedMemPerBlock;
+    return WS3D_OK;
+}

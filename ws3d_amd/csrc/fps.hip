@@ -1,0 +1,305 @@
+// fps.hip -- furthest point sampling for gfx950 (replaces pointnet2_cuda.
+// furthest_point_sampling_wrapper, sampling.cpp:36-46 / sampling_gpu.cu:93-253).
+//
+// Design.  FPS is (m-1) strictly dependent argmax steps; the
+// step is ALU/latency-bound, not HBM-bound, so the whole scene lives ON-CHIP for the
+// entire kernel: one workgroup per scene, every thread keeps PPT points (x,y,z) and
+// their running min-distance in VGPRs (16384 points = 16 per thread of a 1024-thread
+// workgroup = 256 KB of the CU's 512 KB register file).  HBM is touched once on entry
+// (n*12 B) and once per step for the 4-byte index (+12 B of coordinates when the
+// fused gather output is requested).
+//
+// One step = (1) PPT x {3 sub, mul, 2 fma, min, cmp, 2 select} per lane,
+//            (2) wave argmax: 4 DPP max steps + 4 readlanes + ballot/ctz (no LDS),
+//            (3) one 20-byte LDS record per wave, ONE s_barrier (records are double
+//                buffered by step parity), every wave reduces the <=16 records with a
+//                16-lane DPP row reduction and picks up the winner's coordinates with
+//                readlanes -- no dependent global load anywhere in the loop.
+// The reference needs 1 pass over global memory + 11 __syncthreads per step.
+//
+// Tie-breaks are part of the contract (bit-exact indices).  In the reference, thread
+// tid of a bs-thread block (bs = opt_n_threads(n)) owns k = tid, tid+bs, ...; strict
+// '>' keeps the smallest k inside a thread and the shared-memory tree keeps the lower
+// slot on ties, so among exact ties the winner is the candidate with the smallest
+// bit-reversed (k mod bs), then the smallest k.  Here thread u owns the contiguous
+// range [u*PPT, (u+1)*PPT) of positions p = bitrev(k mod bs) * S + k / bs
+// (S = ceil(n/bs)), so that plain "lowest slot, lowest lane, lowest wave wins" IS the
+// reference's tie order -- for any workgroup size, independent of bs.
+#include "common.h"
+
+namespace ws3d {
+
+__device__ __forceinline__ int bitrev_bits(int v, int bits) {
+    return bits == 0 ? 0 : (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits));
+}
+
+// exact p / S for 0 <= p < 2^22 via one float multiply + fix-up (S >= 1)
+__device__ __forceinline__ void divmod_small(int p, int S, float invS, int &q, int &r) {
+    q = (int)((float)p * invS);
+    r = p - q * S;
+    if (r < 0) { q -= 1; r += S; }
+    if (r >= S) { q += 1; r -= S; }
+}
+
+template <int N> struct VecF { typedef float type __attribute__((ext_vector_type(N))); };
+template <> struct VecF<1> { typedef float type; };
+template <int N> using vecf = typename VecF<N>::type;
+template <int N> __device__ __forceinline__ float vec_get(const vecf<N> &v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vec_get<1>(const vecf<1> &v, int) { return v; }
+template <int N> __device__ __forceinline__ void vec_set(vecf<N> &v, int i, float x) { v[i] = x; }
+template <> __device__ __forceinline__ void vec_set<1>(vecf<1> &v, int, float x) { v = x; }
+
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz,
+                                                     float *__restrict__ temp,
+                                                     int32_t *__restrict__ idx,
+                                                     float *__restrict__ new_xyz, int n, int m,
+                                                     int bs, int log2bs, int S) {
+    constexpr int NW = NT / WS3D_WAVE;
+    __shared__ float4 s_cand[2][16];
+    __shared__ int s_k[2][16];
+
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    if (temp) temp += (size_t)b * n;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+
+    const int u = threadIdx.x;
+    const int lane = u & 63;
+    const int w = u >> 6;
+    const float invS = 1.0f / (float)S;
+
+    // ext-vector storage: a wave-uniform dynamic index (the winner's slot) then lowers to
+    // VGPR-indexed moves instead of a 16-way compare/branch chain.
+    vecf<PPT> px, py, pz;
+    float t[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int p = u * PPT + s;
+        const int rb = p / S, sl = p - rb * S;
+        const int k = bitrev_bits(rb, log2bs) + sl * bs;
+        const bool valid = (rb < bs) && (k < n);
+        vec_set<PPT>(px, s, valid ? xyz[k * 3 + 0] : 0.f);
+        vec_set<PPT>(py, s, valid ? xyz[k * 3 + 1] : 0.f);
+        vec_set<PPT>(pz, s, valid ? xyz[k * 3 + 2] : 0.f);
+        t[s] = valid ? (temp ? temp[k] : 1e10f) : -1.0f;  // -1 never beats a real candidate (>= 0)
+    }
+
+    int old = 0;
+    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    if (u == 0) {
+        idx[0] = 0;
+        if (new_xyz) { new_xyz[0] = ox; new_xyz[1] = oy; new_xyz[2] = oz; }
+    }
+
+    for (int j = 1; j < m; ++j) {
+        float best = -1.0f;
+        int bslot = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, vec_get<PPT>(pz, s) - oz);
+            const float d2 = min_f32(d, t[s]);  // == fminf: t[s] is never NaN
+            t[s] = d2;
+            const bool gt = d2 > best;
+            bslot = gt ? s : bslot;
+            best = gt ? d2 : best;
+        }
+        // ---- wave argmax: lowest lane among the lanes holding the wave maximum
+        const float wmax = wave_max(best);
+        const uint64_t eq = __ballot(best == wmax);
+        const int wl = (int)__builtin_ctzll(eq);
+        const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+        const float cx = readlane_f(vec_get<PPT>(px, wslot), wl);
+        const float cy = readlane_f(vec_get<PPT>(py, wslot), wl);
+        const float cz = readlane_f(vec_get<PPT>(pz, wslot), wl);
+        int rb, sl;
+        divmod_small((w * 64 + wl) * PPT + wslot, S, invS, rb, sl);
+        const int kw = bitrev_bits(rb, log2bs) + sl * bs;
+
+        if constexpr (NW == 1) {
+            ox = cx; oy = cy; oz = cz; old = kw;
+        } else {
+            const int buf = j & 1;
+            if (lane == 0) {
+                s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
+                s_k[buf][w] = kw;
+            }
+            __syncthreads();
+            const int e = lane & 15;
+            const float4 c = s_cand[buf][e];
+            const int kc = s_k[buf][e];
+            const float v = e < NW ? c.x : -2.0f;
+            const float vm = row16_max(v);
+            const uint64_t eq2 = __ballot(v == vm);
+            const int sel = (int)__builtin_ctzll(eq2);  // lowest wave among ties
+            ox = readlane_f(c.y, sel);
+            oy = readlane_f(c.z, sel);
+            oz = readlane_f(c.w, sel);
+            old = __builtin_amdgcn_readlane(kc, sel);
+        }
+        if (u == 0) {
+            idx[j] = old;
+            if (new_xyz) { new_xyz[j * 3 + 0] = ox; new_xyz[j * 3 + 1] = oy; new_xyz[j * 3 + 2] = oz; }
+        }
+    }
+
+    if (temp) {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int p = u * PPT + s;
+            const int rb = p / S, sl = p - rb * S;
+            const int k = bitrev_bits(rb, log2bs) + sl * bs;
+            if ((rb < bs) && (k < n)) temp[k] = t[s];
+        }
+    }
+}
+
+// ---- streaming fallback for scenes that do not fit the register file (n > 16384).
+// Natural strided ownership (thread tid owns k = tid, tid+1024, ...: coalesced),
+// min-distance in the caller's temp buffer, explicit tie key = bitrev10(tid).
+__device__ __forceinline__ int row16_min_i(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, DPP_QUAD_XOR2, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, DPP_ROW_MIRROR, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    v = row16_min_i(v);
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__global__ __launch_bounds__(1024) void fps_stream_kernel(const float *__restrict__ xyz,
+                                                          float *__restrict__ temp,
+                                                          int32_t *__restrict__ idx,
+                                                          float *__restrict__ new_xyz, int n,
+                                                          int m) {
+    __shared__ float4 s_cand[2][16];
+    __shared__ int2 s_kk[2][16];  // {k, key}
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    temp += (size_t)b * n;
+    idx += (size_t)b * m;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int key = bitrev_bits(tid, 10);
+
+    int old = 0;
+    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    if (tid == 0) {
+        idx[0] = 0;
+        if (new_xyz) { new_xyz[0] = ox; new_xyz[1] = oy; new_xyz[2] = oz; }
+    }
+    for (int j = 1; j < m; ++j) {
+        float best = -1.0f;
+        int besti = 0;
+        for (int k = tid; k < n; k += 1024) {
+            const float x = xyz[k * 3 + 0], y = xyz[k * 3 + 1], z = xyz[k * 3 + 2];
+            const float d = sqdist3(x - ox, y - oy, z - oz);
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            const bool gt = d2 > best;
+            besti = gt ? k : besti;
+            best = gt ? d2 : best;
+        }
+        const float wmax = wave_max(best);
+        const int mykey = (best == wmax) ? key : (1 << 20);
+        const int wkey = wave_min_i(mykey);
+        const uint64_t eq = __ballot(mykey == wkey);
+        const int wl = (int)__builtin_ctzll(eq);
+        const int kw = __builtin_amdgcn_readlane(besti, wl);
+        const int buf = j & 1;
+        if (lane == 0) {
+            const float cx = xyz[kw * 3 + 0], cy = xyz[kw * 3 + 1], cz = xyz[kw * 3 + 2];
+            s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
+            s_kk[buf][w] = make_int2(kw, wkey);
+        }
+        __syncthreads();
+        const int e = lane & 15;
+        const float4 c = s_cand[buf][e];
+        const int2 kk = s_kk[buf][e];
+        const float vm = row16_max(c.x);
+        const int k2 = (c.x == vm) ? kk.y : (1 << 20);
+        const int kmin = row16_min_i(k2);
+        const uint64_t eq2 = __ballot(k2 == kmin);
+        const int sel = (int)__builtin_ctzll(eq2);
+        ox = readlane_f(c.y, sel);
+        oy = readlane_f(c.z, sel);
+        oz = readlane_f(c.w, sel);
+        old = __builtin_amdgcn_readlane(kk.x, sel);
+        if (tid == 0) {
+            idx[j] = old;
+            if (new_xyz) { new_xyz[j * 3 + 0] = ox; new_xyz[j * 3 + 1] = oy; new_xyz[j * 3 + 2] = oz; }
+        }
+    }
+}
+
+// host: cuda_utils.h:10-14 (same libm expression as the reference's launcher)
+static int opt_n_threads(int work_size) {
+    const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+template <int PPT, int NT>
+static void launch_reg(int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
+                       float *new_xyz, int bs, int log2bs, int S, hipStream_t st) {
+    hipLaunchKernelGGL((fps_reg_kernel<PPT, NT>), dim3(b), dim3(NT), 0, st, xyz, temp, idx, new_xyz,
+                       n, m, bs, log2bs, S);
+}
+
+static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
+                        float *new_xyz, hipStream_t st) {
+    if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && m > 0)) {
+        set_error("ws3d_furthest_point_sampling: invalid argument (b=%d n=%d m=%d)", b, n, m);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || m == 0) return WS3D_OK;  // sampling_gpu.cu:101
+    const int bs = opt_n_threads(n);
+    int log2bs = 0;
+    while ((1 << log2bs) < bs) ++log2bs;
+    const int S = (n + bs - 1) / bs;
+    const long R = (long)bs * S;  // number of tie-order positions
+    if (R <= 64L * 16) {
+        const int ppt = (int)((R + 63) / 64);
+        if (ppt <= 1) launch_reg<1, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else if (ppt <= 2) launch_reg<2, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else if (ppt <= 4) launch_reg<4, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else if (ppt <= 8) launch_reg<8, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else launch_reg<16, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else if (R <= 256L * 16) {
+        const int ppt = (int)((R + 255) / 256);
+        if (ppt <= 8) launch_reg<8, 256>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else launch_reg<16, 256>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else if (R <= 1024L * 16) {
+        const int ppt = (int)((R + 1023) / 1024);
+        if (ppt <= 8) launch_reg<8, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else launch_reg<16, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else {
+        if (!temp) {
+            set_error("ws3d_furthest_point_sampling: n=%d exceeds the in-register capacity (16384); "
+                      "the streaming path needs the caller's temp (b,n) buffer", n);
+            return WS3D_E_WORKSPACE;
+        }
+        hipLaunchKernelGGL(fps_stream_kernel, dim3(b), dim3(1024), 0, st, xyz, temp, idx, new_xyz, n, m);
+    }
+    return check_launch("furthest_point_sampling");
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
+                                            int32_t *idx, ws3d_stream_t stream) {
+    return ws3d::fps_dispatch(b, n, m, xyz, temp, idx, nullptr, ws3d::as_stream(stream));
+}
+
+extern "C" int ws3d_furthest_point_sampling_gather(int b, int n, int m, const float *xyz,
+                                                   float *temp, int32_t *idx, float *new_xyz,
+                                                   ws3d_stream_t stream) {
+    return ws3d::fps_dispatch(b, n, m, xyz, temp, idx, new_xyz, ws3d::as_stream(stream));
+}

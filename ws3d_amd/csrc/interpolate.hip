@@ -1,0 +1,167 @@
+// interpolate.hip -- three_nn / three_interpolate (+grad) for gfx950.  Replaces
+// pointnet2_cuda.{three_nn_wrapper, three_interpolate_wrapper,
+// three_interpolate_grad_wrapper} (interpolate.cpp:14-53, interpolate_gpu.cu:9-160).
+//
+// three_nn: one lane per unknown point, the known set streams through LDS as float4
+// (broadcast reads), a wave-uniform "can anybody still improve?" test skips the
+// insertion for most candidates.  Strict '<' and ascending scan order keep the earlier
+// index on equal distances, as in the reference.  The reference keeps its running
+// bests in double initialised to 1e40 but compares a float d against them; float
+// bests initialised to +inf give bit-identical decisions and outputs ((float)1e40 ==
+// +inf, inf < inf is false exactly like inf < 1e40).
+#include <cmath>
+
+#include "common.h"
+
+namespace ws3d {
+
+constexpr int NN_TILE = 1024;
+
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
+                                                       const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2,
+                                                       int32_t *__restrict__ idx) {
+    __shared__ float4 tile[NN_TILE];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int pi = blockIdx.x * 256 + tid;
+    const bool active = pi < n;
+    unknown += (size_t)b * n * 3;
+    known += (size_t)b * m * 3;
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    if (active) { ux = unknown[pi * 3 + 0]; uy = unknown[pi * 3 + 1]; uz = unknown[pi * 3 + 2]; }
+
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto insert = [&](const float d, const int k) {
+        if (d < b1) {
+            b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
+        } else if (d < b2) {
+            b3 = b2; i3 = i2; b2 = d; i2 = k;
+        } else if (d < b3) {
+            b3 = d; i3 = k;
+        }
+    };
+    for (int base = 0; base < m; base += NN_TILE) {
+        const int lim = min(NN_TILE, m - base);
+        __syncthreads();
+        for (int i = tid; i < lim; i += 256) {
+            const float *p = known + (size_t)(base + i) * 3;
+            tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        int i = 0;
+        for (; i + 4 <= lim; i += 4) {
+            const float4 p0 = tile[i], p1 = tile[i + 1], p2 = tile[i + 2], p3 = tile[i + 3];
+            const float d0 = sqdist3(ux - p0.x, uy - p0.y, uz - p0.z);
+            const float d1 = sqdist3(ux - p1.x, uy - p1.y, uz - p1.z);
+            const float d2 = sqdist3(ux - p2.x, uy - p2.y, uz - p2.z);
+            const float d3 = sqdist3(ux - p3.x, uy - p3.y, uz - p3.z);
+            if (__any((d0 < b3) | (d1 < b3) | (d2 < b3) | (d3 < b3))) {
+                insert(d0, base + i);
+                insert(d1, base + i + 1);
+                insert(d2, base + i + 2);
+                insert(d3, base + i + 3);
+            }
+        }
+        for (; i < lim; ++i) {
+            const float4 p = tile[i];
+            insert(sqdist3(ux - p.x, uy - p.y, uz - p.z), base + i);
+        }
+    }
+    if (active) {
+        float *od = dist2 + ((size_t)b * n + pi) * 3;
+        int32_t *oi = idx + ((size_t)b * n + pi) * 3;
+        od[0] = b1; od[1] = b2; od[2] = b3;
+        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+}
+
+constexpr int TI_CCH = 16;
+
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
+                                                                const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * TI_CCH;
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= n) return;
+    const int32_t *id = idx + ((size_t)b * n + pi) * 3;
+    const float *w = weight + ((size_t)b * n + pi) * 3;
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const float *p = points + ((size_t)b * c + c0) * m;
+    float *o = out + ((size_t)b * c + c0) * n + pi;
+    const int cc = min(TI_CCH, c - c0);
+    for (int ch = 0; ch < cc; ++ch, p += m, o += n)
+        // w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:96) under nvcc's default contraction
+        *o = __builtin_fmaf(w2, p[i2], __builtin_fmaf(w0, p[i0], w1 * p[i1]));
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int32_t *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * TI_CCH;
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    if (pi >= n) return;
+    const int32_t *id = idx + ((size_t)b * n + pi) * 3;
+    const float *w = weight + ((size_t)b * n + pi) * 3;
+    const int i0 = id[0], i1 = id[1], i2 = id[2];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    const float *g = grad_out + ((size_t)b * c + c0) * n + pi;
+    float *gp = grad_points + ((size_t)b * c + c0) * m;
+    const int cc = min(TI_CCH, c - c0);
+    for (int ch = 0; ch < cc; ++ch, g += n, gp += m) {
+        const float gv = *g;
+        atomicAdd(gp + i0, gv * w0);
+        atomicAdd(gp + i1, gv * w1);
+        atomicAdd(gp + i2, gv * w2);
+    }
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                             float *dist2, int32_t *idx, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n < 0 || m < 0 || !unknown || (!known && m > 0) || !dist2 || !idx) {
+        set_error("ws3d_three_nn: invalid argument (b=%d n=%d m=%d)", b, n, m);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || n == 0) return WS3D_OK;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m,
+                       unknown, known, dist2, idx);
+    return check_launch("ws3d_three_nn");
+}
+
+extern "C" int ws3d_three_interpolate(int b, int c, int m, int n, const float *points,
+                                      const int32_t *idx, const float *weight, float *out,
+                                      ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || c < 0 || m <= 0 || n < 0 || !points || !idx || !weight || !out) {
+        set_error("ws3d_three_interpolate: invalid argument (b=%d c=%d m=%d n=%d)", b, c, m, n);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || c == 0 || n == 0) return WS3D_OK;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + TI_CCH - 1) / TI_CCH, b),
+                       dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
+    return check_launch("ws3d_three_interpolate");
+}
+
+extern "C" int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                           const int32_t *idx, const float *weight,
+                                           float *grad_points, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || c < 0 || m <= 0 || n < 0 || !grad_out || !idx || !weight || !grad_points) {
+        set_error("ws3d_three_interpolate_grad: invalid argument (b=%d c=%d n=%d m=%d)", b, c, n, m);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || c == 0 || n == 0) return WS3D_OK;
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3((n + 255) / 256, (c + TI_CCH - 1) / TI_CCH, b),
+                       dim3(256), 0, as_stream(stream), c, n, m, grad_out, idx, weight, grad_points);
+    return check_launch("ws3d_three_interpolate_grad");
+}

@@ -1,0 +1,401 @@
+// iou3d.hip -- rotated-BEV box overlap / IoU and bitmask NMS for gfx950.  Replaces
+// iou3d_cuda.{boxes_overlap_bev_gpu, boxes_iou_bev_gpu, nms_gpu, nms_normal_gpu}
+// (iou3d.cpp:31-170 -> iou3d_kernel.cu:14-387).
+//
+// Design.  ALU-bound (rotated intersection ~1e3 flops/pair),
+// no MFMA.  The reference's 64-bit NMS mask word is exactly one CDNA wavefront, so a
+// workgroup is ONE wave: lane = row box, the 64 column boxes sit in LDS with their
+// frame (rotated corners, cos/sin of +-ry, centre, area) computed ONCE per box instead
+// of once per pair.  Per-lane polygon scratch (<= 16 vertices + angles) lives in LDS in
+// [vertex][lane] order (conflict-free, no scratch-memory spills).  Pairs whose
+// circumscribed circles are separated by more than a safety margin skip the 16
+// edge tests (the reference would find cnt == 0 there, so the result -- overlap 0 --
+// is bit-identical).  Only the upper-triangular block pairs the greedy sweep reads are
+// computed, and the sweep itself runs on the device (no cudaMalloc, no blocking D2H,
+// no host loop: iou3d.cpp:86-116).
+//
+// Arithmetic: plain IEEE fp32 in source order (library built with -ffp-contract=off),
+// sin/cos/atan2 = double libm rounded to float.
+#include "common.h"
+
+namespace ws3d {
+
+struct P2 { float x, y; };
+
+constexpr float IOU_EPS = 1e-8f;  // iou3d_kernel.cu:13
+
+struct BevFrame {
+    float x1, y1, x2, y2;   // raw box (iou3d_kernel.cu:111-112)
+    float cx, cy;           // centre (:115-116)
+    float cosn, sinn;       // cos(-ry), sin(-ry) used by check_in_box2d (:56)
+    float area;             // (x2-x1)*(y2-y1) (:217-218)
+    float rad;              // half diagonal, for the far-pair reject only
+    P2 c[4];                // rotated corners (:124-150)
+};
+constexpr int FRAME_F = 18;  // floats per frame
+
+__device__ __forceinline__ float cross3(P2 p1, P2 p2, P2 p0) {  // :38-40
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+
+__device__ __forceinline__ BevFrame make_bev_frame(const float *box) {
+    BevFrame f;
+    f.x1 = box[0]; f.y1 = box[1]; f.x2 = box[2]; f.y2 = box[3];
+    const float ang = box[4];
+    f.cx = (f.x1 + f.x2) / 2;
+    f.cy = (f.y1 + f.y2) / 2;
+    const float ac = cosf_cr(ang), as = sinf_cr(ang);
+    f.cosn = cosf_cr(-ang);
+    f.sinn = sinf_cr(-ang);
+    f.area = (f.x2 - f.x1) * (f.y2 - f.y1);
+    const float hx = (f.x2 - f.x1) * 0.5f, hy = (f.y2 - f.y1) * 0.5f;
+    f.rad = sqrtf(hx * hx + hy * hy);
+    const float px[4] = {f.x1, f.x2, f.x2, f.x1};
+    const float py[4] = {f.y1, f.y1, f.y2, f.y2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // rotate_around_center :98-102
+        f.c[k].x = (px[k] - f.cx) * ac + (py[k] - f.cy) * as + f.cx;
+        f.c[k].y = -(px[k] - f.cx) * as + (py[k] - f.cy) * ac + f.cy;
+    }
+    return f;
+}
+
+__device__ __forceinline__ void store_frame(float *dst, const BevFrame &f) {
+    dst[0] = f.x1; dst[1] = f.y1; dst[2] = f.x2; dst[3] = f.y2; dst[4] = f.cx; dst[5] = f.cy;
+    dst[6] = f.cosn; dst[7] = f.sinn; dst[8] = f.area; dst[9] = f.rad;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { dst[10 + 2 * k] = f.c[k].x; dst[11 + 2 * k] = f.c[k].y; }
+}
+__device__ __forceinline__ BevFrame load_frame(const float *src) {
+    BevFrame f;
+    f.x1 = src[0]; f.y1 = src[1]; f.x2 = src[2]; f.y2 = src[3]; f.cx = src[4]; f.cy = src[5];
+    f.cosn = src[6]; f.sinn = src[7]; f.area = src[8]; f.rad = src[9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f.c[k].x = src[10 + 2 * k]; f.c[k].y = src[11 + 2 * k]; }
+    return f;
+}
+
+__device__ __forceinline__ bool check_in_box2d(const BevFrame &b, P2 p) {  // :50-65
+    const float MARGIN = 1e-5f;
+    const float rot_x = (p.x - b.cx) * b.cosn + (p.y - b.cy) * b.sinn + b.cx;
+    const float rot_y = -(p.x - b.cx) * b.sinn + (p.y - b.cy) * b.cosn + b.cy;
+    return (rot_x > b.x1 - MARGIN && rot_x < b.x2 + MARGIN && rot_y > b.y1 - MARGIN && rot_y < b.y2 + MARGIN);
+}
+
+__device__ __forceinline__ bool intersection(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans) {  // :67-96
+    // check_rect_cross(p0, p1, q0, q1) :42-48
+    if (!(fminf(p0.x, p1.x) <= fmaxf(q0.x, q1.x) && fminf(q0.x, q1.x) <= fmaxf(p0.x, p1.x) &&
+          fminf(p0.y, p1.y) <= fmaxf(q0.y, q1.y) && fminf(q0.y, q1.y) <= fmaxf(p0.y, p1.y)))
+        return false;
+    const float s1 = cross3(q0, p1, p0);
+    const float s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0);
+    const float s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+// iou3d_kernel.cu:108-212.  vx/vy/va: this lane's polygon scratch in LDS, element v at
+// [v * 64] (the caller passes pointers already offset by the lane id).
+__device__ float box_overlap(const BevFrame &A, const BevFrame &B, float *vx, float *vy, float *va) {
+    // far-pair reject: circumscribed circles separated by > margin => the reference finds
+    // no edge crossing and no contained corner (cnt == 0) and returns 0.
+    {
+        const float dx = A.cx - B.cx, dy = A.cy - B.cy;
+        const float rr = A.rad + B.rad + 0.01f + 1e-5f * (fabsf(A.cx) + fabsf(A.cy) + fabsf(B.cx) + fabsf(B.cy));
+        if (dx * dx + dy * dy > rr * rr * 1.0001f) return 0.0f;
+    }
+    int cnt = 0;
+    float pcx = 0.f, pcy = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            P2 ans;
+            if (intersection(A.c[(i + 1) & 3], A.c[i], B.c[(j + 1) & 3], B.c[j], ans)) {
+                pcx = pcx + ans.x;
+                pcy = pcy + ans.y;
+                vx[cnt * 64] = ans.x;
+                vy[cnt * 64] = ans.y;
+                cnt++;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (check_in_box2d(A, B.c[k])) {
+            pcx = pcx + B.c[k].x; pcy = pcy + B.c[k].y;
+            vx[cnt * 64] = B.c[k].x; vy[cnt * 64] = B.c[k].y;
+            cnt++;
+        }
+        if (check_in_box2d(B, A.c[k])) {
+            pcx = pcx + A.c[k].x; pcy = pcy + A.c[k].y;
+            vx[cnt * 64] = A.c[k].x; vy[cnt * 64] = A.c[k].y;
+            cnt++;
+        }
+    }
+    if (cnt == 0) return 0.0f;  // (0/0 centroid, empty loops, area 0 in the reference)
+    pcx /= cnt;
+    pcy /= cnt;
+    for (int v = 0; v < cnt; ++v) va[v * 64] = atan2f_cr(vy[v * 64] - pcy, vx[v * 64] - pcx);
+    // bubble sort with point_cmp = angle(a) > angle(b) (:104-106,188-196)
+    for (int j = 0; j < cnt - 1; ++j) {
+        for (int i = 0; i < cnt - j - 1; ++i) {
+            const float ta = va[i * 64], tb = va[(i + 1) * 64];
+            if (ta > tb) {
+                va[i * 64] = tb; va[(i + 1) * 64] = ta;
+                const float x0 = vx[i * 64], y0 = vy[i * 64];
+                vx[i * 64] = vx[(i + 1) * 64]; vy[i * 64] = vy[(i + 1) * 64];
+                vx[(i + 1) * 64] = x0; vy[(i + 1) * 64] = y0;
+            }
+        }
+    }
+    float area = 0.f;
+    const float x0 = vx[0], y0 = vy[0];
+    for (int k = 0; k < cnt - 1; ++k) {
+        const float ax = vx[k * 64] - x0, ay = vy[k * 64] - y0;
+        const float bx = vx[(k + 1) * 64] - x0, by = vy[(k + 1) * 64] - y0;
+        area += ax * by - ay * bx;  // cross(a, b) :34-36
+    }
+    return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_from_overlap(const BevFrame &A, const BevFrame &B, float s_overlap) {
+    return s_overlap / fmaxf(A.area + B.area - s_overlap, IOU_EPS);  // :214-221
+}
+
+__device__ __forceinline__ float iou_normal(const float *a, const float *b) {  // :295-303
+    const float left = fmaxf(a[0], b[0]), right = fminf(a[2], b[2]);
+    const float top = fmaxf(a[1], b[1]), bottom = fminf(a[3], b[3]);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float interS = width * height;
+    const float Sa = (a[2] - a[0]) * (a[3] - a[1]);
+    const float Sb = (b[2] - b[0]) * (b[3] - b[1]);
+    return interS / fmaxf(Sa + Sb - interS, IOU_EPS);
+}
+
+// LDS budget of the one-wave workgroups below
+struct WaveScratch {
+    float frames[64 * FRAME_F];
+    float vx[16 * 64], vy[16 * 64], va[16 * 64];
+};
+
+// ans[a, b] for a 64(a) x 64(b) tile: lane = column box b (coalesced row stores),
+// the 64 row boxes a come from LDS.  MODE 0: overlap area (K10), 1: IoU (K11).
+template <int MODE>
+__global__ __launch_bounds__(64) void pair_kernel(int num_a, const float *__restrict__ boxes_a,
+                                                  int num_b, const float *__restrict__ boxes_b,
+                                                  float *__restrict__ ans) {
+    __shared__ WaveScratch s;
+    const int lane = threadIdx.x;
+    const int a0 = blockIdx.y * 64, b0 = blockIdx.x * 64;
+    const int rows = min(64, num_a - a0);
+    if (lane < rows) store_frame(s.frames + lane * FRAME_F, make_bev_frame(boxes_a + (size_t)(a0 + lane) * 5));
+    __syncthreads();
+    const int bi = b0 + lane;
+    if (bi >= num_b) return;
+    const BevFrame B = make_bev_frame(boxes_b + (size_t)bi * 5);
+    for (int r = 0; r < rows; ++r) {
+        const BevFrame A = load_frame(s.frames + r * FRAME_F);
+        const float ov = box_overlap(A, B, s.vx + lane, s.vy + lane, s.va + lane);
+        ans[(size_t)(a0 + r) * num_b + bi] = MODE == 0 ? ov : iou_from_overlap(A, B, ov);
+    }
+}
+
+// K12 / K13: lane = row box i (its own 64-bit word), column boxes from LDS.
+template <bool NORMAL>
+__global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thresh, int full_grid,
+                                                      const float *__restrict__ boxes,
+                                                      uint64_t *__restrict__ mask) {
+    __shared__ WaveScratch s;
+    __shared__ float raw[64 * 5];
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int col_blocks = (boxes_num + 63) / 64;
+    const int row_size = min(boxes_num - row_start * 64, 64);
+    const int col_size = min(boxes_num - col_start * 64, 64);
+    const int cur = row_start * 64 + lane;
+    if (col_start < row_start && !full_grid) {  // never read by the sweep (iou3d.cpp:108)
+        if (lane < row_size) mask[(size_t)cur * col_blocks + col_start] = 0;
+        return;
+    }
+    if (lane < col_size) {
+        const float *src = boxes + (size_t)(col_start * 64 + lane) * 5;
+        if (NORMAL) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) raw[lane * 5 + q] = src[q];
+        } else {
+            store_frame(s.frames + lane * FRAME_F, make_bev_frame(src));
+        }
+    }
+    __syncthreads();
+    if (lane >= row_size) return;
+    const float *cur_box = boxes + (size_t)cur * 5;
+    uint64_t t = 0;
+    const int start = (row_start == col_start) ? lane + 1 : 0;
+    if (NORMAL) {
+        const float a[4] = {cur_box[0], cur_box[1], cur_box[2], cur_box[3]};
+        for (int i = start; i < col_size; ++i)
+            if (iou_normal(a, raw + i * 5) > thresh) t |= 1ULL << i;
+    } else {
+        const BevFrame A = make_bev_frame(cur_box);
+        for (int i = start; i < col_size; ++i) {
+            const BevFrame B = load_frame(s.frames + i * FRAME_F);
+            const float ov = box_overlap(A, B, s.vx + lane, s.vy + lane, s.va + lane);
+            if (iou_from_overlap(A, B, ov) > thresh) t |= 1ULL << i;
+        }
+    }
+    mask[(size_t)cur * col_blocks + col_start] = t;
+}
+
+// iou3d.cpp:100-116 greedy sweep, on the device.  One 256-lane workgroup: wave 0
+// resolves each 64-row chunk serially against the diagonal words (scalar bit ops +
+// readlane), then all lanes OR the kept rows' words into the removed-set in parallel.
+__global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, const uint64_t *__restrict__ mask,
+                                                        int64_t *__restrict__ keep,
+                                                        int32_t *__restrict__ num_keep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint64_t *remv = reinterpret_cast<uint64_t *>(smem);  // col_blocks
+    __shared__ uint64_t kept_s;
+    __shared__ int total_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int col_blocks = (boxes_num + 63) / 64;
+    for (int j = tid; j < col_blocks; j += 256) remv[j] = 0;
+    if (tid == 0) total_s = 0;
+    __syncthreads();
+    for (int c = 0; c < col_blocks; ++c) {
+        const int rows = min(64, boxes_num - c * 64);
+        if (tid < 64) {
+            uint64_t d = 0;
+            if (lane < rows) d = mask[(size_t)(c * 64 + lane) * col_blocks + c];
+            const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
+            uint64_t rem = remv[c];
+            uint64_t kept = 0;
+            for (int i = 0; i < rows; ++i) {
+                if (!((rem >> i) & 1ULL)) {
+                    kept |= 1ULL << i;
+                    const uint32_t lo = __builtin_amdgcn_readlane(dlo, i);
+                    const uint32_t hi = __builtin_amdgcn_readlane(dhi, i);
+                    rem |= ((uint64_t)hi << 32) | lo;
+                }
+            }
+            const int base = total_s;
+            if ((kept >> lane) & 1ULL) keep[base + mbcnt(kept)] = (int64_t)(c * 64 + lane);
+            if (lane == 0) {
+                kept_s = kept;
+                total_s = base + (int)__builtin_popcountll(kept);
+            }
+        }
+        __syncthreads();
+        const uint64_t kept = kept_s;
+        if (kept) {
+            for (int j = c + 1 + tid; j < col_blocks; j += 256) {
+                uint64_t acc = 0;
+                uint64_t kk = kept;
+                while (kk) {
+                    const int i = (int)__builtin_ctzll(kk);
+                    kk &= kk - 1;
+                    acc |= mask[(size_t)(c * 64 + i) * col_blocks + j];
+                }
+                remv[j] |= acc;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *num_keep = total_s;
+}
+
+template <int MODE>
+static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
+                       hipStream_t st, const char *what) {
+    if (num_a < 0 || num_b < 0 || !boxes_a || !boxes_b || !ans) {
+        set_error("%s: invalid argument (num_a=%d num_b=%d)", what, num_a, num_b);
+        return WS3D_E_INVALID;
+    }
+    if (num_a == 0 || num_b == 0) return WS3D_OK;
+    dim3 grid((num_b + 63) / 64, (num_a + 63) / 64);
+    if (grid.y > 65535) { set_error("%s: num_a too large", what); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL((pair_kernel<MODE>), grid, dim3(64), 0, st, num_a, boxes_a, num_b, boxes_b, ans);
+    return check_launch(what);
+}
+
+static int mask_launch(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
+                       uint64_t *mask, hipStream_t st, const char *what) {
+    if (boxes_num < 0 || !boxes || !mask) {
+        set_error("%s: invalid argument (boxes_num=%d)", what, boxes_num);
+        return WS3D_E_INVALID;
+    }
+    if (boxes_num == 0) return WS3D_OK;
+    const int cb = (boxes_num + 63) / 64;
+    if (cb > 65535) { set_error("%s: boxes_num too large", what); return WS3D_E_UNSUPPORTED; }
+    dim3 grid(cb, cb);
+    if (normal)
+        hipLaunchKernelGGL((nms_mask_kernel<true>), grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
+    else
+        hipLaunchKernelGGL((nms_mask_kernel<false>), grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
+    return check_launch(what);
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_boxes_overlap_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                                      float *ans, ws3d_stream_t stream) {
+    return ws3d::pair_launch<0>(num_a, boxes_a, num_b, boxes_b, ans, ws3d::as_stream(stream),
+                                "ws3d_boxes_overlap_bev");
+}
+
+extern "C" int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, const float *boxes_b,
+                                  float *ans, ws3d_stream_t stream) {
+    return ws3d::pair_launch<1>(num_a, boxes_a, num_b, boxes_b, ans, ws3d::as_stream(stream),
+                                "ws3d_boxes_iou_bev");
+}
+
+extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
+                             uint64_t *mask, ws3d_stream_t stream) {
+    return ws3d::mask_launch(boxes_num, boxes, thresh, normal, full_grid, mask, ws3d::as_stream(stream),
+                             "ws3d_nms_mask");
+}
+
+extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
+    if (boxes_num <= 0) return 256;
+    const size_t cb = ((size_t)boxes_num + 63) / 64;
+    return ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
+}
+
+extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, void *workspace,
+                        size_t workspace_bytes, int64_t *keep, int32_t *num_keep, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (boxes_num < 0 || (!boxes && boxes_num > 0) || (!keep && boxes_num > 0) || !num_keep) {
+        set_error("ws3d_nms: invalid argument (boxes_num=%d)", boxes_num);
+        return WS3D_E_INVALID;
+    }
+    hipStream_t st = as_stream(stream);
+    if (boxes_num == 0) {
+        hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+        return WS3D_OK;
+    }
+    if (!workspace || workspace_bytes < ws3d_nms_workspace_bytes(boxes_num)) {
+        set_error("ws3d_nms: workspace too small (%zu < %zu)", workspace_bytes, ws3d_nms_workspace_bytes(boxes_num));
+        return WS3D_E_WORKSPACE;
+    }
+    uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
+    int rc = mask_launch(boxes_num, boxes, thresh, normal, 0, mask, st, "ws3d_nms(mask)");
+    if (rc != WS3D_OK) return rc;
+    const size_t smem = sizeof(uint64_t) * (size_t)((boxes_num + 63) / 64);
+    if (smem > 150 * 1024) { set_error("ws3d_nms: boxes_num too large for the LDS removed-set"); return WS3D_E_UNSUPPORTED; }
+    if (smem > 64 * 1024)
+        hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), smem, st, boxes_num, mask, keep, num_keep);
+    return check_launch("ws3d_nms(sweep)");
+}

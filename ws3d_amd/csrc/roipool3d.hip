@@ -1,0 +1,175 @@
+// roipool3d.hip -- RoI point pooling for gfx950.  Replaces roipool3d_cuda.forward /
+// forward_slow (roipool3d.cpp:15-79 -> roipool3d_kernel.cu:31-237) and gives a device
+// twin of pts_in_boxes3d_cpu (roipool3d.cpp:97-124).
+//
+// Design.  The reference runs three kernels through a
+// B*N*M int32 scratch (cudaMalloc/cudaFree per call, 134 MB/scene at config 5) and
+// scans with ONE THREAD per box.  Here one 256-lane workgroup owns one (scene, box):
+//   1. the box frame (cy, cos, sin, half extents) is computed once;
+//   2. each of the 4 waves scans a contiguous quarter of the scene, 64 points per
+//      step: in-box test -> __ballot -> mbcnt prefix -> ordered append to the wave's
+//      LDS list (ascending point index; no atomics, no barrier inside the scan);
+//   3. the 4 lists are concatenated (their ranges are ordered), truncated to S and
+//      wrap-padded (idx[k] = idx[k % cnt]) in LDS;
+//   4. the S x (3+C) output block of the box is contiguous: the workgroup streams it
+//      out with fully coalesced stores, gathering 512-byte feature rows.
+// No scratch, no allocation, no host sync; the output write (B*M*S*(3+C)*4 bytes) is
+// the only large HBM stream, which makes this an HBM-roofline kernel.
+#include "common.h"
+
+namespace ws3d {
+
+struct BoxFrame {
+    float cx, cy, cz, hh, hw, hl, cosa, sina;
+};
+
+// roipool3d_kernel.cu:14-28 pt_in_box3d, box-constant part.  h/2.0, l/2.0, w/2.0 are
+// exact in both double and float (division by two), so the reference's mixed
+// float/double comparisons reduce to float comparisons against these halves.
+__device__ __forceinline__ BoxFrame make_frame(const float *bx) {
+    BoxFrame f;
+    f.cx = bx[0];
+    f.cz = bx[2];
+    const float h = bx[3], w = bx[4], l = bx[5], angle = bx[6];
+    f.cy = (float)((double)bx[1] - (double)h / 2.0);
+    f.hh = h * 0.5f;
+    f.hw = w * 0.5f;
+    f.hl = l * 0.5f;
+    f.cosa = cosf_cr(angle);
+    f.sina = sinf_cr(angle);
+    return f;
+}
+
+__device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y, float z) {
+    const float max_dis = 10.0f;
+    if ((fabsf(x - f.cx) > max_dis) || (fabsf(y - f.cy) > f.hh) || (fabsf(z - f.cz) > max_dis)) return false;
+    const float x_rot = (x - f.cx) * f.cosa + (z - f.cz) * (-f.sina);
+    const float z_rot = (x - f.cx) * f.sina + (z - f.cz) * f.cosa;
+    return (x_rot >= -f.hl) & (x_rot <= f.hl) & (z_rot >= -f.hw) & (z_rot <= f.hw);
+}
+
+__global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_num, int feat_len,
+                                                        int S, const float *__restrict__ xyz,
+                                                        const float *__restrict__ boxes3d,
+                                                        const float *__restrict__ pts_feature,
+                                                        float *__restrict__ pooled,
+                                                        int32_t *__restrict__ empty_flag,
+                                                        int32_t *__restrict__ pts_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *lists = reinterpret_cast<int *>(smem);  // 4 * S
+    int *sel = lists + 4 * S;                    // S
+    __shared__ int wcnt_s[4];
+
+    const int box = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t bm = (size_t)b * boxes_num + box;
+    xyz += (size_t)b * pts_num * 3;
+    pts_feature += (size_t)b * pts_num * feat_len;
+    const BoxFrame f = make_frame(boxes3d + bm * 7);
+
+    const int Q = (((pts_num + 3) / 4 + 63) / 64) * 64;
+    const int start = min(w * Q, pts_num), end = min(start + Q, pts_num);
+    int *list = lists + w * S;
+    int wcnt = 0;
+    for (int k0 = start; k0 < end && wcnt < S; k0 += 64) {
+        const int k = k0 + lane;
+        bool flag = false;
+        if (k < end) {
+            const float *p = xyz + (size_t)k * 3;
+            flag = pt_in_frame(f, p[0], p[1], p[2]);
+        }
+        const uint64_t mask = __ballot(flag);
+        if (mask) {
+            const int pos = wcnt + mbcnt(mask);
+            if (flag && pos < S) list[pos] = k;
+            wcnt += (int)__builtin_popcountll(mask);
+        }
+    }
+    if (lane == 0) wcnt_s[w] = min(wcnt, S);
+    __syncthreads();
+    const int c0 = wcnt_s[0], c1 = wcnt_s[1], c2 = wcnt_s[2], c3 = wcnt_s[3];
+    const int cnt = min(c0 + c1 + c2 + c3, S);
+    if (cnt == 0) {  // roipool3d_kernel.cu:147-149,181-183: flag the box, leave its rows untouched
+        if (tid == 0) empty_flag[bm] = 1;
+        if (pts_idx)
+            for (int s = tid; s < S; s += 256) pts_idx[bm * S + s] = 0;
+        return;
+    }
+    for (int s = tid; s < S; s += 256) {
+        int t = s < cnt ? s : s % cnt;  // duplicate_idx = k % cnt (roipool3d_kernel.cu:153-157)
+        int v;
+        if (t < c0) v = lists[t];
+        else if ((t -= c0) < c1) v = lists[S + t];
+        else if ((t -= c1) < c2) v = lists[2 * S + t];
+        else v = lists[3 * S + (t - c2)];
+        sel[s] = v;
+        if (pts_idx) pts_idx[bm * S + s] = v;
+    }
+    __syncthreads();
+
+    const int row = 3 + feat_len;
+    float *out = pooled + bm * (size_t)S * row;
+    const int total = S * row;
+    int s = tid / row, j = tid - s * row;
+    const int ds = 256 / row, dj = 256 - ds * row;
+    for (int e = tid; e < total; e += 256) {
+        const int src = sel[s];
+        out[e] = j < 3 ? xyz[(size_t)src * 3 + j] : pts_feature[(size_t)src * feat_len + (j - 3)];
+        s += ds;
+        j += dj;
+        if (j >= row) { j -= row; ++s; }
+    }
+}
+
+__global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int pts_num,
+                                                             const float *__restrict__ pts,
+                                                             const float *__restrict__ boxes3d,
+                                                             int64_t *__restrict__ flag) {
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const BoxFrame f = make_frame(boxes3d + (size_t)i * 7);
+    if (j >= pts_num) return;
+    const float *p = pts + (size_t)j * 3;
+    flag[(size_t)i * pts_num + j] = pt_in_frame(f, p[0], p[1], p[2]) ? 1 : 0;
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                              int sampled_pts_num, const float *xyz, const float *boxes3d,
+                              const float *pts_feature, float *pooled_features,
+                              int32_t *pooled_empty_flag, int32_t *pts_idx, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (batch_size < 0 || pts_num < 0 || boxes_num < 0 || feature_in_len < 0 || sampled_pts_num <= 0 ||
+        !xyz || !boxes3d || (!pts_feature && feature_in_len > 0) || !pooled_features || !pooled_empty_flag) {
+        set_error("ws3d_roipool3d: invalid argument (B=%d N=%d M=%d C=%d S=%d)", batch_size, pts_num,
+                  boxes_num, feature_in_len, sampled_pts_num);
+        return WS3D_E_INVALID;
+    }
+    if (batch_size == 0 || boxes_num == 0) return WS3D_OK;
+    const size_t smem = sizeof(int) * 5 * (size_t)sampled_pts_num;
+    if (smem > 150 * 1024 || boxes_num > 0x7fffffff / 1 || batch_size > 65535) {
+        set_error("ws3d_roipool3d: sampled_pts_num=%d / batch=%d unsupported", sampled_pts_num, batch_size);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (smem > 64 * 1024)
+        hipFuncSetAttribute((const void *)roipool3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(roipool3d_kernel, dim3(boxes_num, batch_size), dim3(256), smem, as_stream(stream),
+                       pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
+                       pooled_features, pooled_empty_flag, pts_idx);
+    return check_launch("ws3d_roipool3d");
+}
+
+extern "C" int ws3d_pts_in_boxes3d(int boxes_num, int pts_num, const float *pts, const float *boxes3d,
+                                   int64_t *flag, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (boxes_num < 0 || pts_num < 0 || !pts || !boxes3d || !flag) {
+        set_error("ws3d_pts_in_boxes3d: invalid argument (M=%d N=%d)", boxes_num, pts_num);
+        return WS3D_E_INVALID;
+    }
+    if (boxes_num == 0 || pts_num == 0) return WS3D_OK;
+    if (boxes_num > 65535) { set_error("ws3d_pts_in_boxes3d: boxes_num > 65535"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(pts_in_boxes3d_kernel, dim3((pts_num + 255) / 256, boxes_num), dim3(256), 0,
+                       as_stream(stream), boxes_num, pts_num, pts, boxes3d, flag);
+    return check_launch("ws3d_pts_in_boxes3d");
+}

@@ -1,0 +1,115 @@
+"""Pure-torch layer builders with the reference's names, constructor keywords and
+``state_dict`` layout (pointnet2_lib/pointnet2/pytorch_utils.py:7-236): ``SharedMLP``,
+``Conv1d``, ``Conv2d``, ``FC``, ``BatchNorm1d/2d``.  These run on rocBLAS/MIOpen through
+PyTorch -- they are not part of the hand-written hot path, but checkpoints trained with
+the reference must load key-for-key (``layer{i}.conv.weight``, ``layer{i}.bn.bn.*``)."""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch.nn as nn
+
+
+class _BN(nn.Sequential):
+    """wrapper that yields the reference's double ``bn.bn`` key (pytorch_utils.py:104-111)"""
+
+    def __init__(self, norm_cls, channels: int, name: str = ""):
+        super().__init__()
+        self.add_module(name + "bn", norm_cls(channels))
+        nn.init.constant_(self[0].weight, 1.0)
+        nn.init.constant_(self[0].bias, 0)
+
+
+class BatchNorm1d(_BN):
+    def __init__(self, in_size: int, *, name: str = ""):
+        super().__init__(nn.BatchNorm1d, in_size, name)
+
+
+class BatchNorm2d(_BN):
+    def __init__(self, in_size: int, name: str = ""):
+        super().__init__(nn.BatchNorm2d, in_size, name)
+
+
+class _ConvBlock(nn.Sequential):
+    """conv -> [bn] -> [activation] (or the pre-activation order), pytorch_utils.py:35-101"""
+
+    def __init__(self, conv_cls, bn_cls, in_cls, in_size, out_size, kernel_size, stride, padding,
+                 activation, bn, init, bias, preact, name, instance_norm):
+        super().__init__()
+        conv = conv_cls(in_size, out_size, kernel_size=kernel_size, stride=stride, padding=padding,
+                        bias=bias and (not bn))
+        init(conv.weight)
+        if conv.bias is not None:
+            nn.init.constant_(conv.bias, 0)
+        norm_width = in_size if preact else out_size
+
+        def add_norm_act():
+            if bn:
+                self.add_module(name + "bn", bn_cls(norm_width))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+            if not bn and instance_norm:
+                self.add_module(name + "in", in_cls(norm_width, affine=False, track_running_stats=False))
+
+        if preact:
+            add_norm_act()
+        self.add_module(name + "conv", conv)
+        if not preact:
+            add_norm_act()
+
+
+class Conv1d(_ConvBlock):
+    def __init__(self, in_size: int, out_size: int, *, kernel_size: int = 1, stride: int = 1,
+                 padding: int = 0, activation=nn.ReLU(inplace=True), bn: bool = False,
+                 init=nn.init.kaiming_normal_, bias: bool = True, preact: bool = False,
+                 name: str = "", instance_norm=False):
+        super().__init__(nn.Conv1d, BatchNorm1d, nn.InstanceNorm1d, in_size, out_size, kernel_size,
+                         stride, padding, activation, bn, init, bias, preact, name, instance_norm)
+
+
+class Conv2d(_ConvBlock):
+    def __init__(self, in_size: int, out_size: int, *, kernel_size: Tuple[int, int] = (1, 1),
+                 stride: Tuple[int, int] = (1, 1), padding: Tuple[int, int] = (0, 0),
+                 activation=nn.ReLU(inplace=True), bn: bool = False, init=nn.init.kaiming_normal_,
+                 bias: bool = True, preact: bool = False, name: str = "", instance_norm=False):
+        super().__init__(nn.Conv2d, BatchNorm2d, nn.InstanceNorm2d, in_size, out_size, kernel_size,
+                         stride, padding, activation, bn, init, bias, preact, name, instance_norm)
+
+
+class SharedMLP(nn.Sequential):
+    """stack of 1x1 Conv2d blocks named layer0, layer1, ... (pytorch_utils.py:5-32)"""
+
+    def __init__(self, args: List[int], *, bn: bool = False, activation=nn.ReLU(inplace=True),
+                 preact: bool = False, first: bool = False, name: str = "", instance_norm: bool = False):
+        super().__init__()
+        for i in range(len(args) - 1):
+            plain = first and preact and i == 0  # the very first pre-act layer has no bn/act
+            self.add_module(name + "layer{}".format(i),
+                            Conv2d(args[i], args[i + 1], bn=bn and not plain,
+                                   activation=None if plain else activation, preact=preact,
+                                   instance_norm=instance_norm))
+
+
+class FC(nn.Sequential):
+    """pytorch_utils.py:204-236"""
+
+    def __init__(self, in_size: int, out_size: int, *, activation=nn.ReLU(inplace=True), bn: bool = False,
+                 init=None, preact: bool = False, name: str = ""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=not bn)
+        if init is not None:
+            init(fc.weight)
+        if not bn:
+            nn.init.constant_(fc.bias, 0)
+
+        def add_norm_act(width):
+            if bn:
+                self.add_module(name + "bn", BatchNorm1d(width))
+            if activation is not None:
+                self.add_module(name + "activation", activation)
+
+        if preact:
+            add_norm_act(in_size)
+        self.add_module(name + "fc", fc)
+        if not preact:
+            add_norm_act(out_size)

@@ -1,0 +1,255 @@
+"""Operator wrappers with the reference's names and signatures
+(pointnet2_lib/pointnet2/pointnet2_utils.py), backed by the MI355X HIP kernels.
+
+Same ``torch.autograd.Function`` surface: ``furthest_point_sample, gather_operation,
+ball_query, grouping_operation, three_nn, three_interpolate, QueryAndGroup, GroupAll``
+(reference lines 36, 73, 228, 197, 105, 153, 231, 267).  Outputs are allocated here
+(like the reference does with ``torch.cuda.*Tensor``) and filled by the library.
+
+Two fused entry points that the reference composes in Python are added:
+``furthest_point_sample_gather`` (FPS + gather, pointnet2_modules.py:30-35) and
+``query_and_group`` (ball_query + 2x grouping + centre subtraction + cat,
+pointnet2_utils.py:241-264).  ``QueryAndGroup`` uses the fused kernel.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import compat as _C
+
+
+def _new(shape, dtype, like):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+class FurthestPointSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        """xyz (B,N,3), N > npoint -> (B,npoint) int32 indices (pointnet2_utils.py:12-31)."""
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        output = _new((B, npoint), torch.int32, xyz)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        _C.furthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample = FurthestPointSampling.apply
+
+
+def furthest_point_sample_gather(xyz: torch.Tensor, npoint: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused FPS + gather: (idx (B,npoint) int32, new_xyz (B,npoint,3)).  new_xyz equals
+    gather_operation(xyz^T, idx)^T bit for bit (pure copies).  No temp buffer is needed for
+    N <= 16384 (the running min-distance lives in registers)."""
+    assert xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    idx = _new((B, npoint), torch.int32, xyz)
+    new_xyz = _new((B, npoint, 3), torch.float32, xyz)
+    temp = None
+    if N > 16384:
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+    with torch.no_grad():
+        _C.furthest_point_sampling_gather(B, N, npoint, xyz, temp, idx, new_xyz)
+    return idx, new_xyz
+
+
+class GatherOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (pointnet2_utils.py:41-60)."""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        output = _new((B, C, npoint), torch.float32, features)
+        _C.gather_points_wrapper(B, C, N, npoint, features, idx, output)
+        ctx.for_backwards = (idx, C, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        _C.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """unknown (B,N,3), known (B,M,3) -> dist (B,N,3) L2 distance, idx (B,N,3)
+        (pointnet2_utils.py:79-99; the kernel returns squared distances, sqrt is taken here)."""
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = _new((B, N, 3), torch.float32, unknown)
+        idx = _new((B, N, 3), torch.int32, unknown)
+        _C.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """features (B,C,M), idx/weight (B,n,3) -> (B,C,n) (pointnet2_utils.py:110-131)."""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        assert weight.is_contiguous()
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        output = _new((B, c, n), torch.float32, features)
+        _C.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
+        _C.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)
+        (pointnet2_utils.py:158-177)."""
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, nfeatures, nsample = idx.size()
+        _, C, N = features.size()
+        output = _new((B, C, nfeatures, nsample), torch.float32, features)
+        _C.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
+        ctx.for_backwards = (idx, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        _C.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        """xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32
+        (pointnet2_utils.py:202-222)."""
+        assert new_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+        _C.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class _QueryAndGroupFused(Function):
+    """Fused QueryAndGroup.forward; backward scatters the feature-channel gradient with
+    the saved neighbour lists (what GroupingOperation.backward does in the reference)."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, use_xyz, xyz, new_xyz, features):
+        B, N, _ = xyz.size()
+        M = new_xyz.size(1)
+        C = 0 if features is None else features.size(1)
+        cx = 3 if use_xyz else 0
+        idx = _new((B, M, nsample), torch.int32, xyz)
+        out = _new((B, cx + C, M, nsample), torch.float32, xyz)
+        _C.query_and_group(B, N, M, C, radius, nsample, use_xyz, xyz, new_xyz, features, idx, out)
+        ctx.saved = (idx, N, cx, C)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_idx=None):
+        idx, N, cx, C = ctx.saved
+        grad_features = None
+        if C > 0 and ctx.needs_input_grad[5]:
+            B, _, M, ns = grad_out.size()
+            g = grad_out[:, cx:].contiguous()
+            grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+            _C.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
+        return None, None, None, None, None, grad_features
+
+
+def query_and_group(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,
+                    features: torch.Tensor = None, use_xyz: bool = True, return_idx: bool = False):
+    """One kernel for ball_query + grouping(xyz) - centre + grouping(features) + cat:
+    (B, 3+C, npoint, nsample) with channel order [dx,dy,dz, features...]."""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    assert features is None or features.is_contiguous()
+    assert use_xyz or features is not None, "Cannot have not features and not use xyz as a feature!"
+    out, idx = _QueryAndGroupFused.apply(radius, nsample, use_xyz, xyz, new_xyz, features)
+    return (out, idx) if return_idx else out
+
+
+class QueryAndGroup(nn.Module):
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        """pointnet2_utils.py:231-239"""
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B,3+C,npoint,nsample)
+        (pointnet2_utils.py:241-264)."""
+        return query_and_group(self.radius, self.nsample, xyz, new_xyz, features, self.use_xyz)
+
+
+class GroupAll(nn.Module):
+    def __init__(self, use_xyz: bool = True):
+        """pointnet2_utils.py:267-270"""
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        """-> (B, C+3, 1, N) (pointnet2_utils.py:272-290): pure views/cat, no kernel."""
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            grouped_features = features.unsqueeze(2)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            new_features = grouped_xyz
+        return new_features
