@@ -59,6 +59,10 @@ def load() -> C.CDLL:
         raise Ws3dError(
             f"{LIB_PATH} is missing: the MI355X HIP library has not been built "
             "(run `python -m ws3d_amd.build`).  ws3d_amd has no CPU fallback.")
+    # torch bundles its own libamdhip64.so.7; it must be in the process BEFORE this library
+    # is dlopen'ed so that both share ONE HIP runtime (same SONAME => the loader reuses it).
+    # Loading ours first would bind torch to /opt/rocm's runtime and break device discovery.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # e.g. libamdhip64.so not found

@@ -41,7 +41,7 @@ def boxes_iou3d_gpu(boxes_a, boxes_b):
 def _nms(boxes, scores, thresh, normal):
     # stable=True: equal scores keep their input order on every device (the reference's
     # unstable sort, iou3d_utils.py:67, is only reproducible for distinct scores)
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
     keep, num = _C.nms_device(boxes[order].contiguous(), thresh, normal)
     return order[keep[:int(num.item())]].contiguous()
 
@@ -59,7 +59,7 @@ def nms_normal_gpu(boxes, scores, thresh):
 def nms_gpu_padded(boxes, scores, thresh, max_out, normal=False):
     """Device-only variant for the data-parallel pipeline: fixed-shape (max_out,) index tensor
     (padded with -1) + count tensor; no host synchronisation."""
-    order = scores.sort(0, descending=True, stable=True)[1]
+    order = scores.sort(dim=0, descending=True, stable=True)[1]
     keep, num = _C.nms_device(boxes[order].contiguous(), thresh, normal)
     n = boxes.shape[0]
     out = torch.full((max_out,), -1, dtype=torch.int64, device=boxes.device)
