@@ -1,0 +1,209 @@
+"""Golden fixtures produced by the REFERENCE's Python harness (tests/golden/make_golden.py,
+run in the build container where /root/reference is mounted).  CPU tests pin the oracle and
+the host logic against them; GPU tests pin the HIP path and the Stage-1 restatement."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from ws3d_amd import synth  # noqa: E402
+from ws3d_amd.seeded import seeded_state_dict  # noqa: E402
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(G, "compositions.npz"))
+
+
+@pytest.fixture(scope="module")
+def meta():
+    return json.load(open(os.path.join(G, "golden_meta.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _qg_inputs():
+    pc = synth.make_batch("lidar", 2, 1024, 31)
+    return pc[:, :, :3].copy(), np.ascontiguousarray(pc[:, :, 3:].transpose(0, 2, 1))
+
+
+# ------------------------------------------------------------------------------- CPU (oracle / host logic)
+def test_oracle_reproduces_reference_compositions(oracle, fx):
+    xyz, feats = _qg_inputs()
+    idx = oracle.furthest_point_sample(xyz, 128)
+    np.testing.assert_array_equal(idx, fx["qg_fps_idx"])
+    new_xyz = np.stack([xyz[b][idx[b]] for b in range(2)])
+    nbr = oracle.ball_query(1.0, 16, xyz, new_xyz)
+    gx = oracle.grouping_operation(np.ascontiguousarray(xyz.transpose(0, 2, 1)), nbr) - new_xyz.transpose(0, 2, 1)[..., None]
+    gf = oracle.grouping_operation(feats, nbr)
+    np.testing.assert_array_equal(np.concatenate([gx, gf], 1), fx["qg_out"])
+    # iou3d: BEV conversion + overlap + NMS index-back
+    bev = synth.boxes3d_to_bev(fx["iou3d_a"])
+    np.testing.assert_array_equal(bev, fx["bev_a"])
+    np.testing.assert_array_equal(oracle.nms(bev, fx["nms_scores"], 0.3, False), fx["nms_keep_rot"])
+    np.testing.assert_array_equal(oracle.nms(bev, fx["nms_scores"], 0.3, True), fx["nms_keep_normal"])
+    np.testing.assert_array_equal(oracle.boxes_iou_bev(bev, synth.boxes3d_to_bev(fx["iou3d_b"])), fx["iou_bev"])
+    # roipool3d_gpu = enlarge (h,w,l += 2e; y += e) then pool
+    pc = synth.make_batch("lidar", 1, 2048, 43)
+    enl = fx["roi_boxes"].copy()
+    enl[..., 3:6] += 2.0
+    enl[..., 1] += 1.0
+    pooled, empty = oracle.roipool3d(pc[:, :, :3], enl, fx["roi_feat"], 64)
+    np.testing.assert_array_equal(empty, fx["roi_empty"])
+    np.testing.assert_array_equal(pooled, fx["roi_pooled"])
+    assert (fx["roi_empty"] == 0).any()
+
+
+def test_stage1_state_dict_layout_matches_reference():
+    from ws3d_amd.stage1 import Stage1Net
+    ref = json.load(open(os.path.join(G, "stage1_state_dict.json")))
+    model = Stage1Net(num_classes=2, use_xyz=True, mode='TEST')
+    mine = {k: list(v.shape) for k, v in model.state_dict().items()}
+    assert list(mine) == list(ref["keys"]), "state_dict key ORDER/NAMES differ from lib.net.point_rcnn.PointRCNN"
+    assert mine == ref["keys"]
+    assert sum(p.numel() for p in model.parameters()) == ref["n_params"] == 3046201
+    assert len(mine) == 208
+    # a reference-layout checkpoint loads strictly
+    model.load_state_dict(seeded_state_dict({k: tuple(v) for k, v in ref["keys"].items()}, 7), strict=True)
+
+
+def test_module_state_dict_layouts(meta):
+    from ws3d_amd import pn2_modules
+    c = meta["cases"]["sa_module"]
+    sa = pn2_modules.PointnetSAModuleMSG(npoint=c["npoint"], radii=c["radii"], nsamples=c["nsamples"],
+                                         mlps=[list(m) for m in c["mlps"]], use_xyz=True, bn=True)
+    assert {k: list(v.shape) for k, v in sa.state_dict().items()} == c["keys"]
+    fp = pn2_modules.PointnetFPModule(mlp=list(meta["cases"]["fp_module"]["mlp"]))
+    assert {k: list(v.shape) for k, v in fp.state_dict().items()} == meta["cases"]["fp_module"]["keys"]
+
+
+def test_decode_center_target_host_logic():
+    """bin argmax + gathered residual, y = 0, added to the point's (x,z) (bbox_transform.py:24-61)"""
+    from ws3d_amd.stage1 import decode_center_target
+    reg = torch.zeros((2, 40))
+    reg[0, 3] = 5.0; reg[0, 10 + 7] = 5.0; reg[0, 20 + 3] = 0.5; reg[0, 30 + 7] = -1.0
+    reg[1, 0] = 1.0; reg[1, 10] = 1.0
+    ctr = torch.tensor([[1.0, 9.0, 2.0], [0.0, 0.0, 0.0]])
+    out = decode_center_target(ctr, reg, 4.0, 0.8)
+    exp0 = [1.0 + 3 * 0.8 + 0.4 - 4.0 + 0.5 * 0.4, 0.0, 2.0 + 7 * 0.8 + 0.4 - 4.0 - 1.0 * 0.4]
+    np.testing.assert_allclose(out[0].numpy(), exp0, atol=1e-6)
+    np.testing.assert_allclose(out[1].numpy(), [-3.6, 0.0, -3.6], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------- GPU (HIP path)
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.gpu
+def test_gpu_query_and_group_matches_reference_harness(fx):
+    from ws3d_amd import pn2_ops
+    xyz, feats = _qg_inputs()
+    idx, new_xyz = pn2_ops.furthest_point_sample_gather(dev(xyz), 128)
+    np.testing.assert_array_equal(idx.cpu().numpy(), fx["qg_fps_idx"])
+    out = pn2_ops.QueryAndGroup(1.0, 16, use_xyz=True)(dev(xyz), new_xyz, dev(feats))
+    np.testing.assert_array_equal(out.cpu().numpy(), fx["qg_out"])
+    # the un-fused reference composition through this package's wrappers gives the same tensor
+    nbr = pn2_ops.ball_query(1.0, 16, dev(xyz), new_xyz)
+    gx = pn2_ops.grouping_operation(dev(xyz).transpose(1, 2).contiguous(), nbr)
+    gx -= new_xyz.transpose(1, 2).unsqueeze(-1)
+    comp = torch.cat([gx, pn2_ops.grouping_operation(dev(feats), nbr)], dim=1)
+    np.testing.assert_array_equal(comp.cpu().numpy(), fx["qg_out"])
+
+
+@pytest.mark.gpu
+def test_gpu_sa_fp_modules_match_reference_harness(fx, meta):
+    from ws3d_amd import pn2_modules
+    xyz, feats = _qg_inputs()
+    c = meta["cases"]["sa_module"]
+    sa = pn2_modules.PointnetSAModuleMSG(npoint=c["npoint"], radii=c["radii"], nsamples=c["nsamples"],
+                                         mlps=[list(m) for m in c["mlps"]], use_xyz=True, bn=True).eval()
+    sa.load_state_dict(seeded_state_dict({k: tuple(v) for k, v in c["keys"].items()}, c["seed"]))
+    sa.cuda()
+    with torch.no_grad():
+        new_xyz, new_feat = sa(dev(xyz), dev(feats))
+    np.testing.assert_array_equal(new_xyz.cpu().numpy(), fx["sa_new_xyz"])
+    np.testing.assert_allclose(new_feat.cpu().numpy(), fx["sa_features"], atol=1e-4, rtol=1e-4)
+    f = meta["cases"]["fp_module"]
+    fp = pn2_modules.PointnetFPModule(mlp=list(f["mlp"])).eval()
+    fp.load_state_dict(seeded_state_dict({k: tuple(v) for k, v in f["keys"].items()}, f["seed"]))
+    fp.cuda()
+    with torch.no_grad():
+        out = fp(dev(xyz), dev(fx["sa_new_xyz"]), dev(feats), dev(fx["sa_features"]))
+    np.testing.assert_allclose(out.cpu().numpy(), fx["fp_out"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_gpu_iou3d_and_roipool_wrappers_match_reference_harness(fx):
+    from ws3d_amd import iou3d_ops, kitti_utils, roipool3d_ops
+    a, b = dev(fx["iou3d_a"]), dev(fx["iou3d_b"])
+    iou2d, iou3d = iou3d_ops.boxes_iou3d_gpu(a, b)
+    np.testing.assert_allclose(iou2d.cpu().numpy(), fx["iou2d"], atol=1e-5)
+    np.testing.assert_allclose(iou3d.cpu().numpy(), fx["iou3d"], atol=1e-5)
+    bev = kitti_utils.boxes3d_to_bev_torch(a)
+    np.testing.assert_array_equal(bev.cpu().numpy(), fx["bev_a"])
+    np.testing.assert_allclose(iou3d_ops.boxes_iou_bev(bev, kitti_utils.boxes3d_to_bev_torch(b)).cpu().numpy(),
+                               fx["iou_bev"], atol=1e-5)
+    s = dev(fx["nms_scores"])
+    np.testing.assert_array_equal(iou3d_ops.nms_gpu(bev, s, 0.3).cpu().numpy(), fx["nms_keep_rot"])
+    np.testing.assert_array_equal(iou3d_ops.nms_normal_gpu(bev, s, 0.3).cpu().numpy(), fx["nms_keep_normal"])
+    pc = synth.make_batch("lidar", 1, 2048, 43)
+    pooled, empty = roipool3d_ops.roipool3d_gpu(dev(pc[:, :, :3]), dev(fx["roi_feat"]), dev(fx["roi_boxes"]), 1.0,
+                                                sampled_pt_num=64)
+    np.testing.assert_array_equal(empty.cpu().numpy(), fx["roi_empty"])
+    np.testing.assert_array_equal(pooled.cpu().numpy(), fx["roi_pooled"])
+
+
+@pytest.mark.gpu
+def test_gpu_stage1_forward_matches_reference_harness(meta):
+    """Full 16384-point Stage-1 forward: FPS indices of all four SA
+    layers and all eight ball-query tensors exact; the four outputs within 1e-4 abs of the
+    reference harness (conv/BN reduction order differs between CPU and MIOpen/rocBLAS)."""
+    from ws3d_amd import pn2_ops
+    from ws3d_amd.stage1 import Stage1Net, decode_center_target
+    ref_keys = json.load(open(os.path.join(G, "stage1_state_dict.json")))["keys"]
+    gold = np.load(os.path.join(G, "stage1_forward.npz"))
+    case = meta["cases"]["stage1"]
+    model = Stage1Net(mode='TEST').eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v) for k, v in ref_keys.items()}, case["seed"]))
+    model.cuda()
+    pts = dev(synth.make_batch("lidar", 1, 16384, case["config_id"]))
+    fps_log, bq_log = [], []
+    orig_fps, orig_qg = pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group
+
+    def fps_tap(xyz, npoint):
+        r = orig_fps(xyz, npoint)
+        fps_log.append(r[0].cpu().numpy())
+        return r
+
+    def qg_tap(radius, nsample, xyz, new_xyz, features=None, use_xyz=True, return_idx=False):
+        out, idx = orig_qg(radius, nsample, xyz, new_xyz, features, use_xyz, return_idx=True)
+        bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
+        return (out, idx) if return_idx else out
+
+    pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
+    try:
+        with torch.no_grad():
+            out = model.rpn_forward({'pts_input': pts})
+    finally:
+        pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = orig_fps, orig_qg
+    assert len(fps_log) == 4 and len(bq_log) == 8
+    for i in range(4):
+        np.testing.assert_array_equal(fps_log[i], gold[f"fps_idx_{i}"])
+    assert bq_log == case["ball_query_sha256"]
+    for name in ("rpn_cls", "rpn_reg", "backbone_xyz", "backbone_features"):
+        arr = out[name].cpu().numpy()
+        assert list(arr.shape) == case["outputs"][name]["shape"]
+        got = arr.reshape(-1)[gold[f"{name}_pos"]]
+        np.testing.assert_allclose(got, gold[f"{name}_val"], atol=1e-4, rtol=1e-4, err_msg=name)
+    dec = decode_center_target(out["backbone_xyz"][0], out["rpn_reg"][0], 4.0, 0.8).cpu().numpy()
+    d = np.abs(dec.reshape(-1)[gold["decode_pos"]] - gold["decode_val"])
+    assert (d < 1e-3).mean() > 0.97  # a bin argmax may flip where two logits are within 1e-4

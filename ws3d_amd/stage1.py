@@ -1,0 +1,220 @@
+"""Stage-1 network of WS3D (the caller of the hot path) on the MI355X ops.
+
+Counterpart of lib/net/pointnet2_msg.py:11-70 (``Pointnet2MSG``), lib/net/rpn.py:10-81
+(``RPN``) and lib/net/point_rcnn.py:45-54 (``PointRCNN.rpn_forward``) for the
+``tools/cfgs/weaklyRPN.yaml`` configuration, with IDENTICAL ``state_dict`` keys and shapes
+(208 keys, 3,046,201 parameters: ``rpn.backbone_net.SA_modules.{k}.mlps.{s}.layer{i}.*``,
+``rpn.backbone_net.FP_modules.{k}.mlp.layer{i}.*``, ``rpn.rpn_cls_layer.{0,2}.*``,
+``rpn.rpn_reg_layer.{0,2}.*``) so that checkpoints trained with the reference load
+key-for-key.  The EasyDict/YAML config tree is replaced by a frozen dataclass holding the
+values of weaklyRPN.yaml:25-56.
+
+Also here: ``decode_center_target`` (lib/utils/bbox_transform.py:24-61) and the on-device
+proposal stage used by the data-parallel driver (score -> boxes -> rotated NMS -> roipool3d).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import iou3d_ops, nn_blocks as pt_utils, roipool3d_ops
+from . import kitti_utils
+from .pn2_modules import PointnetFPModule, PointnetSAModuleMSG
+
+
+@dataclass(frozen=True)
+class RPNConfig:
+    """tools/cfgs/weaklyRPN.yaml:25-56 (+ TEST block :103-107, CLS_MEAN_SIZE :19)"""
+    use_intensity: bool = True
+    use_bn: bool = True
+    num_points: int = 16384
+    npoints: tuple = (4096, 1024, 256, 64)
+    radius: tuple = ((0.1, 0.5), (0.5, 1.0), (1.0, 2.0), (2.0, 4.0))
+    nsample: tuple = ((16, 32), (16, 32), (16, 32), (16, 32))
+    mlps: tuple = (((16, 16, 32), (32, 32, 64)), ((64, 64, 128), (64, 96, 128)),
+                   ((128, 196, 256), (128, 196, 256)), ((256, 256, 512), (256, 384, 512)))
+    fp_mlps: tuple = ((128, 128), (256, 256), (512, 512), (512, 512))
+    cls_fc: tuple = (128,)
+    reg_fc: tuple = (128,)
+    dp_ratio: float = 0.5
+    loc_scope: float = 4.0
+    loc_bin_size: float = 0.8
+    focal_init_pi: float = 0.01
+    score_thresh: float = 0.3
+    rpn_pre_nms_top_n: int = 9000
+    rpn_post_nms_top_n: int = 100
+    rpn_nms_thresh: float = 0.8
+    cls_mean_size: tuple = (1.52563191462, 1.62856739989, 3.88311640418)  # h, w, l
+    roi_sampled_pts: int = 512
+    roi_extra_width: float = 1.0
+
+
+DEFAULT_CFG = RPNConfig()
+
+
+class Pointnet2MSG(nn.Module):
+    """4 SA-MSG + 4 FP layers (lib/net/pointnet2_msg.py:11-70)"""
+
+    def __init__(self, input_channels=6, use_xyz=True, cfg: RPNConfig = DEFAULT_CFG):
+        super().__init__()
+        self.SA_modules = nn.ModuleList()
+        channel_in = input_channels
+        skip_channel_list = [input_channels]
+        channel_out = channel_in
+        for k in range(len(cfg.npoints)):
+            mlps = [[channel_in] + list(m) for m in cfg.mlps[k]]
+            channel_out = sum(m[-1] for m in mlps)
+            self.SA_modules.append(PointnetSAModuleMSG(npoint=cfg.npoints[k], radii=list(cfg.radius[k]),
+                                                       nsamples=list(cfg.nsample[k]), mlps=mlps,
+                                                       use_xyz=use_xyz, bn=cfg.use_bn))
+            skip_channel_list.append(channel_out)
+            channel_in = channel_out
+        self.FP_modules = nn.ModuleList()
+        for k in range(len(cfg.fp_mlps)):
+            pre_channel = cfg.fp_mlps[k + 1][-1] if k + 1 < len(cfg.fp_mlps) else channel_out
+            self.FP_modules.append(PointnetFPModule(mlp=[pre_channel + skip_channel_list[k]] + list(cfg.fp_mlps[k])))
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud: torch.Tensor):
+        xyz, features = self._break_up_pc(pointcloud)
+        l_xyz, l_features = [xyz], [features]
+        for sa in self.SA_modules:
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+            l_xyz.append(li_xyz)
+            l_features.append(li_features)
+        for i in range(-1, -(len(self.FP_modules) + 1), -1):
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+        return l_xyz[0], l_features[0]
+
+
+class RPN(nn.Module):
+    """backbone + point-wise cls / bin-based reg heads (lib/net/rpn.py:10-81; losses omitted:
+    the training runtime is out of scope)"""
+
+    def __init__(self, use_xyz=True, mode='TRAIN', cfg: RPNConfig = DEFAULT_CFG):
+        super().__init__()
+        self.training_mode = (mode == 'TRAIN')
+        self.cfg = cfg
+        self.backbone_net = Pointnet2MSG(input_channels=int(cfg.use_intensity), use_xyz=use_xyz, cfg=cfg)
+
+        def head(fc_dims, out_channels):
+            layers, pre = [], cfg.fp_mlps[0][-1]
+            for width in fc_dims:
+                layers.append(pt_utils.Conv1d(pre, width, bn=cfg.use_bn))
+                pre = width
+            layers.append(pt_utils.Conv1d(pre, out_channels, activation=None))
+            if cfg.dp_ratio >= 0:
+                layers.insert(1, nn.Dropout(cfg.dp_ratio))
+            return nn.Sequential(*layers)
+
+        per_loc_bin_num = int(cfg.loc_scope / cfg.loc_bin_size) * 2
+        self.rpn_cls_layer = head(cfg.cls_fc, 1)
+        self.rpn_reg_layer = head(cfg.reg_fc, per_loc_bin_num * 4)
+        self.init_weights()
+
+    def init_weights(self):
+        pi = self.cfg.focal_init_pi
+        nn.init.constant_(self.rpn_cls_layer[2].conv.bias, -np.log((1 - pi) / pi))
+        nn.init.normal_(self.rpn_reg_layer[-1].conv.weight, mean=0, std=0.001)
+
+    def forward(self, input_data):
+        pts_input = input_data['pts_input']
+        backbone_xyz, backbone_features = self.backbone_net(pts_input)                # (B,N,3), (B,C,N)
+        rpn_cls = self.rpn_cls_layer(backbone_features).transpose(1, 2).contiguous()   # (B,N,1)
+        rpn_reg = self.rpn_reg_layer(backbone_features).transpose(1, 2).contiguous()   # (B,N,40)
+        return {'rpn_cls': rpn_cls, 'rpn_reg': rpn_reg,
+                'backbone_xyz': backbone_xyz, 'backbone_features': backbone_features}
+
+
+class Stage1Net(nn.Module):
+    """``PointRCNN`` restricted to its Stage-1 half (lib/net/point_rcnn.py:10-54): attribute
+    ``rpn`` keeps the checkpoint prefix."""
+
+    def __init__(self, num_classes=2, use_xyz=True, mode='TEST', cfg: RPNConfig = DEFAULT_CFG):
+        super().__init__()
+        self.mode = mode
+        self.cfg = cfg
+        self.rpn = RPN(use_xyz=use_xyz, mode=mode, cfg=cfg)
+
+    def rpn_forward(self, input_data):
+        with torch.set_grad_enabled(self.training):
+            return dict(self.rpn(input_data))
+
+    forward = rpn_forward
+
+
+def decode_center_target(roi_center, pred_reg, loc_scope, loc_bin_size):
+    """(N,3) points + (N,4*bins) bin/residual logits -> (N,3) predicted centres with y = 0
+    (lib/utils/bbox_transform.py:24-61)."""
+    nb = int(loc_scope / loc_bin_size) * 2
+    x_bin = torch.argmax(pred_reg[:, 0:nb], dim=1)
+    z_bin = torch.argmax(pred_reg[:, nb:2 * nb], dim=1)
+    pos_x = x_bin.float() * loc_bin_size + loc_bin_size / 2 - loc_scope
+    pos_z = z_bin.float() * loc_bin_size + loc_bin_size / 2 - loc_scope
+    x_res = torch.gather(pred_reg[:, 2 * nb:3 * nb], dim=1, index=x_bin.unsqueeze(1)).squeeze(1)
+    z_res = torch.gather(pred_reg[:, 3 * nb:4 * nb], dim=1, index=z_bin.unsqueeze(1)).squeeze(1)
+    pos_x = pos_x + x_res * (loc_bin_size / 2)
+    pos_z = pos_z + z_res * (loc_bin_size / 2)
+    ret = torch.stack((pos_x, torch.zeros_like(pos_x), pos_z), dim=1)
+    ret[:, [0, 2]] += roi_center[:, [0, 2]]
+    return ret
+
+
+def synthetic_orientation(n: int, device) -> torch.Tensor:
+    """WS3D's Stage-1 predicts centres only; the op-level NMS/roipool configs
+    need oriented boxes, so every point index gets a fixed pseudo-random heading in [-pi, pi)."""
+    k = torch.arange(n, device=device, dtype=torch.int64)
+    h = (k * 2654435761) % 4294967296
+    return (h.double() / 4294967296.0 * (2 * math.pi) - math.pi).float()
+
+
+@torch.no_grad()
+def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
+    """Per-scene on-device proposal stage (config 3 of BASELINE.json): score = sigmoid(rpn_cls),
+    centre = decode_center_target, box = centre + CLS_MEAN_SIZE + synthetic heading; top
+    RPN_PRE_NMS_TOP_N by score -> rotated NMS (thresh 0.8) -> top RPN_POST_NMS_TOP_N.
+    Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed shapes, zero padded, no host sync."""
+    xyz, reg, cls = out['backbone_xyz'], out['rpn_reg'], out['rpn_cls']
+    B, N, _ = xyz.shape
+    K = cfg.rpn_post_nms_top_n
+    h, w, l = cfg.cls_mean_size
+    ry = synthetic_orientation(N, xyz.device)
+    boxes_out = xyz.new_zeros((B, K, 7))
+    scores_out = xyz.new_zeros((B, K))
+    count = torch.zeros((B,), dtype=torch.int64, device=xyz.device)
+    for b in range(B):
+        score = torch.sigmoid(cls[b, :, 0])
+        centre = decode_center_target(xyz[b], reg[b], cfg.loc_scope, cfg.loc_bin_size)
+        box = torch.stack((centre[:, 0], xyz[b, :, 1] + h / 2, centre[:, 2],
+                           torch.full_like(score, h), torch.full_like(score, w), torch.full_like(score, l), ry), 1)
+        top = min(cfg.rpn_pre_nms_top_n, N)
+        sc, order = torch.topk(score, top, sorted=True)
+        box = box[order]
+        keep, cnt = iou3d_ops.nms_gpu_padded(kitti_utils.boxes3d_to_bev_torch(box), sc, cfg.rpn_nms_thresh, K)
+        safe = keep.clamp(min=0)
+        valid = (keep >= 0).unsqueeze(1)
+        boxes_out[b] = torch.where(valid, box[safe], boxes_out[b])
+        scores_out[b] = torch.where(valid[:, 0], sc[safe], scores_out[b])
+        count[b] = cnt[0]
+    return boxes_out, scores_out, count
+
+
+@torch.no_grad()
+def stage1_inference(model: Stage1Net, pts_input: torch.Tensor, cfg: RPNConfig = DEFAULT_CFG):
+    """Stage-1 forward + proposals + RoI pooling for a batch of scenes (B,N,4)."""
+    out = model.rpn_forward({'pts_input': pts_input})
+    boxes, scores, count = proposals_from_rpn(out, cfg)
+    feats = out['backbone_features'].transpose(1, 2).contiguous()  # (B,N,C)
+    pooled, empty = roipool3d_ops.roipool3d_gpu(out['backbone_xyz'], feats, boxes, cfg.roi_extra_width,
+                                                sampled_pt_num=cfg.roi_sampled_pts)
+    return {'boxes': boxes, 'scores': scores, 'count': count, 'pooled': pooled, 'empty': empty, 'rpn': out}
