@@ -44,7 +44,7 @@ WORKER = textwrap.dedent("""
     assert torch.equal(count, full_c)
     dist.barrier()
     dist.destroy_process_group()
-    open(os.path.join(os.environ["OUT"], "rank%d.ok" % rank), "w").write("ok")
+    open(os.path.join(os.environ["OUT"], "rank%%d.ok" %% rank), "w").write("ok")
 """)
 
 
