@@ -191,7 +191,7 @@ def main():
     world, rank, local = dist_setup(args.gpus)
 
     if args.workload == "c3":
-        from ws3d_amd.stage1_bench import C3
+        from bench_c3 import C3
         wl = C3(args.batch or 8, rank, world, args.kind)
     else:
         wl = C2(args.batch or 256, rank, args.kind)

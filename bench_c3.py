@@ -1,4 +1,4 @@
-"""Config-3 workload for bench.py: full Stage-1 RPN forward (Pointnet2MSG 4 SA + 4 FP +
+"""(part of bench.py) Config-3 workload: full Stage-1 RPN forward (Pointnet2MSG 4 SA + 4 FP +
 heads, weaklyRPN cfg) + on-device proposal NMS + roipool3d on `batch` synthetic scenes per
 GPU, plus the one all-gather of proposals when world > 1 (BASELINE.json configs[2]/[3])."""
 from __future__ import annotations
@@ -9,11 +9,10 @@ import time
 import numpy as np
 import torch
 
-from . import dist as wdist
-from . import synth
-from .seeded import seeded_state_dict
-from .stage1 import DEFAULT_CFG, Stage1Net, proposals_from_rpn
-from . import roipool3d_ops
+from ws3d_amd import dist as wdist
+from ws3d_amd import roipool3d_ops, synth
+from ws3d_amd.seeded import seeded_state_dict
+from ws3d_amd.stage1 import DEFAULT_CFG, Stage1Net, proposals_from_rpn
 
 
 class C3:

@@ -145,10 +145,13 @@ WS3D_API int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int 
  * boxes (n,5) already score-sorted (iou3d_utils.py:67-69).  The reference copies the
  * mask to the host and sweeps there; here mask kernel + greedy sweep both run on the
  * device: keep (n) int64 DEVICE, num_keep (1) int32 DEVICE -- no D2H, no sync.
+ * max_keep > 0 stops the sweep after that many survivors (the first max_keep entries of
+ * the reference's keep list; its callers slice [:RPN_POST_NMS_TOP_N]); <= 0 = all.
  * workspace: ws3d_nms_workspace_bytes(n) bytes of device memory.                     */
 WS3D_API size_t ws3d_nms_workspace_bytes(int boxes_num);
-WS3D_API int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, void *workspace,
-             size_t workspace_bytes, int64_t *keep, int32_t *num_keep, ws3d_stream_t stream);
+WS3D_API int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, int max_keep,
+                      void *workspace, size_t workspace_bytes, int64_t *keep, int32_t *num_keep,
+                      ws3d_stream_t stream);
 
 /* ---------------------------------------------------------------- roipool3d_cuda */
 

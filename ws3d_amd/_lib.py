@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libws3d_hip.so")
+LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(_HERE, "libws3d_hip.so")  # env: A/B builds
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -36,7 +36,7 @@ SIGNATURES = {
     "ws3d_boxes_iou_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "ws3d_nms_mask": (_i, [_i, _vp, _f, _i, _i, _vp, _vp]),
     "ws3d_nms_workspace_bytes": (_sz, [_i]),
-    "ws3d_nms": (_i, [_i, _vp, _f, _i, _vp, _sz, _vp, _vp, _vp]),
+    "ws3d_nms": (_i, [_i, _vp, _f, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_pts_in_boxes3d": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
 }

@@ -194,9 +194,10 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     return 1
 
 
-def nms_device(boxes, thresh, normal=False):
+def nms_device(boxes, thresh, normal=False, max_keep=0):
     """Device-resident NMS: boxes (n,5) score-sorted -> (keep int64 (n,) DEVICE, num int32 (1,)
-    DEVICE).  No host synchronisation (ws3d extension used by the Stage-1 pipeline)."""
+    DEVICE).  No host synchronisation (ws3d extension used by the Stage-1 pipeline).
+    max_keep > 0: stop after that many survivors (== the reference's keep[:max_keep])."""
     dev = _dev(boxes)
     _f32(boxes, "boxes")
     n = boxes.size(0)
@@ -206,8 +207,8 @@ def nms_device(boxes, thresh, normal=False):
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     num = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        check(lib.ws3d_nms(n, _p(boxes), float(thresh), int(bool(normal)), _p(ws), ws_bytes, _p(keep),
-                           _p(num), _stream()), "nms")
+        check(lib.ws3d_nms(n, _p(boxes), float(thresh), int(bool(normal)), int(max_keep), _p(ws), ws_bytes,
+                           _p(keep), _p(num), _stream()), "nms")
     return keep, num
 
 

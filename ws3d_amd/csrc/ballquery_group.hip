@@ -7,7 +7,7 @@
 // Design.  Irregular gather/scatter: no MFMA.  One lane per
 // query centre; the scene's points stream through LDS in float4 tiles (every lane of a
 // wave reads the SAME LDS address = broadcast, conflict-free), so each point is read
-// from global memory once per workgroup instead of once per centre.  A wave-uniform
+// from global memory once per wave of 64 centres instead of once per centre.  A wave-uniform
 // one-axis reject (|dx| >= r  =>  d2 >= r*r, exact in fp32 because rounding is
 // monotone) skips the distance for points no lane can accept.  Neighbour lists are
 // built in LDS rows (stride nsample+1: conflict-free per-lane appends) in ascending
@@ -19,53 +19,63 @@
 
 namespace ws3d {
 
-constexpr int BQ_TILE = 512;
+constexpr int BQ_TILE = 256;  // points per wave-private LDS tile
+constexpr int BQ_NW = 4;      // waves per workgroup: they split the scene's point range
 
-template <int NT, bool FUSED>
-__global__ __launch_bounds__(NT) void ball_query_kernel(int n, int m, int c_feat, float radius,
-                                                        int nsample, int use_xyz,
-                                                        const float *__restrict__ xyz,
-                                                        const float *__restrict__ new_xyz,
-                                                        const float *__restrict__ features,
-                                                        int32_t *__restrict__ idx_out,
-                                                        float *__restrict__ out) {
+// One workgroup = 64 query centres (one per lane) x BQ_NW waves.  Wave w scans the w-th
+// quarter of the scene through its OWN LDS tile (no workgroup barrier inside the scan) and
+// appends hits to its own LDS rows; quarters are ordered, so concatenating the four rows
+// gives the ascending-index neighbour list the reference's serial scan produces.
+template <typename IDX, bool FUSED>
+__global__ __launch_bounds__(64 * BQ_NW) void ball_query_kernel(int n, int m, int c_feat, float radius,
+                                                                int nsample, int use_xyz,
+                                                                const float *__restrict__ xyz,
+                                                                const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ features,
+                                                                int32_t *__restrict__ idx_out,
+                                                                float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *tile = reinterpret_cast<float4 *>(smem);                       // BQ_TILE
-    float4 *cen = tile + BQ_TILE;                                          // NT
-    int *cnt_s = reinterpret_cast<int *>(cen + NT);                        // NT
-    int *rows = cnt_s + NT;                                                // NT * (nsample+1)
-    const int rstride = nsample + 1;
+    float4 *tiles = reinterpret_cast<float4 *>(smem);                       // BQ_NW * BQ_TILE
+    float4 *cen = tiles + BQ_NW * BQ_TILE;                                  // 64
+    int *cnt_s = reinterpret_cast<int *>(cen + 64);                         // BQ_NW * 64
+    IDX *rows = reinterpret_cast<IDX *>(cnt_s + BQ_NW * 64);                // BQ_NW * 64 * rstride
+    const int rstride = nsample + 1;                                        // odd stride: conflict-free appends
 
     const int b = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int m0 = blockIdx.x * NT;
-    const int mi = m0 + tid;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * 64;
+    const int mi = m0 + lane;
     const bool active = mi < m;
     xyz += (size_t)b * n * 3;
     new_xyz += (size_t)b * m * 3;
 
     float cx = 0.f, cy = 0.f, cz = 0.f;
     if (active) { cx = new_xyz[mi * 3 + 0]; cy = new_xyz[mi * 3 + 1]; cz = new_xyz[mi * 3 + 2]; }
-    cen[tid] = make_float4(cx, cy, cz, 0.f);
+    if (w == 0) cen[lane] = make_float4(cx, cy, cz, 0.f);
     const float radius2 = radius * radius;
     const float rabs = fabsf(radius);
-    int *row = rows + tid * rstride;
+    float4 *tile = tiles + w * BQ_TILE;
+    IDX *row = rows + (size_t)(w * 64 + lane) * rstride;
     int cnt = active ? 0 : nsample;  // inactive lanes are "full": they never append
-    bool wave_done = false;
 
-    for (int base = 0; base < n; base += BQ_TILE) {
-        const int lim = min(BQ_TILE, n - base);
-        __syncthreads();
-        for (int i = tid; i < lim; i += NT) {
-            const float *p = xyz + (size_t)(base + i) * 3;
-            tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+    const int Q = ((n + BQ_NW - 1) / BQ_NW + BQ_TILE - 1) / BQ_TILE * BQ_TILE;
+    const int start = min(w * Q, n), end = min(start + Q, n);
+    for (int base = start; base < end; base += BQ_TILE) {
+        const int lim = min(BQ_TILE, end - base);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // previous tile fully consumed (wave-local)
+#pragma unroll
+        for (int q = 0; q < BQ_TILE / 64; ++q) {
+            const int i = lane + 64 * q;
+            if (i < lim) {
+                const float *p = xyz + (size_t)(base + i) * 3;
+                tile[i] = make_float4(p[0], p[1], p[2], 0.f);
+            }
         }
-        __syncthreads();
-        if (wave_done) continue;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // tile visible to every lane of this wave
         auto visit = [&](const float4 p, const int k, const bool near) {
             if (near && cnt < nsample) {
                 const float d2 = sqdist3(cx - p.x, cy - p.y, cz - p.z);
-                if (d2 < radius2) { row[cnt] = k; ++cnt; }
+                if (d2 < radius2) { row[cnt] = (IDX)k; ++cnt; }
             }
         };
         int i = 0;
@@ -84,32 +94,43 @@ __global__ __launch_bounds__(NT) void ball_query_kernel(int n, int m, int c_feat
             const float4 p = tile[i];
             visit(p, base + i, fabsf(cx - p.x) < rabs);
         }
-        wave_done = __all(cnt >= nsample);
+        if (__all(cnt >= nsample)) break;
     }
-
-    // pad every row in LDS: slots [cnt, nsample) repeat the first hit; no hit -> index 0
-    if (active) {
-        const int first = cnt > 0 ? row[0] : 0;
-        for (int s = cnt; s < nsample; ++s) row[s] = first;
-    }
-    cnt_s[tid] = active ? cnt : 0;
+    cnt_s[w * 64 + lane] = active ? cnt : 0;
     __syncthreads();
 
-    const int total = NT * nsample;
+    // concatenate the per-wave rows into wave 0's row (ascending index), truncate to nsample,
+    // pad with the first hit; a centre without any hit groups index 0 / leaves idx untouched
+    if (w == 0 && active) {
+        int total = cnt;  // own (wave 0) hits are already in place
+#pragma unroll
+        for (int ww = 1; ww < BQ_NW; ++ww) {
+            const int cw = cnt_s[ww * 64 + lane];
+            const IDX *src = rows + (size_t)(ww * 64 + lane) * rstride;
+            for (int s = 0; s < cw && total < nsample; ++s) row[total++] = src[s];
+        }
+        const IDX first = total > 0 ? row[0] : (IDX)0;
+        for (int s = total; s < nsample; ++s) row[s] = first;
+        cnt_s[lane] = total;
+    }
+    __syncthreads();
+
+    constexpr int NT = 64 * BQ_NW;
+    const int total_e = 64 * nsample;
     if (!FUSED) {
         // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44)
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
-        for (int e = tid; e < total; e += NT) {
+        for (int e = tid; e < total_e; e += NT) {
             const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m && cnt_s[c] > 0) o[e] = rows[c * rstride + s];
+            if (m0 + c < m && cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
         }
         return;
     }
     if (idx_out) {
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
-        for (int e = tid; e < total; e += NT) {
+        for (int e = tid; e < total_e; e += NT) {
             const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m) o[e] = rows[c * rstride + s];
+            if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
         }
     }
     const int c_xyz = use_xyz ? 3 : 0;
@@ -117,10 +138,10 @@ __global__ __launch_bounds__(NT) void ball_query_kernel(int n, int m, int c_feat
     const size_t plane = (size_t)m * nsample;
     float *ob = out + (size_t)b * c_out * plane + (size_t)m0 * nsample;
     const float *fb = features ? features + (size_t)b * c_feat * n : nullptr;
-    for (int e = tid; e < total; e += NT) {
+    for (int e = tid; e < total_e; e += NT) {
         const int c = e / nsample, s = e - c * nsample;
         if (m0 + c >= m) continue;
-        const int id = rows[c * rstride + s];
+        const int id = (int)rows[(size_t)c * rstride + s];
         if (use_xyz) {
             const float4 ce = cen[c];
             const float *p = xyz + (size_t)id * 3;
@@ -132,8 +153,9 @@ __global__ __launch_bounds__(NT) void ball_query_kernel(int n, int m, int c_feat
     }
 }
 
-static size_t bq_smem(int nt, int nsample) {
-    return sizeof(float4) * (BQ_TILE + nt) + sizeof(int) * nt + sizeof(int) * (size_t)nt * (nsample + 1);
+static size_t bq_smem(int nsample, size_t idx_bytes) {
+    return sizeof(float4) * (BQ_NW * BQ_TILE + 64) + sizeof(int) * BQ_NW * 64 +
+           idx_bytes * (size_t)BQ_NW * 64 * (nsample + 1);
 }
 
 template <bool FUSED>
@@ -150,27 +172,25 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         return WS3D_E_INVALID;
     }
     if (b == 0 || m == 0) return WS3D_OK;
-    // small launches: 64-lane workgroups so that more CUs get work
-    const bool small = (long)b * ((m + 127) / 128) < 512;
-    const int nt = small ? 64 : 128;
-    const size_t smem = bq_smem(nt, nsample);
-    if (smem > 160 * 1024) {
-        set_error("%s: nsample=%d needs %zu B of LDS (> 160 KiB)", what, nsample, smem);
+    const bool small_idx = n <= 65536;  // neighbour lists held as uint16 in LDS
+    const size_t smem = bq_smem(nsample, small_idx ? 2 : 4);
+    if (smem > 160 * 1024 || b > 65535) {
+        set_error("%s: nsample=%d needs %zu B of LDS (> 160 KiB) or batch > 65535", what, nsample, smem);
         return WS3D_E_UNSUPPORTED;
     }
-    dim3 grid((m + nt - 1) / nt, b);
-    if (small) {
+    dim3 grid((m + 63) / 64, b);
+    if (small_idx) {
         if (smem > 64 * 1024)
-            hipFuncSetAttribute((const void *)ball_query_kernel<64, FUSED>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((ball_query_kernel<64, FUSED>), grid, dim3(64), smem, st, n, m, c, radius,
-                           nsample, use_xyz, xyz, new_xyz, features, idx, out);
+            (void)hipFuncSetAttribute((const void *)ball_query_kernel<uint16_t, FUSED>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((ball_query_kernel<uint16_t, FUSED>), grid, dim3(64 * BQ_NW), smem, st, n, m, c,
+                           radius, nsample, use_xyz, xyz, new_xyz, features, idx, out);
     } else {
         if (smem > 64 * 1024)
-            hipFuncSetAttribute((const void *)ball_query_kernel<128, FUSED>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL((ball_query_kernel<128, FUSED>), grid, dim3(128), smem, st, n, m, c, radius,
-                           nsample, use_xyz, xyz, new_xyz, features, idx, out);
+            (void)hipFuncSetAttribute((const void *)ball_query_kernel<int32_t, FUSED>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL((ball_query_kernel<int32_t, FUSED>), grid, dim3(64 * BQ_NW), smem, st, n, m, c,
+                           radius, nsample, use_xyz, xyz, new_xyz, features, idx, out);
     }
     return check_launch(what);
 }

@@ -80,6 +80,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return max_f32(max_f32(a, b), max_f32(c, d));
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).
+// __syncthreads() also drains vmcnt, i.e. it would wait for in-flight GLOBAL stores
+// (~1 us round trip) every time -- fatal inside a latency-bound loop whose cross-wave
+// data all lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
 // number of set bits of `mask` below this lane

@@ -9,6 +9,12 @@
 // (n*12 B) and once per step for the 4-byte index (+12 B of coordinates when the
 // fused gather output is requested).
 //
+// Measured anatomy of one step at N=16384 (us): distance/min/argmax VALU 0.55, wave argmax
+// 0.31, cross-wave exchange 0.43, winner-coordinate extraction 0.07 (ablation builds,
+// DESIGN.md section 5.1).  A variant that replaces the wave argmax + records by ONE 64-bit
+// LDS atomic max per 16-lane row was correct but slower: ds_max_u64 costs ~600 cycles on
+// gfx950 (scripts/ubench/lat.hip).
+//
 // One step = (1) PPT x {3 sub, mul, 2 fma, min, cmp, 2 select} per lane,
 //            (2) wave argmax: 4 DPP max steps + 4 readlanes + ballot/ctz (no LDS),
 //            (3) one 20-byte LDS record per wave, ONE s_barrier (records are double
@@ -25,20 +31,14 @@
 // range [u*PPT, (u+1)*PPT) of positions p = bitrev(k mod bs) * S + k / bs
 // (S = ceil(n/bs)), so that plain "lowest slot, lowest lane, lowest wave wins" IS the
 // reference's tie order -- for any workgroup size, independent of bs.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ws3d {
 
 __device__ __forceinline__ int bitrev_bits(int v, int bits) {
     return bits == 0 ? 0 : (int)(__builtin_bitreverse32((uint32_t)v) >> (32 - bits));
-}
-
-// exact p / S for 0 <= p < 2^22 via one float multiply + fix-up (S >= 1)
-__device__ __forceinline__ void divmod_small(int p, int S, float invS, int &q, int &r) {
-    q = (int)((float)p * invS);
-    r = p - q * S;
-    if (r < 0) { q -= 1; r += S; }
-    if (r >= S) { q += 1; r -= S; }
 }
 
 template <int N> struct VecF { typedef float type __attribute__((ext_vector_type(N))); };
@@ -68,7 +68,6 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     const int u = threadIdx.x;
     const int lane = u & 63;
     const int w = u >> 6;
-    const float invS = 1.0f / (float)S;
 
     // ext-vector storage: a wave-uniform dynamic index (the winner's slot) then lowers to
     // VGPR-indexed moves instead of a 16-way compare/branch chain.
@@ -113,9 +112,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
         const float cx = readlane_f(vec_get<PPT>(px, wslot), wl);
         const float cy = readlane_f(vec_get<PPT>(py, wslot), wl);
         const float cz = readlane_f(vec_get<PPT>(pz, wslot), wl);
-        int rb, sl;
-        divmod_small((w * 64 + wl) * PPT + wslot, S, invS, rb, sl);
-        const int kw = bitrev_bits(rb, log2bs) + sl * bs;
+        const int kw = (w * 64 + wl) * PPT + wslot;  // tie-order POSITION; -> point index after the loop
 
         if constexpr (NW == 1) {
             ox = cx; oy = cy; oz = cz; old = kw;
@@ -125,7 +122,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                 s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
                 s_k[buf][w] = kw;
             }
-            __syncthreads();
+            lds_barrier();
             const int e = lane & 15;
             const float4 c = s_cand[buf][e];
             const int kc = s_k[buf][e];
@@ -142,6 +139,14 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
             idx[j] = old;
             if (new_xyz) { new_xyz[j * 3 + 0] = ox; new_xyz[j * 3 + 1] = oy; new_xyz[j * 3 + 2] = oz; }
         }
+    }
+
+    // positions -> point indices, off the critical path (thread 0 wrote idx[]; same lane reads)
+    __syncthreads();
+    for (int j = 1 + u; j < m; j += NT) {
+        const int p = idx[j];
+        const int rb = p / S, sl = p - rb * S;
+        idx[j] = bitrev_bits(rb, log2bs) + sl * bs;
     }
 
     if (temp) {
@@ -278,7 +283,14 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
         else launch_reg<16, 256>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
     } else if (R <= 1024L * 16) {
         const int ppt = (int)((R + 1023) / 1024);
-        if (ppt <= 8) launch_reg<8, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        // Fewer, fatter waves win: the cross-lane reduction chain (DPP/readlane/ballot) does not
+        // overlap between waves of one SIMD, so 8 waves x 32 points/lane (2 waves/SIMD, 231
+        // VGPRs) beat 16 waves x 16 points/lane by 18 % per step (measured 1.17 vs 1.38 us).
+        // WS3D_FPS_GEOM=0 selects the 1024-thread geometry for A/B runs.
+        static const int geom = getenv("WS3D_FPS_GEOM") ? atoi(getenv("WS3D_FPS_GEOM")) : 1;
+        if (ppt <= 8 && geom != 0) launch_reg<16, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else if (ppt <= 8) launch_reg<8, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else if (geom != 0) launch_reg<32, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
         else launch_reg<16, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
     } else {
         if (!temp) {

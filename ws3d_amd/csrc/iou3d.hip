@@ -259,10 +259,22 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thres
     mask[(size_t)cur * col_blocks + col_start] = t;
 }
 
-// iou3d.cpp:100-116 greedy sweep, on the device.  One 256-lane workgroup: wave 0
-// resolves each 64-row chunk serially against the diagonal words (scalar bit ops +
-// readlane), then all lanes OR the kept rows' words into the removed-set in parallel.
-__global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, const uint64_t *__restrict__ mask,
+// iou3d.cpp:100-116 greedy sweep, on the device.  One 256-lane workgroup.  Per 64-row chunk:
+// wave 0 resolves the chunk against its diagonal words with SCALAR bit operations (the
+// removed-set word, the kept word and the loop counter live in SGPRs; the 64 diagonal
+// words sit one per lane and are fetched with v_readlane), visiting only rows that are
+// still alive; then all 256 lanes OR the kept rows' mask words into the removed-set (LDS)
+// with independent, coalesced loads.  The next chunk's diagonal words are prefetched under
+// the barrier.  max_keep > 0 stops the sweep as soon as that many boxes are kept (the
+// reference returns every survivor and its callers slice [:RPN_POST_NMS_TOP_N] afterwards).
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_keep,
+                                                        const uint64_t *__restrict__ mask,
                                                         int64_t *__restrict__ keep,
                                                         int32_t *__restrict__ num_keep) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -273,45 +285,63 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, const uin
     const int col_blocks = (boxes_num + 63) / 64;
     for (int j = tid; j < col_blocks; j += 256) remv[j] = 0;
     if (tid == 0) total_s = 0;
+    uint64_t d_next = 0;
+    if (tid < 64 && lane < boxes_num) d_next = mask[(size_t)lane * col_blocks];
     __syncthreads();
+    const int limit = max_keep > 0 ? max_keep : boxes_num;
     for (int c = 0; c < col_blocks; ++c) {
         const int rows = min(64, boxes_num - c * 64);
         if (tid < 64) {
-            uint64_t d = 0;
-            if (lane < rows) d = mask[(size_t)(c * 64 + lane) * col_blocks + c];
+            const uint64_t d = d_next;
             const uint32_t dlo = (uint32_t)d, dhi = (uint32_t)(d >> 32);
-            uint64_t rem = remv[c];
+            uint64_t rem = uniform_u64(remv[c]);
+            const uint64_t valid = rows == 64 ? ~0ull : ((1ull << rows) - 1ull);
+            const int base = __builtin_amdgcn_readfirstlane(total_s);
+            int room = limit - base;
             uint64_t kept = 0;
-            for (int i = 0; i < rows; ++i) {
-                if (!((rem >> i) & 1ULL)) {
-                    kept |= 1ULL << i;
-                    const uint32_t lo = __builtin_amdgcn_readlane(dlo, i);
-                    const uint32_t hi = __builtin_amdgcn_readlane(dhi, i);
-                    rem |= ((uint64_t)hi << 32) | lo;
-                }
+            uint64_t cand = ~rem & valid;
+            while (cand != 0 && room > 0) {
+                const int i = (int)__builtin_ctzll(cand);
+                kept |= 1ull << i;
+                --room;
+                const uint32_t lo = __builtin_amdgcn_readlane(dlo, i);
+                const uint32_t hi = __builtin_amdgcn_readlane(dhi, i);
+                rem |= ((uint64_t)hi << 32) | lo;
+                cand = ~rem & valid & ~((2ull << i) - 1ull);  // alive rows above i
             }
-            const int base = total_s;
-            if ((kept >> lane) & 1ULL) keep[base + mbcnt(kept)] = (int64_t)(c * 64 + lane);
+            if ((kept >> lane) & 1ull) keep[base + mbcnt(kept)] = (int64_t)(c * 64 + lane);
             if (lane == 0) {
                 kept_s = kept;
                 total_s = base + (int)__builtin_popcountll(kept);
             }
+            // prefetch the next chunk's diagonal words (independent of the removed-set)
+            const int nr = (c + 1) * 64 + lane;
+            d_next = (c + 1 < col_blocks && nr < boxes_num) ? mask[(size_t)nr * col_blocks + (c + 1)] : 0;
         }
         __syncthreads();
         const uint64_t kept = kept_s;
-        if (kept) {
+        const bool done = total_s >= limit;
+        if (kept && !done) {
+            const uint64_t *rowbase = mask + (size_t)(c * 64) * col_blocks;
             for (int j = c + 1 + tid; j < col_blocks; j += 256) {
-                uint64_t acc = 0;
-                uint64_t kk = kept;
-                while (kk) {
-                    const int i = (int)__builtin_ctzll(kk);
-                    kk &= kk - 1;
-                    acc |= mask[(size_t)(c * 64 + i) * col_blocks + j];
+                uint64_t acc = 0, kk = kept;
+                while (kk) {  // 4 independent loads in flight per trip
+                    uint64_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (kk) {
+                            const int i = (int)__builtin_ctzll(kk);
+                            kk &= kk - 1;
+                            v[q] = rowbase[(size_t)i * col_blocks + j];
+                        }
+                    }
+                    acc |= (v[0] | v[1]) | (v[2] | v[3]);
                 }
                 remv[j] |= acc;
             }
         }
         __syncthreads();
+        if (done) break;
     }
     if (tid == 0) *num_keep = total_s;
 }
@@ -373,8 +403,9 @@ extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
     return ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
 }
 
-extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, void *workspace,
-                        size_t workspace_bytes, int64_t *keep, int32_t *num_keep, ws3d_stream_t stream) {
+extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, int max_keep,
+                        void *workspace, size_t workspace_bytes, int64_t *keep, int32_t *num_keep,
+                        ws3d_stream_t stream) {
     using namespace ws3d;
     if (boxes_num < 0 || (!boxes && boxes_num > 0) || (!keep && boxes_num > 0) || !num_keep) {
         set_error("ws3d_nms: invalid argument (boxes_num=%d)", boxes_num);
@@ -396,6 +427,6 @@ extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int nor
     if (smem > 150 * 1024) { set_error("ws3d_nms: boxes_num too large for the LDS removed-set"); return WS3D_E_UNSUPPORTED; }
     if (smem > 64 * 1024)
         hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), smem, st, boxes_num, mask, keep, num_keep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), smem, st, boxes_num, max_keep, mask, keep, num_keep);
     return check_launch("ws3d_nms(sweep)");
 }

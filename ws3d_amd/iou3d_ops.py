@@ -60,7 +60,7 @@ def nms_gpu_padded(boxes, scores, thresh, max_out, normal=False):
     """Device-only variant for the data-parallel pipeline: fixed-shape (max_out,) index tensor
     (padded with -1) + count tensor; no host synchronisation."""
     order = scores.sort(dim=0, descending=True, stable=True)[1]
-    keep, num = _C.nms_device(boxes[order].contiguous(), thresh, normal)
+    keep, num = _C.nms_device(boxes[order].contiguous(), thresh, normal, max_keep=max_out)
     n = boxes.shape[0]
     out = torch.full((max_out,), -1, dtype=torch.int64, device=boxes.device)
     take = min(max_out, n)
