@@ -125,10 +125,27 @@ class C2:
             e[2].record()
             self.ev.append(e)
 
-    def kernel_ms(self):
-        fps = [a[0].elapsed_time(a[1]) for a in self.ev]
-        qg = [a[1].elapsed_time(a[2]) for a in self.ev]
-        return float(np.mean(fps)), float(np.mean(qg))
+    metric = "KITTI scenes/sec (16384 pts), fused FPS+ball_query+group path; FPS+group HBM GB/s"
+
+    def kernel_table(self):
+        fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
+        qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
+        return [
+            {"name": "fps_reg_kernel<32,512> (furthest_point_sample + gather)", "ms_per_step": fps,
+             "launches_per_step": 1, "alg_bytes_per_step": a_model_fps() * self.B,
+             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_reg_kernel",
+             "comment": "A_model re-reads xyz every step; this design keeps the scene in VGPRs, so the kernel is "
+                        "latency/ALU-bound and its real HBM traffic is ~A_min (see traffic_bytes_per_launch)"},
+            {"name": "ball_query_kernel<u16,fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
+             "launches_per_step": 1, "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_kernel",
+             "comment": "A_model == A_min for this kernel (every input read once, every output written once)"},
+        ]
+
+    def path_gbps(self, scenes_per_s_per_gpu):
+        am, an = (a_model_fps() + a_rest()), (a_min_fps() + a_rest())
+        return {"a_model": am * scenes_per_s_per_gpu / 1e9, "a_model_frac_of_8TBs": am * scenes_per_s_per_gpu / HBM_PEAK,
+                "a_min": an * scenes_per_s_per_gpu / 1e9, "a_model_bytes_per_scene": am, "a_min_bytes_per_scene": an,
+                "fps_steps_per_s_per_scene": None if not self.ev else (M_PTS - 1) / (self.kernel_table()[0]["ms_per_step"] * 1e-3)}
 
     def scenes(self):
         return self.B
@@ -167,7 +184,7 @@ def load_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json),
     already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(p):
+    if kernel_key and os.path.exists(p):
         try:
             return json.load(open(p)).get(kernel_key)
         except Exception:
@@ -210,29 +227,32 @@ def main():
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
-        fps_ms, rest_ms = wl.kernel_ms()
-        per_launch_scenes = wl.scenes()
-        fps_bytes = a_model_fps() * per_launch_scenes
-        achieved = fps_bytes / (fps_ms * 1e-3)
-        path_model = (a_model_fps() + a_rest()) * value / world   # per GPU
-        path_min = (a_min_fps() + a_rest()) * value / world
+        kernels = wl.kernel_table()   # [{name, ms_per_step, launches_per_step, alg_bytes_per_step, traffic_key}]
+        for k in kernels:
+            k["achieved_GBps"] = k["alg_bytes_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9 if k["ms_per_step"] > 0 else 0.0
+            k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
+            tr = load_traffic(k.pop("traffic_key", None))
+            k["traffic_bytes_per_launch"] = tr
+        dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
+        per_gpu = value / world
         out = {
-            "metric": "KITTI scenes/sec (16384 pts), fused FPS+ball_query+group path" if args.workload == "c2"
-                      else "KITTI scenes/sec (16384 pts) Stage-1 RPN fwd",
-            "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
+            "metric": wl.metric, "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
             "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS}, **wl.config()),
-            "roofline": {"bound": "hbm", "kernel": "fps_reg_kernel<16,1024>", "achieved": achieved / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": load_traffic("fps_reg_kernel"),
-                         "note": "A_model algorithmic bytes ((M-1)*N*12+M*4 per scene) / HIP-event launch duration; "
-                                 "FPS is latency/ALU-bound with the scene resident in registers, so real HBM traffic "
-                                 "is ~A_min (see traffic)",
-                         "fps_ms_per_launch": fps_ms, "other_kernels_ms_per_step": rest_ms,
-                         "scenes_per_launch": per_launch_scenes},
-            "path_gbps_per_gpu": {"a_model": path_model / 1e9, "a_model_frac_of_8TBs": path_model / HBM_PEAK,
-                                  "a_min": path_min / 1e9},
+            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom["achieved_GBps"],
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dom["frac_of_8TBps"],
+                         "traffic": (dom["traffic_bytes_per_launch"] or {}).get("hbm_bytes")
+                         if isinstance(dom["traffic_bytes_per_launch"], dict) else None,
+                         "ms_per_launch": dom["ms_per_step"] / max(dom["launches_per_step"], 1),
+                         "alg_bytes_per_launch": dom["alg_bytes_per_step"] / max(dom["launches_per_step"], 1),
+                         "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic "
+                                 "bytes (SURVEY.md 8d byte model, DESIGN.md section 6) / measured duration; "
+                                 "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic.json "
+                                 "(c2 workload, batch 256) or null"},
+            "kernels": kernels,
+            "path_gbps_per_gpu": wl.path_gbps(per_gpu),
         }
         if not args.no_cpu_baseline and world == 1:
             try:

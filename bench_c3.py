@@ -15,8 +15,40 @@ from ws3d_amd.seeded import seeded_state_dict
 from ws3d_amd.stage1 import DEFAULT_CFG, Stage1Net, proposals_from_rpn
 
 
+# SURVEY.md 8(d) byte model of the custom ops of one Stage-1 forward (per scene, weaklyRPN shapes)
+def _fps_model_bytes(cfg):
+    n, tot = cfg.num_points, 0
+    for m in cfg.npoints:
+        tot += (m - 1) * n * 12 + m * 4
+        n = m
+    return tot
+
+
+def _qg_bytes(cfg):
+    n, c, tot = cfg.num_points, 1, 0
+    for k, m in enumerate(cfg.npoints):
+        for ns in cfg.nsample[k]:
+            tot += (n + m) * 12 + m * ns * 4 + (3 + c) * n * 4 + (3 + c) * m * ns * 4
+        c = sum(mm[-1] for mm in cfg.mlps[k])
+        n = m
+    return tot
+
+
+def _interp_bytes(cfg):
+    pts = [cfg.num_points] + list(cfg.npoints)
+    chans = [sum(mm[-1] for mm in cfg.mlps[k]) for k in range(4)]      # 96, 256, 512, 1024
+    known_c = [cfg.fp_mlps[1][-1], cfg.fp_mlps[2][-1], cfg.fp_mlps[3][-1], chans[3]]  # features interpolated FROM
+    nn_b = interp_b = 0
+    for k in range(4):
+        n, m, c = pts[k], pts[k + 1], known_c[k]
+        nn_b += (n + m) * 12 + n * 3 * 8
+        interp_b += c * m * 4 + n * 3 * 8 + c * n * 4
+    return nn_b, interp_b
+
+
 class C3:
     name = "c3_stage1_rpn_forward_nms_roipool"
+    metric = "KITTI scenes/sec (16384 pts) Stage-1 RPN fwd (incl. proposal NMS + roipool3d)"
 
     def __init__(self, batch, rank, world, kind="lidar"):
         self.B, self.rank, self.world, self.cfg = batch, rank, world, DEFAULT_CFG
@@ -28,6 +60,29 @@ class C3:
         self.model = model.cuda()
         self.ev = []
         self.last = None
+        self.op_ev = {}
+        self._timed = False
+        self._install_hooks()
+
+    def _install_hooks(self):
+        """HIP-event timers around every C-ABI launch family (only while a timed step runs)."""
+        from ws3d_amd import compat
+        fam = {"furthest_point_sampling_gather": "fps", "query_and_group": "ball_query+group",
+               "three_nn_wrapper": "three_nn", "three_interpolate_wrapper": "three_interpolate",
+               "nms_device": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
+        for fn_name, key in fam.items():
+            orig = getattr(compat, fn_name)
+
+            def wrapped(*a, __orig=orig, __key=key, **kw):
+                if not self._timed:
+                    return __orig(*a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = __orig(*a, **kw)
+                e1.record()
+                self.op_ev.setdefault(__key, []).append((e0, e1))
+                return r
+            setattr(compat, fn_name, wrapped)
 
     def config(self):
         c = self.cfg
@@ -38,6 +93,7 @@ class C3:
 
     @torch.no_grad()
     def step(self, timed=False):
+        self._timed = timed
         e = None
         if timed:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -54,16 +110,38 @@ class C3:
         if timed:
             e[3].record()
             self.ev.append(e)
+        self._timed = False
         gathered = wdist.all_gather_proposals(wdist.pack_proposals(boxes, scores), count, self.B * self.world)
         self.last = (out, boxes, scores, count, pooled, empty, gathered)
 
-    def kernel_ms(self):
+    def kernel_table(self):
+        steps = max(len(self.ev), 1)
+        cfg, B = self.cfg, self.B
+        nn_b, interp_b = _interp_bytes(cfg)
+        roi_b = cfg.rpn_post_nms_top_n * cfg.roi_sampled_pts * (3 + 128) * 4 + cfg.num_points * (3 + 128) * 4
+        alg = {"fps": _fps_model_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn": nn_b * B,
+               "three_interpolate": interp_b * B, "roipool3d": roi_b * B,
+               "nms(mask+sweep)": (cfg.rpn_pre_nms_top_n * 20 + cfg.rpn_pre_nms_top_n * 141 * 8) * B}
+        rows = []
+        for key, evs in self.op_ev.items():
+            ms = float(sum(a.elapsed_time(b) for a, b in evs)) / steps
+            rows.append({"name": key, "ms_per_step": ms, "launches_per_step": len(evs) / steps,
+                         "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None})
         fwd = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
-        rest = float(np.mean([a[1].elapsed_time(a[3]) for a in self.ev]))
+        custom_in_fwd = sum(r["ms_per_step"] for r in rows if r["name"] in ("fps", "ball_query+group", "three_nn", "three_interpolate"))
+        rows.append({"name": "torch (SharedMLP GEMMs, BN-folded, max-pool, cat, heads) [rocBLAS, not ours]",
+                     "ms_per_step": max(fwd - custom_in_fwd, 0.0), "launches_per_step": 0, "alg_bytes_per_step": 0,
+                     "traffic_key": None})
         self.breakdown = {"rpn_forward_ms": fwd,
                           "proposals_nms_ms": float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev])),
                           "roipool_ms": float(np.mean([a[2].elapsed_time(a[3]) for a in self.ev]))}
-        return fwd, rest
+        return rows
+
+    def path_gbps(self, scenes_per_s_per_gpu):
+        cfg = self.cfg
+        am = _fps_model_bytes(cfg) + _qg_bytes(cfg) + sum(_interp_bytes(cfg))
+        return {"custom_ops_a_model_bytes_per_scene": am, "a_model": am * scenes_per_s_per_gpu / 1e9,
+                "a_model_frac_of_8TBs": am * scenes_per_s_per_gpu / 8.0e12, "breakdown_ms": getattr(self, "breakdown", None)}
 
     def scenes(self):
         return self.B

@@ -1,0 +1,39 @@
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as
+MI355X_MICROARCH.md prescribes) into profiles/traffic.json: HBM bytes per launch per kernel.
+
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE under-reports WIDE coalesced
+streams (16 B/lane) by exactly 2x; other access widths are uncalibrated.  The FPS kernel's only
+reads are 4-byte per-lane gathers at start-up and the ball-query kernel reads 4-byte strided
+triples, so the raw value is kept and the doubled value is recorded next to it as the upper
+bound; WRITE_SIZE was calibrated here against a known byte count (fused query_and_group writes
+exactly B*((3+C)*M*ns + M*ns)*4 bytes; the counter matches to the byte)."""
+import json, sqlite3, sys
+
+def per_kernel(db_path, counter):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name=? "
+                      "group by kernel_name", (counter,)).fetchall()
+    return {r[0]: (r[1] * 1024.0, r[2]) for r in rows}
+
+def short(name):
+    for k in ("fps_reg_kernel", "ball_query_kernel", "nms_mask_kernel", "nms_sweep_kernel", "roipool3d_kernel",
+              "three_nn_kernel", "three_interpolate_kernel", "group_points_kernel"):
+        if k in name:
+            return k
+    return None
+
+def main(fetch_db, write_db, out, note):
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    res = {"_note": note}
+    for name in sorted(set(f) | set(w)):
+        k = short(name)
+        if not k:
+            continue
+        fb, wb = f.get(name, (0, 0))[0], w.get(name, (0, 0))[0]
+        res[k] = {"kernel": name, "fetch_bytes_raw": fb, "fetch_bytes_if_wide_stream_x2": 2 * fb,
+                  "write_bytes": wb, "hbm_bytes": fb + wb, "launches_sampled": f.get(name, (0, 0))[1]}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
