@@ -106,16 +106,19 @@ __device__ __forceinline__ bool intersection(P2 p1, P2 p0, P2 q1, P2 q0, P2 &ans
     return true;
 }
 
+// far-pair reject: circumscribed circles separated by more than a safety margin => the
+// reference finds no edge crossing and no contained corner (cnt == 0) and returns 0.
+__device__ __forceinline__ bool far_apart(float acx, float acy, float arad, float bcx, float bcy, float brad) {
+    const float dx = acx - bcx, dy = acy - bcy;
+    const float rr = arad + brad + 0.01f + 1e-5f * (fabsf(acx) + fabsf(acy) + fabsf(bcx) + fabsf(bcy));
+    return dx * dx + dy * dy > rr * rr * 1.0001f;
+}
+
 // iou3d_kernel.cu:108-212.  vx/vy/va: this lane's polygon scratch in LDS, element v at
-// [v * 64] (the caller passes pointers already offset by the lane id).
+// [v * LS] (LS = lanes sharing the scratch; the caller passes pointers offset by its lane id).
+template <int LS>
 __device__ float box_overlap(const BevFrame &A, const BevFrame &B, float *vx, float *vy, float *va) {
-    // far-pair reject: circumscribed circles separated by > margin => the reference finds
-    // no edge crossing and no contained corner (cnt == 0) and returns 0.
-    {
-        const float dx = A.cx - B.cx, dy = A.cy - B.cy;
-        const float rr = A.rad + B.rad + 0.01f + 1e-5f * (fabsf(A.cx) + fabsf(A.cy) + fabsf(B.cx) + fabsf(B.cy));
-        if (dx * dx + dy * dy > rr * rr * 1.0001f) return 0.0f;
-    }
+    if (far_apart(A.cx, A.cy, A.rad, B.cx, B.cy, B.rad)) return 0.0f;
     int cnt = 0;
     float pcx = 0.f, pcy = 0.f;
 #pragma unroll
@@ -126,8 +129,8 @@ __device__ float box_overlap(const BevFrame &A, const BevFrame &B, float *vx, fl
             if (intersection(A.c[(i + 1) & 3], A.c[i], B.c[(j + 1) & 3], B.c[j], ans)) {
                 pcx = pcx + ans.x;
                 pcy = pcy + ans.y;
-                vx[cnt * 64] = ans.x;
-                vy[cnt * 64] = ans.y;
+                vx[cnt * LS] = ans.x;
+                vy[cnt * LS] = ans.y;
                 cnt++;
             }
         }
@@ -136,36 +139,36 @@ __device__ float box_overlap(const BevFrame &A, const BevFrame &B, float *vx, fl
     for (int k = 0; k < 4; ++k) {
         if (check_in_box2d(A, B.c[k])) {
             pcx = pcx + B.c[k].x; pcy = pcy + B.c[k].y;
-            vx[cnt * 64] = B.c[k].x; vy[cnt * 64] = B.c[k].y;
+            vx[cnt * LS] = B.c[k].x; vy[cnt * LS] = B.c[k].y;
             cnt++;
         }
         if (check_in_box2d(B, A.c[k])) {
             pcx = pcx + A.c[k].x; pcy = pcy + A.c[k].y;
-            vx[cnt * 64] = A.c[k].x; vy[cnt * 64] = A.c[k].y;
+            vx[cnt * LS] = A.c[k].x; vy[cnt * LS] = A.c[k].y;
             cnt++;
         }
     }
     if (cnt == 0) return 0.0f;  // (0/0 centroid, empty loops, area 0 in the reference)
     pcx /= cnt;
     pcy /= cnt;
-    for (int v = 0; v < cnt; ++v) va[v * 64] = atan2f_cr(vy[v * 64] - pcy, vx[v * 64] - pcx);
+    for (int v = 0; v < cnt; ++v) va[v * LS] = atan2f_cr(vy[v * LS] - pcy, vx[v * LS] - pcx);
     // bubble sort with point_cmp = angle(a) > angle(b) (:104-106,188-196)
     for (int j = 0; j < cnt - 1; ++j) {
         for (int i = 0; i < cnt - j - 1; ++i) {
-            const float ta = va[i * 64], tb = va[(i + 1) * 64];
+            const float ta = va[i * LS], tb = va[(i + 1) * LS];
             if (ta > tb) {
-                va[i * 64] = tb; va[(i + 1) * 64] = ta;
-                const float x0 = vx[i * 64], y0 = vy[i * 64];
-                vx[i * 64] = vx[(i + 1) * 64]; vy[i * 64] = vy[(i + 1) * 64];
-                vx[(i + 1) * 64] = x0; vy[(i + 1) * 64] = y0;
+                va[i * LS] = tb; va[(i + 1) * LS] = ta;
+                const float x0 = vx[i * LS], y0 = vy[i * LS];
+                vx[i * LS] = vx[(i + 1) * LS]; vy[i * LS] = vy[(i + 1) * LS];
+                vx[(i + 1) * LS] = x0; vy[(i + 1) * LS] = y0;
             }
         }
     }
     float area = 0.f;
     const float x0 = vx[0], y0 = vy[0];
     for (int k = 0; k < cnt - 1; ++k) {
-        const float ax = vx[k * 64] - x0, ay = vy[k * 64] - y0;
-        const float bx = vx[(k + 1) * 64] - x0, by = vy[(k + 1) * 64] - y0;
+        const float ax = vx[k * LS] - x0, ay = vy[k * LS] - y0;
+        const float bx = vx[(k + 1) * LS] - x0, by = vy[(k + 1) * LS] - y0;
         area += ax * by - ay * bx;  // cross(a, b) :34-36
     }
     return fabsf(area) / 2.0f;
@@ -208,17 +211,15 @@ __global__ __launch_bounds__(64) void pair_kernel(int num_a, const float *__rest
     const BevFrame B = make_bev_frame(boxes_b + (size_t)bi * 5);
     for (int r = 0; r < rows; ++r) {
         const BevFrame A = load_frame(s.frames + r * FRAME_F);
-        const float ov = box_overlap(A, B, s.vx + lane, s.vy + lane, s.va + lane);
+        const float ov = box_overlap<64>(A, B, s.vx + lane, s.vy + lane, s.va + lane);
         ans[(size_t)(a0 + r) * num_b + bi] = MODE == 0 ? ov : iou_from_overlap(A, B, ov);
     }
 }
 
-// K12 / K13: lane = row box i (its own 64-bit word), column boxes from LDS.
-template <bool NORMAL>
-__global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thresh, int full_grid,
-                                                      const float *__restrict__ boxes,
-                                                      uint64_t *__restrict__ mask) {
-    __shared__ WaveScratch s;
+// K13 (axis-aligned): lane = row box i (its own 64-bit word), column boxes from LDS.
+__global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, float thresh, int full_grid,
+                                                             const float *__restrict__ boxes,
+                                                             uint64_t *__restrict__ mask) {
     __shared__ float raw[64 * 5];
     const int row_start = blockIdx.y, col_start = blockIdx.x;
     const int lane = threadIdx.x;
@@ -232,31 +233,91 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int boxes_num, float thres
     }
     if (lane < col_size) {
         const float *src = boxes + (size_t)(col_start * 64 + lane) * 5;
-        if (NORMAL) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) raw[lane * 5 + q] = src[q];
-        } else {
-            store_frame(s.frames + lane * FRAME_F, make_bev_frame(src));
-        }
+        for (int q = 0; q < 5; ++q) raw[lane * 5 + q] = src[q];
     }
     __syncthreads();
     if (lane >= row_size) return;
     const float *cur_box = boxes + (size_t)cur * 5;
     uint64_t t = 0;
     const int start = (row_start == col_start) ? lane + 1 : 0;
-    if (NORMAL) {
-        const float a[4] = {cur_box[0], cur_box[1], cur_box[2], cur_box[3]};
-        for (int i = start; i < col_size; ++i)
-            if (iou_normal(a, raw + i * 5) > thresh) t |= 1ULL << i;
-    } else {
-        const BevFrame A = make_bev_frame(cur_box);
-        for (int i = start; i < col_size; ++i) {
-            const BevFrame B = load_frame(s.frames + i * FRAME_F);
-            const float ov = box_overlap(A, B, s.vx + lane, s.vy + lane, s.va + lane);
-            if (iou_from_overlap(A, B, ov) > thresh) t |= 1ULL << i;
+    const float a[4] = {cur_box[0], cur_box[1], cur_box[2], cur_box[3]};
+    for (int i = start; i < col_size; ++i)
+        if (iou_normal(a, raw + i * 5) > thresh) t |= 1ULL << i;
+    mask[(size_t)cur * col_blocks + col_start] = t;
+}
+
+// K12 (rotated).  A 64x64 tile of box pairs per 256-lane workgroup, in three phases:
+//   0. 128 lanes build the 64 row and 64 column frames (trig once per box) in LDS;
+//   1. all 4096 pairs take the cheap exact far-pair test; survivors are COMPACTED into an
+//      LDS work list (wave ballot + one LDS atomic add per wave);
+//   2. the lanes walk the list -- every lane runs the expensive rotated intersection on a
+//      REAL candidate instead of idling behind a divergent neighbour (with lane = row and a
+//      serial column loop, one overlapping pair stalls all 64 rows of the wave) -- and set
+//      bits with 32-bit LDS atomic ORs;
+//   3. 64 lanes store the tile's mask words.
+struct MaskTileLds {
+    float frames[2][64 * FRAME_F];      // [0] = rows, [1] = columns
+    unsigned short list[4096];
+    unsigned int words[64][2];
+    unsigned int count;
+    float vx[16 * 256], vy[16 * 256], va[16 * 256];
+};
+
+__global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float thresh, int full_grid,
+                                                           const float *__restrict__ boxes,
+                                                           uint64_t *__restrict__ mask) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    MaskTileLds &s = *reinterpret_cast<MaskTileLds *>(smem_raw);
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int col_blocks = (boxes_num + 63) / 64;
+    const int row_size = min(boxes_num - row_start * 64, 64);
+    const int col_size = min(boxes_num - col_start * 64, 64);
+    if (col_start < row_start && !full_grid) {  // never read by the sweep (iou3d.cpp:108)
+        if (tid < row_size) mask[(size_t)(row_start * 64 + tid) * col_blocks + col_start] = 0;
+        return;
+    }
+    if (tid < 128) {
+        const int which = tid >> 6;  // 0: row frames, 1: column frames
+        const int n_here = which ? col_size : row_size;
+        if (lane < n_here)
+            store_frame(s.frames[which] + lane * FRAME_F,
+                        make_bev_frame(boxes + (size_t)((which ? col_start : row_start) * 64 + lane) * 5));
+        if (which == 0) { s.words[lane][0] = 0u; s.words[lane][1] = 0u; }
+    }
+    if (tid == 0) s.count = 0u;
+    __syncthreads();
+    const bool diag = row_start == col_start;
+    for (int e = tid; e < 4096; e += 256) {
+        const int r = e >> 6, c = e & 63;
+        bool cand = r < row_size && c < col_size && (!diag || c > r);
+        if (cand) {
+            const float *fr = s.frames[0] + r * FRAME_F, *fc = s.frames[1] + c * FRAME_F;
+            cand = !far_apart(fr[4], fr[5], fr[9], fc[4], fc[5], fc[9]);
+        }
+        const uint64_t bal = __ballot(cand);
+        if (bal) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s.count, (unsigned)__builtin_popcountll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (cand) s.list[base + mbcnt(bal)] = (unsigned short)e;
         }
     }
-    mask[(size_t)cur * col_blocks + col_start] = t;
+    __syncthreads();
+    const int n_cand = (int)s.count;
+    for (int i = tid; i < n_cand; i += 256) {
+        const int e = s.list[i];
+        const int r = e >> 6, c = e & 63;
+        const BevFrame A = load_frame(s.frames[0] + r * FRAME_F);
+        const BevFrame B = load_frame(s.frames[1] + c * FRAME_F);
+        const float ov = box_overlap<256>(A, B, s.vx + tid, s.vy + tid, s.va + tid);
+        if (iou_from_overlap(A, B, ov) > thresh) atomicOr(&s.words[r][c >> 5], 1u << (c & 31));
+    }
+    __syncthreads();
+    if (tid < row_size)
+        mask[(size_t)(row_start * 64 + tid) * col_blocks + col_start] =
+            ((uint64_t)s.words[tid][1] << 32) | (uint64_t)s.words[tid][0];
 }
 
 // iou3d.cpp:100-116 greedy sweep, on the device.  One 256-lane workgroup.  Per 64-row chunk:
@@ -370,10 +431,18 @@ static int mask_launch(int boxes_num, const float *boxes, float thresh, int norm
     const int cb = (boxes_num + 63) / 64;
     if (cb > 65535) { set_error("%s: boxes_num too large", what); return WS3D_E_UNSUPPORTED; }
     dim3 grid(cb, cb);
-    if (normal)
-        hipLaunchKernelGGL((nms_mask_kernel<true>), grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
-    else
-        hipLaunchKernelGGL((nms_mask_kernel<false>), grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
+    if (normal) {
+        hipLaunchKernelGGL(nms_normal_mask_kernel, grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)nms_rot_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)sizeof(MaskTileLds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(nms_rot_mask_kernel, grid, dim3(256), sizeof(MaskTileLds), st, boxes_num, thresh,
+                           full_grid, boxes, mask);
+    }
     return check_launch(what);
 }
 
