@@ -120,7 +120,7 @@ class C2:
         if timed:
             e[1].record()
         c.query_and_group(B, N_PTS, M_PTS, C_FEAT, RADIUS, NSAMPLE, True, self.xyz, self.new_xyz, self.feat,
-                          self.nbr, self.grouped)
+                          self.nbr, self.grouped, c.sort_points_x(self.xyz))
         if timed:
             e[2].record()
             self.ev.append(e)

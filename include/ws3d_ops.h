@@ -82,9 +82,19 @@ WS3D_API int ws3d_gather_points_grad(int b, int c, int n, int npoints, const flo
 /* ball_query_wrapper(b,n,m,radius,nsample,new_xyz,xyz,idx)   ball_query.cpp:14-25 ->
  * ball_query_gpu.cu:9-67.  new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample),
  * pre-zeroed by the caller (pointnet2_utils.py:218); rows without a hit are left
- * untouched.                                                                        */
+ * untouched.  sorted: NULL, or the output of ws3d_sort_points_x for this xyz.       */
 WS3D_API int ws3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                    const float *xyz, int32_t *idx, ws3d_stream_t stream);
+                    const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream);
+
+/* Optional accelerator for ws3d_ball_query / ws3d_query_and_group (no reference counterpart):
+ * a per-scene copy of xyz counting-sorted into uniform x cells (float4 {x,y,z,index} x n, a
+ * 16-byte header and a cell-start table per scene; opaque to the caller).  With it each centre
+ * scans only the cells overlapping |x - cx| < radius instead of all n points; results are
+ * bit-identical.  ws3d_sorted_points_bytes() returns the buffer size, or 0 when the shape is not
+ * supported (n > 16384): then pass sorted = NULL.  One binning serves every radius queried
+ * against the same xyz.                                                                        */
+WS3D_API size_t ws3d_sorted_points_bytes(int b, int n);
+WS3D_API int ws3d_sort_points_x(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream);
 
 /* group_points_wrapper(b,c,n,npoints,nsample,points,idx,out)   group_points.cpp:25-36
  * -> group_points_gpu.cu:47-86.  points (b,c,n), idx (b,npoints,nsample) ->
@@ -103,7 +113,7 @@ WS3D_API int ws3d_group_points_grad(int b, int c, int n, int npoints, int nsampl
  * given it receives exactly what ws3d_ball_query would write into a zeroed idx.     */
 WS3D_API int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
                          const float *xyz, const float *new_xyz, const float *features,
-                         int32_t *idx_out, float *out, ws3d_stream_t stream);
+                         int32_t *idx_out, float *out, const void *sorted, ws3d_stream_t stream);
 
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   interpolate.cpp:14-23 ->
  * interpolate_gpu.cu:9-67.  unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3)

@@ -52,7 +52,7 @@ def test_invalid_arguments_return_codes(lib):
     lib.ws3d_last_error.restype = ctypes.c_char_p
     rc = lib.ws3d_furthest_point_sampling(1, 0, 4, None, None, None, None)
     assert rc == -1 and b"invalid" in lib.ws3d_last_error()
-    assert lib.ws3d_ball_query(1, 16, 4, ctypes.c_float(0.5), 0, None, None, None, None) == -1
+    assert lib.ws3d_ball_query(1, 16, 4, ctypes.c_float(0.5), 0, None, None, None, None, None) == -1
     assert lib.ws3d_roipool3d(1, 16, 4, 3, 0, None, None, None, None, None, None, None) == -1
     assert lib.ws3d_nms(8, None, ctypes.c_float(0.5), 0, 0, None, ctypes.c_size_t(0), None, None, None) == -1
     # zero-sized problems are no-ops that succeed (sampling_gpu.cu:101 "if (m <= 0) return")

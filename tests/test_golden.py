@@ -184,8 +184,8 @@ def test_gpu_stage1_forward_matches_reference_harness(meta):
         fps_log.append(r[0].cpu().numpy())
         return r
 
-    def qg_tap(radius, nsample, xyz, new_xyz, features=None, use_xyz=True, return_idx=False):
-        out, idx = orig_qg(radius, nsample, xyz, new_xyz, features, use_xyz, return_idx=True)
+    def qg_tap(radius, nsample, xyz, new_xyz, features=None, use_xyz=True, return_idx=False, sorted_xyz=None):
+        out, idx = orig_qg(radius, nsample, xyz, new_xyz, features, use_xyz, return_idx=True, sorted_xyz=sorted_xyz)
         bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
         return (out, idx) if return_idx else out
 

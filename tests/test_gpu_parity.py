@@ -125,6 +125,44 @@ def test_ball_query_and_group_bit_exact(ops, oracle, B, N, M, r, ns, kind):
     np.testing.assert_array_equal(host(qg2(dev(xyz), dev(new_xyz), dev(feats))), ref_g)
 
 
+@pytest.mark.parametrize("N,M,r,ns,kind", [(16384, 4096, 0.1, 64, "lidar"), (16384, 1024, 0.5, 32, "uniform"),
+                                          (4096, 1024, 1.0, 16, "lidar"), (2048, 300, 50.0, 8, "lidar"),
+                                          (8192, 500, 0.3, 5, "dups")])
+def test_ball_query_sorted_slab_equals_bruteforce(ops, oracle, N, M, r, ns, kind):
+    """the x-sorted slab path, the LDS-tiled brute-force path and the oracle agree bit for bit,
+    including slabs longer than the fallback threshold (r=50) and heavy duplication"""
+    if kind == "dups":
+        base = synth.lidar_cloud(64, 3)[:, :3]
+        xyz = base[np.random.default_rng(0).integers(0, 64, N)][None].copy()
+    else:
+        xyz = synth.make_batch(kind, 1, N, 33)[:, :, :3].copy()
+    xyz = np.ascontiguousarray(np.concatenate([xyz, xyz[:, ::-1]], 0))  # 2 scenes
+    cidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(2)])
+    ref = oracle.ball_query(r, ns, xyz, new_xyz)
+    x, c = dev(xyz), dev(new_xyz)
+    srt = ops.c.sort_points_x(x)
+    assert srt is not None
+    stride = srt.numel() // 2
+    for sc in range(2):  # binned copy: a permutation of the scene, cell starts non-decreasing, x grouped by cell
+        raw = host(srt[sc * stride:(sc + 1) * stride])
+        pts = raw[:N * 16].view(np.float32).reshape(N, 4)
+        np.testing.assert_array_equal(np.sort(pts[:, 3].view(np.int32)), np.arange(N))
+        np.testing.assert_array_equal(pts[:, :3], xyz[sc][pts[:, 3].view(np.int32)])
+        start = raw[N * 16 + 16:N * 16 + 16 + 2049 * 4].view(np.int32)
+        assert start[0] == 0 and start[-1] == N and (np.diff(start) >= 0).all()
+        cell_of = np.searchsorted(start, np.arange(N), side="right") - 1
+        xmax_per_cell = np.maximum.accumulate(np.where(np.diff(start) > 0, np.maximum.reduceat(
+            pts[:, 0], np.minimum(start[:-1], N - 1)), -np.inf))
+        assert (pts[:, 0] >= np.concatenate([[-np.inf], xmax_per_cell[:-1]])[cell_of] - 1e-3).all()
+    a = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
+    bb = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, a, srt)
+    ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, bb, None)
+    np.testing.assert_array_equal(host(a), ref)
+    np.testing.assert_array_equal(host(bb), ref)
+
+
 def test_ball_query_no_hit_rows_untouched(ops, oracle):
     xyz = synth.uniform_cloud(300, 5)[None, :, :3].copy()
     far = (xyz[:, :10] + np.float32(1000.0)).copy()

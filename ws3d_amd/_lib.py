@@ -25,10 +25,12 @@ SIGNATURES = {
     "ws3d_furthest_point_sampling_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_sorted_points_bytes": (_sz, [_i, _i]),
+    "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

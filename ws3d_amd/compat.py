@@ -102,13 +102,33 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
     return 1
 
 
-def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor):
-    """ball_query.cpp:14-25"""
-    dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor)
+SORTED_MIN_N = 2048  # below this the LDS-tiled brute-force scan is already cheap
+
+
+def sort_points_x(xyz):
+    """(B,N,3) -> opaque uint8 buffer (per scene: N float4 {x,y,z,bits(index)} binned by x, a
+    header and a cell-start table), or None when the x-binned path does not apply (N < 2048 or
+    N > 16384).  ws3d extension."""
+    dev = _dev(xyz)
+    _f32(xyz, "xyz")
+    b, n = xyz.size(0), xyz.size(1)
+    lib = _lib.load()
+    nbytes = lib.ws3d_sorted_points_bytes(b, n)
+    if n < SORTED_MIN_N or nbytes == 0:
+        return None
+    out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_sort_points_x(b, n, _p(xyz), _p(out), _stream()), "sort_points_x")
+    return out
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz=None):
+    """ball_query.cpp:14-25 (sorted_xyz: optional output of sort_points_x for this xyz)"""
+    dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz)
     _f32(xyz_tensor, "xyz"); _f32(new_xyz_tensor, "new_xyz"); _i32(idx_tensor, "idx")
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_ball_query(b, n, m, float(radius), nsample, _p(new_xyz_tensor),
-                                           _p(xyz_tensor), _p(idx_tensor), _stream()), "ball_query")
+                                           _p(xyz_tensor), _p(idx_tensor), _p(sorted_xyz), _stream()), "ball_query")
     return 1
 
 
@@ -133,14 +153,14 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_te
     return 1
 
 
-def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features, idx_out, out):
+def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features, idx_out, out, sorted_xyz=None):
     """fused a5 (ws3d extension)"""
-    dev = _dev(xyz, new_xyz, features, idx_out, out)
+    dev = _dev(xyz, new_xyz, features, idx_out, out, sorted_xyz)
     _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_query_and_group(b, n, m, c, float(radius), nsample, int(bool(use_xyz)),
                                                 _p(xyz), _p(new_xyz), _p(features), _p(idx_out), _p(out),
-                                                _stream()), "query_and_group")
+                                                _p(sorted_xyz), _stream()), "query_and_group")
     return 1
 
 

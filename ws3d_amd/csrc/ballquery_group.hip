@@ -19,6 +19,51 @@
 
 namespace ws3d {
 
+// Shared epilogue: NC centres' padded neighbour rows (LDS) -> idx tensor and/or the fused
+// (B, 3+C, M, ns) grouped tensor, coalesced along (m, s).
+template <typename IDX, bool FUSED, int NT, int NC>
+__device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, int c_feat, int nsample,
+                                        int use_xyz, const float *__restrict__ xyz /* scene base */,
+                                        const float *__restrict__ features, int32_t *__restrict__ idx_out,
+                                        float *__restrict__ out, const IDX *rows, int rstride,
+                                        const int *cnt_s, const float4 *cen) {
+    const int total_e = NC * nsample;
+    if (!FUSED) {
+        // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44)
+        int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
+        for (int e = tid; e < total_e; e += NT) {
+            const int c = e / nsample, s = e - c * nsample;
+            if (m0 + c < m && cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+        }
+        return;
+    }
+    if (idx_out) {
+        int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
+        for (int e = tid; e < total_e; e += NT) {
+            const int c = e / nsample, s = e - c * nsample;
+            if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+        }
+    }
+    const int c_xyz = use_xyz ? 3 : 0;
+    const int c_out = c_xyz + c_feat;
+    const size_t plane = (size_t)m * nsample;
+    float *ob = out + (size_t)b * c_out * plane + (size_t)m0 * nsample;
+    const float *fb = features ? features + (size_t)b * c_feat * n : nullptr;
+    for (int e = tid; e < total_e; e += NT) {
+        const int c = e / nsample, s = e - c * nsample;
+        if (m0 + c >= m) continue;
+        const int id = (int)rows[(size_t)c * rstride + s];
+        if (use_xyz) {
+            const float4 ce = cen[c];
+            const float *p = xyz + (size_t)id * 3;
+            ob[e] = p[0] - ce.x;                 // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
+            ob[plane + e] = p[1] - ce.y;
+            ob[2 * plane + e] = p[2] - ce.z;
+        }
+        for (int ch = 0; ch < c_feat; ++ch) ob[(size_t)(c_xyz + ch) * plane + e] = fb[(size_t)ch * n + id];
+    }
+}
+
 constexpr int BQ_TILE = 256;  // points per wave-private LDS tile
 constexpr int BQ_NW = 4;      // waves per workgroup: they split the scene's point range
 
@@ -115,42 +160,191 @@ __global__ __launch_bounds__(64 * BQ_NW) void ball_query_kernel(int n, int m, in
     }
     __syncthreads();
 
-    constexpr int NT = 64 * BQ_NW;
-    const int total_e = 64 * nsample;
-    if (!FUSED) {
-        // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44)
-        int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
-        for (int e = tid; e < total_e; e += NT) {
-            const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m && cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
-        }
-        return;
+    bq_emit<IDX, FUSED, 64 * BQ_NW, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out,
+                                         rows, rstride, cnt_s, cen);
+}
+
+// ----------------------------------------------------------------------------------------
+// x-binned ball query.  A per-scene copy of the points counting-sorted into BQS_CELLS uniform
+// x cells (float4 {x,y,z,index} + a cell-start table) turns the O(N) scan per centre into a scan
+// of the cells overlapping |x - cx| < r only (r=0.1 in an 80 m scene: ~1/400 of the points).
+// The slab arrives in arbitrary order, so each lane keeps the nsample SMALLEST indices seen
+// (insertion into its sorted LDS row) -- exactly the reference's "first nsample by index" set;
+// distance test, padding and no-hit rules are unchanged, so the result is bit-identical to the
+// brute-force scan (and independent of the order inside a cell).  Slabs longer than
+// BQS_MAX_SLAB (pathological density) fall back to the ordered full scan for that lane.
+constexpr int BQS_MAX_SLAB = 3072;
+constexpr int SORT_MAX_N = 16384;
+constexpr int BQS_CELLS = 2048;
+
+struct BinHeader { float xmin, inv_w; int n, pad; };   // 16 bytes, follows the float4 array
+
+__host__ __device__ inline size_t bin_scene_stride(int n) {
+    return (size_t)n * 16 + sizeof(BinHeader) + (((size_t)(BQS_CELLS + 1) * 4 + 15) / 16) * 16;
+}
+
+// monotone non-decreasing in x for finite x; NaN -> cell 0 (a NaN point can never be a hit)
+__device__ __forceinline__ int x_cell(float x, float xmin, float inv_w) {
+    const float t = (x - xmin) * inv_w;
+    int c = t > 0.f ? (t < (float)(BQS_CELLS - 1) ? (int)t : BQS_CELLS - 1) : 0;
+    return c;
+}
+
+// one workgroup per scene: min/max of x, LDS histogram, exclusive scan, scatter
+__global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *__restrict__ xyz,
+                                                            char *__restrict__ ws) {
+    __shared__ int hist[BQS_CELLS];
+    __shared__ int wsum[16];
+    __shared__ float red_min[16], red_max[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    xyz += (size_t)b * n * 3;
+    char *base = ws + (size_t)b * bin_scene_stride(n);
+    float4 *sorted = reinterpret_cast<float4 *>(base);
+    BinHeader *hdr = reinterpret_cast<BinHeader *>(base + (size_t)n * 16);
+    int *start = reinterpret_cast<int *>(base + (size_t)n * 16 + sizeof(BinHeader));
+
+    float mn = INFINITY, mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float x = xyz[(size_t)i * 3];
+        if (fabsf(x) < INFINITY) { mn = fminf(mn, x); mx = fmaxf(mx, x); }  // finite only
     }
-    if (idx_out) {
-        int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
-        for (int e = tid; e < total_e; e += NT) {
-            const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (lane == 0) { red_min[w] = mn; red_max[w] = mx; }
+    for (int i = tid; i < BQS_CELLS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    mn = red_min[0]; mx = red_max[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) { mn = fminf(mn, red_min[i]); mx = fmaxf(mx, red_max[i]); }
+    const float xmin = mn <= mx ? mn : 0.f;
+    const float width = mn <= mx ? (mx - mn) : 0.f;
+    const float inv_w = width > 0.f ? (float)BQS_CELLS / width : 0.f;
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[x_cell(xyz[(size_t)i * 3], xmin, inv_w)], 1);
+    __syncthreads();
+    // exclusive scan of 2048 counters: 2 per thread, wave scan + cross-wave offsets
+    const int a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
+    int v = a0 + a1;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    const int excl = off + v - (a0 + a1);
+    __syncthreads();
+    hist[2 * tid] = excl;            // becomes the running scatter cursor
+    hist[2 * tid + 1] = excl + a0;
+    start[2 * tid] = excl;
+    start[2 * tid + 1] = excl + a0;
+    if (tid == 0) { start[BQS_CELLS] = n; hdr->xmin = xmin; hdr->inv_w = inv_w; hdr->n = n; hdr->pad = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float *p = xyz + (size_t)i * 3;
+        const int pos = atomicAdd(&hist[x_cell(p[0], xmin, inv_w)], 1);
+        sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+    }
+}
+
+// One workgroup = 64 centres (one per lane) x 4 waves; wave j scans the j-th quarter of every
+// centre's slab and keeps its own "nsample smallest indices" row; wave 0 then 4-way merges.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, int c_feat, float radius,
+                                                                int nsample, int use_xyz,
+                                                                const float *__restrict__ xyz,
+                                                                const char *__restrict__ ws,
+                                                                const float *__restrict__ new_xyz,
+                                                                const float *__restrict__ features,
+                                                                int32_t *__restrict__ idx_out,
+                                                                float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
+    int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 4 * 64 (partial counts), then [0,64) = final
+    uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 256);        // final rows: 64 * rstride
+    const int rstride = nsample + 1;
+    uint16_t *part = rows + 64 * rstride;                              // partial rows: 4 * 64 * rstride
+
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.x * 64;
+    const int mi = m0 + lane;
+    const bool active = mi < m;
+    xyz += (size_t)b * n * 3;
+    const char *base = ws + (size_t)b * bin_scene_stride(n);
+    const float4 *sorted = reinterpret_cast<const float4 *>(base);
+    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)n * 16);
+    const int *start = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader));
+    new_xyz += (size_t)b * m * 3;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    if (active) { cx = new_xyz[mi * 3 + 0]; cy = new_xyz[mi * 3 + 1]; cz = new_xyz[mi * 3 + 2]; }
+    if (w == 0) cen[lane] = make_float4(cx, cy, cz, 0.f);
+    __syncthreads();
+
+    const float radius2 = radius * radius;
+    const float rabs = fabsf(radius);
+    uint16_t *row = part + (size_t)(w * 64 + lane) * rstride;
+    int cnt = 0;
+    auto insert = [&](const int id) {  // keep the nsample smallest indices, ascending
+        if (cnt == nsample) {
+            if (id >= (int)row[nsample - 1]) return;
+            --cnt;
+        }
+        int pos = cnt;
+        while (pos > 0 && (int)row[pos - 1] > id) { row[pos] = row[pos - 1]; --pos; }
+        row[pos] = (uint16_t)id;
+        ++cnt;
+    };
+    if (active && cx == cx) {
+        // cells overlapping |x - cx| < r: x_cell is monotone, one extra cell each side absorbs the
+        // rounding of cx -+ r (cell width >> 1 ulp of x)
+        const int c_lo = max(0, x_cell(cx - rabs, hdr.xmin, hdr.inv_w) - 1);
+        const int c_hi = min(BQS_CELLS - 1, x_cell(cx + rabs, hdr.xmin, hdr.inv_w) + 1);
+        const int k0 = start[c_lo], kend = start[c_hi + 1];
+        if (kend - k0 <= BQS_MAX_SLAB) {
+            const int q = (kend - k0 + 3) >> 2;               // this wave's quarter of the slab
+            int k = min(kend, k0 + w * q);
+            const int ke = min(kend, k + q);
+            for (; k < ke; ++k) {
+                const float4 p = sorted[k];
+                const float dx = cx - p.x;
+                if (fabsf(dx) < rabs) {
+                    const float d2 = sqdist3(dx, cy - p.y, cz - p.z);
+                    if (d2 < radius2) insert(__float_as_int(p.w));
+                }
+            }
+        } else if (w == 0) {
+            // pathological slab: ordered full scan with early exit (the reference's own loop)
+            for (int q = 0; q < n && cnt < nsample; ++q) {
+                const float d2 = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]);
+                if (d2 < radius2) { row[cnt] = (uint16_t)q; ++cnt; }
+            }
         }
     }
-    const int c_xyz = use_xyz ? 3 : 0;
-    const int c_out = c_xyz + c_feat;
-    const size_t plane = (size_t)m * nsample;
-    float *ob = out + (size_t)b * c_out * plane + (size_t)m0 * nsample;
-    const float *fb = features ? features + (size_t)b * c_feat * n : nullptr;
-    for (int e = tid; e < total_e; e += NT) {
-        const int c = e / nsample, s = e - c * nsample;
-        if (m0 + c >= m) continue;
-        const int id = (int)rows[(size_t)c * rstride + s];
-        if (use_xyz) {
-            const float4 ce = cen[c];
-            const float *p = xyz + (size_t)id * 3;
-            ob[e] = p[0] - ce.x;                 // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
-            ob[plane + e] = p[1] - ce.y;
-            ob[2 * plane + e] = p[2] - ce.z;
+    cnt_s[w * 64 + lane] = cnt;
+    __syncthreads();
+    if (w == 0) {
+        // 4-way merge of the ascending partial rows: the nsample smallest indices overall
+        const uint16_t *r0 = part + (size_t)(0 * 64 + lane) * rstride, *r1 = part + (size_t)(1 * 64 + lane) * rstride;
+        const uint16_t *r2 = part + (size_t)(2 * 64 + lane) * rstride, *r3 = part + (size_t)(3 * 64 + lane) * rstride;
+        const int c0 = cnt_s[lane], c1 = cnt_s[64 + lane], c2 = cnt_s[128 + lane], c3 = cnt_s[192 + lane];
+        int i0 = 0, i1 = 0, i2 = 0, i3 = 0, total = 0;
+        uint16_t *dst = rows + (size_t)lane * rstride;
+        while (total < nsample) {
+            const int v0 = i0 < c0 ? (int)r0[i0] : 0x7fffffff, v1 = i1 < c1 ? (int)r1[i1] : 0x7fffffff;
+            const int v2 = i2 < c2 ? (int)r2[i2] : 0x7fffffff, v3 = i3 < c3 ? (int)r3[i3] : 0x7fffffff;
+            const int mn = min(min(v0, v1), min(v2, v3));
+            if (mn == 0x7fffffff) break;
+            dst[total++] = (uint16_t)mn;
+            i0 += (v0 == mn); i1 += (v1 == mn); i2 += (v2 == mn); i3 += (v3 == mn);
         }
-        for (int ch = 0; ch < c_feat; ++ch) ob[(size_t)(c_xyz + ch) * plane + e] = fb[(size_t)ch * n + id];
+        const uint16_t first = total > 0 ? dst[0] : (uint16_t)0;
+        for (int s = total; s < nsample; ++s) dst[s] = first;
     }
+    __syncthreads();
+    if (w == 0) {
+        // final count AFTER every lane has read the partial counts (cnt_s[0..63] is reused)
+        const int total = min(nsample, cnt_s[lane] + cnt_s[64 + lane] + cnt_s[128 + lane] + cnt_s[192 + lane]);
+        cnt_s[lane] = active ? total : 0;
+    }
+    __syncthreads();
+    bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows,
+                                      rstride, cnt_s, cen);
 }
 
 static size_t bq_smem(int nsample, size_t idx_bytes) {
@@ -161,7 +355,7 @@ static size_t bq_smem(int nsample, size_t idx_bytes) {
 template <bool FUSED>
 static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
                      const float *xyz, const float *new_xyz, const float *features, int32_t *idx,
-                     float *out, hipStream_t st, const char *what) {
+                     float *out, const void *sorted, hipStream_t st, const char *what) {
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0 || !xyz || !new_xyz) {
         set_error("%s: invalid argument (b=%d n=%d m=%d nsample=%d c=%d)", what, b, n, m, nsample, c);
         return WS3D_E_INVALID;
@@ -172,6 +366,19 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         return WS3D_E_INVALID;
     }
     if (b == 0 || m == 0) return WS3D_OK;
+    if (sorted && n <= SORT_MAX_N && b <= 65535) {
+        const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
+                              sizeof(uint16_t) * (size_t)5 * 64 * (nsample + 1);
+        if (smem_s <= 150 * 1024) {
+            if (smem_s > 64 * 1024)
+                (void)hipFuncSetAttribute((const void *)ball_query_sorted_kernel<FUSED>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+            hipLaunchKernelGGL((ball_query_sorted_kernel<FUSED>), dim3((m + 63) / 64, b), dim3(256), smem_s, st, n,
+                               m, c, radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted),
+                               new_xyz, features, idx, out);
+            return check_launch(what);
+        }
+    }
     const bool small_idx = n <= 65536;  // neighbour lists held as uint16 in LDS
     const size_t smem = bq_smem(nsample, small_idx ? 2 : 4);
     if (smem > 160 * 1024 || b > 65535) {
@@ -250,18 +457,35 @@ static int group_launch(bool grad, int b, int c, int n, int npoints, int nsample
 
 }  // namespace ws3d
 
+extern "C" size_t ws3d_sorted_points_bytes(int b, int n) {
+    if (b <= 0 || n <= 0 || n > ws3d::SORT_MAX_N) return 0;
+    return (size_t)b * ws3d::bin_scene_stride(n);
+}
+
+extern "C" int ws3d_sort_points_x(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || n > SORT_MAX_N || !xyz || !sorted) {
+        set_error("ws3d_sort_points_x: invalid argument (b=%d n=%d; n must be <= %d)", b, n, SORT_MAX_N);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0) return WS3D_OK;
+    hipLaunchKernelGGL(bin_points_x_kernel, dim3(b), dim3(1024), 0, as_stream(stream), n, xyz,
+                       reinterpret_cast<char *>(sorted));
+    return check_launch("ws3d_sort_points_x");
+}
+
 extern "C" int ws3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
-                               const float *xyz, int32_t *idx, ws3d_stream_t stream) {
-    return ws3d::bq_launch<false>(b, n, m, 0, radius, nsample, 0, xyz, new_xyz, nullptr, idx, nullptr,
+                               const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream) {
+    return ws3d::bq_launch<false>(b, n, m, 0, radius, nsample, 0, xyz, new_xyz, nullptr, idx, nullptr, sorted,
                                   ws3d::as_stream(stream), "ws3d_ball_query");
 }
 
 extern "C" int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample,
                                     int use_xyz, const float *xyz, const float *new_xyz,
                                     const float *features, int32_t *idx_out, float *out,
-                                    ws3d_stream_t stream) {
+                                    const void *sorted, ws3d_stream_t stream) {
     return ws3d::bq_launch<true>(b, n, m, features ? c : 0, radius, nsample, use_xyz, xyz, new_xyz,
-                                 features, idx_out, out, ws3d::as_stream(stream), "ws3d_query_and_group");
+                                 features, idx_out, out, sorted, ws3d::as_stream(stream), "ws3d_query_and_group");
 }
 
 extern "C" int ws3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,

@@ -32,8 +32,13 @@ class _PointnetSAModuleBase(nn.Module):
         if new_xyz is None and self.npoint is not None:
             _, new_xyz = pointnet2_utils.furthest_point_sample_gather(xyz, self.npoint)
         pooled = []
+        # one x-sorted copy of the points serves every scale of the layer
+        sorted_xyz = pointnet2_utils.sort_points_x(xyz) if self.npoint is not None else None
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped = grouper(xyz, new_xyz, features)          # (B, C, npoint, nsample)
+            if isinstance(grouper, pointnet2_utils.QueryAndGroup):
+                grouped = grouper(xyz, new_xyz, features, sorted_xyz=sorted_xyz)   # (B, C, npoint, nsample)
+            else:
+                grouped = grouper(xyz, new_xyz, features)
             grouped = mlp(grouped)                              # (B, mlp[-1], npoint, nsample)
             if self.pool_method == 'max_pool':
                 grouped = F.max_pool2d(grouped, kernel_size=[1, grouped.size(3)])

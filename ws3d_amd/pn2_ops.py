@@ -172,7 +172,7 @@ class BallQuery(Function):
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
-        _C.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        _C.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx, _C.sort_points_x(xyz))
         ctx.mark_non_differentiable(idx)
         return idx
 
@@ -189,14 +189,16 @@ class _QueryAndGroupFused(Function):
     the saved neighbour lists (what GroupingOperation.backward does in the reference)."""
 
     @staticmethod
-    def forward(ctx, radius, nsample, use_xyz, xyz, new_xyz, features):
+    def forward(ctx, radius, nsample, use_xyz, xyz, new_xyz, features, sorted_xyz=None):
         B, N, _ = xyz.size()
         M = new_xyz.size(1)
         C = 0 if features is None else features.size(1)
         cx = 3 if use_xyz else 0
         idx = _new((B, M, nsample), torch.int32, xyz)
         out = _new((B, cx + C, M, nsample), torch.float32, xyz)
-        _C.query_and_group(B, N, M, C, radius, nsample, use_xyz, xyz, new_xyz, features, idx, out)
+        if sorted_xyz is None:
+            sorted_xyz = _C.sort_points_x(xyz)
+        _C.query_and_group(B, N, M, C, radius, nsample, use_xyz, xyz, new_xyz, features, idx, out, sorted_xyz)
         ctx.saved = (idx, N, cx, C)
         return out, idx
 
@@ -209,17 +211,24 @@ class _QueryAndGroupFused(Function):
             g = grad_out[:, cx:].contiguous()
             grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
             _C.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
-        return None, None, None, None, None, grad_features
+        return None, None, None, None, None, grad_features, None
+
+
+def sort_points_x(xyz: torch.Tensor):
+    """Per-scene x-sorted copy of xyz (or None when it does not pay): pass it to several
+    ``query_and_group`` / ``QueryAndGroup`` calls on the same xyz (multi-scale grouping)."""
+    return _C.sort_points_x(xyz)
 
 
 def query_and_group(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,
-                    features: torch.Tensor = None, use_xyz: bool = True, return_idx: bool = False):
+                    features: torch.Tensor = None, use_xyz: bool = True, return_idx: bool = False,
+                    sorted_xyz: torch.Tensor = None):
     """One kernel for ball_query + grouping(xyz) - centre + grouping(features) + cat:
     (B, 3+C, npoint, nsample) with channel order [dx,dy,dz, features...]."""
     assert xyz.is_contiguous() and new_xyz.is_contiguous()
     assert features is None or features.is_contiguous()
     assert use_xyz or features is not None, "Cannot have not features and not use xyz as a feature!"
-    out, idx = _QueryAndGroupFused.apply(radius, nsample, use_xyz, xyz, new_xyz, features)
+    out, idx = _QueryAndGroupFused.apply(radius, nsample, use_xyz, xyz, new_xyz, features, sorted_xyz)
     return (out, idx) if return_idx else out
 
 
@@ -229,10 +238,13 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None,
+                sorted_xyz: torch.Tensor = None):
         """xyz (B,N,3), new_xyz (B,npoint,3), features (B,C,N) -> (B,3+C,npoint,nsample)
-        (pointnet2_utils.py:241-264)."""
-        return query_and_group(self.radius, self.nsample, xyz, new_xyz, features, self.use_xyz)
+        (pointnet2_utils.py:241-264).  sorted_xyz: optional ``sort_points_x(xyz)`` shared by the
+        scales of an MSG layer."""
+        return query_and_group(self.radius, self.nsample, xyz, new_xyz, features, self.use_xyz,
+                               sorted_xyz=sorted_xyz)
 
 
 class GroupAll(nn.Module):
