@@ -37,7 +37,7 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
         }
         return;
     }
-    if (idx_out) {
+    if (idx_out && blockIdx.z == 0) {
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
         for (int e = tid; e < total_e; e += NT) {
             const int c = e / nsample, s = e - c * nsample;
@@ -49,18 +49,22 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
     const size_t plane = (size_t)m * nsample;
     float *ob = out + (size_t)b * c_out * plane + (size_t)m0 * nsample;
     const float *fb = features ? features + (size_t)b * c_feat * n : nullptr;
+    // gridDim.z workgroups share a tile of centres: each repeats the (cheap) search and emits
+    // its own slice of the feature channels, so wide layers (C = 256..512) fill the chip
+    const int chunk = (c_feat + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int ch_lo = (int)blockIdx.z * chunk, ch_hi = min(c_feat, ch_lo + chunk);
     for (int e = tid; e < total_e; e += NT) {
         const int c = e / nsample, s = e - c * nsample;
         if (m0 + c >= m) continue;
         const int id = (int)rows[(size_t)c * rstride + s];
-        if (use_xyz) {
+        if (use_xyz && blockIdx.z == 0) {
             const float4 ce = cen[c];
             const float *p = xyz + (size_t)id * 3;
             ob[e] = p[0] - ce.x;                 // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
             ob[plane + e] = p[1] - ce.y;
             ob[2 * plane + e] = p[2] - ce.z;
         }
-        for (int ch = 0; ch < c_feat; ++ch) ob[(size_t)(c_xyz + ch) * plane + e] = fb[(size_t)ch * n + id];
+        for (int ch = ch_lo; ch < ch_hi; ++ch) ob[(size_t)(c_xyz + ch) * plane + e] = fb[(size_t)ch * n + id];
     }
 }
 
@@ -366,6 +370,12 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         return WS3D_E_INVALID;
     }
     if (b == 0 || m == 0) return WS3D_OK;
+    // channel split (fused only): enough workgroups to fill 256 CUs, at least 8 channels each
+    int gz = 1;
+    if (FUSED && c >= 16) {
+        const long tiles = (long)b * ((m + 63) / 64);
+        while (gz < 64 && tiles * gz < 1024 && c / (gz * 2) >= 8) gz *= 2;
+    }
     if (sorted && n <= SORT_MAX_N && b <= 65535) {
         const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
                               sizeof(uint16_t) * (size_t)5 * 64 * (nsample + 1);
@@ -373,7 +383,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
             if (smem_s > 64 * 1024)
                 (void)hipFuncSetAttribute((const void *)ball_query_sorted_kernel<FUSED>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
-            hipLaunchKernelGGL((ball_query_sorted_kernel<FUSED>), dim3((m + 63) / 64, b), dim3(256), smem_s, st, n,
+            hipLaunchKernelGGL((ball_query_sorted_kernel<FUSED>), dim3((m + 63) / 64, b, gz), dim3(256), smem_s, st, n,
                                m, c, radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted),
                                new_xyz, features, idx, out);
             return check_launch(what);
@@ -385,7 +395,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         set_error("%s: nsample=%d needs %zu B of LDS (> 160 KiB) or batch > 65535", what, nsample, smem);
         return WS3D_E_UNSUPPORTED;
     }
-    dim3 grid((m + 63) / 64, b);
+    dim3 grid((m + 63) / 64, b, gz);
     if (small_idx) {
         if (smem > 64 * 1024)
             (void)hipFuncSetAttribute((const void *)ball_query_kernel<uint16_t, FUSED>,

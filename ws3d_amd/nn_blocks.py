@@ -63,13 +63,8 @@ class _ConvBlock(nn.Sequential):
         self._pointwise = (not preact and not instance_norm and name == "" and all(k == 1 for k in ks)
                            and all(v == 1 for v in st) and all(v == 0 for v in pd))
 
-    def forward(self, x):
-        """Inference fast path for the 1x1 case: conv + eval-mode BatchNorm folded into ONE
-        (O,C) x (B,C,L) GEMM (+bias, +ReLU) on rocBLAS.  MIOpen resolves several of these 1x1
-        NCHW fp32 shapes to its naive direct-convolution kernel on gfx950 (56 % of a Stage-1
-        forward in the round-1 profile); training keeps the stock module path."""
-        if self.training or not self._pointwise or torch.is_grad_enabled() and x.requires_grad:
-            return super().forward(x)
+    def _folded(self):
+        """(w (O,C), shift (O,) or None, activation) with eval-mode BatchNorm folded in"""
         conv = self.conv
         w = conv.weight.reshape(conv.weight.shape[0], -1)
         shift = conv.bias
@@ -79,10 +74,35 @@ class _ConvBlock(nn.Sequential):
             scale = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
             w = w * scale[:, None]
             shift = bn.bias - bn.running_mean * scale + (0 if shift is None else shift * scale)
+        return w, shift, getattr(self, "activation", None)
+
+    def fast_path_ok(self, x):
+        return not (self.training or not self._pointwise or (torch.is_grad_enabled() and x.requires_grad))
+
+    def forward_then_max(self, x):
+        """y = max over the last axis of this block's output, computed as
+        act(max_s(W x_s) + shift): bias add and ReLU are monotone non-decreasing and rounding is
+        monotone, so they commute with the max EXACTLY -- and run on a tensor nsample times
+        smaller.  x (B,C,M,S) -> (B,O,M)."""
+        w, shift, act = self._folded()
+        assert act is None or isinstance(act, nn.ReLU)
+        B, C, M, S = x.shape
+        y = torch.matmul(w, x.reshape(B, C, M * S)).reshape(B, -1, M, S).amax(dim=3)
+        if shift is not None:
+            y = y + shift[None, :, None]
+        return torch.relu_(y) if act is not None else y
+
+    def forward(self, x):
+        """Inference fast path for the 1x1 case: conv + eval-mode BatchNorm folded into ONE
+        (O,C) x (B,C,L) GEMM (+bias, +ReLU) on rocBLAS.  MIOpen resolves several of these 1x1
+        NCHW fp32 shapes to its naive direct-convolution kernel on gfx950 (56 % of a Stage-1
+        forward in the round-1 profile); training keeps the stock module path."""
+        if not self.fast_path_ok(x):
+            return super().forward(x)
+        w, shift, act = self._folded()
         y = torch.matmul(w, x.reshape(x.shape[0], x.shape[1], -1))
         if shift is not None:
             y = y + shift[None, :, None]
-        act = getattr(self, "activation", None)
         if act is not None:
             y = torch.relu_(y) if isinstance(act, nn.ReLU) else act(y)
         return y.reshape(x.shape[0], -1, *x.shape[2:])

@@ -39,6 +39,14 @@ class _PointnetSAModuleBase(nn.Module):
                 grouped = grouper(xyz, new_xyz, features, sorted_xyz=sorted_xyz)   # (B, C, npoint, nsample)
             else:
                 grouped = grouper(xyz, new_xyz, features)
+            last = mlp[len(mlp) - 1]
+            if (self.pool_method == 'max_pool' and hasattr(last, "forward_then_max") and last.fast_path_ok(grouped)
+                    and isinstance(getattr(last, "activation", None), (nn.ReLU, type(None)))):
+                # inference: pool BEFORE the last layer's bias+ReLU (exactly equal, nsample x less work)
+                for i in range(len(mlp) - 1):
+                    grouped = mlp[i](grouped)
+                pooled.append(last.forward_then_max(grouped))
+                continue
             grouped = mlp(grouped)                              # (B, mlp[-1], npoint, nsample)
             if self.pool_method == 'max_pool':
                 grouped = F.max_pool2d(grouped, kernel_size=[1, grouped.size(3)])
