@@ -53,6 +53,35 @@ __global__ void probe(float *out, long long *cyc, float seed) {
             if (lane == 0) lds[tid >> 6] = v;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             v += lds[(lane & 15)];
+        } else if (MODE == 10) {  // 32x dependent {v_cmp_gt ; v_cndmask value ; v_cndmask index}
+            float best = -1.0f; int bi = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float x = v + (float)(i * 7 % 11);
+                const bool gt = x > best;
+                bi = gt ? i : bi;
+                best = gt ? x : best;
+            }
+            v = best * 0.001f + (float)bi;
+        } else if (MODE == 11) {  // 32x dependent v_max_f32 (same inputs)
+            float best = -1.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float x = v + (float)(i * 7 % 11);
+                asm("v_max_f32 %0, %1, %2" : "=v"(best) : "v"(best), "v"(x));
+            }
+            v = best * 0.001f;
+        } else if (MODE == 12) {  // 32 independent v_cmp_eq -> SGPR masks, scalar OR + ff1
+            unsigned long long any = 0; int slot = 0;
+            const float key = readlane_f(v, 5) + 3.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float x = v + (float)(i * 7 % 11);
+                const unsigned long long mk = __ballot(x == key);
+                slot = (any == 0 && mk != 0) ? i : slot;
+                any |= mk;
+            }
+            v = v * 0.5f + (float)slot + (float)__builtin_ctzll(any | (1ull << 63));
         } else if (MODE == 9) {  // movrel-style dynamic register index (uniform)
             typedef float f16 __attribute__((ext_vector_type(16)));
             f16 a; 
@@ -84,7 +113,7 @@ void run(const char *name, int threads) {
 }
 
 int main() {
-    for (int th : {64, 256, 1024}) {
+    for (int th : {64, 512}) {
         run<0>("16 dependent v_fma", th);
         run<1>("4 DPP max stages (+1 add)", th);
         run<2>("4x readlane->VALU round trips", th);
@@ -95,6 +124,9 @@ int main() {
         run<7>("waitcnt+s_barrier", th);
         run<8>("lane0 write + barrier + read", th);
         run<9>("readfirstlane + movrel index", th);
+        run<10>("32x dep cmp+2cndmask (+32 add)", th);
+        run<11>("32x dep v_max (+32 add)", th);
+        run<12>("32x indep cmp_eq->sgpr + scalar", th);
     }
     return 0;
 }

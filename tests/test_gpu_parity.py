@@ -72,6 +72,37 @@ def test_fps_ties(ops, oracle, case):
                                   oracle.furthest_point_sample(xyz, m))
 
 
+def test_fps_bucket_kernel_subprocess(oracle, tmp_path):
+    """the experimental pruned (bucket) FPS kernel is selected by an env var read once per
+    process: run it in a child and compare with the oracle, incl. heavy duplication (tie rounds)"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(2, 16384, 1024, "lidar", 0.02), (1, 5000, 300, "uniform", 0.0), (1, 12345, 777, "lidar", 0.3)]
+    refs = []
+    for i, (B, N, M, kind, dup) in enumerate(cases):
+        pcs = synth.make_batch(kind, B, N, 7, dup_frac=dup)[:, :, :3].copy()
+        np.save(tmp_path / f"in{i}.npy", pcs)
+        refs.append(oracle.furthest_point_sample(pcs, M))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import pn2_ops
+        for i, M in enumerate({[c[2] for c in cases]!r}):
+            x = torch.from_numpy(np.load({str(tmp_path)!r} + f"/in{{i}}.npy")).cuda()
+            idx, new_xyz = pn2_ops.furthest_point_sample_gather(x, M)
+            np.save({str(tmp_path)!r} + f"/out{{i}}.npy", idx.cpu().numpy())
+            np.save({str(tmp_path)!r} + f"/xyz{{i}}.npy", new_xyz.cpu().numpy())
+    """)
+    r = subprocess.run([sys.executable, "-B", "-c", code], env=dict(os.environ, WS3D_FPS_BUCKET="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, ref in enumerate(refs):
+        np.testing.assert_array_equal(np.load(tmp_path / f"out{i}.npy"), ref)
+        pcs = np.load(tmp_path / f"in{i}.npy")
+        np.testing.assert_array_equal(np.load(tmp_path / f"xyz{i}.npy"),
+                                      np.stack([pcs[b][ref[b]] for b in range(pcs.shape[0])]))
+
+
 def test_fps_temp_contract(ops, oracle):
     """the wrapper-level entry point takes the caller's temp (pre-filled 1e10) and leaves the
     final running min-distance in it, like the reference kernel does (sampling_gpu.cu:134-135)."""

@@ -74,10 +74,21 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 }
 
 // max over the whole wave, wave-uniform result
+#ifndef WS3D_WAVE_MAX_BCAST
+#define WS3D_WAVE_MAX_BCAST 1
+#endif
 __device__ __forceinline__ float wave_max(float v) {
     v = row16_max(v);
+#if WS3D_WAVE_MAX_BCAST
+    // fold the four row maxima in the VALU: row_bcast:15 (rows 1,3 <- lane 15 of rows 0,2), then
+    // row_bcast:31 (rows 2,3 <- lane 31); lane 63 ends with the wave maximum -> ONE v_readlane
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return readlane_f(v, 63);
+#else
     const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
     return max_f32(max_f32(a, b), max_f32(c, d));
+#endif
 }
 
 // Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier).

@@ -35,6 +35,24 @@
 
 #include "common.h"
 
+#ifndef WS3D_FPS_PACKED
+#define WS3D_FPS_PACKED 1
+#endif
+#ifndef WS3D_FPS_TREE
+#define WS3D_FPS_TREE 1
+#endif
+
+#ifdef WS3D_FPS_PROF
+__device__ long long g_fps_prof[16 * 8];
+#define PROF_DECL long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_last = clock64();
+#define PROF(i) { const long long now_ = clock64(); prof_acc[i] += now_ - prof_last; prof_last = now_; }
+#define PROF_STORE if (lane == 0 && blockIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) g_fps_prof[w * 8 + i_] = prof_acc[i_]; }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_STORE
+#endif
+
 namespace ws3d {
 
 __device__ __forceinline__ int bitrev_bits(int v, int bits) {
@@ -48,6 +66,25 @@ template <int N> __device__ __forceinline__ float vec_get(const vecf<N> &v, int 
 template <> __device__ __forceinline__ float vec_get<1>(const vecf<1> &v, int) { return v; }
 template <int N> __device__ __forceinline__ void vec_set(vecf<N> &v, int i, float x) { v[i] = x; }
 template <> __device__ __forceinline__ void vec_set<1>(vecf<1> &v, int, float x) { v = x; }
+
+// pairwise tournament with compile-time widths only (fully static register indexing)
+template <int W>
+__device__ __forceinline__ void tourney(const float (&v)[W], const int (&i)[W], float &best, int &bslot) {
+    if constexpr (W == 1) {
+        best = v[0];
+        bslot = i[0];
+    } else {
+        float v2[W / 2];
+        int i2[W / 2];
+#pragma unroll
+        for (int s = 0; s < W / 2; ++s) {
+            const bool gt = v[2 * s + 1] > v[2 * s];   // lower slot wins ties
+            v2[s] = gt ? v[2 * s + 1] : v[2 * s];
+            i2[s] = gt ? i[2 * s + 1] : i[2 * s];
+        }
+        tourney<W / 2>(v2, i2, best, bslot);
+    }
+}
 
 template <int PPT, int NT>
 __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ xyz,
@@ -92,27 +129,72 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
         if (new_xyz) { new_xyz[0] = ox; new_xyz[1] = oy; new_xyz[2] = oz; }
     }
 
+    PROF_DECL
     for (int j = 1; j < m; ++j) {
+        PROF(0)
         float best = -1.0f;
         int bslot = 0;
+        if constexpr (PPT >= 2 && NT == 64 && WS3D_FPS_PACKED) {  // pays only for the single-wave shapes (measured)
+            // two points per instruction for the distance (v_pk_add/mul/fma_f32: same IEEE
+            // results per element as the scalar forms)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 o_x = {ox, ox}, o_y = {oy, oy}, o_z = {oz, oz};
 #pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, vec_get<PPT>(pz, s) - oz);
-            const float d2 = min_f32(d, t[s]);  // == fminf: t[s] is never NaN
-            t[s] = d2;
-            const bool gt = d2 > best;
-            bslot = gt ? s : bslot;
-            best = gt ? d2 : best;
+            for (int s = 0; s < PPT; s += 2) {
+                const f2 dx = f2{px[s], px[s + 1]} - o_x, dy = f2{py[s], py[s + 1]} - o_y, dz = f2{pz[s], pz[s + 1]} - o_z;
+                const f2 d = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float d2 = min_f32(d[q], t[s + q]);
+                    t[s + q] = d2;
+                    const bool gt = d2 > best;
+                    bslot = gt ? s + q : bslot;
+                    best = gt ? d2 : best;
+                }
+            }
+        } else if constexpr (PPT >= 4 && WS3D_FPS_TREE) {
+            // all distances first (independent), then a pairwise tournament over the slots: the
+            // serial best/bslot recurrence (2 dependent ops per slot) left the SIMD idle ~40 % of
+            // the sweep at 2 waves/SIMD.  Lower slot wins ties at every level (strict '>').
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, vec_get<PPT>(pz, s) - oz);
+                t[s] = min_f32(d, t[s]);  // == fminf: t[s] is never NaN
+            }
+            float tv[PPT / 2];
+            int ti[PPT / 2];
+#pragma unroll
+            for (int s = 0; s < PPT / 2; ++s) {
+                const bool gt = t[2 * s + 1] > t[2 * s];
+                tv[s] = gt ? t[2 * s + 1] : t[2 * s];
+                ti[s] = gt ? 2 * s + 1 : 2 * s;
+            }
+            tourney<PPT / 2>(tv, ti, best, bslot);
+        } else {
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, vec_get<PPT>(pz, s) - oz);
+                const float d2 = min_f32(d, t[s]);  // == fminf: t[s] is never NaN
+                t[s] = d2;
+                const bool gt = d2 > best;
+                bslot = gt ? s : bslot;
+                best = gt ? d2 : best;
+            }
         }
+        PROF(1)
         // ---- wave argmax: lowest lane among the lanes holding the wave maximum
         const float wmax = wave_max(best);
         const uint64_t eq = __ballot(best == wmax);
         const int wl = (int)__builtin_ctzll(eq);
         const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+        PROF(2)
+        // VGPR-indexed moves (s_set_gpr_idx): measured faster than a tree of scalar branches over
+        // statically indexed registers (1.17 vs 1.48 us/step) -- taken branches are expensive here
         const float cx = readlane_f(vec_get<PPT>(px, wslot), wl);
         const float cy = readlane_f(vec_get<PPT>(py, wslot), wl);
         const float cz = readlane_f(vec_get<PPT>(pz, wslot), wl);
         const int kw = (w * 64 + wl) * PPT + wslot;  // tie-order POSITION; -> point index after the loop
+        PROF(3)
 
         if constexpr (NW == 1) {
             ox = cx; oy = cy; oz = cz; old = kw;
@@ -122,7 +204,9 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                 s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
                 s_k[buf][w] = kw;
             }
+            PROF(4)
             lds_barrier();
+            PROF(5)
             const int e = lane & 15;
             const float4 c = s_cand[buf][e];
             const int kc = s_k[buf][e];
@@ -134,6 +218,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
             oy = readlane_f(c.z, sel);
             oz = readlane_f(c.w, sel);
             old = __builtin_amdgcn_readlane(kc, sel);
+            PROF(6)
         }
         if (u == 0) {
             idx[j] = old;
@@ -141,6 +226,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
         }
     }
 
+    PROF_STORE
     // positions -> point indices, off the critical path (thread 0 wrote idx[]; same lane reads)
     __syncthreads();
     for (int j = 1 + u; j < m; j += NT) {
@@ -258,6 +344,9 @@ static void launch_reg(int b, int n, int m, const float *xyz, float *temp, int32
                        n, m, bs, log2bs, S);
 }
 
+int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
+                      int bs, int log2bs, int S, hipStream_t st);  // fps_bucket.hip
+
 static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
                         float *new_xyz, hipStream_t st) {
     if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && m > 0)) {
@@ -270,6 +359,11 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     while ((1 << log2bs) < bs) ++log2bs;
     const int S = (n + bs - 1) / bs;
     const long R = (long)bs * S;  // number of tie-order positions
+    // pruned (bucket) kernel for the large layers; WS3D_FPS_BUCKET=0 keeps the dense kernel (A/B runs)
+    // (experimental, OFF by default: exact, but its per-step chain is not shorter than the dense one)
+    static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : 0;
+    if (use_bucket && n > 4096 && n <= 16384 && m > 1)
+        return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
     if (R <= 64L * 16) {
         const int ppt = (int)((R + 63) / 64);
         if (ppt <= 1) launch_reg<1, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
