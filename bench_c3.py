@@ -69,7 +69,7 @@ class C3:
         from ws3d_amd import compat
         fam = {"furthest_point_sampling_gather": "fps", "query_and_group": "ball_query+group",
                "three_nn_wrapper": "three_nn", "three_interpolate_wrapper": "three_interpolate",
-               "nms_device": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
+               "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
         for fn_name, key in fam.items():
             orig = getattr(compat, fn_name)
 

@@ -163,6 +163,12 @@ WS3D_API int ws3d_nms(int boxes_num, const float *boxes, float thresh, int norma
                       void *workspace, size_t workspace_bytes, int64_t *keep, int32_t *num_keep,
                       ws3d_stream_t stream);
 
+/* The same for a batch of scenes in ONE launch pair: boxes (batch,n,5), keep (batch,n),
+ * num_keep (batch); workspace >= batch * ws3d_nms_workspace_bytes(n).                      */
+WS3D_API int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, float thresh, int normal,
+                              int max_keep, void *workspace, size_t workspace_bytes, int64_t *keep,
+                              int32_t *num_keep, ws3d_stream_t stream);
+
 /* ---------------------------------------------------------------- roipool3d_cuda */
 
 /* forward(xyz,boxes3d,pts_feature,pooled_features,pooled_empty_flag)

@@ -382,6 +382,51 @@ def test_nms_mask_and_keep(ops, oracle, n, thresh, normal, spread):
     np.testing.assert_array_equal(keep_cpu.numpy()[:cnt], ref_keep)
 
 
+def test_nms_batched_and_proposal_stage(ops, oracle):
+    """one launch pair for a batch of scenes == per-scene NMS == oracle; the vectorised proposal
+    stage == a per-scene composition of the reference-named wrappers"""
+    from ws3d_amd import kitti_utils, stage1
+    B, n = 3, 700
+    boxes = np.stack([_bev(n, 10 + b, 6.0)[0] for b in range(B)])
+    scores = np.stack([synth.distinct_scores(n, 20 + b) for b in range(B)])
+    order = np.argsort(-scores, axis=1, kind="stable")
+    sorted_boxes = np.ascontiguousarray(np.take_along_axis(boxes, order[:, :, None], 1))
+    keep, num = ops.c.nms_device_batched(dev(sorted_boxes), 0.5, False, 0)
+    for b in range(B):
+        ref = oracle.nms_sorted(sorted_boxes[b], 0.5, False)
+        assert int(num[b]) == len(ref)
+        np.testing.assert_array_equal(host(keep[b])[:len(ref)], ref)
+    idx, cnt = ops.iou.nms_gpu_padded_batched(dev(boxes), dev(scores), 0.5, 40)
+    for b in range(B):
+        ref = oracle.nms(boxes[b], scores[b], 0.5, False)[:40]
+        assert int(cnt[b]) == len(ref)
+        np.testing.assert_array_equal(host(idx[b])[:len(ref)], ref)
+        assert (host(idx[b])[len(ref):] == -1).all()
+    # proposal stage on a synthetic rpn output
+    rng = np.random.default_rng(0)
+    N = 2048
+    cfg = stage1.RPNConfig(rpn_pre_nms_top_n=1500, rpn_post_nms_top_n=30)
+    pc = synth.make_batch("lidar", 2, N, 55)
+    out = {"backbone_xyz": dev(pc[:, :, :3].copy()),
+           "rpn_reg": dev(rng.standard_normal((2, N, 40)).astype(np.float32)),
+           "rpn_cls": dev((rng.permutation(2 * N).reshape(2, N, 1) / (2 * N) * 8 - 4).astype(np.float32))}
+    pb, ps, pcnt = stage1.proposals_from_rpn(out, cfg)
+    h, w, l = cfg.cls_mean_size
+    for b in range(2):
+        score = torch.sigmoid(out["rpn_cls"][b, :, 0])
+        ctr = stage1.decode_center_target(out["backbone_xyz"][b], out["rpn_reg"][b], cfg.loc_scope, cfg.loc_bin_size)
+        box = torch.stack((ctr[:, 0], out["backbone_xyz"][b, :, 1] + h / 2, ctr[:, 2], torch.full_like(score, h),
+                           torch.full_like(score, w), torch.full_like(score, l),
+                           stage1.synthetic_orientation(N, score.device)), 1)
+        sc, o = torch.topk(score, 1500, sorted=True)
+        box = box[o]
+        k = ops.iou.nms_gpu(kitti_utils.boxes3d_to_bev_torch(box), sc, cfg.rpn_nms_thresh)[:30]
+        assert int(pcnt[b]) == len(k)
+        np.testing.assert_array_equal(host(pb[b, :len(k)]), host(box[k]))
+        np.testing.assert_array_equal(host(ps[b, :len(k)]), host(sc[k]))
+        assert (host(pb[b, len(k):]) == 0).all()
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_errors_are_exceptions_not_exit(ops):
     from ws3d_amd._lib import Ws3dError

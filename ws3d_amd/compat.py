@@ -232,6 +232,23 @@ def nms_device(boxes, thresh, normal=False, max_keep=0):
     return keep, num
 
 
+def nms_device_batched(boxes, thresh, normal=False, max_keep=0):
+    """boxes (B,n,5), every scene score-sorted -> keep (B,n) int64, num (B,) int32, both on the
+    device; one mask launch + one sweep launch for the whole batch, no host synchronisation."""
+    dev = _dev(boxes)
+    _f32(boxes, "boxes")
+    B, n = boxes.size(0), boxes.size(1)
+    lib = _lib.load()
+    ws_bytes = lib.ws3d_nms_workspace_bytes(n) * max(B, 1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty((B, max(n, 1)), dtype=torch.int64, device=dev)
+    num = torch.zeros(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_nms_batched(B, n, _p(boxes), float(thresh), int(bool(normal)), int(max_keep), _p(ws),
+                                   ws_bytes, _p(keep), _p(num), _stream()), "nms_batched")
+    return keep, num
+
+
 def _nms_into_cpu_keep(boxes, keep, thresh, normal):
     if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
         raise Ws3dError("keep must be a contiguous CPU int64 tensor (iou3d.cpp:73-82)")

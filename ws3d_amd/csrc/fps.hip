@@ -39,7 +39,7 @@
 #define WS3D_FPS_PACKED 1
 #endif
 #ifndef WS3D_FPS_TREE
-#define WS3D_FPS_TREE 1
+#define WS3D_FPS_TREE 0  // measured 1.9x SLOWER: v_cmp->SGPR-pair->v_cndmask chains stall (scripts/ubench/lat.hip)
 #endif
 
 #ifdef WS3D_FPS_PROF

@@ -220,6 +220,11 @@ __global__ __launch_bounds__(64) void pair_kernel(int num_a, const float *__rest
 __global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, float thresh, int full_grid,
                                                              const float *__restrict__ boxes,
                                                              uint64_t *__restrict__ mask) {
+    {   // batched launch: blockIdx.z = scene (boxes (B,n,5), mask (B,n,ceil(n/64)))
+        const size_t z_ = blockIdx.z;
+        boxes += z_ * (size_t)boxes_num * 5;
+        mask += z_ * (size_t)boxes_num * (size_t)((boxes_num + 63) / 64);
+    }
     __shared__ float raw[64 * 5];
     const int row_start = blockIdx.y, col_start = blockIdx.x;
     const int lane = threadIdx.x;
@@ -267,6 +272,11 @@ struct MaskTileLds {
 __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float thresh, int full_grid,
                                                            const float *__restrict__ boxes,
                                                            uint64_t *__restrict__ mask) {
+    {   // batched launch: blockIdx.z = scene (boxes (B,n,5), mask (B,n,ceil(n/64)))
+        const size_t z_ = blockIdx.z;
+        boxes += z_ * (size_t)boxes_num * 5;
+        mask += z_ * (size_t)boxes_num * (size_t)((boxes_num + 63) / 64);
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     MaskTileLds &s = *reinterpret_cast<MaskTileLds *>(smem_raw);
     const int row_start = blockIdx.y, col_start = blockIdx.x;
@@ -338,6 +348,12 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_k
                                                         const uint64_t *__restrict__ mask,
                                                         int64_t *__restrict__ keep,
                                                         int32_t *__restrict__ num_keep) {
+    {   // batched launch: blockIdx.x = scene
+        const size_t z_ = blockIdx.x;
+        mask += z_ * (size_t)boxes_num * (size_t)((boxes_num + 63) / 64);
+        keep += z_ * (size_t)boxes_num;
+        num_keep += z_;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint64_t *remv = reinterpret_cast<uint64_t *>(smem);  // col_blocks
     __shared__ uint64_t kept_s;
@@ -421,16 +437,16 @@ static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *
     return check_launch(what);
 }
 
-static int mask_launch(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
+static int mask_launch(int batch, int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
                        uint64_t *mask, hipStream_t st, const char *what) {
-    if (boxes_num < 0 || !boxes || !mask) {
-        set_error("%s: invalid argument (boxes_num=%d)", what, boxes_num);
+    if (batch < 0 || boxes_num < 0 || !boxes || !mask) {
+        set_error("%s: invalid argument (batch=%d boxes_num=%d)", what, batch, boxes_num);
         return WS3D_E_INVALID;
     }
-    if (boxes_num == 0) return WS3D_OK;
+    if (boxes_num == 0 || batch == 0) return WS3D_OK;
     const int cb = (boxes_num + 63) / 64;
-    if (cb > 65535) { set_error("%s: boxes_num too large", what); return WS3D_E_UNSUPPORTED; }
-    dim3 grid(cb, cb);
+    if (cb > 65535 || batch > 65535) { set_error("%s: boxes_num/batch too large", what); return WS3D_E_UNSUPPORTED; }
+    dim3 grid(cb, cb, batch);
     if (normal) {
         hipLaunchKernelGGL(nms_normal_mask_kernel, grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
     } else {
@@ -462,7 +478,7 @@ extern "C" int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, co
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
                              uint64_t *mask, ws3d_stream_t stream) {
-    return ws3d::mask_launch(boxes_num, boxes, thresh, normal, full_grid, mask, ws3d::as_stream(stream),
+    return ws3d::mask_launch(1, boxes_num, boxes, thresh, normal, full_grid, mask, ws3d::as_stream(stream),
                              "ws3d_nms_mask");
 }
 
@@ -472,30 +488,42 @@ extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
     return ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
 }
 
-extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, int max_keep,
-                        void *workspace, size_t workspace_bytes, int64_t *keep, int32_t *num_keep,
-                        ws3d_stream_t stream) {
+extern "C" int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, float thresh, int normal,
+                                int max_keep, void *workspace, size_t workspace_bytes, int64_t *keep,
+                                int32_t *num_keep, ws3d_stream_t stream) {
     using namespace ws3d;
-    if (boxes_num < 0 || (!boxes && boxes_num > 0) || (!keep && boxes_num > 0) || !num_keep) {
-        set_error("ws3d_nms: invalid argument (boxes_num=%d)", boxes_num);
+    if (batch < 0 || boxes_num < 0 || (!boxes && boxes_num > 0 && batch > 0) ||
+        (!keep && boxes_num > 0 && batch > 0) || (!num_keep && batch > 0)) {
+        set_error("ws3d_nms: invalid argument (batch=%d boxes_num=%d)", batch, boxes_num);
         return WS3D_E_INVALID;
     }
     hipStream_t st = as_stream(stream);
+    if (batch == 0) return WS3D_OK;
     if (boxes_num == 0) {
-        hipMemsetAsync(num_keep, 0, sizeof(int32_t), st);
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int32_t) * (size_t)batch, st);
         return WS3D_OK;
     }
-    if (!workspace || workspace_bytes < ws3d_nms_workspace_bytes(boxes_num)) {
-        set_error("ws3d_nms: workspace too small (%zu < %zu)", workspace_bytes, ws3d_nms_workspace_bytes(boxes_num));
+    const size_t need = ws3d_nms_workspace_bytes(boxes_num) * (size_t)batch;
+    if (!workspace || workspace_bytes < need) {
+        set_error("ws3d_nms: workspace too small (%zu < %zu)", workspace_bytes, need);
         return WS3D_E_WORKSPACE;
     }
     uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
-    int rc = mask_launch(boxes_num, boxes, thresh, normal, 0, mask, st, "ws3d_nms(mask)");
+    // per-scene mask stride inside the kernels is n*ceil(n/64) words; the workspace query rounds
+    // each scene up to 256 B, which is >= that, so the packed layout always fits
+    int rc = mask_launch(batch, boxes_num, boxes, thresh, normal, 0, mask, st, "ws3d_nms(mask)");
     if (rc != WS3D_OK) return rc;
     const size_t smem = sizeof(uint64_t) * (size_t)((boxes_num + 63) / 64);
     if (smem > 150 * 1024) { set_error("ws3d_nms: boxes_num too large for the LDS removed-set"); return WS3D_E_UNSUPPORTED; }
     if (smem > 64 * 1024)
-        hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), smem, st, boxes_num, max_keep, mask, keep, num_keep);
+        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, boxes_num, max_keep, mask, keep, num_keep);
     return check_launch("ws3d_nms(sweep)");
+}
+
+extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, int max_keep,
+                        void *workspace, size_t workspace_bytes, int64_t *keep, int32_t *num_keep,
+                        ws3d_stream_t stream) {
+    return ws3d_nms_batched(1, boxes_num, boxes, thresh, normal, max_keep, workspace, workspace_bytes, keep,
+                            num_keep, stream);
 }

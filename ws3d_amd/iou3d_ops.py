@@ -69,3 +69,20 @@ def nms_gpu_padded(boxes, scores, thresh, max_out, normal=False):
     valid = pos < cnt
     out[:take] = torch.where(valid, order[keep[:take].clamp(min=0, max=max(n - 1, 0))], out[:take])
     return out, cnt
+
+
+def nms_gpu_padded_batched(boxes, scores, thresh, max_out, normal=False):
+    """boxes (B,n,5), scores (B,n) -> (idx (B,max_out) int64 padded with -1, count (B,) int64);
+    idx refers to the input order of each scene.  Whole batch in one launch pair."""
+    B, n = scores.shape
+    order = scores.sort(dim=1, descending=True, stable=True)[1]                      # (B,n)
+    sorted_boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, n, boxes.shape[2])).contiguous()
+    keep, num = _C.nms_device_batched(sorted_boxes, thresh, normal, max_keep=max_out)
+    take = min(max_out, n)
+    cnt = torch.clamp(num.to(torch.int64), max=max_out)
+    pos = torch.arange(take, device=boxes.device).unsqueeze(0)
+    valid = pos < cnt.unsqueeze(1)
+    picked = torch.gather(order, 1, keep[:, :take].clamp(min=0, max=max(n - 1, 0)))
+    out = torch.full((B, max_out), -1, dtype=torch.int64, device=boxes.device)
+    out[:, :take] = torch.where(valid, picked, out[:, :take])
+    return out, cnt

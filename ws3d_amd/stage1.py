@@ -180,33 +180,31 @@ def synthetic_orientation(n: int, device) -> torch.Tensor:
 
 @torch.no_grad()
 def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
-    """Per-scene on-device proposal stage (config 3 of BASELINE.json): score = sigmoid(rpn_cls),
-    centre = decode_center_target, box = centre + CLS_MEAN_SIZE + synthetic heading; top
-    RPN_PRE_NMS_TOP_N by score -> rotated NMS (thresh 0.8) -> top RPN_POST_NMS_TOP_N.
-    Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed shapes, zero padded, no host sync."""
+    """On-device proposal stage for the whole batch (config 3 of BASELINE.json): score =
+    sigmoid(rpn_cls), centre = decode_center_target, box = centre + CLS_MEAN_SIZE + synthetic
+    heading; top RPN_PRE_NMS_TOP_N by score -> rotated NMS (thresh 0.8) -> first
+    RPN_POST_NMS_TOP_N survivors.  Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed
+    shapes, zero padded, batched torch ops + ONE NMS launch pair, no host synchronisation."""
     xyz, reg, cls = out['backbone_xyz'], out['rpn_reg'], out['rpn_cls']
     B, N, _ = xyz.shape
     K = cfg.rpn_post_nms_top_n
     h, w, l = cfg.cls_mean_size
-    ry = synthetic_orientation(N, xyz.device)
-    boxes_out = xyz.new_zeros((B, K, 7))
-    scores_out = xyz.new_zeros((B, K))
-    count = torch.zeros((B,), dtype=torch.int64, device=xyz.device)
-    for b in range(B):
-        score = torch.sigmoid(cls[b, :, 0])
-        centre = decode_center_target(xyz[b], reg[b], cfg.loc_scope, cfg.loc_bin_size)
-        box = torch.stack((centre[:, 0], xyz[b, :, 1] + h / 2, centre[:, 2],
-                           torch.full_like(score, h), torch.full_like(score, w), torch.full_like(score, l), ry), 1)
-        top = min(cfg.rpn_pre_nms_top_n, N)
-        sc, order = torch.topk(score, top, sorted=True)
-        box = box[order]
-        keep, cnt = iou3d_ops.nms_gpu_padded(kitti_utils.boxes3d_to_bev_torch(box), sc, cfg.rpn_nms_thresh, K)
-        safe = keep.clamp(min=0)
-        valid = (keep >= 0).unsqueeze(1)
-        boxes_out[b] = torch.where(valid, box[safe], boxes_out[b])
-        scores_out[b] = torch.where(valid[:, 0], sc[safe], scores_out[b])
-        count[b] = cnt[0]
-    return boxes_out, scores_out, count
+    score = torch.sigmoid(cls[:, :, 0])                                                   # (B,N)
+    centre = decode_center_target(xyz.reshape(B * N, 3), reg.reshape(B * N, -1), cfg.loc_scope,
+                                  cfg.loc_bin_size).view(B, N, 3)
+    ry = synthetic_orientation(N, xyz.device).unsqueeze(0).expand(B, N)
+    box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h),
+                       torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
+    top = min(cfg.rpn_pre_nms_top_n, N)
+    sc, order = torch.topk(score, top, dim=1, sorted=True)                                # (B,top)
+    box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
+    bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
+    keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K)           # (B,K), (B,)
+    valid = keep >= 0
+    safe = keep.clamp(min=0)
+    boxes_out = torch.gather(box, 1, safe.unsqueeze(-1).expand(B, K, 7)) * valid.unsqueeze(-1)
+    scores_out = torch.gather(sc, 1, safe) * valid
+    return boxes_out, scores_out, cnt
 
 
 @torch.no_grad()
