@@ -82,6 +82,49 @@ __global__ void probe(float *out, long long *cyc, float seed) {
                 any |= mk;
             }
             v = v * 0.5f + (float)slot + (float)__builtin_ctzll(any | (1ull << 63));
+        } else if (MODE == 13) {  // throughput: 8 independent chains x 8 fma = 64 VALU
+            float a[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[c] = v + c;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[c] = __builtin_fmaf(a[c], 1.0001f, 0.5f);
+            v = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        } else if (MODE == 14) {  // throughput: 8 independent chains x 4 x (cmp + 2 cndmask) = 96 VALU
+            float bv[8]; int bi[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { bv[c] = v + c; bi[c] = c; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float x = lds[(c * 4 + i + lane) & 1023];
+                    const bool gt = x > bv[c];
+                    bi[c] = gt ? i : bi[c];
+                    bv[c] = gt ? x : bv[c];
+                }
+            float sv = 0; int si = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { sv += bv[c]; si += bi[c]; }
+            v = sv * 0.01f + si;
+        } else if (MODE == 15) {  // throughput: 8 independent chains x 4 x (xor, min_u32, lshl_add, min_u32) = 128 VALU int ops
+            unsigned k[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) k[c] = 1000u + c;
+            const unsigned mbits = __float_as_uint(v);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned x = __float_as_uint(lds[(c * 4 + i + lane) & 1023]) ^ mbits;
+                    const unsigned y = min(x, 1u);
+                    k[c] = min(k[c], (y << 6) + (unsigned)(c * 4 + i));
+                }
+            unsigned sk = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) sk += k[c];
+            v = v * 0.5f + (float)(sk & 1023);
         } else if (MODE == 9) {  // movrel-style dynamic register index (uniform)
             typedef float f16 __attribute__((ext_vector_type(16)));
             f16 a; 
@@ -113,7 +156,7 @@ void run(const char *name, int threads) {
 }
 
 int main() {
-    for (int th : {64, 512}) {
+    for (int th : {64, 512, 1024}) {
         run<0>("16 dependent v_fma", th);
         run<1>("4 DPP max stages (+1 add)", th);
         run<2>("4x readlane->VALU round trips", th);
@@ -127,6 +170,9 @@ int main() {
         run<10>("32x dep cmp+2cndmask (+32 add)", th);
         run<11>("32x dep v_max (+32 add)", th);
         run<12>("32x indep cmp_eq->sgpr + scalar", th);
+        run<13>("TP 64 fma (8 chains)", th);
+        run<14>("TP 32 lds + 96 cmp/cndmask (8 chains)", th);
+        run<15>("TP 32 lds + 128 int ops (8 chains)", th);
     }
     return 0;
 }

@@ -38,6 +38,9 @@
 #ifndef WS3D_FPS_PACKED
 #define WS3D_FPS_PACKED 1
 #endif
+#ifndef WS3D_FPS_CHAINS
+#define WS3D_FPS_CHAINS 0  // neutral (1.20 vs 1.17 us/step): the sweep is issue-bound, cmp/cndmask cost 2 slots each
+#endif
 #ifndef WS3D_FPS_TREE
 #define WS3D_FPS_TREE 0  // measured 1.9x SLOWER: v_cmp->SGPR-pair->v_cndmask chains stall (scripts/ubench/lat.hip)
 #endif
@@ -170,6 +173,52 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                 ti[s] = gt ? 2 * s + 1 : 2 * s;
             }
             tourney<PPT / 2>(tv, ti, best, bslot);
+        } else if constexpr (PPT >= 4 && WS3D_FPS_CHAINS) {
+            // CH independent argmax chains over contiguous slot ranges, advanced in lock step so
+            // that CH distance computations (each a 7-deep dependent chain) and CH compare/select
+            // recurrences are in flight at once; the single-chain form left one wave with no
+            // ILP (the scheduler reused three temporaries for all 32 points).  Chains are merged
+            // in range order with strict '>', i.e. the lowest slot still wins exact ties.
+            constexpr int CH = 4, LEN = PPT / CH;
+            float cb[CH];
+            int cs[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) { cb[c] = -1.0f; cs[c] = c * LEN; }
+#pragma unroll
+            for (int i = 0; i < LEN; ++i) {
+                float dx[CH], dy[CH], dz[CH], d[CH];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    dx[c] = vec_get<PPT>(px, c * LEN + i) - ox;
+                    dy[c] = vec_get<PPT>(py, c * LEN + i) - oy;
+                    dz[c] = vec_get<PPT>(pz, c * LEN + i) - oz;
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[c] = dy[c] * dy[c];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[c] = __builtin_fmaf(dx[c], dx[c], d[c]);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) d[c] = __builtin_fmaf(dz[c], dz[c], d[c]);   // == sqdist3
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    d[c] = min_f32(d[c], t[c * LEN + i]);  // == fminf: t is never NaN
+                    t[c * LEN + i] = d[c];
+                }
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const bool gt = d[c] > cb[c];
+                    cs[c] = gt ? c * LEN + i : cs[c];
+                    cb[c] = gt ? d[c] : cb[c];
+                }
+            }
+            best = cb[0];
+            bslot = cs[0];
+#pragma unroll
+            for (int c = 1; c < CH; ++c) {
+                const bool gt = cb[c] > best;
+                bslot = gt ? cs[c] : bslot;
+                best = gt ? cb[c] : best;
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {

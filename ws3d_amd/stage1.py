@@ -165,9 +165,9 @@ def decode_center_target(roi_center, pred_reg, loc_scope, loc_bin_size):
     z_res = torch.gather(pred_reg[:, 3 * nb:4 * nb], dim=1, index=z_bin.unsqueeze(1)).squeeze(1)
     pos_x = pos_x + x_res * (loc_bin_size / 2)
     pos_z = pos_z + z_res * (loc_bin_size / 2)
-    ret = torch.stack((pos_x, torch.zeros_like(pos_x), pos_z), dim=1)
-    ret[:, [0, 2]] += roi_center[:, [0, 2]]
-    return ret
+    # (the reference adds the point's x,z through `ret[:, [0, 2]] += ...`; the list index would
+    # stage an index tensor through the host, which a hipGraph capture does not allow)
+    return torch.stack((pos_x + roi_center[:, 0], torch.zeros_like(pos_x), pos_z + roi_center[:, 2]), dim=1)
 
 
 def synthetic_orientation(n: int, device) -> torch.Tensor:
