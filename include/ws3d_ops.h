@@ -169,6 +169,17 @@ WS3D_API int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, floa
                               int max_keep, void *workspace, size_t workspace_bytes, int64_t *keep,
                               int32_t *num_keep, ws3d_stream_t stream);
 
+/* ------------------------------------------------ Stage-1 proposal stage */
+
+/* Greedy radius NMS of centre proposals, replacing the reference's Python loops
+ * (generate_box_dataset.py:127-140, tools/eval_auto.py:270-284: one host sync per candidate).
+ * centers (batch,n,2) = (x,z) per scene, sorted by descending score; candidate i is kept iff
+ * distance_2 (lib/utils/distance.py:3, fp32) to every kept centre is > radius.  Outputs and
+ * workspace as ws3d_nms_batched (workspace >= batch * ws3d_nms_workspace_bytes(n)).          */
+WS3D_API int ws3d_radius_nms_batched(int batch, int n, const float *centers, float radius, int max_keep,
+                                     void *workspace, size_t workspace_bytes, int64_t *keep,
+                                     int32_t *num_keep, ws3d_stream_t stream);
+
 /* ---------------------------------------------------------------- roipool3d_cuda */
 
 /* forward(xyz,boxes3d,pts_feature,pooled_features,pooled_empty_flag)

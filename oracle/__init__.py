@@ -287,6 +287,15 @@ def nms(boxes: np.ndarray, scores: np.ndarray, thresh: float, normal: bool = Fal
     return order[keep]
 
 
+def radius_nms_sorted(centers_xz: np.ndarray, radius: float) -> np.ndarray:
+    """centres (n,2) sorted by descending score -> kept indices (generate_box_dataset.py:127-140)"""
+    c, pc = _f(centers_xz)
+    n = c.shape[0]
+    keep = np.zeros((max(n, 1),), dtype=np.int64)
+    cnt = lib().ws3d_oracle_radius_nms(pc, keep.ctypes.data_as(_i64p), n, C.c_float(radius))
+    return keep[:cnt].copy()
+
+
 def box_overlap_pair(a, b) -> float:
     a, pa = _f(a)
     b, pb = _f(b)

@@ -427,6 +427,58 @@ def test_nms_batched_and_proposal_stage(ops, oracle):
         assert (host(pb[b, len(k):]) == 0).all()
 
 
+@pytest.mark.parametrize("B,n,r", [(1, 1, 0.3), (2, 300, 0.3), (3, 1000, 1.0), (1, 4000, 0.3), (2, 65, 0.05)])
+def test_radius_nms_bit_exact(ops, oracle, B, n, r):
+    rng = np.random.default_rng(n)
+    c = (rng.uniform(-4, 4, (B, n, 2)) + rng.integers(0, 3, (B, n, 1)) * 0.2).astype(np.float32)
+    if n > 10:
+        c[:, 5] = c[:, 2]
+        c[:, 7] = c[:, 3] + np.float32([r, 0])
+    keep, num = ops.c.radius_nms_device_batched(dev(c), r)
+    for b in range(B):
+        ref = oracle.radius_nms_sorted(c[b], r)
+        assert int(num[b]) == len(ref)
+        np.testing.assert_array_equal(host(keep[b])[:len(ref)], ref)
+    keep2, num2 = ops.c.radius_nms_device_batched(dev(c), r, max_keep=7)
+    for b in range(B):
+        ref = oracle.radius_nms_sorted(c[b], r)[:7]
+        assert int(num2[b]) == len(ref)
+        np.testing.assert_array_equal(host(keep2[b])[:len(ref)], ref)
+
+
+def test_center_proposal_stage_matches_reference_loop(ops):
+    """stage1.center_proposals == the reference's inline proposal code (generate_box_dataset.py:
+    92-140) restated with torch ops + its Python keep loop"""
+    from ws3d_amd import stage1
+    rng = np.random.default_rng(3)
+    N = 3000
+    pc = synth.make_batch("lidar", 1, N, 77)
+    out = {"backbone_xyz": dev(pc[:, :, :3].copy()),
+           "rpn_reg": dev(rng.standard_normal((1, N, 40)).astype(np.float32)),
+           "rpn_cls": dev(rng.normal(-0.5, 1.5, (1, N, 1)).astype(np.float32))}
+    cfg = stage1.DEFAULT_CFG
+    ctr, norm, raw = stage1.center_proposals(out, cfg)
+    xyz = out["backbone_xyz"].view(-1, 3)
+    s_raw = out["rpn_cls"].view(-1)
+    s_norm = torch.sigmoid(s_raw)
+    rois = stage1.decode_center_target(xyz, out["rpn_reg"].view(-1, 40), cfg.loc_scope, cfg.loc_bin_size).view(-1, 3)
+    reg_dist = rois - xyz
+    mask = (s_norm > cfg.score_thresh) & (reg_dist[:, [0, 2]].pow(2).sum(-1).sqrt() > 0.2)
+    rois, s_norm, s_raw = rois[mask], s_norm[mask], s_raw[mask]
+    order = torch.argsort(-s_norm, stable=True)
+    rois, s_norm, s_raw = rois[order], s_norm[order], s_raw[order]
+    a = rois[:, [0, 2]]
+    d = torch.sqrt(torch.sum((a[None, :] - a[:, None]) ** 2, dim=2))
+    keep = [0]
+    for i in range(1, rois.shape[0]):
+        if torch.min(d[keep, i], dim=-1)[0] > 0.3:
+            keep.append(i)
+    assert 10 < len(keep) < rois.shape[0]
+    np.testing.assert_array_equal(host(ctr), host(rois[keep]))
+    np.testing.assert_array_equal(host(norm), host(s_norm[keep]))
+    np.testing.assert_array_equal(host(raw), host(s_raw[keep]))
+
+
 # ------------------------------------------------------------------------------- error behaviour
 def test_errors_are_exceptions_not_exit(ops):
     from ws3d_amd._lib import Ws3dError

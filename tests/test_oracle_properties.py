@@ -246,3 +246,20 @@ def test_nms_mask_and_sweep(oracle, n, thresh, normal, seed):
     order = np.argsort(-scores, kind="stable")
     np.testing.assert_array_equal(oracle.nms(boxes, scores, thresh, normal),
                                   order[oracle.nms_sorted(boxes[order], thresh, normal)])
+
+
+@pytest.mark.parametrize("n,r,seed", [(1, 0.3, 0), (2, 0.3, 1), (200, 0.3, 2), (700, 1.0, 3), (65, 0.05, 4)])
+def test_radius_nms(oracle, n, r, seed):
+    """greedy centre-distance NMS of the Stage-1 proposals (generate_box_dataset.py:127-140),
+    re-derived with the reference's own formulation: dense distance matrix + Python loop"""
+    rng = np.random.default_rng(seed)
+    c = (rng.uniform(-3, 3, (n, 2)) + rng.integers(0, 3, (n, 1)) * 0.2).astype(np.float32)
+    if n > 10:
+        c[5] = c[2]                                    # exact duplicate: distance 0 <= r
+        c[7] = c[3] + np.float32([r, 0])               # (almost) exactly at the radius
+    d = np.sqrt(((c[None, :, :] - c[:, None, :]) ** 2).sum(2, dtype=np.float32)).astype(np.float32)
+    keep = [0]
+    for i in range(1, n):
+        if d[keep, i].min() > np.float32(r):
+            keep.append(i)
+    np.testing.assert_array_equal(oracle.radius_nms_sorted(c, r), np.asarray(keep))

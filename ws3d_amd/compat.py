@@ -249,6 +249,23 @@ def nms_device_batched(boxes, thresh, normal=False, max_keep=0):
     return keep, num
 
 
+def radius_nms_device_batched(centers, radius, max_keep=0):
+    """centers (B,n,2) = (x,z), every scene sorted by descending score -> keep (B,n) int64,
+    num (B,) int32 on the device (ws3d extension)."""
+    dev = _dev(centers)
+    _f32(centers, "centers")
+    B, n = centers.size(0), centers.size(1)
+    lib = _lib.load()
+    ws_bytes = lib.ws3d_nms_workspace_bytes(n) * max(B, 1)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    keep = torch.empty((B, max(n, 1)), dtype=torch.int64, device=dev)
+    num = torch.zeros(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_radius_nms_batched(B, n, _p(centers), float(radius), int(max_keep), _p(ws), ws_bytes,
+                                          _p(keep), _p(num), _stream()), "radius_nms")
+    return keep, num
+
+
 def _nms_into_cpu_keep(boxes, keep, thresh, normal):
     if keep.is_cuda or keep.dtype != torch.int64 or not keep.is_contiguous():
         raise Ws3dError("keep must be a contiguous CPU int64 tensor (iou3d.cpp:73-82)")

@@ -252,6 +252,43 @@ __global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, floa
     mask[(size_t)cur * col_blocks + col_start] = t;
 }
 
+// Radius NMS of Stage-1 centre proposals (generate_box_dataset.py:127-140, eval_auto.py:270-284:
+// a Python loop with a host sync per candidate in the reference).  Same 64-bit mask layout as
+// K12/K13; bit t of word c of row i = distance_2(centre_i, centre_{64c+t}) <= radius, so the
+// greedy sweep above (drop j when a kept i < j has the bit set) keeps exactly the candidates whose
+// distance to every kept centre is > radius.  distance_2 = sqrtf(dx*dx + dz*dz), fp32, unfused.
+__global__ __launch_bounds__(64) void radius_mask_kernel(int n, float radius, const float *__restrict__ centers,
+                                                         uint64_t *__restrict__ mask) {
+    {
+        const size_t z_ = blockIdx.z;
+        centers += z_ * (size_t)n * 2;
+        mask += z_ * (size_t)n * (size_t)((n + 63) / 64);
+    }
+    __shared__ float2 col[64];
+    const int row_start = blockIdx.y, col_start = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int col_blocks = (n + 63) / 64;
+    const int row_size = min(n - row_start * 64, 64);
+    const int col_size = min(n - col_start * 64, 64);
+    const int cur = row_start * 64 + lane;
+    if (col_start < row_start) {
+        if (lane < row_size) mask[(size_t)cur * col_blocks + col_start] = 0;
+        return;
+    }
+    if (lane < col_size) col[lane] = make_float2(centers[(size_t)(col_start * 64 + lane) * 2], centers[(size_t)(col_start * 64 + lane) * 2 + 1]);
+    __syncthreads();
+    if (lane >= row_size) return;
+    const float cx = centers[(size_t)cur * 2], cz = centers[(size_t)cur * 2 + 1];
+    uint64_t t = 0;
+    const int start = (row_start == col_start) ? lane + 1 : 0;
+    for (int i = start; i < col_size; ++i) {
+        const float dx = col[i].x - cx, dz = col[i].y - cz;
+        const float dist = sqrtf(dx * dx + dz * dz);
+        if (!(dist > radius)) t |= 1ULL << i;
+    }
+    mask[(size_t)cur * col_blocks + col_start] = t;
+}
+
 // K12 (rotated).  A 64x64 tile of box pairs per 256-lane workgroup, in three phases:
 //   0. 128 lanes build the 64 row and 64 column frames (trig once per box) in LDS;
 //   1. all 4096 pairs take the cheap exact far-pair test; survivors are COMPACTED into an
@@ -526,4 +563,40 @@ extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int nor
                         ws3d_stream_t stream) {
     return ws3d_nms_batched(1, boxes_num, boxes, thresh, normal, max_keep, workspace, workspace_bytes, keep,
                             num_keep, stream);
+}
+
+extern "C" int ws3d_radius_nms_batched(int batch, int n, const float *centers, float radius, int max_keep,
+                                       void *workspace, size_t workspace_bytes, int64_t *keep,
+                                       int32_t *num_keep, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (batch < 0 || n < 0 || (!centers && n > 0 && batch > 0) || (!keep && n > 0 && batch > 0) ||
+        (!num_keep && batch > 0)) {
+        set_error("ws3d_radius_nms: invalid argument (batch=%d n=%d)", batch, n);
+        return WS3D_E_INVALID;
+    }
+    hipStream_t st = as_stream(stream);
+    if (batch == 0) return WS3D_OK;
+    if (n == 0) {
+        (void)hipMemsetAsync(num_keep, 0, sizeof(int32_t) * (size_t)batch, st);
+        return WS3D_OK;
+    }
+    const size_t need = ws3d_nms_workspace_bytes(n) * (size_t)batch;
+    if (!workspace || workspace_bytes < need) {
+        set_error("ws3d_radius_nms: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return WS3D_E_WORKSPACE;
+    }
+    const int cb = (n + 63) / 64;
+    const size_t smem = sizeof(uint64_t) * (size_t)cb;
+    if (cb > 65535 || batch > 65535 || smem > 150 * 1024) {
+        set_error("ws3d_radius_nms: n/batch too large");
+        return WS3D_E_UNSUPPORTED;
+    }
+    uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
+    hipLaunchKernelGGL(radius_mask_kernel, dim3(cb, cb, batch), dim3(64), 0, st, n, radius, centers, mask);
+    int rc = check_launch("ws3d_radius_nms(mask)");
+    if (rc != WS3D_OK) return rc;
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, n, max_keep, mask, keep, num_keep);
+    return check_launch("ws3d_radius_nms(sweep)");
 }

@@ -208,6 +208,33 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
 
 
 @torch.no_grad()
+def center_proposals(out: dict, cfg: RPNConfig = DEFAULT_CFG, prop_dist: float = 0.3, min_reg_dist: float = 0.2):
+    """WS3D's live Stage-1 proposal stage (generate_box_dataset.py:92-140, tools/eval_auto.py:
+    248-284) for ONE scene: sigmoid score, decode_center_target, keep points with
+    score > SCORE_THRESH and |centre - point|_xz > 0.2, sort by score, greedy radius NMS (0.3 m).
+    The reference's O(K^2) Python loop (one device sync per candidate) is one mask launch + one
+    sweep launch here.  Returns (centres (K,3), sigmoid scores (K,), raw scores (K,))."""
+    from . import compat as _C
+    xyz = out['backbone_xyz'].reshape(-1, 3)
+    raw = out['rpn_cls'].reshape(-1)
+    norm = torch.sigmoid(raw)
+    rois = decode_center_target(xyz, out['rpn_reg'].reshape(xyz.shape[0], -1), cfg.loc_scope, cfg.loc_bin_size)
+    reg_dist = rois - xyz
+    mask = (norm > cfg.score_thresh) & (torch.stack((reg_dist[:, 0], reg_dist[:, 2]), 1).pow(2).sum(-1).sqrt() > min_reg_dist)
+    rois, raw, norm = rois[mask], raw[mask], norm[mask]          # dynamic shape, like the reference
+    if rois.shape[0] == 0:
+        return rois, norm, raw
+    order = torch.argsort(-norm, stable=True)
+    rois, raw, norm = rois[order], raw[order], norm[order]
+    if rois.shape[0] > 1:
+        cxz = torch.stack((rois[:, 0], rois[:, 2]), 1).contiguous().unsqueeze(0)
+        keep, num = _C.radius_nms_device_batched(cxz, prop_dist)
+        k = keep[0, :int(num[0])]
+        rois, raw, norm = rois[k], raw[k], norm[k]
+    return rois, norm, raw
+
+
+@torch.no_grad()
 def stage1_inference(model: Stage1Net, pts_input: torch.Tensor, cfg: RPNConfig = DEFAULT_CFG):
     """Stage-1 forward + proposals + RoI pooling for a batch of scenes (B,N,4)."""
     out = model.rpn_forward({'pts_input': pts_input})
