@@ -180,6 +180,92 @@ class C2:
                 "gpu_matches_oracle_on_sample": ok}
 
 
+class C5:
+    """BASELINE.json configs[4]: dense scan stress -- N=65536 points, 512 proposals per scene,
+    roipool3d (S=512, C=128) + rotated NMS (thresh 0.7); `batch` scenes per launch."""
+
+    name = "c5_roipool3d_nms_dense"
+    metric = "scenes/sec, roipool3d + rotated NMS at N=65536, 512 proposals/scene; roipool HBM GB/s"
+    N, M, C, S, THR = 65536, 512, 128, 512, 0.7
+
+    def __init__(self, batch, rank, kind="lidar"):
+        from ws3d_amd import compat, kitti_utils, synth
+        self.c, self.B = compat, batch
+        pc = np.stack([synth.lidar_cloud(self.N, 1000 * 5 + rank * batch + s) for s in range(batch)])
+        boxes = synth.proposal_boxes(batch, self.M, 5)
+        for b in range(batch):   # half of the proposals sit exactly on the synthetic cars (non-empty RoIs)
+            cars = synth.random_boxes3d(15, (1000 * 5 + rank * batch + b) * 7919 + 13)
+            boxes[b, :self.M // 2] = cars[np.arange(self.M // 2) % 15]
+            boxes[b, :self.M // 2, [0, 2]] += np.random.default_rng(b).normal(0, 0.3, (2, self.M // 2)).astype(np.float32)
+        self.pc_host, self.boxes_host = pc, boxes
+        self.xyz = torch.from_numpy(pc[:, :, :3].copy()).cuda()
+        self.feat = torch.randn((batch, self.N, self.C), device="cuda")
+        enl = kitti_utils.enlarge_box3d(torch.from_numpy(boxes).view(-1, 7), 1.0).view(batch, self.M, 7)
+        self.boxes = enl.cuda().contiguous()
+        self.pooled = torch.zeros((batch, self.M, self.S, 3 + self.C), device="cuda")
+        self.empty = torch.zeros((batch, self.M), dtype=torch.int32, device="cuda")
+        scores = np.stack([synth.distinct_scores(self.M, 50 + b) for b in range(batch)])
+        order = np.argsort(-scores, axis=1, kind="stable")
+        bev = np.stack([synth.boxes3d_to_bev(boxes[b])[order[b]] for b in range(batch)])
+        self.bev_sorted = torch.from_numpy(np.ascontiguousarray(bev)).cuda()
+        self.ev = []
+
+    def config(self):
+        return {"n_points": self.N, "proposals": self.M, "channels": self.C, "sampled": self.S, "nms_thresh": self.THR}
+
+    def step(self, timed=False):
+        if timed:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        self.c.roipool3d_forward(self.xyz, self.boxes, self.feat, self.pooled, self.empty)
+        if timed:
+            e[1].record()
+        self.keep, self.num = self.c.nms_device_batched(self.bev_sorted, self.THR, False, 0)
+        if timed:
+            e[2].record()
+            self.ev.append(e)
+
+    def scenes(self):
+        return self.B
+
+    def kernel_table(self):
+        roi = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
+        nms = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
+        nonempty = float((self.empty == 0).float().mean().item())
+        roi_bytes = (self.M * self.S * (3 + self.C) * 4 + self.N * (3 + self.C) * 4) * self.B
+        return [
+            {"name": "roipool3d_kernel (select + wrap-pad + copy, fused)", "ms_per_step": roi, "launches_per_step": 1,
+             "alg_bytes_per_step": roi_bytes, "traffic_key": None,
+             "comment": "A_min of SURVEY 8d (171,720,704 B/scene) assumes every RoI is non-empty; rows of empty "
+                        "RoIs are left untouched by contract: non-empty fraction here = %.2f" % nonempty},
+            {"name": "nms_rot_mask_kernel + nms_sweep_kernel (n=512)", "ms_per_step": nms, "launches_per_step": 2,
+             "alg_bytes_per_step": (self.M * 20 + self.M * 8 * 8) * self.B, "traffic_key": None,
+             "comment": "ALU-bound: %d box pairs per scene" % (self.M * (self.M - 1) // 2)},
+        ]
+
+    def path_gbps(self, scenes_per_s_per_gpu):
+        b = self.M * self.S * (3 + self.C) * 4 + self.N * (3 + self.C) * 4
+        return {"roipool_a_min_bytes_per_scene": b, "a_min": b * scenes_per_s_per_gpu / 1e9,
+                "nms_pairs_per_s": self.M * (self.M - 1) // 2 * scenes_per_s_per_gpu}
+
+    def cpu_baseline(self):
+        import oracle
+        threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
+        oracle.set_threads(threads)
+        boxes = self.boxes[:1].cpu().numpy()
+        t0 = time.perf_counter()
+        pooled, empty = oracle.roipool3d(self.pc_host[:1, :, :3], boxes, self.feat[:1].cpu().numpy(), self.S)
+        keep = oracle.nms_sorted(self.bev_sorted[0].cpu().numpy(), self.THR, False)
+        dt = time.perf_counter() - t0
+        oracle.set_threads(1)
+        ok = bool(np.array_equal(self.empty[0].cpu().numpy(), empty[0]) and
+                  np.array_equal(self.pooled[0].cpu().numpy(), pooled[0]) and
+                  np.array_equal(self.keep[0, :int(self.num[0])].cpu().numpy(), keep))
+        return {"value": 1.0 / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
+                "sample": "1 scene (roipool3d 65536 pts x 512 boxes + NMS 512) on oracle/ws3d_oracle.c, OpenMP over boxes, "
+                          "wall %.2f s" % dt, "gpu_matches_oracle_on_sample": ok}
+
+
 def load_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json),
     already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
@@ -197,7 +283,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 256, c3 default 8)")
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,6 +297,8 @@ def main():
     if args.workload == "c3":
         from bench_c3 import C3
         wl = C3(args.batch or 8, rank, world, args.kind)
+    elif args.workload == "c5":
+        wl = C5(args.batch or 8, rank, args.kind)
     else:
         wl = C2(args.batch or 256, rank, args.kind)
 
@@ -252,7 +340,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
-            "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS}, **wl.config()),
+            "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS}, **wl.config()),  # (c5 overrides n_points)
             "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom["achieved_GBps"],
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dom["frac_of_8TBps"],
                          "traffic": (dom["traffic_bytes_per_launch"] or {}).get("hbm_bytes")
