@@ -4,15 +4,15 @@
 //
 // Design.  The reference runs three kernels through a
 // B*N*M int32 scratch (cudaMalloc/cudaFree per call, 134 MB/scene at config 5) and
-// scans with ONE THREAD per box.  Here one 256-lane workgroup owns one (scene, box):
-//   1. the box frame (cy, cos, sin, half extents) is computed once;
+// scans with ONE THREAD per box.  Here one 256-lane workgroup owns 1 or 4 boxes of a scene:
+//   1. the box frames (cy, cos, sin, half extents) are computed once;
 //   2. each of the 4 waves scans a contiguous quarter of the scene, 64 points per
 //      step: in-box test -> __ballot -> mbcnt prefix -> ordered append to the wave's
 //      LDS list (ascending point index; no atomics, no barrier inside the scan);
 //   3. the 4 lists are concatenated (their ranges are ordered), truncated to S and
 //      wrap-padded (idx[k] = idx[k % cnt]) in LDS;
-//   4. the S x (3+C) output block of the box is contiguous: the workgroup streams it
-//      out with fully coalesced stores, gathering 512-byte feature rows.
+//   4. the S x (3+C) output block of a box is contiguous: the workgroup streams it out
+//      with fully coalesced 16-byte stores, gathering 512-byte feature rows.
 // No scratch, no allocation, no host sync; the output write (B*M*S*(3+C)*4 bytes) is
 // the only large HBM stream, which makes this an HBM-roofline kernel.
 #include "common.h"
@@ -48,6 +48,10 @@ __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y,
     return (x_rot >= -f.hl) & (x_rot <= f.hl) & (z_rot >= -f.hw) & (z_rot <= f.hw);
 }
 
+// BG boxes of one scene per workgroup: every point loaded by the scan is tested against BG box
+// frames, so the scene is streamed from L2 once per BG boxes instead of once per box (at config 5
+// the per-box rescans were 3x the output bytes).
+template <int BG>
 __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_num, int feat_len,
                                                         int S, const float *__restrict__ xyz,
                                                         const float *__restrict__ boxes3d,
@@ -56,68 +60,105 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
                                                         int32_t *__restrict__ empty_flag,
                                                         int32_t *__restrict__ pts_idx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *lists = reinterpret_cast<int *>(smem);  // 4 * S
-    int *sel = lists + 4 * S;                    // S
-    __shared__ int wcnt_s[4];
+    int *lists = reinterpret_cast<int *>(smem);  // BG * 4 * S
+    int *sel = lists + BG * 4 * S;               // S
+    __shared__ int wcnt_s[BG * 4];
 
-    const int box = blockIdx.x, b = blockIdx.y;
+    const int box0 = blockIdx.x * BG, b = blockIdx.y;
+    const int nb = min(BG, boxes_num - box0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const size_t bm = (size_t)b * boxes_num + box;
     xyz += (size_t)b * pts_num * 3;
     pts_feature += (size_t)b * pts_num * feat_len;
-    const BoxFrame f = make_frame(boxes3d + bm * 7);
+    BoxFrame f[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) f[g] = make_frame(boxes3d + ((size_t)b * boxes_num + box0 + min(g, nb - 1)) * 7);
 
     const int Q = (((pts_num + 3) / 4 + 63) / 64) * 64;
     const int start = min(w * Q, pts_num), end = min(start + Q, pts_num);
-    int *list = lists + w * S;
-    int wcnt = 0;
-    for (int k0 = start; k0 < end && wcnt < S; k0 += 64) {
+    int wcnt[BG];
+#pragma unroll
+    for (int g = 0; g < BG; ++g) wcnt[g] = g < nb ? 0 : S;
+    for (int k0 = start; k0 < end; k0 += 64) {
         const int k = k0 + lane;
-        bool flag = false;
-        if (k < end) {
-            const float *p = xyz + (size_t)k * 3;
-            flag = pt_in_frame(f, p[0], p[1], p[2]);
+        float x = 0.f, y = 0.f, z = 0.f;
+        const bool in_range = k < end;
+        if (in_range) { const float *p = xyz + (size_t)k * 3; x = p[0]; y = p[1]; z = p[2]; }
+        bool all_full = true;
+#pragma unroll
+        for (int g = 0; g < BG; ++g) {
+            if (wcnt[g] < S) {  // wave-uniform
+                const bool flag = in_range && pt_in_frame(f[g], x, y, z);
+                const uint64_t mask = __ballot(flag);
+                if (mask) {
+                    const int pos = wcnt[g] + mbcnt(mask);
+                    if (flag && pos < S) lists[(g * 4 + w) * S + pos] = k;
+                    wcnt[g] += (int)__builtin_popcountll(mask);
+                }
+                all_full = all_full && wcnt[g] >= S;
+            }
         }
-        const uint64_t mask = __ballot(flag);
-        if (mask) {
-            const int pos = wcnt + mbcnt(mask);
-            if (flag && pos < S) list[pos] = k;
-            wcnt += (int)__builtin_popcountll(mask);
-        }
+        if (all_full) break;
     }
-    if (lane == 0) wcnt_s[w] = min(wcnt, S);
-    __syncthreads();
-    const int c0 = wcnt_s[0], c1 = wcnt_s[1], c2 = wcnt_s[2], c3 = wcnt_s[3];
-    const int cnt = min(c0 + c1 + c2 + c3, S);
-    if (cnt == 0) {  // roipool3d_kernel.cu:147-149,181-183: flag the box, leave its rows untouched
-        if (tid == 0) empty_flag[bm] = 1;
-        if (pts_idx)
-            for (int s = tid; s < S; s += 256) pts_idx[bm * S + s] = 0;
-        return;
-    }
-    for (int s = tid; s < S; s += 256) {
-        int t = s < cnt ? s : s % cnt;  // duplicate_idx = k % cnt (roipool3d_kernel.cu:153-157)
-        int v;
-        if (t < c0) v = lists[t];
-        else if ((t -= c0) < c1) v = lists[S + t];
-        else if ((t -= c1) < c2) v = lists[2 * S + t];
-        else v = lists[3 * S + (t - c2)];
-        sel[s] = v;
-        if (pts_idx) pts_idx[bm * S + s] = v;
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < BG; ++g) wcnt_s[g * 4 + w] = min(wcnt[g], S);
     }
     __syncthreads();
 
     const int row = 3 + feat_len;
-    float *out = pooled + bm * (size_t)S * row;
     const int total = S * row;
-    int s = tid / row, j = tid - s * row;
-    const int ds = 256 / row, dj = 256 - ds * row;
-    for (int e = tid; e < total; e += 256) {
-        const int src = sel[s];
-        out[e] = j < 3 ? xyz[(size_t)src * 3 + j] : pts_feature[(size_t)src * feat_len + (j - 3)];
-        s += ds;
-        j += dj;
-        if (j >= row) { j -= row; ++s; }
+    for (int g = 0; g < nb; ++g) {
+        const size_t bm = (size_t)b * boxes_num + box0 + g;
+        const int *lg = lists + g * 4 * S;
+        const int c0 = wcnt_s[g * 4 + 0], c1 = wcnt_s[g * 4 + 1], c2 = wcnt_s[g * 4 + 2], c3 = wcnt_s[g * 4 + 3];
+        const int cnt = min(c0 + c1 + c2 + c3, S);
+        if (cnt == 0) {  // roipool3d_kernel.cu:147-149,181-183: flag the box, leave its rows untouched
+            if (tid == 0) empty_flag[bm] = 1;
+            if (pts_idx)
+                for (int q = tid; q < S; q += 256) pts_idx[bm * S + q] = 0;
+            continue;  // wave-uniform for the whole workgroup
+        }
+        for (int q = tid; q < S; q += 256) {
+            int t = q < cnt ? q : q % cnt;  // duplicate_idx = k % cnt (roipool3d_kernel.cu:153-157)
+            int v;
+            if (t < c0) v = lg[t];
+            else if ((t -= c0) < c1) v = lg[S + t];
+            else if ((t -= c1) < c2) v = lg[2 * S + t];
+            else v = lg[3 * S + (t - c2)];
+            sel[q] = v;
+            if (pts_idx) pts_idx[bm * S + q] = v;
+        }
+        __syncthreads();
+        float *out = pooled + bm * (size_t)S * row;
+        auto fetch = [&](int sr, int j) -> float {
+            const int src = sel[sr];
+            return j < 3 ? xyz[(size_t)src * 3 + j] : pts_feature[(size_t)src * feat_len + (j - 3)];
+        };
+        if ((total & 3) == 0 && ((bm * (size_t)total) & 3) == 0) {
+            // the S x (3+C) block of a box is contiguous and 16-byte aligned: 4 elements per store
+            int sr = (4 * tid) / row, j = 4 * tid - sr * row;
+            const int ds = 1024 / row, dj = 1024 - ds * row;
+            for (int e = 4 * tid; e < total; e += 1024) {
+                float4 v4;
+                int s1 = sr, j1 = j;
+                v4.x = fetch(s1, j1); if (++j1 == row) { j1 = 0; ++s1; }
+                v4.y = fetch(s1, j1); if (++j1 == row) { j1 = 0; ++s1; }
+                v4.z = fetch(s1, j1); if (++j1 == row) { j1 = 0; ++s1; }
+                v4.w = fetch(s1, j1);
+                *reinterpret_cast<float4 *>(out + e) = v4;
+                sr += ds; j += dj;
+                if (j >= row) { j -= row; ++sr; }
+            }
+        } else {
+            int sr = tid / row, j = tid - sr * row;
+            const int ds = 256 / row, dj = 256 - ds * row;
+            for (int e = tid; e < total; e += 256) {
+                out[e] = fetch(sr, j);
+                sr += ds; j += dj;
+                if (j >= row) { j -= row; ++sr; }
+            }
+        }
+        __syncthreads();  // sel is reused by the next box
     }
 }
 
@@ -147,16 +188,27 @@ extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int fe
         return WS3D_E_INVALID;
     }
     if (batch_size == 0 || boxes_num == 0) return WS3D_OK;
-    const size_t smem = sizeof(int) * 5 * (size_t)sampled_pts_num;
-    if (smem > 150 * 1024 || boxes_num > 0x7fffffff / 1 || batch_size > 65535) {
+    // 4 boxes per workgroup when that still leaves >= 2 workgroups per CU
+    const bool grouped = (long)batch_size * ((boxes_num + 3) / 4) >= 512 && sampled_pts_num <= 1024;
+    const int bg = grouped ? 4 : 1;
+    const size_t smem = sizeof(int) * (size_t)(bg * 4 + 1) * (size_t)sampled_pts_num;
+    if (smem > 150 * 1024 || batch_size > 65535) {
         set_error("ws3d_roipool3d: sampled_pts_num=%d / batch=%d unsupported", sampled_pts_num, batch_size);
         return WS3D_E_UNSUPPORTED;
     }
-    if (smem > 64 * 1024)
-        hipFuncSetAttribute((const void *)roipool3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(roipool3d_kernel, dim3(boxes_num, batch_size), dim3(256), smem, as_stream(stream),
-                       pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
-                       pooled_features, pooled_empty_flag, pts_idx);
+    if (grouped) {
+        if (smem > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(roipool3d_kernel<4>, dim3((boxes_num + 3) / 4, batch_size), dim3(256), smem,
+                           as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,
+                           pts_feature, pooled_features, pooled_empty_flag, pts_idx);
+    } else {
+        if (smem > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(roipool3d_kernel<1>, dim3(boxes_num, batch_size), dim3(256), smem, as_stream(stream),
+                           pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
+                           pooled_features, pooled_empty_flag, pts_idx);
+    }
     return check_launch("ws3d_roipool3d");
 }
 
