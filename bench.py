@@ -288,6 +288,7 @@ def main():
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
+    ap.add_argument("--pipeline-depth", type=int, default=3, help="c3: batches in flight (one HIP stream + graph each)")
     args = ap.parse_args()
 
     from ws3d_amd import _lib
@@ -296,7 +297,7 @@ def main():
 
     if args.workload == "c3":
         from bench_c3 import C3
-        wl = C3(args.batch or 8, rank, world, args.kind)
+        wl = C3(args.batch or 8, rank, world, args.kind, depth=args.pipeline_depth)
     elif args.workload == "c5":
         wl = C5(args.batch or 8, rank, args.kind)
     else:

@@ -50,11 +50,13 @@ class C3:
     name = "c3_stage1_rpn_forward_nms_roipool"
     metric = "KITTI scenes/sec (16384 pts) Stage-1 RPN fwd (incl. proposal NMS + roipool3d)"
 
-    def __init__(self, batch, rank, world, kind="lidar"):
+    def __init__(self, batch, rank, world, kind="lidar", depth=2):
         self.B, self.rank, self.world, self.cfg = batch, rank, world, DEFAULT_CFG
+        self.depth = max(1, depth)
         self.pc_host = np.stack([synth.lidar_cloud(16384, 1000 * 3 + rank * batch + s) if kind == "lidar"
                                  else synth.uniform_cloud(16384, 1000 * 3 + rank * batch + s) for s in range(batch)])
         self.pts = torch.from_numpy(self.pc_host).cuda()
+        self._i = 0
         model = Stage1Net(mode='TEST').eval()
         model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
         self.model = model.cuda()
@@ -90,12 +92,13 @@ class C3:
                 "pre_nms": c.rpn_pre_nms_top_n, "nms_thresh": c.rpn_nms_thresh, "post_nms": c.rpn_post_nms_top_n,
                 "roipool": {"sampled": c.roi_sampled_pts, "channels": 128, "extra_width": c.roi_extra_width},
                 "exchange": "all_gather of (B,100,8) proposals" if self.world > 1 else "none (1 GPU)",
-                "launch": "hipGraph replay of the whole step" if getattr(self, "_graph", None) is not None
+                "launch": ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth)
+                if getattr(self, "_graph", None) is not None
                 else "eager (graph capture failed: %s)" % getattr(self, "_graph_err", "not attempted")}
 
     @torch.no_grad()
-    def _body(self):
-        out = self.model.rpn_forward({'pts_input': self.pts})
+    def _body(self, pts=None):
+        out = self.model.rpn_forward({'pts_input': self.pts if pts is None else pts})
         boxes, scores, count = proposals_from_rpn(out, self.cfg)
         feats = out['backbone_features'].transpose(1, 2).contiguous()
         pooled, empty = roipool3d_ops.roipool3d_gpu(out['backbone_xyz'], feats, boxes, self.cfg.roi_extra_width,
@@ -104,20 +107,27 @@ class C3:
 
     def capture(self):
         """Record the whole step (all torch ops + every C-ABI launch: no entry point allocates or
-        synchronises) into ONE hipGraph; returns True on success.  Replay removes the launch gaps
-        of ~450 small kernels."""
+        synchronises) into hipGraphs, one per pipeline slot; returns True on success.  Replay
+        removes the launch gaps of ~450 small kernels, and `depth` batches are kept in flight on
+        separate HIP streams: FPS of the next batch (8 workgroups = 8 of 256 CUs for 4.8 ms) runs
+        under the MLP / NMS / roipool work of the previous one."""
         try:
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(2):
-                    self._body()
-            torch.cuda.current_stream().wait_stream(s)
+            self._slots = []
+            for d in range(self.depth):
+                stream = torch.cuda.Stream()
+                pts = self.pts.clone()
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    for _ in range(2):
+                        self._body(pts)
+                torch.cuda.current_stream().wait_stream(stream)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    outs = self._body(pts)
+                self._slots.append((stream, g, outs, pts))
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._graph_out = self._body()
-            self._graph = g
+            self._graph = True
             return True
         except Exception as e:  # pragma: no cover - depends on the runtime
             self._graph = None
@@ -127,9 +137,13 @@ class C3:
     @torch.no_grad()
     def step(self, timed=False):
         if getattr(self, "_graph", None) is not None and not timed:
-            self._graph.replay()
-            out, boxes, scores, count, pooled, empty = self._graph_out
-            gathered = wdist.all_gather_proposals(wdist.pack_proposals(boxes, scores), count, self.B * self.world)
+            stream, g, outs, _ = self._slots[self._i % self.depth]
+            self._i += 1
+            with torch.cuda.stream(stream):
+                g.replay()
+                out, boxes, scores, count, pooled, empty = outs
+                gathered = wdist.all_gather_proposals(wdist.pack_proposals(boxes, scores), count,
+                                                      self.B * self.world)
             self.last = (out, boxes, scores, count, pooled, empty, gathered)
             return
         self._timed = timed

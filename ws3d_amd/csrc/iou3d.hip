@@ -289,6 +289,14 @@ __global__ __launch_bounds__(64) void radius_mask_kernel(int n, float radius, co
     mask[(size_t)cur * col_blocks + col_start] = t;
 }
 
+// one lane per box: the frame (double-precision trig, rotated corners) once per box instead of
+// once per 64x64 tile it takes part in (141x at n = 9000)
+__global__ __launch_bounds__(256) void bev_frames_kernel(long total, const float *__restrict__ boxes,
+                                                         float *__restrict__ frames) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) store_frame(frames + i * FRAME_F, make_bev_frame(boxes + i * 5));
+}
+
 // K12 (rotated).  A 64x64 tile of box pairs per 256-lane workgroup, in three phases:
 //   0. 128 lanes build the 64 row and 64 column frames (trig once per box) in LDS;
 //   1. all 4096 pairs take the cheap exact far-pair test; survivors are COMPACTED into an
@@ -308,11 +316,13 @@ struct MaskTileLds {
 
 __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float thresh, int full_grid,
                                                            const float *__restrict__ boxes,
+                                                           const float *__restrict__ frames,
                                                            uint64_t *__restrict__ mask) {
     {   // batched launch: blockIdx.z = scene (boxes (B,n,5), mask (B,n,ceil(n/64)))
         const size_t z_ = blockIdx.z;
         boxes += z_ * (size_t)boxes_num * 5;
         mask += z_ * (size_t)boxes_num * (size_t)((boxes_num + 63) / 64);
+        if (frames) frames += z_ * (size_t)boxes_num * FRAME_F;
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     MaskTileLds &s = *reinterpret_cast<MaskTileLds *>(smem_raw);
@@ -328,9 +338,17 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
     if (tid < 128) {
         const int which = tid >> 6;  // 0: row frames, 1: column frames
         const int n_here = which ? col_size : row_size;
-        if (lane < n_here)
-            store_frame(s.frames[which] + lane * FRAME_F,
-                        make_bev_frame(boxes + (size_t)((which ? col_start : row_start) * 64 + lane) * 5));
+        if (lane < n_here) {
+            const size_t bi = (size_t)((which ? col_start : row_start) * 64 + lane);
+            if (frames) {  // precomputed once per box by bev_frames_kernel (no trig in the tile loop)
+                const float *src = frames + bi * FRAME_F;
+                float *dst = s.frames[which] + lane * FRAME_F;
+#pragma unroll
+                for (int q = 0; q < FRAME_F; ++q) dst[q] = src[q];
+            } else {
+                store_frame(s.frames[which] + lane * FRAME_F, make_bev_frame(boxes + bi * 5));
+            }
+        }
         if (which == 0) { s.words[lane][0] = 0u; s.words[lane][1] = 0u; }
     }
     if (tid == 0) s.count = 0u;
@@ -341,7 +359,8 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
         bool cand = r < row_size && c < col_size && (!diag || c > r);
         if (cand) {
             const float *fr = s.frames[0] + r * FRAME_F, *fc = s.frames[1] + c * FRAME_F;
-            cand = !far_apart(fr[4], fr[5], fr[9], fc[4], fc[5], fc[9]);
+            // a far pair has overlap 0 => IoU 0: its bit is clear unless 0 > thresh
+            cand = !(thresh >= 0.0f) || !far_apart(fr[4], fr[5], fr[9], fc[4], fc[5], fc[9]);
         }
         const uint64_t bal = __ballot(cand);
         if (bal) {
@@ -475,7 +494,7 @@ static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *
 }
 
 static int mask_launch(int batch, int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
-                       uint64_t *mask, hipStream_t st, const char *what) {
+                       uint64_t *mask, float *frames, hipStream_t st, const char *what) {
     if (batch < 0 || boxes_num < 0 || !boxes || !mask) {
         set_error("%s: invalid argument (batch=%d boxes_num=%d)", what, batch, boxes_num);
         return WS3D_E_INVALID;
@@ -493,8 +512,13 @@ static int mask_launch(int batch, int boxes_num, const float *boxes, float thres
                                       (int)sizeof(MaskTileLds));
             attr_set = true;
         }
+        if (frames) {
+            const long total = (long)batch * boxes_num;
+            hipLaunchKernelGGL(bev_frames_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
+                               boxes, frames);
+        }
         hipLaunchKernelGGL(nms_rot_mask_kernel, grid, dim3(256), sizeof(MaskTileLds), st, boxes_num, thresh,
-                           full_grid, boxes, mask);
+                           full_grid, boxes, frames, mask);
     }
     return check_launch(what);
 }
@@ -515,14 +539,16 @@ extern "C" int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, co
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
                              uint64_t *mask, ws3d_stream_t stream) {
-    return ws3d::mask_launch(1, boxes_num, boxes, thresh, normal, full_grid, mask, ws3d::as_stream(stream),
-                             "ws3d_nms_mask");
+    return ws3d::mask_launch(1, boxes_num, boxes, thresh, normal, full_grid, mask, nullptr,
+                             ws3d::as_stream(stream), "ws3d_nms_mask");
 }
 
 extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
     if (boxes_num <= 0) return 256;
     const size_t cb = ((size_t)boxes_num + 63) / 64;
-    return ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t mask_b = ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t frame_b = ((size_t)boxes_num * ws3d::FRAME_F * sizeof(float) + 255) & ~(size_t)255;
+    return mask_b + frame_b;  // per scene: mask words + precomputed box frames
 }
 
 extern "C" int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, float thresh, int normal,
@@ -546,9 +572,13 @@ extern "C" int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, fl
         return WS3D_E_WORKSPACE;
     }
     uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
-    // per-scene mask stride inside the kernels is n*ceil(n/64) words; the workspace query rounds
-    // each scene up to 256 B, which is >= that, so the packed layout always fits
-    int rc = mask_launch(batch, boxes_num, boxes, thresh, normal, 0, mask, st, "ws3d_nms(mask)");
+    // layout: [batch packed masks (n*ceil(n/64) words each)] [batch packed frame arrays]; the
+    // per-scene query rounds both parts up to 256 B, so the packed layout always fits
+    const size_t mask_words = (size_t)batch * boxes_num * (size_t)((boxes_num + 63) / 64);
+    float *frames = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
+                                              ((mask_words * sizeof(uint64_t) + 255) & ~(size_t)255));
+    int rc = mask_launch(batch, boxes_num, boxes, thresh, normal, 0, mask, normal ? nullptr : frames, st,
+                         "ws3d_nms(mask)");
     if (rc != WS3D_OK) return rc;
     const size_t smem = sizeof(uint64_t) * (size_t)((boxes_num + 63) / 64);
     if (smem > 150 * 1024) { set_error("ws3d_nms: boxes_num too large for the LDS removed-set"); return WS3D_E_UNSUPPORTED; }
