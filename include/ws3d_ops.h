@@ -132,6 +132,11 @@ WS3D_API int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float
                                 const int32_t *idx, const float *weight, float *grad_points,
                                 ws3d_stream_t stream);
 
+/* y[b,o,l] = relu?(y[b,o,l] + bias[o]) in place, one pass: the epilogue of the SharedMLP
+ * (1x1 conv + eval-mode BatchNorm folded into one GEMM, pytorch_utils.py:20-101).  ws3d extension. */
+WS3D_API int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,
+                                   ws3d_stream_t stream);
+
 /* -------------------------------------------------------------------- iou3d_cuda */
 
 /* boxes_overlap_bev_gpu(boxes_a,boxes_b,ans)   iou3d.cpp:31-50 -> iou3d_kernel.cu:

@@ -193,6 +193,17 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weig
               "three_interpolate_grad")
 
 
+def bias_act_inplace(y, bias, relu=True):
+    """y (B,O,L...) contiguous: y = relu?(y + bias[o]) in place, one pass (ws3d extension)"""
+    dev = _dev(y, bias)
+    _f32(y, "y"); _f32(bias, "bias")
+    B, O = y.size(0), y.size(1)
+    L = y.numel() // max(B * O, 1)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_bias_act_inplace(B, O, L, int(bool(relu)), _p(y), _p(bias), _stream()), "bias_act")
+    return y
+
+
 # ------------------------------------------------------------------ iou3d_cuda
 def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
     """iou3d.cpp:31-50"""

@@ -9,6 +9,7 @@
 // bests in double initialised to 1e40 but compares a float d against them; float
 // bests initialised to +inf give bit-identical decisions and outputs ((float)1e40 ==
 // +inf, inf < inf is false exactly like inf < 1e40).
+#include <algorithm>
 #include <cmath>
 
 #include "common.h"
@@ -123,7 +124,42 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     }
 }
 
+// y[b, o, l] = act(y[b, o, l] + bias[o]) in place, one pass (the SharedMLP GEMM epilogue that
+// rocBLAS' strided-batched GEMM does not fuse for a per-row bias): float4 along l.
+__global__ __launch_bounds__(256) void bias_act_kernel(int o_ch, long l, int relu, float *__restrict__ y,
+                                                       const float *__restrict__ bias) {
+    const long row = blockIdx.y;                       // b * o_ch + o
+    const float bv = bias[row % o_ch];
+    float *p = y + row * l;
+    const long l4 = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? (l >> 2) : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < l4; i += (long)gridDim.x * 256) {
+        float4 v = reinterpret_cast<float4 *>(p)[i];
+        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        reinterpret_cast<float4 *>(p)[i] = v;
+    }
+    for (long i = l4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < l; i += (long)gridDim.x * 256) {
+        float v = p[i] + bv;
+        p[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
 }  // namespace ws3d
+
+extern "C" int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,
+                                     ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || o_ch <= 0 || l < 0 || !y || !bias || (long)b * o_ch > 65535L * 16) {
+        set_error("ws3d_bias_act_inplace: invalid argument (b=%d o=%d l=%ld)", b, o_ch, l);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || l == 0) return WS3D_OK;
+    const long rows = (long)b * o_ch;
+    if (rows > 65535) { set_error("ws3d_bias_act_inplace: too many rows"); return WS3D_E_UNSUPPORTED; }
+    const unsigned gx = (unsigned)std::min<long>(64, (l / 4 + 255) / 256 + 1);
+    hipLaunchKernelGGL(bias_act_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, as_stream(stream), o_ch, l, relu, y, bias);
+    return check_launch("ws3d_bias_act_inplace");
+}
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
                              float *dist2, int32_t *idx, ws3d_stream_t stream) {

@@ -101,6 +101,10 @@ class _ConvBlock(nn.Sequential):
             return super().forward(x)
         w, shift, act = self._folded()
         y = torch.matmul(w, x.reshape(x.shape[0], x.shape[1], -1))
+        if x.is_cuda and shift is not None and (act is None or isinstance(act, nn.ReLU)):
+            from . import compat as _C       # one fused epilogue pass instead of add + clamp
+            _C.bias_act_inplace(y, shift.contiguous(), relu=act is not None)
+            return y.reshape(x.shape[0], -1, *x.shape[2:])
         if shift is not None:
             y = y + shift[None, :, None]
         if act is not None:
