@@ -427,6 +427,38 @@ def test_nms_batched_and_proposal_stage(ops, oracle):
         assert (host(pb[b, len(k):]) == 0).all()
 
 
+@pytest.mark.parametrize("normal", [False, True])
+@pytest.mark.parametrize("max_keep", [1, 5, 40, 200])
+def test_nms_max_keep_leading_block_ladder(ops, oracle, normal, max_keep):
+    """max_keep > 0 builds only a leading block of the mask and widens it when the sweep runs out
+    of rows; scenes of one batch finish at different levels (sparse: first level, crowded: all
+    levels).  The result must be the full greedy sweep's first max_keep survivors."""
+    n = 3000
+    scenes = [_bev(n, 31, 40.0)[0], _bev(n, 32, 1.5)[0], _bev(n, 33, 6.0)[0]]
+    scenes[1][:, 4] = 0.0 if normal else scenes[1][:, 4]
+    boxes = np.ascontiguousarray(np.stack(scenes))
+    thresh = 0.05
+    keep, num = ops.c.nms_device_batched(dev(boxes), thresh, normal, max_keep)
+    full = [oracle.nms_sorted(boxes[b], thresh, normal) for b in range(3)]
+    assert len(full[1]) < len(full[2]) < len(full[0])      # crowded < medium < sparse
+    for b in range(3):
+        ref = full[b][:max_keep]
+        assert int(num[b]) == len(ref)
+        np.testing.assert_array_equal(host(keep[b])[:len(ref)], ref)
+
+
+def test_radius_nms_max_keep_ladder(ops, oracle):
+    rng = np.random.default_rng(5)
+    n = 2500
+    c = np.stack([rng.uniform(-40, 40, (n, 2)), rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-3, 3, (n, 2))]).astype(np.float32)
+    for max_keep in (1, 6, 50):
+        keep, num = ops.c.radius_nms_device_batched(dev(c), 0.3, max_keep=max_keep)
+        for b in range(3):
+            ref = oracle.radius_nms_sorted(c[b], 0.3)[:max_keep]
+            assert int(num[b]) == len(ref)
+            np.testing.assert_array_equal(host(keep[b])[:len(ref)], ref)
+
+
 @pytest.mark.parametrize("B,n,r", [(1, 1, 0.3), (2, 300, 0.3), (3, 1000, 1.0), (1, 4000, 0.3), (2, 65, 0.05)])
 def test_radius_nms_bit_exact(ops, oracle, B, n, r):
     rng = np.random.default_rng(n)

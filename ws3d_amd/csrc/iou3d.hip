@@ -216,10 +216,26 @@ __global__ __launch_bounds__(64) void pair_kernel(int num_a, const float *__rest
     }
 }
 
+// Speculative leading block for "keep the first max_keep" NMS.  The greedy sweep only ever reads
+// mask[i][j] for rows/columns below the row at which the max_keep-th box is kept, so the device
+// NMS entry points first build just the leading lead x lead chunk triangle and sweep it; a per-
+// scene done flag then turns every later (larger) level into an early exit.  Results are those of
+// the full mask + full sweep, bit for bit (same greedy order, same pair tests).
+struct LeadArgs {
+    const int *done;   // per-scene flag written by the previous level's sweep (nullptr: first level)
+    int prev_lead;     // tiles with row < prev_lead && col < prev_lead were built by that level
+    int internal;      // 1: mask lives in the NMS workspace, lower-triangle zero fill is skipped
+    __device__ __forceinline__ bool skip_tile(int row, int col, int scene) const {
+        if (done && done[scene]) return true;
+        if (row < prev_lead && col < prev_lead) return true;
+        return internal && col < row;
+    }
+};
+
 // K13 (axis-aligned): lane = row box i (its own 64-bit word), column boxes from LDS.
 __global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, float thresh, int full_grid,
                                                              const float *__restrict__ boxes,
-                                                             uint64_t *__restrict__ mask) {
+                                                             uint64_t *__restrict__ mask, LeadArgs la) {
     {   // batched launch: blockIdx.z = scene (boxes (B,n,5), mask (B,n,ceil(n/64)))
         const size_t z_ = blockIdx.z;
         boxes += z_ * (size_t)boxes_num * 5;
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, floa
     const int row_size = min(boxes_num - row_start * 64, 64);
     const int col_size = min(boxes_num - col_start * 64, 64);
     const int cur = row_start * 64 + lane;
+    if (la.skip_tile(row_start, col_start, blockIdx.z)) return;
     if (col_start < row_start && !full_grid) {  // never read by the sweep (iou3d.cpp:108)
         if (lane < row_size) mask[(size_t)cur * col_blocks + col_start] = 0;
         return;
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(64) void nms_normal_mask_kernel(int boxes_num, floa
 // greedy sweep above (drop j when a kept i < j has the bit set) keeps exactly the candidates whose
 // distance to every kept centre is > radius.  distance_2 = sqrtf(dx*dx + dz*dz), fp32, unfused.
 __global__ __launch_bounds__(64) void radius_mask_kernel(int n, float radius, const float *__restrict__ centers,
-                                                         uint64_t *__restrict__ mask) {
+                                                         uint64_t *__restrict__ mask, LeadArgs la) {
     {
         const size_t z_ = blockIdx.z;
         centers += z_ * (size_t)n * 2;
@@ -271,6 +288,7 @@ __global__ __launch_bounds__(64) void radius_mask_kernel(int n, float radius, co
     const int row_size = min(n - row_start * 64, 64);
     const int col_size = min(n - col_start * 64, 64);
     const int cur = row_start * 64 + lane;
+    if (la.skip_tile(row_start, col_start, blockIdx.z)) return;
     if (col_start < row_start) {
         if (lane < row_size) mask[(size_t)cur * col_blocks + col_start] = 0;
         return;
@@ -317,7 +335,7 @@ struct MaskTileLds {
 __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float thresh, int full_grid,
                                                            const float *__restrict__ boxes,
                                                            const float *__restrict__ frames,
-                                                           uint64_t *__restrict__ mask) {
+                                                           uint64_t *__restrict__ mask, LeadArgs la) {
     {   // batched launch: blockIdx.z = scene (boxes (B,n,5), mask (B,n,ceil(n/64)))
         const size_t z_ = blockIdx.z;
         boxes += z_ * (size_t)boxes_num * 5;
@@ -331,6 +349,7 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
     const int col_blocks = (boxes_num + 63) / 64;
     const int row_size = min(boxes_num - row_start * 64, 64);
     const int col_size = min(boxes_num - col_start * 64, 64);
+    if (la.skip_tile(row_start, col_start, blockIdx.z)) return;
     if (col_start < row_start && !full_grid) {  // never read by the sweep (iou3d.cpp:108)
         if (tid < row_size) mask[(size_t)(row_start * 64 + tid) * col_blocks + col_start] = 0;
         return;
@@ -403,9 +422,13 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_keep,
                                                         const uint64_t *__restrict__ mask,
                                                         int64_t *__restrict__ keep,
-                                                        int32_t *__restrict__ num_keep) {
+                                                        int32_t *__restrict__ num_keep, int chunk_limit,
+                                                        const int *__restrict__ done_in,
+                                                        int *__restrict__ done_out) {
     {   // batched launch: blockIdx.x = scene
         const size_t z_ = blockIdx.x;
+        if (done_in && done_in[z_]) return;  // an earlier (smaller) level already kept max_keep boxes
+        if (done_out) done_out += z_;
         mask += z_ * (size_t)boxes_num * (size_t)((boxes_num + 63) / 64);
         keep += z_ * (size_t)boxes_num;
         num_keep += z_;
@@ -422,7 +445,8 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_k
     if (tid < 64 && lane < boxes_num) d_next = mask[(size_t)lane * col_blocks];
     __syncthreads();
     const int limit = max_keep > 0 ? max_keep : boxes_num;
-    for (int c = 0; c < col_blocks; ++c) {
+    const int c_end = min(col_blocks, chunk_limit);  // columns >= c_end are not built at this level
+    for (int c = 0; c < c_end; ++c) {
         const int rows = min(64, boxes_num - c * 64);
         if (tid < 64) {
             const uint64_t d = d_next;
@@ -449,14 +473,14 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_k
             }
             // prefetch the next chunk's diagonal words (independent of the removed-set)
             const int nr = (c + 1) * 64 + lane;
-            d_next = (c + 1 < col_blocks && nr < boxes_num) ? mask[(size_t)nr * col_blocks + (c + 1)] : 0;
+            d_next = (c + 1 < c_end && nr < boxes_num) ? mask[(size_t)nr * col_blocks + (c + 1)] : 0;
         }
         __syncthreads();
         const uint64_t kept = kept_s;
         const bool done = total_s >= limit;
         if (kept && !done) {
             const uint64_t *rowbase = mask + (size_t)(c * 64) * col_blocks;
-            for (int j = c + 1 + tid; j < col_blocks; j += 256) {
+            for (int j = c + 1 + tid; j < c_end; j += 256) {
                 uint64_t acc = 0, kk = kept;
                 while (kk) {  // 4 independent loads in flight per trip
                     uint64_t v[4] = {0, 0, 0, 0};
@@ -476,7 +500,10 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_k
         __syncthreads();
         if (done) break;
     }
-    if (tid == 0) *num_keep = total_s;
+    if (tid == 0) {
+        *num_keep = total_s;
+        if (done_out) *done_out = (total_s >= limit || c_end >= col_blocks) ? 1 : 0;
+    }
 }
 
 template <int MODE>
@@ -493,8 +520,10 @@ static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *
     return check_launch(what);
 }
 
+// grid_chunks: the launch covers the leading grid_chunks x grid_chunks tiles of each scene
 static int mask_launch(int batch, int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
-                       uint64_t *mask, float *frames, hipStream_t st, const char *what) {
+                       uint64_t *mask, float *frames, bool build_frames, int grid_chunks, LeadArgs la,
+                       hipStream_t st, const char *what) {
     if (batch < 0 || boxes_num < 0 || !boxes || !mask) {
         set_error("%s: invalid argument (batch=%d boxes_num=%d)", what, batch, boxes_num);
         return WS3D_E_INVALID;
@@ -502,9 +531,10 @@ static int mask_launch(int batch, int boxes_num, const float *boxes, float thres
     if (boxes_num == 0 || batch == 0) return WS3D_OK;
     const int cb = (boxes_num + 63) / 64;
     if (cb > 65535 || batch > 65535) { set_error("%s: boxes_num/batch too large", what); return WS3D_E_UNSUPPORTED; }
-    dim3 grid(cb, cb, batch);
+    const int gc = grid_chunks > 0 ? std::min(grid_chunks, cb) : cb;
+    dim3 grid(gc, gc, batch);
     if (normal) {
-        hipLaunchKernelGGL(nms_normal_mask_kernel, grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask);
+        hipLaunchKernelGGL(nms_normal_mask_kernel, grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask, la);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
@@ -512,14 +542,54 @@ static int mask_launch(int batch, int boxes_num, const float *boxes, float thres
                                       (int)sizeof(MaskTileLds));
             attr_set = true;
         }
-        if (frames) {
+        if (frames && build_frames) {
             const long total = (long)batch * boxes_num;
             hipLaunchKernelGGL(bev_frames_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
                                boxes, frames);
         }
         hipLaunchKernelGGL(nms_rot_mask_kernel, grid, dim3(256), sizeof(MaskTileLds), st, boxes_num, thresh,
-                           full_grid, boxes, frames, mask);
+                           full_grid, boxes, frames, mask, la);
     }
+    return check_launch(what);
+}
+
+// workspace layout: [batch packed masks (n*ceil(n/64) words each)] [batch packed frame arrays]
+// [batch done flags]; ws3d_nms_workspace_bytes rounds each part up to 256 B per scene, so the
+// packed layout always fits in batch * that.
+struct NmsWorkspace {
+    uint64_t *mask;
+    float *frames;
+    int *done;
+};
+static NmsWorkspace carve(void *workspace, int batch, int n) {
+    char *base = reinterpret_cast<char *>(workspace);
+    const size_t mask_b = (((size_t)batch * n * (size_t)((n + 63) / 64)) * sizeof(uint64_t) + 255) & ~(size_t)255;
+    const size_t frame_b = ((size_t)batch * n * FRAME_F * sizeof(float) + 255) & ~(size_t)255;
+    return {reinterpret_cast<uint64_t *>(base), reinterpret_cast<float *>(base + mask_b),
+            reinterpret_cast<int *>(base + mask_b + frame_b)};
+}
+
+// leading-block ladder: chunk counts of the speculative levels, last entry = all chunks
+static int lead_levels(int cb, int boxes_num, int max_keep, int out[3]) {
+    int nl = 0;
+    if (max_keep > 0 && max_keep < boxes_num) {
+        const int l1 = std::max(4, (max_keep * 8 + 63) / 64);
+        const int l2 = l1 * 4;
+        if (l1 * 2 <= cb) out[nl++] = l1;
+        if (l2 * 2 <= cb) out[nl++] = l2;
+    }
+    out[nl++] = cb;
+    return nl;
+}
+
+static int sweep_launch(int batch, int n, int max_keep, const uint64_t *mask, int64_t *keep, int32_t *num_keep,
+                        int chunk_limit, const int *done_in, int *done_out, hipStream_t st, const char *what) {
+    const size_t smem = sizeof(uint64_t) * (size_t)((n + 63) / 64);
+    if (smem > 150 * 1024) { set_error("%s: boxes_num too large for the LDS removed-set", what); return WS3D_E_UNSUPPORTED; }
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, n, max_keep, mask, keep, num_keep,
+                       chunk_limit, done_in, done_out);
     return check_launch(what);
 }
 
@@ -539,8 +609,8 @@ extern "C" int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, co
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
                              uint64_t *mask, ws3d_stream_t stream) {
-    return ws3d::mask_launch(1, boxes_num, boxes, thresh, normal, full_grid, mask, nullptr,
-                             ws3d::as_stream(stream), "ws3d_nms_mask");
+    return ws3d::mask_launch(1, boxes_num, boxes, thresh, normal, full_grid, mask, nullptr, false, 0,
+                             ws3d::LeadArgs{nullptr, 0, 0}, ws3d::as_stream(stream), "ws3d_nms_mask");
 }
 
 extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
@@ -548,7 +618,7 @@ extern "C" size_t ws3d_nms_workspace_bytes(int boxes_num) {
     const size_t cb = ((size_t)boxes_num + 63) / 64;
     const size_t mask_b = ((size_t)boxes_num * cb * sizeof(uint64_t) + 255) & ~(size_t)255;
     const size_t frame_b = ((size_t)boxes_num * ws3d::FRAME_F * sizeof(float) + 255) & ~(size_t)255;
-    return mask_b + frame_b;  // per scene: mask words + precomputed box frames
+    return mask_b + frame_b + 256;  // per scene: mask words + precomputed box frames + done flag
 }
 
 extern "C" int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, float thresh, int normal,
@@ -571,21 +641,20 @@ extern "C" int ws3d_nms_batched(int batch, int boxes_num, const float *boxes, fl
         set_error("ws3d_nms: workspace too small (%zu < %zu)", workspace_bytes, need);
         return WS3D_E_WORKSPACE;
     }
-    uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
-    // layout: [batch packed masks (n*ceil(n/64) words each)] [batch packed frame arrays]; the
-    // per-scene query rounds both parts up to 256 B, so the packed layout always fits
-    const size_t mask_words = (size_t)batch * boxes_num * (size_t)((boxes_num + 63) / 64);
-    float *frames = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) +
-                                              ((mask_words * sizeof(uint64_t) + 255) & ~(size_t)255));
-    int rc = mask_launch(batch, boxes_num, boxes, thresh, normal, 0, mask, normal ? nullptr : frames, st,
-                         "ws3d_nms(mask)");
-    if (rc != WS3D_OK) return rc;
-    const size_t smem = sizeof(uint64_t) * (size_t)((boxes_num + 63) / 64);
-    if (smem > 150 * 1024) { set_error("ws3d_nms: boxes_num too large for the LDS removed-set"); return WS3D_E_UNSUPPORTED; }
-    if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, boxes_num, max_keep, mask, keep, num_keep);
-    return check_launch("ws3d_nms(sweep)");
+    const NmsWorkspace ws = carve(workspace, batch, boxes_num);
+    const int cb = (boxes_num + 63) / 64;
+    int levels[3];
+    const int nl = lead_levels(cb, boxes_num, max_keep, levels);
+    for (int k = 0; k < nl; ++k) {
+        const LeadArgs la{k ? ws.done : nullptr, k ? levels[k - 1] : 0, 1};
+        int rc = mask_launch(batch, boxes_num, boxes, thresh, normal, 0, ws.mask, normal ? nullptr : ws.frames,
+                             k == 0, levels[k], la, st, "ws3d_nms(mask)");
+        if (rc != WS3D_OK) return rc;
+        rc = sweep_launch(batch, boxes_num, max_keep, ws.mask, keep, num_keep, levels[k], k ? ws.done : nullptr,
+                          k + 1 < nl ? ws.done : nullptr, st, "ws3d_nms(sweep)");
+        if (rc != WS3D_OK) return rc;
+    }
+    return WS3D_OK;
 }
 
 extern "C" int ws3d_nms(int boxes_num, const float *boxes, float thresh, int normal, int max_keep,
@@ -621,12 +690,18 @@ extern "C" int ws3d_radius_nms_batched(int batch, int n, const float *centers, f
         set_error("ws3d_radius_nms: n/batch too large");
         return WS3D_E_UNSUPPORTED;
     }
-    uint64_t *mask = reinterpret_cast<uint64_t *>(workspace);
-    hipLaunchKernelGGL(radius_mask_kernel, dim3(cb, cb, batch), dim3(64), 0, st, n, radius, centers, mask);
-    int rc = check_launch("ws3d_radius_nms(mask)");
-    if (rc != WS3D_OK) return rc;
-    if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, n, max_keep, mask, keep, num_keep);
-    return check_launch("ws3d_radius_nms(sweep)");
+    const NmsWorkspace ws = carve(workspace, batch, n);
+    int levels[3];
+    const int nl = lead_levels(cb, n, max_keep, levels);
+    for (int k = 0; k < nl; ++k) {
+        const LeadArgs la{k ? ws.done : nullptr, k ? levels[k - 1] : 0, 1};
+        hipLaunchKernelGGL(radius_mask_kernel, dim3(levels[k], levels[k], batch), dim3(64), 0, st, n, radius,
+                           centers, ws.mask, la);
+        int rc = check_launch("ws3d_radius_nms(mask)");
+        if (rc != WS3D_OK) return rc;
+        rc = sweep_launch(batch, n, max_keep, ws.mask, keep, num_keep, levels[k], k ? ws.done : nullptr,
+                          k + 1 < nl ? ws.done : nullptr, st, "ws3d_radius_nms(sweep)");
+        if (rc != WS3D_OK) return rc;
+    }
+    return WS3D_OK;
 }
