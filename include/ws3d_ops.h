@@ -137,6 +137,12 @@ WS3D_API int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float
 WS3D_API int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,
                                    ws3d_stream_t stream);
 
+/* out[b,o,m] = relu?(max_s y[b,o,m,s] + bias[o]) (bias may be NULL): the set-abstraction pool
+ * F.max_pool2d(new_features, kernel_size=[1, nsample]) (pointnet2_modules.py:51-58) fused with
+ * the last SharedMLP layer's bias + ReLU, which commute with the max exactly.  ws3d extension. */
+WS3D_API int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, const float *y, const float *bias,
+                                  float *out, ws3d_stream_t stream);
+
 /* -------------------------------------------------------------------- iou3d_cuda */
 
 /* boxes_overlap_bev_gpu(boxes_a,boxes_b,ans)   iou3d.cpp:31-50 -> iou3d_kernel.cu:

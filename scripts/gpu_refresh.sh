@@ -1,0 +1,29 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): full GPU test suite, the bench lines and the rocprofv3
+# evidence of one code state.  Everything lands in gpurun_out/refresh/; copy what should be
+# judged into profiles/ afterwards (see profiles/README.md).
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/refresh
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+python bench.py                             2>$OUT/bench_c2_b256.err | tail -1 > $OUT/bench_c2_b256.json
+python bench.py --batch 8 --no-cpu-baseline 2>$OUT/bench_c2_b8.err   | tail -1 > $OUT/bench_c2_b8.json
+python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 > $OUT/bench_c3_b8.json
+python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
+python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
+for w in c2 c3 c5; do
+  extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph"
+  rm -rf /tmp/prof_$w
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o $w -- python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline $extra > $OUT/prof_$w.log 2>&1
+  db=$(find /tmp/prof_$w -name '*.db' | head -1)
+  python scripts/rocpd_stats.py "$db" > $OUT/${w}_kernel_stats.csv 2>>$OUT/prof_$w.log
+done
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o pmc -- python bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+done
+python scripts/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \
+  $OUT/traffic.json "c2 batch 256, bytes per launch, rocprofv3 --pmc in separate passes" > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
+ls -la $OUT

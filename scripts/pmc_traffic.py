@@ -16,7 +16,7 @@ def per_kernel(db_path, counter):
     return {r[0]: (r[1] * 1024.0, r[2]) for r in rows}
 
 def short(name):
-    for k in ("fps_reg_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_mask_kernel", "nms_sweep_kernel", "roipool3d_kernel",
+    for k in ("fps_reg_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_rot_mask_kernel", "nms_sweep_kernel", "bev_frames_kernel", "roipool3d_kernel",
               "three_nn_kernel", "three_interpolate_kernel", "group_points_kernel"):
         if k in name:
             return k

@@ -522,3 +522,22 @@ def test_errors_are_exceptions_not_exit(ops):
                                  torch.zeros((1, 4, 1), dtype=torch.int32, device="cuda"))
     with pytest.raises(AssertionError):
         ops.pn.furthest_point_sample(torch.zeros((1, 16, 6), device="cuda")[:, :, :3], 4)  # non-contiguous
+
+
+@pytest.mark.parametrize("B,O,M,S", [(2, 5, 7, 16), (1, 3, 33, 32), (2, 4, 9, 5), (1, 2, 3, 4), (1, 1, 5, 64), (2, 3, 4, 256)])
+def test_mlp_epilogues_bit_exact(ops, B, O, M, S):
+    """SharedMLP epilogue kernels == the torch ops they replace (single fp32 add / max: bit-exact)"""
+    g = torch.Generator().manual_seed(B * 100 + S)
+    y = torch.randn((B, O, M, S), generator=g).cuda()
+    y[0, 0, 0, 1] = float("nan")
+    bias = torch.randn(O, generator=g).cuda()
+    for relu in (True, False):
+        ref = y.amax(dim=3) + bias[None, :, None]
+        ref = torch.relu(ref) if relu else ref
+        got = ops.c.rowmax_bias_act(y, bias, relu=relu)
+        np.testing.assert_array_equal(host(got), host(ref))
+        ref2 = y + bias[None, :, None, None]
+        ref2 = torch.relu(ref2) if relu else ref2
+        got2 = ops.c.bias_act_inplace(y.clone(), bias, relu=relu)
+        np.testing.assert_array_equal(host(got2), host(ref2))
+    np.testing.assert_array_equal(host(ops.c.rowmax_bias_act(y, None, relu=False)), host(y.amax(dim=3)))

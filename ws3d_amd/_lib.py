@@ -35,6 +35,7 @@ SIGNATURES = {
     "ws3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),
+    "ws3d_rowmax_bias_act": (_i, [_i, _i, C.c_long, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "ws3d_boxes_iou_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
     "ws3d_nms_mask": (_i, [_i, _vp, _f, _i, _i, _vp, _vp]),

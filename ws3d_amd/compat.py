@@ -204,6 +204,20 @@ def bias_act_inplace(y, bias, relu=True):
     return y
 
 
+def rowmax_bias_act(y, bias=None, relu=True):
+    """y (B,O,M,S) contiguous -> (B,O,M): relu?(max over S + bias[o]) in one pass (ws3d extension)"""
+    dev = _dev(y) if bias is None else _dev(y, bias)
+    _f32(y, "y")
+    if bias is not None:
+        _f32(bias, "bias")
+    B, O, M, S = y.shape
+    out = torch.empty((B, O, M), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_rowmax_bias_act(B, O, M, S, int(bool(relu)), _p(y), _p(bias) if bias is not None else None,
+                                               _p(out), _stream()), "rowmax_bias_act")
+    return out
+
+
 # ------------------------------------------------------------------ iou3d_cuda
 def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
     """iou3d.cpp:31-50"""

@@ -124,6 +124,8 @@ __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
     }
 }
 
+__device__ __forceinline__ float relu_f(float v) { return v < 0.f ? 0.f : v; }  // NaN stays NaN (torch.relu)
+
 // y[b, o, l] = act(y[b, o, l] + bias[o]) in place, one pass (the SharedMLP GEMM epilogue that
 // rocBLAS' strided-batched GEMM does not fuse for a per-row bias): float4 along l.
 __global__ __launch_bounds__(256) void bias_act_kernel(int o_ch, long l, int relu, float *__restrict__ y,
@@ -135,13 +137,53 @@ __global__ __launch_bounds__(256) void bias_act_kernel(int o_ch, long l, int rel
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < l4; i += (long)gridDim.x * 256) {
         float4 v = reinterpret_cast<float4 *>(p)[i];
         v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (relu) { v.x = relu_f(v.x); v.y = relu_f(v.y); v.z = relu_f(v.z); v.w = relu_f(v.w); }
         reinterpret_cast<float4 *>(p)[i] = v;
     }
     for (long i = l4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < l; i += (long)gridDim.x * 256) {
         float v = p[i] + bv;
-        p[i] = relu ? fmaxf(v, 0.f) : v;
+        p[i] = relu ? relu_f(v) : v;
     }
+}
+
+// out[b, o, m] = act(max_s y[b, o, m, s] + bias[o]): the SA module's pool over nsample fused with
+// the last layer's bias + ReLU (they commute with the max exactly: both are monotone
+// non-decreasing and so is fp32 rounding).  G = s/4 adjacent lanes own one (b,o,m) row and read
+// it as float4 (fully coalesced); the group maximum is folded with DPP-width shuffles.  NaN
+// propagates like torch.amax / F.max_pool2d.
+__device__ __forceinline__ float nanmax(float a, float b) { return (b > a || b != b) ? b : a; }
+
+template <int G>
+__global__ __launch_bounds__(256) void rowmax_bias_act_kernel(int o_ch, long m, long rows, int relu,
+                                                              const float *__restrict__ y,
+                                                              const float *__restrict__ bias,
+                                                              float *__restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t / G;
+    float v = -INFINITY;
+    if (row < rows) {
+        const float4 q = reinterpret_cast<const float4 *>(y)[t];
+        v = nanmax(nanmax(q.x, q.y), nanmax(q.z, q.w));
+    }
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) v = nanmax(v, __shfl_xor(v, d, 64));
+    if (row < rows && (t % G) == 0) {
+        if (bias) v += bias[(row / m) % o_ch];
+        out[row] = relu ? relu_f(v) : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rowmax_bias_act_generic_kernel(int o_ch, long m, long rows, int s, int relu,
+                                                                      const float *__restrict__ y,
+                                                                      const float *__restrict__ bias,
+                                                                      float *__restrict__ out) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const float *p = y + row * s;
+    float v = -INFINITY;
+    for (int i = 0; i < s; ++i) v = nanmax(v, p[i]);
+    if (bias) v += bias[(row / m) % o_ch];
+    out[row] = relu ? relu_f(v) : v;
 }
 
 }  // namespace ws3d
@@ -159,6 +201,38 @@ extern "C" int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y
     const unsigned gx = (unsigned)std::min<long>(64, (l / 4 + 255) / 256 + 1);
     hipLaunchKernelGGL(bias_act_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, as_stream(stream), o_ch, l, relu, y, bias);
     return check_launch("ws3d_bias_act_inplace");
+}
+
+extern "C" int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, const float *y, const float *bias,
+                                    float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || o_ch <= 0 || m < 0 || s <= 0 || !y || !out) {
+        set_error("ws3d_rowmax_bias_act: invalid argument (b=%d o=%d m=%ld s=%d)", b, o_ch, m, s);
+        return WS3D_E_INVALID;
+    }
+    const long rows = (long)b * o_ch * m;
+    if (rows == 0) return WS3D_OK;
+    hipStream_t st = as_stream(stream);
+    const bool vec = (s % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    const int g = vec ? s / 4 : 0;
+    const long threads = vec ? rows * g : rows;
+    const long blocks = (threads + 255) / 256;
+    if (blocks > 0x7fffffffL) { set_error("ws3d_rowmax_bias_act: tensor too large"); return WS3D_E_UNSUPPORTED; }
+#define WS3D_RM(G) hipLaunchKernelGGL((rowmax_bias_act_kernel<G>), dim3((unsigned)blocks), dim3(256), 0, st, o_ch, m, rows, relu, y, bias, out)
+    switch (g) {
+        case 1: WS3D_RM(1); break;
+        case 2: WS3D_RM(2); break;
+        case 4: WS3D_RM(4); break;
+        case 8: WS3D_RM(8); break;
+        case 16: WS3D_RM(16); break;
+        case 32: WS3D_RM(32); break;
+        case 64: WS3D_RM(64); break;
+        default:
+            hipLaunchKernelGGL(rowmax_bias_act_generic_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st,
+                               o_ch, m, rows, s, relu, y, bias, out);
+    }
+#undef WS3D_RM
+    return check_launch("ws3d_rowmax_bias_act");
 }
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
