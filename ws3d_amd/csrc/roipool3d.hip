@@ -15,9 +15,21 @@
 //      with fully coalesced 16-byte stores, gathering 512-byte feature rows.
 // No scratch, no allocation, no host sync; the output write (B*M*S*(3+C)*4 bytes) is
 // the only large HBM stream, which makes this an HBM-roofline kernel.
+#include <cstdlib>
+
 #include "common.h"
 
+#ifdef WS3D_ROI_PROF   // scripts/ubench/roi_prof.hip: per-workgroup wall-clock timeline (100 MHz)
+__device__ long long g_roi_prof[8192 * 4];
+#define ROI_PROF(slot) if (threadIdx.x == 0) g_roi_prof[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + slot] = wall_clock64();
+#else
+#define ROI_PROF(slot)
+#endif
+
 namespace ws3d {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float4v float4u __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
 
 struct BoxFrame {
     float cx, cy, cz, hh, hw, hl, cosa, sina;
@@ -40,12 +52,23 @@ __device__ __forceinline__ BoxFrame make_frame(const float *bx) {
     return f;
 }
 
+// roipool3d_kernel.cu:14-28 pt_in_box3d as ONE ordered comparison.  The reference's early
+// "return 0" exits only skip work, so the flag is the AND of
+//   !(|dx| > 10), !(|dy| > hh), !(|dz| > 10), -hl <= x_rot <= hl, -hw <= z_rot <= hw.
+// For fp32 a <= b  <=>  fl(a - b) <= 0 (the sign of a difference is exact, subnormals kept), and
+// -e <= v <= e  <=>  |v| <= e, so with t = (|x_rot|-hl, |z_rot|-hw, |dx|-10, |dy|-hh, |dz|-10) the
+// flag is max(t) <= 0 -- except for NaN, which v_max3_f32 drops while the reference's >= / <= on a
+// NaN x_rot / z_rot (NaN or inf coordinates, angle or extent) say "outside" and its '>' tests on a
+// NaN |dy| say "keep going".  x_rot and z_rot are NaN together (shared operands; |dx|,|dz| <= 10
+// and |cos|,|sin| <= 1 exclude inf - inf), so one ordered-compare of t0, t1 restores that.
 __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y, float z) {
-    const float max_dis = 10.0f;
-    if ((fabsf(x - f.cx) > max_dis) || (fabsf(y - f.cy) > f.hh) || (fabsf(z - f.cz) > max_dis)) return false;
-    const float x_rot = (x - f.cx) * f.cosa + (z - f.cz) * (-f.sina);
-    const float z_rot = (x - f.cx) * f.sina + (z - f.cz) * f.cosa;
-    return (x_rot >= -f.hl) & (x_rot <= f.hl) & (z_rot >= -f.hw) & (z_rot <= f.hw);
+    const float dx = x - f.cx, dy = y - f.cy, dz = z - f.cz;
+    const float x_rot = dx * f.cosa + dz * (-f.sina);
+    const float z_rot = dx * f.sina + dz * f.cosa;
+    const float t0 = fabsf(x_rot) - f.hl, t1 = fabsf(z_rot) - f.hw;
+    const float t2 = fabsf(dx) - 10.0f, t3 = fabsf(dy) - f.hh, t4 = fabsf(dz) - 10.0f;
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)), t4);
+    return !(m > 0.0f) & !__builtin_isunordered(t0, t1);
 }
 
 // BG boxes of one scene per workgroup: every point loaded by the scan is tested against BG box
@@ -64,6 +87,7 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
     int *sel = lists + BG * 4 * S;               // S
     __shared__ int wcnt_s[BG * 4];
 
+    ROI_PROF(0)
     const int box0 = blockIdx.x * BG, b = blockIdx.y;
     const int nb = min(BG, boxes_num - box0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -73,30 +97,67 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
 #pragma unroll
     for (int g = 0; g < BG; ++g) f[g] = make_frame(boxes3d + ((size_t)b * boxes_num + box0 + min(g, nb - 1)) * 7);
 
+    ROI_PROF(3)
     const int Q = (((pts_num + 3) / 4 + 63) / 64) * 64;
     const int start = min(w * Q, pts_num), end = min(start + Q, pts_num);
     int wcnt[BG];
 #pragma unroll
     for (int g = 0; g < BG; ++g) wcnt[g] = g < nb ? 0 : S;
-    for (int k0 = start; k0 < end; k0 += 64) {
-        const int k = k0 + lane;
-        float x = 0.f, y = 0.f, z = 0.f;
-        const bool in_range = k < end;
-        if (in_range) { const float *p = xyz + (size_t)k * 3; x = p[0]; y = p[1]; z = p[2]; }
-        bool all_full = true;
+    // 4 sub-blocks of 64 points per trip, software-pipelined: the 12 loads of trip t+1 are issued
+    // before the tests of trip t, so the L2 round trip hides behind ~500 instructions of tests
+    float nx[4], ny[4], nz[4];
+    auto load_trip = [&](int k0) {
 #pragma unroll
-        for (int g = 0; g < BG; ++g) {
-            if (wcnt[g] < S) {  // wave-uniform
-                const bool flag = in_range && pt_in_frame(f[g], x, y, z);
-                const uint64_t mask = __ballot(flag);
-                if (mask) {
-                    const int pos = wcnt[g] + mbcnt(mask);
-                    if (flag && pos < S) lists[(g * 4 + w) * S + pos] = k;
-                    wcnt[g] += (int)__builtin_popcountll(mask);
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 64 + lane;   // loads are clamped, never branched; a lane past the
+            const float *p = xyz + (size_t)min(k, pts_num - 1) * 3;  // wave's range gets x = NaN = "outside"
+#ifdef WS3D_ROI_NO_LOAD   // ablation: synthetic coordinates, no memory traffic in the scan
+            nx[u] = k < end ? (float)(k & 1023) * 0.07f - 35.f : __builtin_nanf(""); ny[u] = 1.5f; nz[u] = (float)(k >> 10) + (p == nullptr ? 1.f : 0.f);
+#else
+            nx[u] = k < end ? p[0] : __builtin_nanf(""); ny[u] = p[1]; nz[u] = p[2];
+#endif
+        }
+    };
+#ifdef WS3D_ROI_MIXED     // ablation: odd workgroups skip the scan, even ones skip the copy
+    const bool skip_scan = (blockIdx.x >> 3) & 1;
+    if (skip_scan) for (int g = 0; g < BG; ++g) { if (lane < 40) lists[(g * 4 + w) * S + lane] = start + lane * 7; wcnt[g] = g < nb ? 40 : S; }
+    if (!skip_scan) load_trip(start);
+    for (int k0 = skip_scan ? end : start; k0 < end; k0 += 256) {
+#elif defined(WS3D_ROI_NO_SCAN)   // ablation: pretend every wave found 40 points
+    for (int g = 0; g < BG; ++g) { if (lane < 40) lists[(g * 4 + w) * S + lane] = start + lane * 7; wcnt[g] = g < nb ? 40 : S; }
+    for (int k0 = end; k0 < end; k0 += 256) {
+#else
+    if (start < end) load_trip(start);
+    for (int k0 = start; k0 < end; k0 += 256) {
+#endif
+        float x[4], y[4], z[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x[u] = nx[u]; y[u] = ny[u]; z[u] = nz[u]; }
+        load_trip(k0 + 256);
+        // all 4 x BG tests first (independent VALU work, masks in SGPRs), bookkeeping afterwards:
+        // a test followed directly by its own ballot branch serialises on VALU->SALU round trips
+        uint64_t mask[4][BG];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame(f[g], x[u], y[u], z[u]));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 64 + lane;
+#pragma unroll
+            for (int g = 0; g < BG; ++g) {
+                const uint64_t mk = mask[u][g];
+                if (mk) {  // wave-uniform; a full list (wcnt >= S) takes no more appends: pos < S fails
+                    const int wc = __builtin_amdgcn_readfirstlane(wcnt[g]);
+                    const int pos = wc + mbcnt(mk);
+                    if (((mk >> lane) & 1ull) && pos < S) lists[(g * 4 + w) * S + pos] = k;
+                    wcnt[g] = min(wc + (int)__builtin_popcountll(mk), S);
                 }
-                all_full = all_full && wcnt[g] >= S;
             }
         }
+        bool all_full = true;
+#pragma unroll
+        for (int g = 0; g < BG; ++g) all_full = all_full && wcnt[g] >= S;
         if (all_full) break;
     }
     if (lane == 0) {
@@ -104,9 +165,11 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
         for (int g = 0; g < BG; ++g) wcnt_s[g * 4 + w] = min(wcnt[g], S);
     }
     __syncthreads();
+    ROI_PROF(1)
 
     const int row = 3 + feat_len;
     const int total = S * row;
+    const bool vec_rows = feat_len >= 4 && (feat_len & 3) == 0 && (reinterpret_cast<uintptr_t>(pts_feature) & 15) == 0;
     for (int g = 0; g < nb; ++g) {
         const size_t bm = (size_t)b * boxes_num + box0 + g;
         const int *lg = lists + g * 4 * S;
@@ -129,12 +192,47 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
             if (pts_idx) pts_idx[bm * S + q] = v;
         }
         __syncthreads();
+#ifdef WS3D_ROI_NO_COPY
+        if (pts_num >= 0) continue;
+#endif
+#ifdef WS3D_ROI_MIXED
+        if (!((blockIdx.x >> 3) & 1)) continue;
+#endif
         float *out = pooled + bm * (size_t)S * row;
         auto fetch = [&](int sr, int j) -> float {
             const int src = sel[sr];
             return j < 3 ? xyz[(size_t)src * 3 + j] : pts_feature[(size_t)src * feat_len + (j - 3)];
         };
-        if ((total & 3) == 0 && ((bm * (size_t)total) & 3) == 0) {
+        if (vec_rows) {
+            // feature rows are 16-byte aligned in the source: 32 lanes move one row with aligned
+            // 16-byte loads and (4-byte aligned) 16-byte stores, lanes 0-2 carry x, y, z; 4 rows
+            // per half-wave and trip keep 8 loads in flight per lane
+            const int half = tid >> 5, l32 = tid & 31;
+            const int f4 = feat_len >> 2;
+            for (int sr0 = half * 4; sr0 < S; sr0 += 32) {
+                int src[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) src[u] = sel[min(sr0 + u, S - 1)];
+                for (int c = l32; c < f4; c += 32) {
+                    float4v v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        v[u] = reinterpret_cast<const float4v *>(pts_feature + (size_t)src[u] * feat_len)[c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (sr0 + u < S) {
+                            // streaming store: the output is never re-read here, the gathered rows are
+                            // (overlapping boxes share points) -- keep those in L2/MALL (measured -7 %)
+                            __builtin_nontemporal_store(v[u], reinterpret_cast<float4u *>(out + (size_t)(sr0 + u) * row + 3 + 4 * c));
+                        }
+                }
+                if (l32 < 3) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (sr0 + u < S) out[(size_t)(sr0 + u) * row + l32] = xyz[(size_t)src[u] * 3 + l32];
+                }
+            }
+        } else if ((total & 3) == 0 && ((bm * (size_t)total) & 3) == 0) {
             // the S x (3+C) block of a box is contiguous and 16-byte aligned: 4 elements per store
             int sr = (4 * tid) / row, j = 4 * tid - sr * row;
             const int ds = 1024 / row, dj = 1024 - ds * row;
@@ -160,6 +258,7 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
         }
         __syncthreads();  // sel is reused by the next box
     }
+    ROI_PROF(2)
 }
 
 __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int pts_num,
@@ -188,27 +287,27 @@ extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int fe
         return WS3D_E_INVALID;
     }
     if (batch_size == 0 || boxes_num == 0) return WS3D_OK;
-    // 4 boxes per workgroup when that still leaves >= 2 workgroups per CU
-    const bool grouped = (long)batch_size * ((boxes_num + 3) / 4) >= 512 && sampled_pts_num <= 1024;
-    const int bg = grouped ? 4 : 1;
+    // boxes per workgroup: sharing the scene scan among 4 boxes pays when that still leaves >= 2
+    // workgroups per CU (WS3D_ROI_BG overrides for A/B runs)
+    static const int bg_env = getenv("WS3D_ROI_BG") ? atoi(getenv("WS3D_ROI_BG")) : 0;
+    int bg = ((long)batch_size * ((boxes_num + 3) / 4) >= 512 && sampled_pts_num <= 1024) ? 4 : 1;
+    if (bg_env == 1 || bg_env == 2 || bg_env == 4) bg = bg_env;
     const size_t smem = sizeof(int) * (size_t)(bg * 4 + 1) * (size_t)sampled_pts_num;
     if (smem > 150 * 1024 || batch_size > 65535) {
         set_error("ws3d_roipool3d: sampled_pts_num=%d / batch=%d unsupported", sampled_pts_num, batch_size);
         return WS3D_E_UNSUPPORTED;
     }
-    if (grouped) {
-        if (smem > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(roipool3d_kernel<4>, dim3((boxes_num + 3) / 4, batch_size), dim3(256), smem,
-                           as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,
-                           pts_feature, pooled_features, pooled_empty_flag, pts_idx);
-    } else {
-        if (smem > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(roipool3d_kernel<1>, dim3(boxes_num, batch_size), dim3(256), smem, as_stream(stream),
-                           pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
-                           pooled_features, pooled_empty_flag, pts_idx);
+#define WS3D_ROI_LAUNCH(BGV)                                                                                       \
+    {                                                                                                              \
+        if (smem > 64 * 1024)                                                                                      \
+            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<BGV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem);                                                                  \
+        hipLaunchKernelGGL(roipool3d_kernel<BGV>, dim3((boxes_num + BGV - 1) / BGV, batch_size), dim3(256), smem, \
+                           as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,   \
+                           pts_feature, pooled_features, pooled_empty_flag, pts_idx);                              \
     }
+    if (bg == 4) WS3D_ROI_LAUNCH(4) else if (bg == 2) WS3D_ROI_LAUNCH(2) else WS3D_ROI_LAUNCH(1)
+#undef WS3D_ROI_LAUNCH
     return check_launch("ws3d_roipool3d");
 }
 
