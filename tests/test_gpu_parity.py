@@ -1,6 +1,8 @@
 """GPU parity: the HIP kernels (through the C ABI of libws3d_hip.so) against the CPU
 oracle on the same seeded inputs.  Bit-exact for every index/mask output and for the
 pure-copy float outputs; 1e-5 for interpolated features (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -541,3 +543,24 @@ def test_mlp_epilogues_bit_exact(ops, B, O, M, S):
         got2 = ops.c.bias_act_inplace(y.clone(), bias, relu=relu)
         np.testing.assert_array_equal(host(got2), host(ref2))
     np.testing.assert_array_equal(host(ops.c.rowmax_bias_act(y, None, relu=False)), host(y.amax(dim=3)))
+
+
+def test_kitti_directory_to_result_files(ops, tmp_path):
+    """ingest -> Stage-1 forward -> proposals -> KITTI result files on a synthetic KITTI tree"""
+    from ws3d_amd import infer_kitti, kitti_io
+    root, out = str(tmp_path / "kitti"), str(tmp_path / "res")
+    synth.write_kitti_tree(root, [(7, 60000, 1), (8, 9000, 2), (11, 30000, 3)])
+    files = infer_kitti.run(root, "val", out, batch=2)
+    assert [os.path.basename(f) for f in files] == ["000007.txt", "000008.txt", "000011.txt"]
+    for f in files:
+        objs = kitti_io.read_label_file(f)
+        assert len(objs) <= 100
+        for o in objs:
+            assert o.cls_type == "Car" and np.isfinite(o.box3d()).all() and 0.0 <= o.box2d[0] <= o.box2d[2] <= 1241.0
+    again = infer_kitti.run(root, "val", str(tmp_path / "res2"), batch=3)
+    for a, b in zip(files, again):   # another batch size: same proposals (GEMM kernels differ in the last ulps)
+        oa, ob = kitti_io.read_label_file(a), kitti_io.read_label_file(b)
+        assert len(oa) == len(ob)
+        for x, y in zip(oa, ob):
+            np.testing.assert_allclose(x.box3d(), y.box3d(), atol=2e-3)
+            np.testing.assert_allclose(x.box2d, y.box2d, atol=5e-2)

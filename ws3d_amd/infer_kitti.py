@@ -1,0 +1,65 @@
+"""Stage-1 inference over a KITTI directory: ``.bin`` scans in, KITTI-format result files out.
+
+    python -m ws3d_amd.infer_kitti --root /data/KITTI/object --split val --out results/ [--ckpt x.pth]
+
+The counterpart of the reference's ``tools/eval_auto.py`` / ``generate_box_dataset.py`` drivers
+for the part of the pipeline this repository implements: ingest
+(``ws3d_amd.kitti_io``) -> Stage-1 forward -> on-device proposal stage -> ``save_kitti_format``.
+Weights come from a reference checkpoint (``model_state``, identical keys) or, without one, from
+the seeded initialisation used by the benchmarks.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from . import kitti_io, stage1
+
+
+def run(root: str, split: str, out_dir: str, batch: int = 8, ckpt: str | None = None, npoints: int = 16384,
+        seed: int = 666, device: str = "cuda:0", cfg: stage1.RPNConfig = stage1.DEFAULT_CFG) -> list:
+    """returns the list of result files written (one per scene, possibly empty)"""
+    dev = torch.device(device)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg).to(dev).eval()
+    if ckpt:
+        state = torch.load(ckpt, map_location="cpu")
+        model.load_state_dict(state.get("model_state", state), strict=True)
+    else:
+        from .seeded import seeded_state_dict
+        model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 0))
+    rng = np.random.RandomState(seed)           # eval_auto.py:139 seeds numpy with 666 before sampling
+    scenes = kitti_io.KittiScenes(root, split, npoints=npoints, rng=rng)
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    with torch.no_grad():
+        for i0 in range(0, len(scenes), batch):
+            samples = [scenes[i] for i in range(i0, min(i0 + batch, len(scenes)))]
+            pts = torch.from_numpy(kitti_io.collate_scenes(samples)["pts_input"]).to(dev)
+            out = model.rpn_forward({"pts_input": pts})
+            boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
+            boxes, scores, count = boxes.cpu().numpy(), scores.cpu().numpy(), count.cpu().numpy()
+            for j, s in enumerate(samples):
+                sid, k = s["sample_id"], int(count[j])
+                written.append(kitti_io.save_kitti_format(sid, scenes.get_calib(sid), boxes[j, :k], out_dir,
+                                                          scores[j, :k], scenes.get_image_shape(sid), "Car"))
+    return written
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--root", required=True)
+    ap.add_argument("--split", default="val")
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--ckpt", default=None)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--npoints", type=int, default=16384)
+    a = ap.parse_args()
+    files = run(a.root, a.split, a.out, a.batch, a.ckpt, a.npoints)
+    print(f"{len(files)} result files in {a.out}")
+
+
+if __name__ == "__main__":
+    main()

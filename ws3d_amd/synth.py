@@ -145,3 +145,66 @@ def boxes3d_to_bev(boxes3d: np.ndarray) -> np.ndarray:
     out[:, 2], out[:, 3] = b[:, 0] + half_l, b[:, 2] + half_w
     out[:, 4] = b[:, 6]
     return out
+
+
+# --------------------------------------------------------------------------- synthetic KITTI directory
+KITTI_CALIB_TEXT = """P0: 7.215377e+02 0.000000e+00 6.095593e+02 0.000000e+00 0.000000e+00 7.215377e+02 1.728540e+02 0.000000e+00 0.000000e+00 0.000000e+00 1.000000e+00 0.000000e+00
+P1: 7.215377e+02 0.000000e+00 6.095593e+02 -3.875744e+02 0.000000e+00 7.215377e+02 1.728540e+02 0.000000e+00 0.000000e+00 0.000000e+00 1.000000e+00 0.000000e+00
+P2: 7.215377e+02 0.000000e+00 6.095593e+02 4.485728e+01 0.000000e+00 7.215377e+02 1.728540e+02 2.163791e-01 0.000000e+00 0.000000e+00 1.000000e+00 2.745884e-03
+P3: 7.215377e+02 0.000000e+00 6.095593e+02 -3.395242e+02 0.000000e+00 7.215377e+02 1.728540e+02 2.199936e+00 0.000000e+00 0.000000e+00 1.000000e+00 2.729905e-03
+R0_rect: 9.999239e-01 9.837760e-03 -7.445048e-03 -9.869795e-03 9.999421e-01 -4.278459e-03 7.402527e-03 4.351614e-03 9.999631e-01
+Tr_velo_to_cam: 7.533745e-03 -9.999714e-01 -6.166020e-04 -4.069766e-03 1.480249e-02 7.280733e-04 -9.998902e-01 -7.631618e-02 9.998621e-01 7.523790e-03 1.480755e-02 -2.717806e-01
+Tr_imu_to_velo: 9.999976e-01 7.553071e-04 -2.035826e-03 -8.086759e-01 -7.854027e-04 9.998898e-01 -1.482298e-02 3.195559e-01 2.024406e-03 1.482454e-02 9.998881e-01 -7.997231e-01
+"""
+
+KITTI_LABEL_TEXT = """Car 0.00 0 -1.58 587.01 173.33 614.12 200.12 1.65 1.67 3.64 -0.65 1.71 46.70 -1.59
+Car 0.00 1 1.85 387.63 181.54 423.81 203.12 1.67 1.87 3.69 -16.53 2.39 58.49 1.57
+Pedestrian 0.00 0 0.21 423.17 173.67 433.17 224.03 1.60 0.38 0.30 -5.87 1.63 23.11 -0.03
+DontCare -1 -1 -10 503.89 169.71 590.61 190.13 -1 -1 -1 -1000 -1000 -1000 -10
+"""
+
+
+def _blank_png(width: int, height: int) -> bytes:
+    """a valid all-black 8-bit RGB PNG, written with zlib only"""
+    import struct
+    import zlib
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    raw = (b"\x00" + b"\x00" * (3 * width)) * height
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+
+
+def velodyne_scan(n: int, seed: int) -> np.ndarray:
+    """(n,4) float32 velodyne-frame points: x forward, y left, z up; a forward wedge wider than the
+    camera frustum with a ground sheet and some elevated clutter, reflectance in [0,1)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = 1.0 + 77.0 * rng.uniform(0, 1, n) ** 2.5        # lidar returns thin out with range
+    y = rng.uniform(-0.75, 0.75, n) * (x + 4.0)
+    ground = rng.uniform(0, 1, n) < 0.7
+    z = np.where(ground, -1.73 + rng.normal(0, 0.03, n), rng.uniform(-1.7, 1.2, n))
+    refl = rng.uniform(0, 1, n)
+    return np.stack((x, y, z, refl), axis=1).astype(np.float32)
+
+
+def write_kitti_tree(root: str, scenes) -> None:
+    """scenes: iterable of (sample_id, n_points, seed).  Lays out root/ImageSets/val.txt and
+    root/training/{velodyne,calib,image_2,label_2}/%06d.* like the KITTI object benchmark."""
+    import os
+    for sub in ("velodyne", "calib", "image_2", "label_2"):
+        os.makedirs(os.path.join(root, "training", sub), exist_ok=True)
+    os.makedirs(os.path.join(root, "ImageSets"), exist_ok=True)
+    ids = []
+    for sample_id, n, seed in scenes:
+        ids.append("%06d" % sample_id)
+        velodyne_scan(n, seed).tofile(os.path.join(root, "training", "velodyne", "%06d.bin" % sample_id))
+        with open(os.path.join(root, "training", "calib", "%06d.txt" % sample_id), "w") as f:
+            f.write(KITTI_CALIB_TEXT)
+        with open(os.path.join(root, "training", "image_2", "%06d.png" % sample_id), "wb") as f:
+            f.write(_blank_png(1242, 375))
+        with open(os.path.join(root, "training", "label_2", "%06d.txt" % sample_id), "w") as f:
+            f.write(KITTI_LABEL_TEXT)
+    with open(os.path.join(root, "ImageSets", "val.txt"), "w") as f:
+        f.write("\n".join(ids) + "\n")
