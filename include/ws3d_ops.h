@@ -117,9 +117,11 @@ WS3D_API int ws3d_query_and_group(int b, int n, int m, int c, float radius, int 
 
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   interpolate.cpp:14-23 ->
  * interpolate_gpu.cu:9-67.  unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3)
- * SQUARED distances, idx (b,n,3).                                                   */
+ * SQUARED distances, idx (b,n,3).  sorted_known: NULL (full scan) or the x-binned copy of
+ * `known` from ws3d_sort_points_x(b, m, known, ...) -- same result, the search then only visits
+ * the known points whose x is closer than the running third-best distance.            */
 WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
-                  int32_t *idx, ws3d_stream_t stream);
+                  int32_t *idx, const void *sorted_known, ws3d_stream_t stream);
 
 /* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   interpolate.cpp:26-39 ->
  * interpolate_gpu.cu:77-117.  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n).    */

@@ -65,3 +65,75 @@ if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("
                 continue
             for srt in (False, True):
                 bq_case(B, N, M, r, ns, C, srt)
+
+
+def s2_case(B):
+    """Stage-2 (RCNN) set-abstraction shapes: 512-point RoI clouds (lib/config.py:122-129)"""
+    pts = synth.roi_clouds(B, 512, 5)
+    xyz = torch.from_numpy(pts).cuda()
+    feat = torch.randn((B, 128, 512), device="cuda")
+    idx1 = torch.empty((B, 128), dtype=torch.int32, device="cuda"); new1 = torch.empty((B, 128, 3), device="cuda")
+    idx2 = torch.empty((B, 32), dtype=torch.int32, device="cuda"); new2 = torch.empty((B, 32, 3), device="cuda")
+    nbr1 = torch.empty((B, 128, 64), dtype=torch.int32, device="cuda"); out1 = torch.empty((B, 131, 128, 64), device="cuda")
+    nbr2 = torch.empty((B, 32, 64), dtype=torch.int32, device="cuda"); out2 = torch.empty((B, 131, 32, 64), device="cuda")
+    feat2 = torch.randn((B, 128, 128), device="cuda")
+    t = {}
+    t["fps1"] = timeit(lambda: c.furthest_point_sampling_gather(B, 512, 128, xyz, None, idx1, new1))[0]
+    t["qg1"] = timeit(lambda: c.query_and_group(B, 512, 128, 128, 0.2, 64, True, xyz, new1, feat, nbr1, out1, None))[0]
+    t["fps2"] = timeit(lambda: c.furthest_point_sampling_gather(B, 128, 32, new1, None, idx2, new2))[0]
+    t["qg2"] = timeit(lambda: c.query_and_group(B, 128, 32, 128, 0.4, 64, True, new1, new2, feat2, nbr2, out2, None))[0]
+    gb1, gb2 = out1.numel() * 4 / 1e9, out2.numel() * 4 / 1e9
+    print(f"s2 B={B}: " + " ".join(f"{k}={v:.3f}ms" for k, v in t.items()) +
+          f"  qg1 {gb1 / t['qg1'] * 1e3:.0f} GB/s  qg2 {gb2 / t['qg2'] * 1e3:.0f} GB/s (output bytes only)")
+
+
+if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "s2":
+    for B in (64, 800):
+        s2_case(B)
+
+
+def copy_ops_case(B):
+    """the standalone copy kernels at Stage-2 / Stage-1 shapes: GB/s of bytes written"""
+    xyz = torch.from_numpy(synth.roi_clouds(B, 512, 5)).cuda()
+    feat = torch.randn((B, 128, 512), device="cuda")
+    idx = torch.randint(0, 512, (B, 128, 64), dtype=torch.int32, device="cuda")
+    out = torch.empty((B, 128, 128, 64), device="cuda")
+    t = timeit(lambda: c.group_points_wrapper(B, 128, 512, 128, 64, feat, idx, out))[0]
+    print(f"group_points B={B} C=128 N=512 M=128 ns=64: {t:.3f} ms  {out.numel() * 4 / t / 1e6:.0f} GB/s written")
+    gi = torch.randint(0, 512, (B, 128), dtype=torch.int32, device="cuda")
+    go = torch.empty((B, 128, 128), device="cuda")
+    t = timeit(lambda: c.gather_points_wrapper(B, 128, 512, 128, feat, gi, go))[0]
+    print(f"gather_points B={B} C=128 N=512 M=128: {t:.3f} ms  {go.numel() * 4 / t / 1e6:.0f} GB/s written")
+    B2 = max(B // 100, 1)
+    known = torch.randn((B2, 256, 4096), device="cuda")
+    ii = torch.randint(0, 4096, (B2, 16384, 3), dtype=torch.int32, device="cuda")
+    ww = torch.rand((B2, 16384, 3), device="cuda")
+    oo = torch.empty((B2, 256, 16384), device="cuda")
+    t = timeit(lambda: c.three_interpolate_wrapper(B2, 256, 4096, 16384, known, ii, ww, oo))[0]
+    print(f"three_interpolate B={B2} C=256 M=4096 N=16384: {t:.3f} ms  {oo.numel() * 4 / t / 1e6:.0f} GB/s written")
+
+
+if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "copy":
+    for B in (64, 800):
+        copy_ops_case(B)
+
+
+def nn_case(B, N, M):
+    pc = synth.make_batch("lidar", B, N, 2)[:, :, :3].copy()
+    unk = torch.from_numpy(pc).cuda()
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); kn = torch.empty((B, M, 3), device="cuda")
+    c.furthest_point_sampling_gather(B, N, M, unk, None, idx, kn)
+    d2 = torch.empty((B, N, 3), device="cuda"); i2 = torch.empty((B, N, 3), dtype=torch.int32, device="cuda")
+    t_b = timeit(lambda: c.three_nn_wrapper(B, N, M, unk, kn, d2, i2))[0]
+    srt = c.sort_points_x(kn, min_n=64)
+    if srt is None:
+        print(f"three_nn B={B} N={N} M={M}: brute {t_b:.3f} ms")
+        return
+    t_sort = timeit(lambda: c.sort_points_x(kn, min_n=64))[0]
+    t_s = timeit(lambda: c.three_nn_wrapper(B, N, M, unk, kn, d2, i2, srt))[0]
+    print(f"three_nn B={B} N={N} M={M}: brute {t_b:.3f} ms, binned {t_s:.3f} ms + sort {t_sort:.3f} ms")
+
+
+if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "nn":
+    for (B, N, M) in [(8, 16384, 4096), (8, 4096, 1024), (8, 1024, 256), (8, 256, 64), (64, 16384, 4096)]:
+        nn_case(B, N, M)

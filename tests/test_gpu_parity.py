@@ -257,6 +257,44 @@ def test_three_nn_bit_exact(ops, oracle, B, n, m, seed):
     np.testing.assert_array_equal(host(d2), d2_ref)  # squared distances: bit-exact
 
 
+@pytest.mark.parametrize("B,n,m,kind,seed", [(2, 4096, 2048, "lidar", 1), (1, 16384, 4096, "lidar", 2), (2, 3000, 2500, "uniform", 3),
+                                             (1, 5000, 2048, "dups", 4), (1, 4096, 2100, "line", 5), (1, 2500, 2048, "outside", 6),
+                                             (1, 2048, 2048, "samex", 7), (1, 7000, 6000, "lidar", 8)])
+def test_three_nn_binned_search_bit_exact(ops, oracle, B, n, m, kind, seed):
+    """the x-binned 3-NN == the full ascending scan, including equal-distance tie-breaks (duplicated
+    known points), unknown points outside the known x range (clamped cells), a degenerate x
+    extent (one cell) and points strung along x"""
+    rng = np.random.default_rng(seed)
+    base = synth.make_batch("uniform" if kind == "uniform" else "lidar", B, n, seed + 20)[:, :, :3].copy()
+    unk = base
+    kn = np.stack([base[b][rng.permutation(n)[:m]] for b in range(B)])
+    if kind == "dups":      # every known point 4 times at scattered indices: ties on all three slots
+        kn[:, m // 4:] = np.tile(kn[:, :m // 4], (1, 3, 1))[:, :m - m // 4]
+        kn = np.stack([kn[b][rng.permutation(m)] for b in range(B)])
+    if kind == "line":      # y = z = 0: distance = |dx| only, many exact ties from a regular grid
+        kn[:, :, 1:] = 0
+        kn[:, :, 0] = (rng.integers(0, 400, (B, m)) * 0.25).astype(np.float32)
+        unk[:, :, 1:] = 0
+        unk[:, :, 0] = (rng.integers(0, 800, (B, n)) * 0.125).astype(np.float32)
+    if kind == "outside":   # unknown x range is 3x the known one
+        unk[:, :, 0] *= 3.0
+    if kind == "samex":     # all known points share one x: zero-width binning
+        kn[:, :, 0] = 1.25
+    kn = np.ascontiguousarray(kn.astype(np.float32)); unk = np.ascontiguousarray(unk.astype(np.float32))
+    d2_ref, idx_ref = oracle.three_nn_dist2(unk, kn)
+    srt = ops.c.sort_points_x(dev(kn))
+    assert srt is not None
+    d2 = torch.empty((B, n, 3), device="cuda"); i2 = torch.empty((B, n, 3), dtype=torch.int32, device="cuda")
+    ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2, i2, srt)
+    np.testing.assert_array_equal(host(i2), idx_ref)
+    np.testing.assert_array_equal(host(d2), d2_ref)
+    d2b = torch.empty_like(d2); i2b = torch.empty_like(i2)
+    ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2b, i2b)          # full scan kernel
+    np.testing.assert_array_equal(host(i2b), host(i2))
+    dist, idx = ops.pn.three_nn(dev(unk), dev(kn), srt)
+    np.testing.assert_array_equal(host(idx), idx_ref)
+
+
 def test_three_interpolate_and_grad(ops, oracle):
     rng = np.random.default_rng(0)
     feat = rng.standard_normal((2, 37, 64)).astype(np.float32)
@@ -271,6 +309,21 @@ def test_three_interpolate_and_grad(ops, oracle):
     g = rng.standard_normal(ref.shape).astype(np.float32)
     out.backward(dev(g))
     np.testing.assert_allclose(host(f.grad), oracle.three_interpolate_grad(g, idx, w, 64), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,C,M,N", [(2, 5, 300, 2048), (1, 9, 4097, 1024), (2, 3, 64, 1028), (1, 4, 7, 603),
+                                     (1, 130, 1024, 4096)])
+def test_three_interpolate_kernel_variants(ops, oracle, B, C, M, N):
+    """rows-in-LDS (n >= 1024, n % 4 == 0, row fits), 4-points-per-lane and scalar kernels: all
+    bit-equal to the oracle's fmaf expression"""
+    rng = np.random.default_rng(N + M)
+    feat = rng.standard_normal((B, C, M)).astype(np.float32)
+    idx = rng.integers(0, M, (B, N, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    out = torch.empty((B, C, N), device="cuda")
+    ops.c.three_interpolate_wrapper(B, C, M, N, dev(feat), dev(idx), dev(w), out)
+    np.testing.assert_array_equal(host(out), oracle.three_interpolate(feat, idx, w))
 
 
 # ------------------------------------------------------------------------------- roipool3d

@@ -31,7 +31,7 @@ SIGNATURES = {
     "ws3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ws3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),

@@ -40,7 +40,7 @@ def hipcc() -> str:
 
 
 def _deps(src: str):
-    return [src, os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
+    return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "binning.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
             os.path.abspath(__file__)]
 
 

@@ -105,16 +105,16 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
 SORTED_MIN_N = 2048  # below this the LDS-tiled brute-force scan is already cheap
 
 
-def sort_points_x(xyz):
+def sort_points_x(xyz, min_n=None):
     """(B,N,3) -> opaque uint8 buffer (per scene: N float4 {x,y,z,bits(index)} binned by x, a
-    header and a cell-start table), or None when the x-binned path does not apply (N < 2048 or
-    N > 16384).  ws3d extension."""
+    header and a cell-start table), or None when the x-binned path does not apply (N < min_n,
+    default 2048 -- where the binned ball query starts to pay -- or N > 16384).  ws3d extension."""
     dev = _dev(xyz)
     _f32(xyz, "xyz")
     b, n = xyz.size(0), xyz.size(1)
     lib = _lib.load()
     nbytes = lib.ws3d_sorted_points_bytes(b, n)
-    if n < SORTED_MIN_N or nbytes == 0:
+    if n < (SORTED_MIN_N if min_n is None else min_n) or nbytes == 0:
         return None
     out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
@@ -164,13 +164,14 @@ def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features
     return 1
 
 
-def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor):
-    """interpolate.cpp:14-23"""
+def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor, sorted_known=None):
+    """interpolate.cpp:14-23 (+ optional x-binned copy of `known` from sort_points_x: same result)"""
     dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)
     _f32(unknown_tensor, "unknown"); _f32(known_tensor, "known"); _i32(idx_tensor, "idx")
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_three_nn(b, n, m, _p(unknown_tensor), _p(known_tensor), _p(dist2_tensor),
-                                         _p(idx_tensor), _stream()), "three_nn")
+                                         _p(idx_tensor), _p(sorted_known) if sorted_known is not None else None,
+                                         _stream()), "three_nn")
 
 
 def three_interpolate_wrapper(b, c, m, n, points_tensor, idx_tensor, weight_tensor, out_tensor):

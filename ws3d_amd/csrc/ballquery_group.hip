@@ -16,8 +16,23 @@
 // rows never go back to global memory: the same workgroup emits the centred xyz and
 // the feature channels straight into the (B, 3+C, M, ns) tensor the SharedMLP consumes.
 #include "common.h"
+#include "binning.h"
 
 namespace ws3d {
+
+// 16-byte store; streaming (non-temporal) when the grouped tensor is far larger than the last-level
+// cache (stage-2 shapes: 3.4 GB per launch, 0.98 -> 0.75 ms), plain otherwise so that the SharedMLP
+// GEMM that follows still finds a small tensor in L2 / MALL
+__device__ __forceinline__ void st4(float *p, const float4 v, const bool stream) {
+    if (stream) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v *>(p));
+    } else {
+        *reinterpret_cast<float4 *>(p) = v;
+    }
+}
+constexpr size_t STREAM_STORE_BYTES = (size_t)512 << 20;
 
 // Shared epilogue: NC centres' padded neighbour rows (LDS) -> idx tensor and/or the fused
 // (B, 3+C, M, ns) grouped tensor, coalesced along (m, s).
@@ -53,6 +68,42 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
     // its own slice of the feature channels, so wide layers (C = 256..512) fill the chip
     const int chunk = (c_feat + (int)gridDim.z - 1) / (int)gridDim.z;
     const int ch_lo = (int)blockIdx.z * chunk, ch_hi = min(c_feat, ch_lo + chunk);
+    if ((nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        const bool stream = (size_t)gridDim.y * c_out * plane * sizeof(float) > STREAM_STORE_BYTES;
+        // 4 consecutive samples of one centre per lane: 16-byte stores along (m, s), 4 independent
+        // gathers per channel, two channels in flight
+        for (int q = tid; q < total_e / 4; q += NT) {
+            const int e = 4 * q;
+            const int c = e / nsample, s = e - c * nsample;
+            if (m0 + c >= m) continue;
+            const IDX *r = rows + (size_t)c * rstride + s;
+            const int i0 = (int)r[0], i1 = (int)r[1], i2 = (int)r[2], i3 = (int)r[3];
+            if (use_xyz && blockIdx.z == 0) {
+                const float4 ce = cen[c];
+                const float *p0 = xyz + (size_t)i0 * 3, *p1 = xyz + (size_t)i1 * 3, *p2 = xyz + (size_t)i2 * 3,
+                            *p3 = xyz + (size_t)i3 * 3;   // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
+                *reinterpret_cast<float4 *>(ob + e) = make_float4(p0[0] - ce.x, p1[0] - ce.x, p2[0] - ce.x, p3[0] - ce.x);
+                *reinterpret_cast<float4 *>(ob + plane + e) = make_float4(p0[1] - ce.y, p1[1] - ce.y, p2[1] - ce.y, p3[1] - ce.y);
+                *reinterpret_cast<float4 *>(ob + 2 * plane + e) = make_float4(p0[2] - ce.z, p1[2] - ce.z, p2[2] - ce.z, p3[2] - ce.z);
+            }
+            int ch = ch_lo;
+            for (; ch + 4 <= ch_hi; ch += 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float *f = fb + (size_t)(ch + u) * n;
+                    v[u] = make_float4(f[i0], f[i1], f[i2], f[i3]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) st4(ob + (size_t)(c_xyz + ch + u) * plane + e, v[u], stream);
+            }
+            for (; ch < ch_hi; ++ch) {
+                const float *f0 = fb + (size_t)ch * n;
+                st4(ob + (size_t)(c_xyz + ch) * plane + e, make_float4(f0[i0], f0[i1], f0[i2], f0[i3]), stream);
+            }
+        }
+        return;
+    }
     for (int e = tid; e < total_e; e += NT) {
         const int c = e / nsample, s = e - c * nsample;
         if (m0 + c >= m) continue;
@@ -178,22 +229,6 @@ __global__ __launch_bounds__(64 * BQ_NW) void ball_query_kernel(int n, int m, in
 // brute-force scan (and independent of the order inside a cell).  Slabs longer than
 // BQS_MAX_SLAB (pathological density) fall back to the ordered full scan for that lane.
 constexpr int BQS_MAX_SLAB = 3072;
-constexpr int SORT_MAX_N = 16384;
-constexpr int BQS_CELLS = 2048;
-
-struct BinHeader { float xmin, inv_w; int n, pad; };   // 16 bytes, follows the float4 array
-
-__host__ __device__ inline size_t bin_scene_stride(int n) {
-    return (size_t)n * 16 + sizeof(BinHeader) + (((size_t)(BQS_CELLS + 1) * 4 + 15) / 16) * 16;
-}
-
-// monotone non-decreasing in x for finite x; NaN -> cell 0 (a NaN point can never be a hit)
-__device__ __forceinline__ int x_cell(float x, float xmin, float inv_w) {
-    const float t = (x - xmin) * inv_w;
-    int c = t > 0.f ? (t < (float)(BQS_CELLS - 1) ? (int)t : BQS_CELLS - 1) : 0;
-    return c;
-}
-
 // one workgroup per scene: min/max of x, LDS histogram, exclusive scan, scatter
 __global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *__restrict__ xyz,
                                                             char *__restrict__ ws) {
@@ -430,6 +465,37 @@ __global__ __launch_bounds__(256) void group_points_kernel(int c, int n, int pla
     for (int ch = 0; ch < cc; ++ch) dst[(size_t)ch * plane] = src[(size_t)ch * n];
 }
 
+// plane % 4 == 0: 4 consecutive (m, s) slots per lane -- one 16-byte index load, 4 gathers per
+// channel, 16-byte stores; 4 channels in flight
+__global__ __launch_bounds__(256) void group_points_vec4_kernel(int c, int n, int plane,
+                                                                const float *__restrict__ points,
+                                                                const int32_t *__restrict__ idx,
+                                                                float *__restrict__ out, int stream) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * GRP_CCH;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= plane) return;
+    const int4 id = *reinterpret_cast<const int4 *>(idx + (size_t)b * plane + e);
+    const float *src = points + ((size_t)b * c + c0) * n;
+    float *dst = out + ((size_t)b * c + c0) * plane + e;
+    const int cc = min(GRP_CCH, c - c0);
+    int ch = 0;
+    for (; ch + 4 <= cc; ch += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float *f = src + (size_t)(ch + u) * n;
+            v[u] = make_float4(f[id.x], f[id.y], f[id.z], f[id.w]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) st4(dst + (size_t)(ch + u) * plane, v[u], stream);
+    }
+    for (; ch < cc; ++ch) {
+        const float *f = src + (size_t)ch * n;
+        st4(dst + (size_t)ch * plane, make_float4(f[id.x], f[id.y], f[id.z], f[id.w]), stream);
+    }
+}
+
 __global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, int plane,
                                                                 const float *__restrict__ grad_out,
                                                                 const int32_t *__restrict__ idx,
@@ -458,6 +524,12 @@ static int group_launch(bool grad, int b, int c, int n, int npoints, int nsample
         return WS3D_E_UNSUPPORTED;
     }
     dim3 grid((unsigned)((plane + 255) / 256), (c + GRP_CCH - 1) / GRP_CCH, b);
+    if (!grad && (plane & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0) {
+        const int stream = (size_t)b * c * plane * sizeof(float) > STREAM_STORE_BYTES;
+        grid.x = (unsigned)((plane / 4 + 255) / 256);
+        hipLaunchKernelGGL(group_points_vec4_kernel, grid, dim3(256), 0, st, c, n, (int)plane, src, idx, dst, stream);
+        return check_launch(what);
+    }
     if (grad)
         hipLaunchKernelGGL(group_points_grad_kernel, grid, dim3(256), 0, st, c, n, (int)plane, src, idx, dst);
     else

@@ -1,0 +1,26 @@
+// binning.h -- layout of the per-scene x-binned point copy built by bin_points_x_kernel
+// (ballquery_group.hip) and read by the binned ball query and the binned three_nn.
+//   [n x float4 {x, y, z, original index}] [BinHeader] [BQS_CELLS + 1 cell start offsets]
+// Points are counting-sorted by cell; the order inside a cell is unspecified.
+#pragma once
+#include "common.h"
+
+namespace ws3d {
+
+constexpr int SORT_MAX_N = 16384;
+constexpr int BQS_CELLS = 2048;
+
+struct BinHeader { float xmin, inv_w; int n, pad; };   // 16 bytes, follows the float4 array
+
+__host__ __device__ inline size_t bin_scene_stride(int n) {
+    return (size_t)n * 16 + sizeof(BinHeader) + (((size_t)(BQS_CELLS + 1) * 4 + 15) / 16) * 16;
+}
+
+// monotone non-decreasing in x for finite x; NaN -> cell 0 (a NaN point can never be a hit)
+__device__ __forceinline__ int x_cell(float x, float xmin, float inv_w) {
+    const float t = (x - xmin) * inv_w;
+    int c = t > 0.f ? (t < (float)(BQS_CELLS - 1) ? (int)t : BQS_CELLS - 1) : 0;
+    return c;
+}
+
+}  // namespace ws3d

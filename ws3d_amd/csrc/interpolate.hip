@@ -13,6 +13,7 @@
 #include <cmath>
 
 #include "common.h"
+#include "binning.h"
 
 namespace ws3d {
 
@@ -79,6 +80,89 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     }
 }
 
+// Exact 3-NN against an x-binned copy of the known set (binning.h; built once per FP layer by
+// ws3d_sort_points_x).  The reference's ascending scan with strict '<' keeps, among equal
+// distances, the smaller index in front: its result is the 3 smallest (d2, index) pairs in
+// lexicographic order, which is order-independent.  Each lane walks the sorted array outwards from
+// its own x cell, left and right, and stops on a side once a LOWER BOUND of every remaining
+// squared distance on that side exceeds its third best.  The array is ordered by cell, so a point
+// further out than p has a cell index >= cell(p), hence an x within one cell width of p.x or
+// beyond: dx > (p.x - ux) - slack with slack = 2 cell widths (1 from the cell order, the rest
+// covers the <= 5e-4 cell fp32 error of the cell coordinate and the clamped end cells); and
+// d2 = fmaf(dz,dz,fmaf(dx,dx,dy*dy)) >= fl(dx*dx) because rounding is monotone.  At equality the
+// point is still examined (index tie-break); a non-finite p.x (clamped into an end cell by the
+// binning) never stops the walk.
+// LDS = true: the whole binned known set (m <= 4096 points, 64 KB) is staged in LDS first -- the
+// walk is bound by the rate of its random 16-byte reads, and LDS serves those an order of
+// magnitude faster than the global gather path (0.20 -> see DESIGN.md 5.3).
+template <bool LDS>
+__global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, const float *__restrict__ unknown,
+                                                              const char *__restrict__ ws,
+                                                              float *__restrict__ dist2, int32_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_nn[];
+    const int b = blockIdx.y;
+    const int pi = blockIdx.x * 512 + threadIdx.x;
+    const char *base = ws + (size_t)b * bin_scene_stride(m);
+    const float4 *sorted = reinterpret_cast<const float4 *>(base);
+    if (LDS) {
+        float4 *stage = reinterpret_cast<float4 *>(smem_nn);
+        for (int i = threadIdx.x; i < m; i += 512) stage[i] = sorted[i];
+        __syncthreads();
+        sorted = stage;
+    }
+    if (pi >= n) return;
+    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)m * 16);
+    const int *start = reinterpret_cast<const int *>(base + (size_t)m * 16 + sizeof(BinHeader));
+    const float *u = unknown + ((size_t)b * n + pi) * 3;
+    const float ux = u[0], uy = u[1], uz = u[2];
+    const float slack = hdr.inv_w > 0.f ? 2.0f / hdr.inv_w : INFINITY;   // two cell widths, see above
+
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    auto before = [](float d, int k, float bd, int bi) { return d < bd || (d == bd && k < bi); };
+    auto visit = [&](const float4 p) {
+        const float d = sqdist3(ux - p.x, uy - p.y, uz - p.z);
+        const int k = __float_as_int(p.w);
+        if (before(d, k, b3, i3)) {
+            if (before(d, k, b2, i2)) {
+                b3 = b2; i3 = i2;
+                if (before(d, k, b1, i1)) { b2 = b1; i2 = i1; b1 = d; i1 = k; } else { b2 = d; i2 = k; }
+            } else {
+                b3 = d; i3 = k;
+            }
+        }
+    };
+    const int c0 = x_cell(ux, hdr.xmin, hdr.inv_w);
+    int R = start[c0], L = R - 1;
+    bool go_r = R < m, go_l = L >= 0;
+    // 4 points per side and trip: the 8 loads are independent of the tests (addresses only depend
+    // on R / L), so the walk pays one memory round trip per 8 candidates instead of per candidate;
+    // loads past the stopping point or the array ends are clamped and their results unused
+    while (go_r || go_l) {
+        float4 pr[4], pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pr[q] = sorted[min(R + q, m - 1)];
+            pl[q] = sorted[max(L - q, 0)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (go_r) {
+                const float lb = (pr[q].x - ux) - slack;   // every point further right has dx > lb
+                if (lb > 0.f && lb * lb > b3 && pr[q].x < INFINITY) { go_r = false; } else { visit(pr[q]); go_r = ++R < m; }
+            }
+            if (go_l) {
+                const float lb = (ux - pl[q].x) - slack;   // every point further left has -dx > lb
+                if (lb > 0.f && lb * lb > b3 && pl[q].x > -INFINITY) { go_l = false; } else { visit(pl[q]); go_l = --L >= 0; }
+            }
+        }
+    }
+    float *od = dist2 + ((size_t)b * n + pi) * 3;
+    int32_t *oi = idx + ((size_t)b * n + pi) * 3;
+    od[0] = b1; od[1] = b2; od[2] = b3;
+    oi[0] = i1; oi[1] = i2; oi[2] = i3;
+}
+
 constexpr int TI_CCH = 16;
 
 __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
@@ -100,6 +184,105 @@ __global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, in
     for (int ch = 0; ch < cc; ++ch, p += m, o += n)
         // w0*p0 + w1*p1 + w2*p2 (interpolate_gpu.cu:96) under nvcc's default contraction
         *o = __builtin_fmaf(w2, p[i2], __builtin_fmaf(w0, p[i0], w1 * p[i1]));
+}
+
+// n % 4 == 0: 4 consecutive points per lane -- indices and weights arrive as three 16-byte loads
+// each, every channel costs 12 gathers and ONE 16-byte store; 2 channels in flight
+__global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(int c, int m, int n,
+                                                                     const float *__restrict__ points,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ out) {
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * TI_CCH;
+    const int pi = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (pi >= n) return;
+    int id[12];
+    float w[12];
+    {
+        const int4 *ip = reinterpret_cast<const int4 *>(idx + ((size_t)b * n + pi) * 3);
+        const float4 *wp = reinterpret_cast<const float4 *>(weight + ((size_t)b * n + pi) * 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int4 iv = ip[q];
+            const float4 wv = wp[q];
+            id[4 * q] = iv.x; id[4 * q + 1] = iv.y; id[4 * q + 2] = iv.z; id[4 * q + 3] = iv.w;
+            w[4 * q] = wv.x; w[4 * q + 1] = wv.y; w[4 * q + 2] = wv.z; w[4 * q + 3] = wv.w;
+        }
+    }
+    const float *p = points + ((size_t)b * c + c0) * m;
+    float *o = out + ((size_t)b * c + c0) * n + pi;
+    const int cc = min(TI_CCH, c - c0);
+    auto blend = [&](const float *row) {
+        float4 r;  // w0*p0 + w1*p1 + w2*p2 under nvcc's default contraction, as in the scalar kernel
+        r.x = __builtin_fmaf(w[2], row[id[2]], __builtin_fmaf(w[0], row[id[0]], w[1] * row[id[1]]));
+        r.y = __builtin_fmaf(w[5], row[id[5]], __builtin_fmaf(w[3], row[id[3]], w[4] * row[id[4]]));
+        r.z = __builtin_fmaf(w[8], row[id[8]], __builtin_fmaf(w[6], row[id[6]], w[7] * row[id[7]]));
+        r.w = __builtin_fmaf(w[11], row[id[11]], __builtin_fmaf(w[9], row[id[9]], w[10] * row[id[10]]));
+        return r;
+    };
+    int ch = 0;
+    for (; ch + 2 <= cc; ch += 2) {
+        const float4 r0 = blend(p + (size_t)ch * m), r1 = blend(p + (size_t)(ch + 1) * m);
+        *reinterpret_cast<float4 *>(o + (size_t)ch * n) = r0;
+        *reinterpret_cast<float4 *>(o + (size_t)(ch + 1) * n) = r1;
+    }
+    if (ch < cc) *reinterpret_cast<float4 *>(o + (size_t)ch * n) = blend(p + (size_t)ch * m);
+}
+
+// Rows-in-LDS variant: the 3 gathers per output element hit a (b, ch) row of m floats; with the row
+// resident in LDS they cost an LDS read instead of a trip through the texture path (random 4-byte
+// global gathers run at a fraction of the store bandwidth).  One workgroup = CH rows x all n points
+// (4 consecutive points per lane and trip): rows staged once with 16-byte loads, every output
+// written with 16-byte stores.  Same fmaf expression as the scalar kernel.
+template <int CH>
+__global__ __launch_bounds__(512) void three_interpolate_lds_kernel(int c, int m, int n,
+                                                                    const float *__restrict__ points,
+                                                                    const int32_t *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ti[];
+    float *rows = reinterpret_cast<float *>(smem_ti);  // CH * m
+    const int b = blockIdx.z;
+    const int c0 = blockIdx.y * CH;
+    const int cc = min(CH, c - c0);
+    const float *p = points + ((size_t)b * c + c0) * m;
+    const int tot = cc * m;   // the cc rows are contiguous in global memory
+    if ((m & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        for (int i = threadIdx.x; i < tot / 4; i += 512) reinterpret_cast<float4 *>(rows)[i] = reinterpret_cast<const float4 *>(p)[i];
+    } else {
+        for (int i = threadIdx.x; i < tot; i += 512) rows[i] = p[i];
+    }
+    __syncthreads();
+    const int per_x = (n / 4 + (int)gridDim.x - 1) / (int)gridDim.x;   // groups of 4 points per x-slice
+    const int g_lo = blockIdx.x * per_x, g_hi = min(n / 4, g_lo + per_x);
+    for (int g = g_lo + threadIdx.x; g < g_hi; g += 512) {
+        const int pi = 4 * g;
+        int id[12];
+        float w[12];
+        const int4 *ip = reinterpret_cast<const int4 *>(idx + ((size_t)b * n + pi) * 3);
+        const float4 *wp = reinterpret_cast<const float4 *>(weight + ((size_t)b * n + pi) * 3);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int4 iv = ip[q];
+            const float4 wv = wp[q];
+            id[4 * q] = iv.x; id[4 * q + 1] = iv.y; id[4 * q + 2] = iv.z; id[4 * q + 3] = iv.w;
+            w[4 * q] = wv.x; w[4 * q + 1] = wv.y; w[4 * q + 2] = wv.z; w[4 * q + 3] = wv.w;
+        }
+        float *o = out + ((size_t)b * c + c0) * n + pi;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) {
+            if (ch < cc) {
+                const float *row = rows + ch * m;
+                float4 r;
+                r.x = __builtin_fmaf(w[2], row[id[2]], __builtin_fmaf(w[0], row[id[0]], w[1] * row[id[1]]));
+                r.y = __builtin_fmaf(w[5], row[id[5]], __builtin_fmaf(w[3], row[id[3]], w[4] * row[id[4]]));
+                r.z = __builtin_fmaf(w[8], row[id[8]], __builtin_fmaf(w[6], row[id[6]], w[7] * row[id[7]]));
+                r.w = __builtin_fmaf(w[11], row[id[11]], __builtin_fmaf(w[9], row[id[9]], w[10] * row[id[10]]));
+                *reinterpret_cast<float4 *>(o + (size_t)ch * n) = r;
+            }
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
@@ -236,13 +419,23 @@ extern "C" int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, co
 }
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
-                             float *dist2, int32_t *idx, ws3d_stream_t stream) {
+                             float *dist2, int32_t *idx, const void *sorted_known, ws3d_stream_t stream) {
     using namespace ws3d;
     if (b < 0 || n < 0 || m < 0 || !unknown || (!known && m > 0) || !dist2 || !idx) {
         set_error("ws3d_three_nn: invalid argument (b=%d n=%d m=%d)", b, n, m);
         return WS3D_E_INVALID;
     }
     if (b == 0 || n == 0) return WS3D_OK;
+    if (sorted_known && m >= 3 && m <= SORT_MAX_N) {
+        const size_t lds = (size_t)m * sizeof(float4);
+        if (lds <= 64 * 1024)
+            hipLaunchKernelGGL(three_nn_sorted_kernel<true>, dim3((n + 511) / 512, b), dim3(512), lds, as_stream(stream),
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);
+        else
+            hipLaunchKernelGGL(three_nn_sorted_kernel<false>, dim3((n + 511) / 512, b), dim3(512), 0, as_stream(stream),
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);
+        return check_launch("ws3d_three_nn(sorted)");
+    }
     hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m,
                        unknown, known, dist2, idx);
     return check_launch("ws3d_three_nn");
@@ -257,8 +450,21 @@ extern "C" int ws3d_three_interpolate(int b, int c, int m, int n, const float *p
         return WS3D_E_INVALID;
     }
     if (b == 0 || c == 0 || n == 0) return WS3D_OK;
-    hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + TI_CCH - 1) / TI_CCH, b),
-                       dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(out);
+    if ((n & 3) == 0 && (al & 15) == 0 && (size_t)m * 4 * 4 <= 64 * 1024 && n >= 1024) {
+        // rows in LDS: 4 channels per workgroup; split n over x only as far as needed to fill the chip
+        constexpr int CH = 4;
+        const int rows_wg = (c + CH - 1) / CH;
+        int gx = 1;
+        while ((long)gx * rows_wg * b < 1024 && (n / 4) / (gx * 2) >= 512) gx *= 2;
+        hipLaunchKernelGGL((three_interpolate_lds_kernel<CH>), dim3(gx, rows_wg, b), dim3(512),
+                           (size_t)CH * m * sizeof(float), as_stream(stream), c, m, n, points, idx, weight, out);
+    } else if ((n & 3) == 0 && (al & 15) == 0)
+        hipLaunchKernelGGL(three_interpolate_vec4_kernel, dim3((n / 4 + 255) / 256, (c + TI_CCH - 1) / TI_CCH, b),
+                           dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
+    else
+        hipLaunchKernelGGL(three_interpolate_kernel, dim3((n + 255) / 256, (c + TI_CCH - 1) / TI_CCH, b),
+                           dim3(256), 0, as_stream(stream), c, m, n, points, idx, weight, out);
     return check_launch("ws3d_three_interpolate");
 }
 

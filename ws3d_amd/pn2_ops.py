@@ -89,22 +89,23 @@ gather_operation = GatherOperation.apply
 
 class ThreeNN(Function):
     @staticmethod
-    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor, sorted_known=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """unknown (B,N,3), known (B,M,3) -> dist (B,N,3) L2 distance, idx (B,N,3)
-        (pointnet2_utils.py:79-99; the kernel returns squared distances, sqrt is taken here)."""
+        (pointnet2_utils.py:79-99; the kernel returns squared distances, sqrt is taken here).
+        sorted_known: optional ``sort_points_x(known)`` -- identical result, pruned search."""
         assert unknown.is_contiguous()
         assert known.is_contiguous()
         B, N, _ = unknown.size()
         m = known.size(1)
         dist2 = _new((B, N, 3), torch.float32, unknown)
         idx = _new((B, N, 3), torch.int32, unknown)
-        _C.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        _C.three_nn_wrapper(B, N, m, unknown, known, dist2, idx, sorted_known)
         ctx.mark_non_differentiable(idx)
         return torch.sqrt(dist2), idx
 
     @staticmethod
     def backward(ctx, a=None, b=None):
-        return None, None
+        return None, None, None
 
 
 three_nn = ThreeNN.apply
@@ -214,10 +215,11 @@ class _QueryAndGroupFused(Function):
         return None, None, None, None, None, grad_features, None
 
 
-def sort_points_x(xyz: torch.Tensor):
+def sort_points_x(xyz: torch.Tensor, min_n=None):
     """Per-scene x-sorted copy of xyz (or None when it does not pay): pass it to several
-    ``query_and_group`` / ``QueryAndGroup`` calls on the same xyz (multi-scale grouping)."""
-    return _C.sort_points_x(xyz)
+    ``query_and_group`` / ``QueryAndGroup`` calls on the same xyz (multi-scale grouping) or to
+    ``three_nn`` as the binned copy of the known set."""
+    return _C.sort_points_x(xyz, min_n)
 
 
 def query_and_group(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,

@@ -208,3 +208,18 @@ def write_kitti_tree(root: str, scenes) -> None:
             f.write(KITTI_LABEL_TEXT)
     with open(os.path.join(root, "ImageSets", "val.txt"), "w") as f:
         f.write("\n".join(ids) + "\n")
+
+
+def roi_clouds(batch: int, n: int, config_id: int) -> np.ndarray:
+    """(batch, n, 3) float32 Stage-2 inputs: the points pooled for one proposal, in the box's
+    canonical frame (car-sized box enlarged by 1 m: |x| < 2.9, y in (-2.5, 0.5), |z| < 1.8), denser
+    on the object's surface than in the margin"""
+    rng = np.random.Generator(np.random.PCG64(1000 * config_id + 17))
+    half = np.array([2.94, 1.5, 1.81], dtype=np.float64)
+    centre = np.array([0.0, -1.0, 0.0])
+    u = rng.uniform(-1, 1, (batch, n, 3))
+    shell = rng.uniform(0, 1, (batch, n, 1)) < 0.6
+    axis = rng.integers(0, 3, (batch, n))
+    snap = np.where(np.arange(3)[None, None, :] == axis[:, :, None], np.sign(u) * 0.66, u * 0.66)
+    pts = np.where(shell, snap, u) * half + centre
+    return pts.astype(np.float32)
