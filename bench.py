@@ -14,6 +14,9 @@ already resident in HBM:
        (r=0.1, nsample=64, 3 xyz + 1 feature channel)             [BASELINE.json configs[1]]
   c3 : full Stage-1 RPN forward (Pointnet2MSG 4 SA + 4 FP + heads) + proposal NMS +
        roipool3d, batch 8 scenes/GPU                               [BASELINE.json configs[2]]
+  c5 : N=65536, 512 proposals: roipool3d + rotated NMS, batch 8    [BASELINE.json configs[4]]
+  s2 : the Stage-2 (RCNN) set-abstraction shapes of the same ops: 800 RoI clouds of 512 points,
+       128 channels
 
 Extra objects on the JSON line (tier contract): "roofline" for the dominant kernel (FPS:
 algorithmic bytes A_model = (M-1)*N*12 + M*4 per scene) with the per-launch
@@ -266,6 +269,114 @@ class C5:
                           "wall %.2f s" % dt, "gpu_matches_oracle_on_sample": ok}
 
 
+class S2:
+    """Stage-2 (RCNN) set-abstraction shapes of the same ops (lib/config.py:122-129):
+    `batch` RoI clouds of 512 points with 128 feature channels; SA1 = FPS 512->128 + fused
+    ball_query/group (r=0.2, ns=64), SA2 = FPS 128->32 + fused query (r=0.4, ns=64) on 128-channel
+    features, SA3 = GroupAll.  Thousands of tiny scenes: FPS runs one wave per cloud and the grouped
+    tensors (4.3 MB per RoI) make this the HBM-write-bound regime of the grouping kernel."""
+
+    name = "s2_rcnn_sa_shapes"
+    unit = "RoI clouds/s"
+    metric = "RoI clouds/sec (512 pts, 128 ch), Stage-2 SA ops (FPS + fused ball_query/group x2 + GroupAll); group HBM GB/s"
+    N, C, M1, M2, NS, R1, R2 = 512, 128, 128, 32, 64, 0.2, 0.4
+
+    def __init__(self, batch, rank, kind="lidar"):
+        from ws3d_amd import compat, pn2_ops, synth
+        self.c, self.pn, self.B = compat, pn2_ops, batch
+        self.pts_host = synth.roi_clouds(batch, self.N, 6 + rank)
+        B, N, C, M1, M2, NS = batch, self.N, self.C, self.M1, self.M2, self.NS
+        self.xyz = torch.from_numpy(self.pts_host).cuda()
+        g = torch.Generator().manual_seed(1234 + rank)
+        self.feat = torch.randn((B, C, N), generator=g).cuda()
+        self.feat2 = torch.randn((B, C, M1), generator=g).cuda()      # stands for the SA1 MLP output
+        self.feat3 = torch.randn((B, 2 * C, M2), generator=g).cuda()  # ... SA2 MLP output
+        self.idx1 = torch.empty((B, M1), dtype=torch.int32, device="cuda"); self.new1 = torch.empty((B, M1, 3), device="cuda")
+        self.idx2 = torch.empty((B, M2), dtype=torch.int32, device="cuda"); self.new2 = torch.empty((B, M2, 3), device="cuda")
+        self.nbr1 = torch.empty((B, M1, NS), dtype=torch.int32, device="cuda")
+        self.nbr2 = torch.empty((B, M2, NS), dtype=torch.int32, device="cuda")
+        self.out1 = torch.empty((B, 3 + C, M1, NS), device="cuda")
+        self.out2 = torch.empty((B, 3 + C, M2, NS), device="cuda")
+        self.group_all = self.pn.GroupAll(use_xyz=True)
+        self.ev = []
+
+    def config(self):
+        return {"n_points": self.N, "channels": self.C, "npoint": [self.M1, self.M2, None], "radius": [self.R1, self.R2, 100],
+                "nsample": self.NS}
+
+    def step(self, timed=False):
+        c, B = self.c, self.B
+        if timed:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            e[0].record()
+        c.furthest_point_sampling_gather(B, self.N, self.M1, self.xyz, None, self.idx1, self.new1)
+        if timed: e[1].record()
+        c.query_and_group(B, self.N, self.M1, self.C, self.R1, self.NS, True, self.xyz, self.new1, self.feat, self.nbr1,
+                          self.out1, None)
+        if timed: e[2].record()
+        c.furthest_point_sampling_gather(B, self.M1, self.M2, self.new1, None, self.idx2, self.new2)
+        if timed: e[3].record()
+        c.query_and_group(B, self.M1, self.M2, self.C, self.R2, self.NS, True, self.new1, self.new2, self.feat2, self.nbr2,
+                          self.out2, None)
+        if timed: e[4].record()
+        self.out3 = self.group_all(self.new2, None, self.feat3)
+        if timed:
+            e[5].record()
+            self.ev.append(e)
+
+    def scenes(self):
+        return self.B
+
+    def _bytes(self, n, m, c):
+        return (3 + c) * m * self.NS * 4 + m * self.NS * 4 + (3 + c) * n * 4 + m * 12
+
+    def kernel_table(self):
+        t = [float(np.mean([a[i].elapsed_time(a[i + 1]) for a in self.ev])) for i in range(5)]
+        B = self.B
+        return [
+            {"name": "ball_query_kernel<fused> SA1 (512 -> 128 x 64, 3+128 ch)", "ms_per_step": t[1], "launches_per_step": 1,
+             "alg_bytes_per_step": self._bytes(self.N, self.M1, self.C) * B, "traffic_key": None,
+             "comment": "A_model == A_min: grouped tensor + neighbour indices written once, xyz/features read once"},
+            {"name": "ball_query_kernel<fused> SA2 (128 -> 32 x 64, 3+128 ch)", "ms_per_step": t[3], "launches_per_step": 1,
+             "alg_bytes_per_step": self._bytes(self.M1, self.M2, self.C) * B, "traffic_key": None, "comment": ""},
+            {"name": "fps_reg_kernel<*,64> SA1+SA2 (one wave per cloud)", "ms_per_step": t[0] + t[2], "launches_per_step": 2,
+             "alg_bytes_per_step": ((self.M1 - 1) * self.N * 12 + (self.M2 - 1) * self.M1 * 12) * B, "traffic_key": None,
+             "comment": "A_model (re-read per step); real traffic is the 6 KB cloud once"},
+            {"name": "GroupAll (torch cat)", "ms_per_step": t[4], "launches_per_step": 0,
+             "alg_bytes_per_step": 2 * (3 + 2 * self.C) * self.M2 * 4 * B, "traffic_key": None, "comment": "not ours"},
+        ]
+
+    def path_gbps(self, rois_per_s_per_gpu):
+        b = self._bytes(self.N, self.M1, self.C) + self._bytes(self.M1, self.M2, self.C)
+        return {"group_a_min_bytes_per_roi": b, "a_min": b * rois_per_s_per_gpu / 1e9,
+                "a_min_frac_of_8TBs": b * rois_per_s_per_gpu / HBM_PEAK}
+
+    def cpu_baseline(self):
+        import oracle
+        threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
+        oracle.set_threads(threads)
+        ns = int(min(self.B, 2 * threads))
+        xyz = np.ascontiguousarray(self.pts_host[:ns])
+        feat, feat2 = self.feat[:ns].cpu().numpy(), self.feat2[:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        i1 = oracle.furthest_point_sample(xyz, self.M1)
+        n1 = np.stack([xyz[b][i1[b]] for b in range(ns)])
+        q1 = oracle.ball_query(self.R1, self.NS, xyz, n1)
+        g1 = oracle.grouping_operation(feat, q1)
+        i2 = oracle.furthest_point_sample(n1, self.M2)
+        n2 = np.stack([n1[b][i2[b]] for b in range(ns)])
+        q2 = oracle.ball_query(self.R2, self.NS, n1, n2)
+        g2 = oracle.grouping_operation(feat2, q2)
+        dt = time.perf_counter() - t0
+        oracle.set_threads(1)
+        ok = bool(np.array_equal(self.idx1[:ns].cpu().numpy(), i1) and np.array_equal(self.nbr1[:ns].cpu().numpy(), q1) and
+                  np.array_equal(self.out1[:ns, 3:].cpu().numpy(), g1) and np.array_equal(self.idx2[:ns].cpu().numpy(), i2) and
+                  np.array_equal(self.nbr2[:ns].cpu().numpy(), q2) and np.array_equal(self.out2[:ns, 3:].cpu().numpy(), g2))
+        return {"value": ns / dt, "unit": "RoI clouds/s", "cores": threads, "kind": "port",
+                "sample": f"{ns} of the {self.B} RoI clouds, both SA levels (FPS, ball query, feature grouping) on "
+                          f"oracle/ws3d_oracle.c with OpenMP, wall {dt:.2f} s", "gpu_matches_oracle_on_sample": ok}
+
+
 def load_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json),
     already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
@@ -283,7 +394,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "s2"])
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 256, c3 default 8)")
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -300,6 +411,8 @@ def main():
         wl = C3(args.batch or 8, rank, world, args.kind, depth=args.pipeline_depth)
     elif args.workload == "c5":
         wl = C5(args.batch or 8, rank, args.kind)
+    elif args.workload == "s2":
+        wl = S2(args.batch or 800, rank, args.kind)
     else:
         wl = C2(args.batch or 256, rank, args.kind)
 
@@ -337,7 +450,7 @@ def main():
         dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
         per_gpu = value / world
         out = {
-            "metric": wl.metric, "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "metric": wl.metric, "value": value, "unit": getattr(wl, "unit", "scenes/s"), "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",

@@ -617,3 +617,42 @@ def test_kitti_directory_to_result_files(ops, tmp_path):
         for x, y in zip(oa, ob):
             np.testing.assert_allclose(x.box3d(), y.box3d(), atol=2e-3)
             np.testing.assert_allclose(x.box2d, y.box2d, atol=5e-2)
+
+
+# ------------------------------------------------------------------------------- Stage-2 (RCNN) shapes, SURVEY 8f.3
+@pytest.mark.parametrize("B", [3, 96])
+def test_stage2_sa_shapes_bit_exact(ops, oracle, B):
+    """thousands-of-tiny-clouds regime (lib/config.py:122-129): npoint 128/32/None, r 0.2/0.4/100,
+    nsample 64 on 512-point RoI clouds -- FPS runs one wave per cloud, the fused group emits
+    (B,131,128,64); everything bit-equal to the oracle, and PointnetSAModule(npoint=None) == GroupAll"""
+    from ws3d_amd import pn2_modules
+    pts = synth.roi_clouds(B, 512, 9)
+    pts[0, 10] = pts[0, 3]                       # exact duplicate: FPS / ball-query tie rules
+    feat = np.random.default_rng(B).standard_normal((B, 128, 512)).astype(np.float32)
+    i1 = oracle.furthest_point_sample(pts, 128)
+    n1 = np.stack([pts[b][i1[b]] for b in range(B)])
+    q1 = oracle.ball_query(0.2, 64, pts, n1)
+    g1 = oracle.grouping_operation(feat, q1)
+    gx1 = oracle.grouping_operation(np.ascontiguousarray(pts.transpose(0, 2, 1)), q1) - n1.transpose(0, 2, 1)[..., None]
+    idx1 = ops.pn.furthest_point_sample(dev(pts), 128)
+    np.testing.assert_array_equal(host(idx1), i1)
+    out1 = ops.pn.QueryAndGroup(0.2, 64, use_xyz=True)(dev(pts), dev(n1), dev(feat))
+    assert tuple(out1.shape) == (B, 131, 128, 64)
+    np.testing.assert_array_equal(host(out1[:, 3:]), g1)
+    np.testing.assert_array_equal(host(out1[:, :3]), gx1)
+    i2 = oracle.furthest_point_sample(n1, 32)
+    n2 = np.stack([n1[b][i2[b]] for b in range(B)])
+    np.testing.assert_array_equal(host(ops.pn.furthest_point_sample(dev(n1), 32)), i2)
+    q2 = oracle.ball_query(0.4, 64, n1, n2)
+    idx2 = ops.pn.ball_query(0.4, 64, dev(n1), dev(n2))
+    np.testing.assert_array_equal(host(idx2), q2)
+    # third level: npoint=None -> GroupAll + SharedMLP + max over all 32 points
+    f3 = np.random.default_rng(1).standard_normal((B, 16, 32)).astype(np.float32)
+    ga = ops.pn.GroupAll(use_xyz=True)(dev(n2), None, dev(f3))
+    np.testing.assert_array_equal(host(ga), np.concatenate([n2.transpose(0, 2, 1), f3], 1)[:, :, None, :])
+    sa = pn2_modules.PointnetSAModule(mlp=[16, 8], npoint=None, radius=None, nsample=None, use_xyz=True, bn=True).cuda().eval()
+    with torch.no_grad():
+        xyz3, out3 = sa(dev(n2), dev(f3))
+        ref3 = sa.mlps[0](ga).amax(dim=3)           # SharedMLP on the GroupAll tensor, pooled over the 32 points
+    assert xyz3 is None and tuple(out3.shape) == (B, 8, 1)
+    np.testing.assert_allclose(host(out3), host(ref3), atol=1e-5)
