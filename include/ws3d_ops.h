@@ -134,6 +134,22 @@ WS3D_API int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float
                                 const int32_t *idx, const float *weight, float *grad_points,
                                 ws3d_stream_t stream);
 
+/* Deterministic backward.  Same results as the *_grad entry points above up to the
+ * summation order, which is FIXED here: every gradient element is the sum of its contributions in
+ * ascending slot order (slot = m*nsample+s, or point*3+k), i.e. bit-identical to the sequential
+ * loop `for slot: dst[idx[slot]] += v[slot]` and to itself from run to run (the reference's float
+ * atomicAdd scatter is neither).  grad_points is fully written (no pre-zeroing needed).
+ * workspace: ws3d_scatter_workspace_bytes(b, n_targets, slots_per_scene) bytes of device memory,
+ * n_targets = n (group/gather) or m (three_interpolate), slots_per_scene = npoints*nsample or n*3.
+ * gather_points_grad == group_points_grad_det with nsample = 1.                                  */
+WS3D_API size_t ws3d_scatter_workspace_bytes(int b, int n_targets, long slots_per_scene);
+WS3D_API int ws3d_group_points_grad_det(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                                        const int32_t *idx, float *grad_points, void *workspace,
+                                        size_t workspace_bytes, ws3d_stream_t stream);
+WS3D_API int ws3d_three_interpolate_grad_det(int b, int c, int n, int m, const float *grad_out, const int32_t *idx,
+                                             const float *weight, float *grad_points, void *workspace,
+                                             size_t workspace_bytes, ws3d_stream_t stream);
+
 /* y[b,o,l] = relu?(y[b,o,l] + bias[o]) in place, one pass: the epilogue of the SharedMLP
  * (1x1 conv + eval-mode BatchNorm folded into one GEMM, pytorch_utils.py:20-101).  ws3d extension. */
 WS3D_API int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,

@@ -137,3 +137,17 @@ def nn_case(B, N, M):
 if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "nn":
     for (B, N, M) in [(8, 16384, 4096), (8, 4096, 1024), (8, 1024, 256), (8, 256, 64), (64, 16384, 4096)]:
         nn_case(B, N, M)
+
+
+def grad_case(B, C, N, M, ns):
+    idx = torch.randint(0, N, (B, M, ns), dtype=torch.int32, device="cuda")
+    g = torch.randn((B, C, M, ns), device="cuda")
+    out = torch.zeros((B, C, N), device="cuda")
+    ta = timeit(lambda: (out.zero_(), c.group_points_grad_wrapper(B, C, N, M, ns, g, idx, out)))[0]
+    td = timeit(lambda: c.group_points_grad_det(B, C, N, M, ns, g, idx, out))[0]
+    print(f"group_points_grad B={B} C={C} N={N} M={M} ns={ns}: atomic {ta:.3f} ms, deterministic {td:.3f} ms")
+
+
+if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "grad":
+    for shp in [(16, 32, 16384, 4096, 16), (16, 64, 16384, 4096, 32), (16, 128, 4096, 1024, 32), (16, 512, 256, 64, 32)]:
+        grad_case(*shp)

@@ -656,3 +656,74 @@ def test_stage2_sa_shapes_bit_exact(ops, oracle, B):
         ref3 = sa.mlps[0](ga).amax(dim=3)           # SharedMLP on the GroupAll tensor, pooled over the 32 points
     assert xyz3 is None and tuple(out3.shape) == (B, 8, 1)
     np.testing.assert_allclose(host(out3), host(ref3), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------- deterministic backward, SURVEY 8f.2
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 300, 40, 16), (1, 19, 4096, 1024, 32), (3, 8, 64, 64, 1), (1, 3, 10, 0, 4)])
+def test_group_and_gather_grad_deterministic_bit_exact(ops, oracle, B, C, N, M, ns):
+    """sorted-segment accumulation == the sequential loop `dst[idx[slot]] += g[slot]` (oracle),
+    bit for bit, and identical across repeated launches (the atomic kernel is neither)"""
+    rng = np.random.default_rng(N + M)
+    idx = rng.integers(0, max(N // 3, 1), (B, M, ns)).astype(np.int32)        # heavy collisions
+    g = (rng.standard_normal((B, C, M, ns)) * 10 ** rng.uniform(-3, 3, (B, C, M, ns))).astype(np.float32)
+    ref = oracle.grouping_operation_grad(g, idx, N)
+    outs = []
+    for _ in range(3):
+        out = torch.full((B, C, N), float("nan"), device="cuda")
+        ops.c.group_points_grad_det(B, C, N, M, ns, dev(g), dev(idx), out)
+        outs.append(host(out))
+    np.testing.assert_array_equal(outs[0], ref)
+    np.testing.assert_array_equal(outs[0], outs[1]); np.testing.assert_array_equal(outs[0], outs[2])
+    if M > 0:   # the atomic kernel agrees up to summation order
+        at = torch.zeros((B, C, N), device="cuda")
+        ops.c.group_points_grad_wrapper(B, C, N, M, ns, dev(g), dev(idx), at)
+        np.testing.assert_allclose(host(at), ref, rtol=1e-4, atol=1e-3 * np.abs(g).max())
+
+
+def test_three_interpolate_grad_deterministic_bit_exact(ops, oracle):
+    rng = np.random.default_rng(4)
+    B, C, n, m = 2, 21, 1500, 90
+    idx = rng.integers(0, m, (B, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
+    g = rng.standard_normal((B, C, n)).astype(np.float32)
+    ref = oracle.three_interpolate_grad(g, idx, w, m)
+    out = torch.empty((B, C, m), device="cuda")
+    ops.c.three_interpolate_grad_det(B, C, n, m, dev(g), dev(idx), dev(w), out)
+    np.testing.assert_array_equal(host(out), ref)
+
+
+def test_autograd_backward_is_reproducible(ops):
+    """a small SA + FP stack: two backward passes give bit-identical parameter gradients with the
+    deterministic kernels"""
+    from ws3d_amd import pn2_modules
+    assert ops.pn.DETERMINISTIC_BACKWARD
+    torch.manual_seed(0)
+    sa = pn2_modules.PointnetSAModuleMSG(npoint=256, radii=[0.5, 1.0], nsamples=[16, 32], mlps=[[4, 8, 8], [4, 8, 16]],
+                                         use_xyz=True, bn=False).cuda()
+    fp = pn2_modules.PointnetFPModule(mlp=[24 + 4, 16], bn=False).cuda()
+    pc = synth.make_batch("lidar", 2, 2048, 3)
+    xyz = dev(pc[:, :, :3].copy())
+    feat = dev(np.ascontiguousarray(np.repeat(pc[:, :, 3:], 4, axis=2).transpose(0, 2, 1)))
+    grads = []
+    for _ in range(2):
+        f = feat.clone().requires_grad_(True)
+        for p in list(sa.parameters()) + list(fp.parameters()):
+            p.grad = None
+        nx, nf = sa(xyz, f)
+        up = fp(xyz, nx, f, nf)
+        (up * up).sum().backward()
+        grads.append([host(f.grad)] + [host(p.grad) for p in list(sa.parameters()) + list(fp.parameters())])
+    # the gradient w.r.t. the input features flows through group_points_grad (both scales),
+    # three_interpolate_grad and the data-gradient convolutions only: bit-identical.  The conv
+    # WEIGHT gradients are MIOpen reductions whose order is not ours to fix: tolerance.
+    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4)
+    ops.pn.DETERMINISTIC_BACKWARD = False
+    try:
+        f = feat.clone().requires_grad_(True)
+        nx, nf = sa(xyz, f)
+        (fp(xyz, nx, f, nf) ** 2).sum().backward()
+        np.testing.assert_allclose(host(f.grad), grads[0][0], rtol=1e-3, atol=1e-3)   # atomic path: same up to order
+    finally:
+        ops.pn.DETERMINISTIC_BACKWARD = True

@@ -194,6 +194,34 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weig
               "three_interpolate_grad")
 
 
+def group_points_grad_det(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor, grad_points_tensor):
+    """deterministic group_points_grad / gather_points_grad (nsample=1): fixed summation order
+    (ascending slot), bit-identical run to run and to the sequential CPU loop.  ws3d extension."""
+    dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
+    _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(grad_points_tensor, "grad_points")
+    lib = _lib.load()
+    nbytes = lib.ws3d_scatter_workspace_bytes(b, n, npoints * nsample)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_group_points_grad_det(b, c, n, npoints, nsample, _p(grad_out_tensor), _p(idx_tensor),
+                                             _p(grad_points_tensor), _p(ws), nbytes, _stream()), "group_points_grad_det")
+    return 1
+
+
+def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor):
+    """deterministic three_interpolate_grad (see group_points_grad_det).  ws3d extension."""
+    dev = _dev(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
+    _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
+    lib = _lib.load()
+    nbytes = lib.ws3d_scatter_workspace_bytes(b, m, n * 3)
+    ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_three_interpolate_grad_det(b, c, n, m, _p(grad_out_tensor), _p(idx_tensor), _p(weight_tensor),
+                                                  _p(grad_points_tensor), _p(ws), nbytes, _stream()),
+              "three_interpolate_grad_det")
+    return 1
+
+
 def bias_act_inplace(y, bias, relu=True):
     """y (B,O,L...) contiguous: y = relu?(y + bias[o]) in place, one pass (ws3d extension)"""
     dev = _dev(y, bias)

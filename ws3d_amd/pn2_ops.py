@@ -21,6 +21,11 @@ from torch.autograd import Function
 
 from . import compat as _C
 
+# Backward of gather / group / three_interpolate: True = sorted-segment accumulation with a fixed
+# summation order (bit-reproducible, equals the sequential CPU loop); False = float atomicAdd
+# scatter like the reference (order, and so the low bits, vary from run to run).
+DETERMINISTIC_BACKWARD = True
+
 
 def _new(shape, dtype, like):
     return torch.empty(shape, dtype=dtype, device=like.device)
@@ -79,8 +84,12 @@ class GatherOperation(Function):
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        _C.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
+        if DETERMINISTIC_BACKWARD:
+            grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+            _C.group_points_grad_det(B, C, N, npoint, 1, grad_out.contiguous(), idx, grad_features)
+        else:
+            grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+            _C.gather_points_grad_wrapper(B, C, N, npoint, grad_out.contiguous(), idx, grad_features)
         return grad_features, None
 
 
@@ -129,8 +138,12 @@ class ThreeInterpolate(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
-        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
-        _C.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        if DETERMINISTIC_BACKWARD:
+            grad_features = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
+            _C.three_interpolate_grad_det(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
+        else:
+            grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
+            _C.three_interpolate_grad_wrapper(B, c, n, m, grad_out.contiguous(), idx, weight, grad_features)
         return grad_features, None, None
 
 
@@ -155,8 +168,12 @@ class GroupingOperation(Function):
     def backward(ctx, grad_out: torch.Tensor):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
-        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-        _C.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        if DETERMINISTIC_BACKWARD:
+            grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+            _C.group_points_grad_det(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        else:
+            grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+            _C.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out.contiguous(), idx, grad_features)
         return grad_features, None
 
 
@@ -210,8 +227,12 @@ class _QueryAndGroupFused(Function):
         if C > 0 and ctx.needs_input_grad[5]:
             B, _, M, ns = grad_out.size()
             g = grad_out[:, cx:].contiguous()
-            grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
-            _C.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
+            if DETERMINISTIC_BACKWARD:
+                grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
+                _C.group_points_grad_det(B, C, N, M, ns, g, idx, grad_features)
+            else:
+                grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+                _C.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
         return None, None, None, None, None, grad_features, None
 
 
