@@ -1,0 +1,319 @@
+"""Stage-1 (RPN) trainer: the counterpart of the reference's ``tools/train_rpn.py`` for this
+repository's network and kernels.
+
+    python -m ws3d_amd.train_rpn --synthetic 64 --batch_size 8 --total_iters 200 --output_dir out/
+    python -m ws3d_amd.train_rpn --data_root /data/KITTI/object --batch_size 25 --total_iters 8000
+
+Same flags as the reference (train_rpn.py:24-46): --batch_size, --total_iters, --ckpt_save_interval,
+--workers, --output_dir, --mgpus, --ckpt, --pretrain_ckpt, --noise_kind, --weakly_num (+ --cfg_file,
+accepted for command-line compatibility: the weaklyRPN.yaml values live in ``stage1.RPNConfig`` and
+``TrainConfig``).  What it reproduces:
+  * optimizer 'adam_onecycle' (train_rpn.py:84-101 + learning_schedules_fastai.py:54-77): Adam
+    betas (mom, 0.99), decoupled weight decay p *= 1 - wd*lr on every parameter (fastai
+    ``OptimWrapper(true_wd=True, bn_wd=True)``), one-cycle cosine lr / momentum schedule stepped
+    every iteration; gradient-norm clipping at 1.0; BN-momentum step decay (train_rpn.py:113-118);
+  * the loss (``ws3d_amd.losses.rpn_loss``) on Gaussian centre labels;
+  * checkpoints ``ckpt/checkpoint_iter_%05d.pth`` = {'it', 'model_state', 'optimizer_state'}
+    (train_utils.py:67-99) -- ``model_state`` interchanges with the reference (identical keys).
+Not reproduced: the reference's data augmentation and GT-sampling database (its data loader),
+tensorboard, the periodic evaluation pass.  ``--mgpus`` maps to one process per GPU
+(``torchrun``, DistributedDataParallel over RCCL) instead of ``nn.DataParallel``.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import math
+import os
+from dataclasses import dataclass
+from typing import Iterator, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import clip_grad_norm_
+
+from . import kitti_io, losses, stage1
+
+
+@dataclass(frozen=True)
+class TrainConfig:
+    """TRAIN block of tools/cfgs/weaklyRPN.yaml:69-96"""
+    lr: float = 0.002
+    weight_decay: float = 0.001
+    moms: tuple = (0.95, 0.85)
+    div_factor: float = 10.0
+    pct_start: float = 0.4
+    grad_norm_clip: float = 1.0
+    bn_momentum: float = 0.1
+    bn_decay: float = 0.5
+    bnm_clip: float = 0.01
+    bn_decay_step_list: tuple = (1000,)
+
+
+# ----------------------------------------------------------------------------- schedules
+def annealing_cos(start: float, end: float, pct: float) -> float:
+    return end + (start - end) / 2 * (math.cos(math.pi * pct) + 1)
+
+
+def one_cycle(step: int, total_step: int, lr_max: float, moms=(0.95, 0.85), div_factor: float = 10.0,
+              pct_start: float = 0.4):
+    """(lr, momentum) at iteration `step` (learning_schedules_fastai.py:40-77): cosine from
+    lr_max/div_factor up to lr_max over the first pct_start of training, then down to 2e-6;
+    momentum mirrors it between moms[0] and moms[1]"""
+    a1 = int(pct_start * total_step)
+    low = lr_max / div_factor
+    if step >= a1:
+        pct = (step - a1) / (total_step - a1)
+        return annealing_cos(lr_max, 2e-6, pct), annealing_cos(moms[1], moms[0], pct)
+    pct = step / a1
+    return annealing_cos(low, lr_max, pct), annealing_cos(moms[0], moms[1], pct)
+
+
+def bn_momentum_at(it: int, cfg: TrainConfig) -> float:
+    decay = 1.0
+    for s in cfg.bn_decay_step_list:
+        if it >= s:
+            decay *= cfg.bn_decay
+    return max(cfg.bn_momentum * decay, cfg.bnm_clip)
+
+
+def set_bn_momentum(model: nn.Module, momentum: float) -> None:
+    for m in model.modules():
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.momentum = momentum
+
+
+class AdamOneCycle:
+    """Adam + decoupled weight decay + per-iteration one-cycle schedule (see module docstring)"""
+
+    def __init__(self, params, total_step: int, cfg: TrainConfig = TrainConfig()):
+        self.cfg, self.total_step = cfg, total_step
+        self.opt = torch.optim.Adam([p for p in params if p.requires_grad], lr=cfg.lr / cfg.div_factor,
+                                    betas=(cfg.moms[0], 0.99))
+        self.lr, self.mom = cfg.lr / cfg.div_factor, cfg.moms[0]
+
+    def schedule(self, it: int) -> None:
+        self.lr, self.mom = one_cycle(it, self.total_step, self.cfg.lr, self.cfg.moms, self.cfg.div_factor, self.cfg.pct_start)
+        for g in self.opt.param_groups:
+            g["lr"] = self.lr
+            g["betas"] = (self.mom, g["betas"][1])
+
+    def zero_grad(self) -> None:
+        self.opt.zero_grad(set_to_none=True)
+
+    @torch.no_grad()
+    def step(self) -> None:
+        for g in self.opt.param_groups:
+            for p in g["params"]:
+                p.mul_(1 - self.cfg.weight_decay * g["lr"])
+        self.opt.step()
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd)
+
+
+# ----------------------------------------------------------------------------- checkpoints
+def checkpoint_state(model: Optional[nn.Module] = None, optimizer=None, it=None) -> dict:
+    if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)):
+        model = model.module
+    return {"it": it, "model_state": None if model is None else model.state_dict(),
+            "optimizer_state": None if optimizer is None else optimizer.state_dict()}
+
+
+def save_checkpoint(state: dict, filename: str = "checkpoint") -> str:
+    path = "{}.pth".format(filename)
+    torch.save(state, path)
+    return path
+
+
+def load_checkpoint(model: Optional[nn.Module] = None, optimizer=None, filename: str = "checkpoint", logger=None):
+    """-> (it, epoch); accepts checkpoints written by the reference's train_utils.save_checkpoint"""
+    if not os.path.isfile(filename):
+        raise FileNotFoundError(filename)
+    ck = torch.load(filename, map_location="cpu")
+    if model is not None and ck.get("model_state") is not None:
+        model.load_state_dict(ck["model_state"])
+    if optimizer is not None and ck.get("optimizer_state") is not None:
+        optimizer.load_state_dict(ck["optimizer_state"])
+    if logger:
+        logger.info("==> loaded checkpoint '%s' (it %s)", filename, ck.get("it"))
+    return ck.get("it", 0), ck.get("epoch", -1)
+
+
+# ----------------------------------------------------------------------------- data
+class SyntheticCenters:
+    """`count` seeded KITTI-shaped scenes with car-centre annotations (the weak labels of WS3D are
+    BEV centre clicks): {'pts_input' (N,4), 'gt_centers' (K,3), 'rpn_cls_label', 'rpn_reg_label'}"""
+
+    def __init__(self, count: int, npoints: int = 16384, config_id: int = 8):
+        from . import synth
+        self.synth, self.count, self.npoints, self.config_id = synth, count, npoints, config_id
+
+    def __len__(self):
+        return self.count
+
+    def __getitem__(self, i: int) -> dict:
+        seed = 1000 * self.config_id + i
+        pc = self.synth.lidar_cloud(self.npoints, seed)
+        centres = self.synth.random_boxes3d(15, seed * 7919 + 13)[:, :3].astype(np.float32)
+        cls, reg = losses.gaussian_center_labels(pc[:, :3], centres)
+        return {"sample_id": i, "pts_input": pc, "gt_centers": centres, "rpn_cls_label": cls.astype(np.float32),
+                "rpn_reg_label": reg}
+
+
+class KittiCenters:
+    """KITTI directory: scans through ``kitti_io`` (no augmentation), centre annotations from
+    label_2 (``noise_kind`` selects another label directory like the reference's --noise_kind), the
+    first ``weakly_num`` scenes that contain a Car/Van"""
+
+    def __init__(self, root: str, split: str = "train", npoints: int = 16384, noise_kind: Optional[str] = None,
+                 weakly_num: int = 500, rng=np.random):
+        self.scenes = kitti_io.KittiScenes(root, split, npoints=npoints, rng=rng)
+        self.label_sub = noise_kind or "label_2"
+        keep = []
+        for sid in self.scenes.sample_id_list:
+            if any(o.cls_type in ("Car", "Van") for o in self._objects(sid)):
+                keep.append(sid)
+            if len(keep) >= weakly_num:
+                break
+        self.ids = keep
+
+    def _objects(self, sid):
+        path = os.path.join(self.scenes.imageset_dir, self.label_sub, "%06d.txt" % sid)
+        return kitti_io.read_label_file(path) if os.path.isfile(path) else []
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i: int) -> dict:
+        sid = self.ids[i]
+        pts = kitti_io.rpn_input_from_scan(self.scenes.get_lidar(sid), self.scenes.get_calib(sid),
+                                           self.scenes.get_image_shape(sid), self.scenes.npoints, True, self.scenes.rng)
+        centres = np.array([o.pos for o in self._objects(sid) if o.cls_type in ("Car", "Van")], dtype=np.float32).reshape(-1, 3)
+        cls, reg = losses.gaussian_center_labels(pts[:, :3], centres)
+        return {"sample_id": sid, "pts_input": pts.astype(np.float32), "gt_centers": centres,
+                "rpn_cls_label": cls.astype(np.float32), "rpn_reg_label": reg}
+
+
+def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0, world: int = 1) -> Iterator[dict]:
+    """endless shuffled mini-batches (drop_last, like the reference's DataLoader); with world > 1
+    every rank takes its own slice of each global batch"""
+    n = len(dataset)
+    if n < batch_size * world:
+        raise ValueError(f"{n} scenes < global batch {batch_size * world}")
+    while True:
+        order = rng.permutation(n)
+        for i0 in range(0, n - batch_size * world + 1, batch_size * world):
+            ids = order[i0 + rank * batch_size:i0 + (rank + 1) * batch_size]
+            items = [dataset[int(i)] for i in ids]
+            yield {"pts_input": np.stack([s["pts_input"] for s in items]).astype(np.float32),
+                   "rpn_cls_label": np.stack([s["rpn_cls_label"] for s in items]),
+                   "rpn_reg_label": np.stack([s["rpn_reg_label"] for s in items]),
+                   "sample_id": [s["sample_id"] for s in items]}
+
+
+# ----------------------------------------------------------------------------- training
+def train_step(model: nn.Module, optimizer: AdamOneCycle, batch: dict, it: int, net_cfg: stage1.RPNConfig,
+               train_cfg: TrainConfig, device) -> dict:
+    """one iteration of Trainer._train_it (train_utils.py:137-147) with the per-iteration schedules"""
+    set_bn_momentum(model, bn_momentum_at(it, train_cfg))
+    optimizer.schedule(it)
+    model.train()
+    optimizer.zero_grad()
+    pts = torch.from_numpy(batch["pts_input"]).to(device)
+    out = model({"pts_input": pts})
+    loss, tb = losses.rpn_loss(out["rpn_cls"], out["rpn_reg"], torch.from_numpy(batch["rpn_cls_label"]).to(device).float(),
+                               torch.from_numpy(batch["rpn_reg_label"]).to(device).float(), net_cfg.loc_scope,
+                               net_cfg.loc_bin_size)
+    loss.backward()
+    tb["grad_norm"] = float(clip_grad_norm_(model.parameters(), train_cfg.grad_norm_clip))
+    optimizer.step()
+    tb["lr"], tb["loss"] = optimizer.lr, float(loss.item())
+    return tb
+
+
+def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] = None, ckpt: Optional[str] = None,
+          pretrain_ckpt: Optional[str] = None, ckpt_save_interval: int = 20, seed: int = 0, device: str = "cuda:0",
+          net_cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, train_cfg: TrainConfig = TrainConfig(), logger=None,
+          distributed: bool = False) -> dict:
+    """-> {'model', 'optimizer', 'it', 'history' (loss per iteration), 'checkpoints'}"""
+    log = logger or logging.getLogger("ws3d_amd.train_rpn")
+    rank, world = 0, 1
+    if distributed:
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(seed)
+    dev = torch.device(device)
+    model = stage1.Stage1Net(mode="TRAIN", cfg=net_cfg).to(dev)
+    optimizer = AdamOneCycle(model.parameters(), total_iters, train_cfg)
+    it = 0
+    if pretrain_ckpt:
+        load_checkpoint(model, None, pretrain_ckpt, log)
+        it = int(total_iters * 9 / 30)                   # train_rpn.py:186
+    if ckpt:
+        it, _ = load_checkpoint(model, optimizer, ckpt, log)
+        it = int(it)
+    net = nn.parallel.DistributedDataParallel(model, device_ids=[dev.index]) if distributed else model
+    ckpt_dir = os.path.join(output_dir, "ckpt") if output_dir else None
+    if ckpt_dir and rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+    per_epoch = max(len(dataset) // (batch_size * world), 1)
+    n_epochs = max(int(total_iters / per_epoch), 1)
+    save_every = max(int(n_epochs / min(n_epochs, ckpt_save_interval)), 1) * per_epoch
+    stream = batches(dataset, batch_size, np.random.RandomState(seed), rank, world)
+    history, saved = [], []
+    while it < total_iters:
+        tb = train_step(net, optimizer, next(stream), it, net_cfg, train_cfg, dev)
+        it += 1
+        history.append(tb["loss"])
+        if rank == 0 and (it % 10 == 0 or it == total_iters):
+            log.info("it %5d  loss %.4f  cls %.4f  reg %.4f  fg %d  lr %.2e", it, tb["loss"], tb["rpn_loss_cls"],
+                     tb["rpn_loss_reg"], tb["rpn_fg_sum"], tb["lr"])
+        if ckpt_dir and rank == 0 and (it % save_every == 0 or it == total_iters):
+            saved.append(save_checkpoint(checkpoint_state(model, optimizer, it),
+                                         os.path.join(ckpt_dir, "checkpoint_iter_%05d" % it)))
+    return {"model": model, "optimizer": optimizer, "it": it, "history": history, "checkpoints": saved}
+
+
+def main():
+    ap = argparse.ArgumentParser(description="Stage-1 RPN trainer (flags of the reference's tools/train_rpn.py)")
+    ap.add_argument("--cfg_file", type=str, default="cfgs/", help="accepted for compatibility; weaklyRPN values are built in")
+    ap.add_argument("--batch_size", type=int, default=25)
+    ap.add_argument("--total_iters", type=int, default=8000)
+    ap.add_argument("--ckpt_save_interval", type=int, default=20)
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--output_dir", type=str, default=None)
+    ap.add_argument("--mgpus", action="store_true", default=False, help="one process per GPU under torchrun (DDP over RCCL)")
+    ap.add_argument("--ckpt", type=str, default=None)
+    ap.add_argument("--pretrain_ckpt", type=str, default=None)
+    ap.add_argument("--noise_kind", type=str, default="label_noise")
+    ap.add_argument("--weakly_num", type=int, default=500)
+    ap.add_argument("--data_root", type=str, default=None, help="KITTI object directory (ImageSets/, training/)")
+    ap.add_argument("--synthetic", type=int, default=0, help="train on this many seeded synthetic scenes instead")
+    a = ap.parse_args()
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s  %(levelname)5s  %(message)s")
+    out_dir = a.output_dir or os.path.join("output", "rpn", "weaklyRPN")
+    distributed = a.mgpus and int(os.environ.get("WORLD_SIZE", "1")) > 1
+    local = 0
+    if distributed:
+        from . import dist as wdist
+        _, _, local = wdist.init()
+    if a.synthetic:
+        ds = SyntheticCenters(a.synthetic)
+    elif a.data_root:
+        label_dir = a.noise_kind if os.path.isdir(os.path.join(a.data_root, "training", a.noise_kind)) else None
+        ds = KittiCenters(a.data_root, "train", noise_kind=label_dir, weakly_num=a.weakly_num)
+    else:
+        ap.error("give --data_root or --synthetic N")
+    res = train(ds, a.total_iters, a.batch_size, out_dir, a.ckpt, a.pretrain_ckpt, a.ckpt_save_interval,
+                device=f"cuda:{local}", distributed=distributed)
+    logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s", res["it"],
+                                                 res["checkpoints"][-1] if res["checkpoints"] else None)
+
+
+if __name__ == "__main__":
+    main()
