@@ -13,7 +13,8 @@ python bench.py --batch 8 --no-cpu-baseline 2>$OUT/bench_c2_b8.err   | tail -1 >
 python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 > $OUT/bench_c3_b8.json
 python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
 python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
-for w in c2 c3 c5; do
+python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
+for w in c2 c3 c5 s2; do
   extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph"
   rm -rf /tmp/prof_$w
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o $w -- python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline $extra > $OUT/prof_$w.log 2>&1

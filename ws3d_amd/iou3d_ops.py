@@ -71,12 +71,18 @@ def nms_gpu_padded(boxes, scores, thresh, max_out, normal=False):
     return out, cnt
 
 
-def nms_gpu_padded_batched(boxes, scores, thresh, max_out, normal=False):
+def nms_gpu_padded_batched(boxes, scores, thresh, max_out, normal=False, scores_sorted=False):
     """boxes (B,n,5), scores (B,n) -> (idx (B,max_out) int64 padded with -1, count (B,) int64);
-    idx refers to the input order of each scene.  Whole batch in one launch pair."""
+    idx refers to the input order of each scene.  Whole batch in one launch pair.
+    scores_sorted=True: every row of `scores` is already non-increasing (e.g. it comes from
+    ``topk(sorted=True)``); the stable descending sort would be the identity and is skipped."""
     B, n = scores.shape
-    order = scores.sort(dim=1, descending=True, stable=True)[1]                      # (B,n)
-    sorted_boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, n, boxes.shape[2])).contiguous()
+    if scores_sorted:
+        order = torch.arange(n, device=scores.device).unsqueeze(0).expand(B, n)
+        sorted_boxes = boxes.contiguous()
+    else:
+        order = scores.sort(dim=1, descending=True, stable=True)[1]                  # (B,n)
+        sorted_boxes = torch.gather(boxes, 1, order.unsqueeze(-1).expand(B, n, boxes.shape[2])).contiguous()
     keep, num = _C.nms_device_batched(sorted_boxes, thresh, normal, max_keep=max_out)
     take = min(max_out, n)
     cnt = torch.clamp(num.to(torch.int64), max=max_out)

@@ -199,7 +199,7 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
     sc, order = torch.topk(score, top, dim=1, sorted=True)                                # (B,top)
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
     bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
-    keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K)           # (B,K), (B,)
+    keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K, scores_sorted=True)   # (B,K), (B,)
     valid = keep >= 0
     safe = keep.clamp(min=0)
     boxes_out = torch.gather(box, 1, safe.unsqueeze(-1).expand(B, K, 7)) * valid.unsqueeze(-1)
