@@ -32,6 +32,7 @@
 // (S = ceil(n/bs)), so that plain "lowest slot, lowest lane, lowest wave wins" IS the
 // reference's tie order -- for any workgroup size, independent of bs.
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -40,6 +41,9 @@
 #endif
 #ifndef WS3D_FPS_CHAINS
 #define WS3D_FPS_CHAINS 0  // neutral (1.20 vs 1.17 us/step): the sweep is issue-bound, cmp/cndmask cost 2 slots each
+#endif
+#ifndef WS3D_FPS_GMAX
+#define WS3D_FPS_GMAX 0  // group maxima in the sweep + slot search afterwards: sweep -260 clk, search +370 clk => 1.23 vs 1.17 us/step
 #endif
 #ifndef WS3D_FPS_TREE
 #define WS3D_FPS_TREE 0  // measured 1.9x SLOWER: v_cmp->SGPR-pair->v_cndmask chains stall (scripts/ubench/lat.hip)
@@ -137,7 +141,24 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
         PROF(0)
         float best = -1.0f;
         int bslot = 0;
-        if constexpr (PPT >= 2 && NT == 64 && WS3D_FPS_PACKED) {  // pays only for the single-wave shapes (measured)
+        constexpr bool GMAX = PPT >= 8 && NT > 64 && WS3D_FPS_GMAX;
+        constexpr int GS = PPT >= 4 ? PPT / 4 : 1;   // slots per group
+        float gm[4] = {-1.0f, -1.0f, -1.0f, -1.0f};
+        if constexpr (GMAX) {
+            // The running (best, slot) pair costs a v_cmp and two v_cndmask per point -- 6 issue
+            // slots of the 13 a point costs (compares and selects issue at half rate here).  Only
+            // the VALUE is needed until the workgroup winner is known: keep 4 group maxima per
+            // lane (one v_max per point) and look the slot up afterwards, in the winning lane,
+            // lowest slot first -- the same (slot, lane, wave) tie order as before.
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, vec_get<PPT>(pz, s) - oz);
+                const float d2 = min_f32(d, t[s]);  // == fminf: t[s] is never NaN
+                t[s] = d2;
+                gm[s / GS] = max_f32(gm[s / GS], d2);
+            }
+            best = max_f32(max_f32(gm[0], gm[1]), max_f32(gm[2], gm[3]));
+        } else if constexpr (PPT >= 2 && NT == 64 && WS3D_FPS_PACKED) {  // pays only for the single-wave shapes (measured)
             // two points per instruction for the distance (v_pk_add/mul/fma_f32: same IEEE
             // results per element as the scalar forms)
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -235,7 +256,28 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
         const float wmax = wave_max(best);
         const uint64_t eq = __ballot(best == wmax);
         const int wl = (int)__builtin_ctzll(eq);
-        const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+        int wslot;
+        if constexpr (GMAX) {
+            int gsel = 3;
+            gsel = gm[2] == wmax ? 2 : gsel;
+            gsel = gm[1] == wmax ? 1 : gsel;
+            gsel = gm[0] == wmax ? 0 : gsel;
+            const int gw = __builtin_amdgcn_readlane(gsel, wl);   // the winning lane's lowest group holding wmax
+            int ls = GS - 1;
+            auto find = [&](auto G) {
+#pragma unroll
+                for (int q = GS - 2; q >= 0; --q) ls = t[decltype(G)::value * GS + q] == wmax ? q : ls;
+            };
+            switch (gw) {   // wave-uniform: one block of GS statically indexed compares
+                case 0: find(std::integral_constant<int, 0>{}); break;
+                case 1: find(std::integral_constant<int, 1>{}); break;
+                case 2: find(std::integral_constant<int, 2>{}); break;
+                default: find(std::integral_constant<int, 3>{}); break;
+            }
+            wslot = gw * GS + __builtin_amdgcn_readlane(ls, wl);
+        } else {
+            wslot = __builtin_amdgcn_readlane(bslot, wl);
+        }
         PROF(2)
         // VGPR-indexed moves (s_set_gpr_idx): measured faster than a tree of scalar branches over
         // statically indexed registers (1.17 vs 1.48 us/step) -- taken branches are expensive here
