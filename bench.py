@@ -134,10 +134,10 @@ class C2:
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
         return [
-            {"name": "fps_reg_kernel<32,512> (furthest_point_sample + gather)", "ms_per_step": fps,
+            {"name": ("fps_zlds_kernel<32,512>" if self.B > 256 else "fps_reg_kernel<32,512>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
              "launches_per_step": 1, "alg_bytes_per_step": a_model_fps() * self.B,
-             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_reg_kernel",
-             "comment": "A_model re-reads xyz every step; this design keeps the scene in VGPRs, so the kernel is "
+             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_zlds_kernel" if self.B > 256 else "fps_reg_kernel",
+             "comment": "A_model re-reads xyz every step; this design keeps the scene on chip (VGPRs, z in LDS when two scenes share a CU), so the kernel is "
                         "latency/ALU-bound and its real HBM traffic is ~A_min (see traffic_bytes_per_launch)"},
             {"name": "bin_points_x + ball_query_sorted_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
              "launches_per_step": 2, "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_sorted_kernel",
@@ -377,6 +377,14 @@ class S2:
                           f"oracle/ws3d_oracle.c with OpenMP, wall {dt:.2f} s", "gpu_matches_oracle_on_sample": ok}
 
 
+def traffic_batch():
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return int(json.load(open(p)).get("_scenes_per_launch", 256))
+    except Exception:
+        return -1
+
+
 def load_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json),
     already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
@@ -395,7 +403,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "s2"])
-    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 256, c3 default 8)")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 512, c3/c5 default 8, s2 default 800)")
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
@@ -414,7 +422,7 @@ def main():
     elif args.workload == "s2":
         wl = S2(args.batch or 800, rank, args.kind)
     else:
-        wl = C2(args.batch or 256, rank, args.kind)
+        wl = C2(args.batch or 512, rank, args.kind)
 
     for _ in range(args.warmup):
         wl.step()
@@ -445,8 +453,8 @@ def main():
             k["achieved_GBps"] = k["alg_bytes_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9 if k["ms_per_step"] > 0 else 0.0
             k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
             tr = load_traffic(k.pop("traffic_key", None))
-            # the committed PMC passes were taken at 256 scenes per launch: only comparable at that batch
-            k["traffic_bytes_per_launch"] = tr if wl.scenes() == 256 else None
+            # the committed PMC passes were taken at one batch size: only comparable at that batch
+            k["traffic_bytes_per_launch"] = tr if wl.scenes() == traffic_batch() else None
         dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
         per_gpu = value / world
         out = {
@@ -464,7 +472,7 @@ def main():
                          "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic "
                                  "bytes (SURVEY.md 8d byte model, DESIGN.md section 6) / measured duration; "
                                  "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic.json "
-                                 "(c2 workload, batch 256) or null"},
+                                 "(c2 workload at the batch recorded there) or null"},
             "kernels": kernels,
             "path_gbps_per_gpu": wl.path_gbps(per_gpu),
         }

@@ -34,7 +34,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     if a.what == "fps":
         for (B, N, M) in [(8, 16384, 4096), (8, 8192, 4096), (8, 4096, 1024), (256, 4096, 1024), (8, 1024, 256),
-                          (256, 16384, 4096), (8, 256, 64), (800, 512, 128)]:
+                          (256, 16384, 4096), (512, 16384, 4096), (1024, 16384, 4096), (8, 256, 64), (800, 512, 128)]:
             fps_case(B, N, M)
 
 

@@ -8,7 +8,8 @@ OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-python bench.py                             2>$OUT/bench_c2_b256.err | tail -1 > $OUT/bench_c2_b256.json
+python bench.py                             2>$OUT/bench_c2_b512.err | tail -1 > $OUT/bench_c2_b512.json
+python bench.py --batch 256 --no-cpu-baseline 2>$OUT/bench_c2_b256.err | tail -1 > $OUT/bench_c2_b256.json
 python bench.py --batch 8 --no-cpu-baseline 2>$OUT/bench_c2_b8.err   | tail -1 > $OUT/bench_c2_b8.json
 python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 > $OUT/bench_c3_b8.json
 python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
@@ -26,5 +27,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o pmc -- python bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
 done
 python scripts/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \
-  $OUT/traffic.json "c2 batch 256, bytes per launch, rocprofv3 --pmc in separate passes" > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
+  $OUT/traffic.json "c2 batch 512, bytes per launch, rocprofv3 --pmc in separate passes" 512 > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
 ls -la $OUT

@@ -16,15 +16,15 @@ def per_kernel(db_path, counter):
     return {r[0]: (r[1] * 1024.0, r[2]) for r in rows}
 
 def short(name):
-    for k in ("fps_reg_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_rot_mask_kernel", "nms_sweep_kernel", "bev_frames_kernel", "roipool3d_kernel",
+    for k in ("fps_zlds_kernel", "fps_reg_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_rot_mask_kernel", "nms_sweep_kernel", "bev_frames_kernel", "roipool3d_kernel",
               "three_nn_kernel", "three_interpolate_kernel", "group_points_kernel"):
         if k in name:
             return k
     return None
 
-def main(fetch_db, write_db, out, note):
+def main(fetch_db, write_db, out, note, scenes=512):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
-    res = {"_note": note}
+    res = {"_note": note, "_scenes_per_launch": int(scenes)}
     for name in sorted(set(f) | set(w)):
         k = short(name)
         if not k:
@@ -36,4 +36,4 @@ def main(fetch_db, write_db, out, note):
     print(json.dumps(res, indent=1))
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "", sys.argv[5] if len(sys.argv) > 5 else 512)

@@ -105,6 +105,43 @@ def test_fps_bucket_kernel_subprocess(oracle, tmp_path):
                                       np.stack([pcs[b][ref[b]] for b in range(pcs.shape[0])]))
 
 
+def test_fps_two_scenes_per_cu_kernel_subprocess(ops, oracle, tmp_path):
+    """fps_zlds_kernel (z in LDS, two workgroups per CU; chosen when the batch exceeds the CU count)
+    forced with WS3D_FPS_PAIR=1 in a child process: indices, gathered centres and the final
+    min-distance buffer against the oracle, incl. duplicated points and a ragged size"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(3, 16384, 4096, "lidar", 0.02), (1, 12345, 777, "lidar", 0.3), (2, 9000, 300, "uniform", 0.0)]
+    refs = []
+    for i, (B, N, M, kind, dup) in enumerate(cases):
+        pcs = synth.make_batch(kind, B, N, 11, dup_frac=dup)[:, :, :3].copy()
+        np.save(tmp_path / f"in{i}.npy", pcs)
+        refs.append(oracle.furthest_point_sample(pcs, M, return_temp=True))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import compat
+        for i, M in enumerate({[c[2] for c in cases]!r}):
+            x = torch.from_numpy(np.load({str(tmp_path)!r} + f"/in{{i}}.npy")).cuda()
+            B, N = x.shape[0], x.shape[1]
+            idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); nx = torch.empty((B, M, 3), device="cuda")
+            temp = torch.full((B, N), 1e10, device="cuda")
+            compat.furthest_point_sampling_gather(B, N, M, x, temp, idx, nx)
+            np.save({str(tmp_path)!r} + f"/out{{i}}.npy", idx.cpu().numpy())
+            np.save({str(tmp_path)!r} + f"/xyz{{i}}.npy", nx.cpu().numpy())
+            np.save({str(tmp_path)!r} + f"/tmp{{i}}.npy", temp.cpu().numpy())
+    """)
+    r = subprocess.run([sys.executable, "-B", "-c", code], env=dict(os.environ, WS3D_FPS_PAIR="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for i, (ref, ref_temp) in enumerate(refs):
+        np.testing.assert_array_equal(np.load(tmp_path / f"out{i}.npy"), ref)
+        pcs = np.load(tmp_path / f"in{i}.npy")
+        np.testing.assert_array_equal(np.load(tmp_path / f"xyz{i}.npy"),
+                                      np.stack([pcs[b][ref[b]] for b in range(pcs.shape[0])]))
+        np.testing.assert_array_equal(np.load(tmp_path / f"tmp{i}.npy"), ref_temp)
+
+
 def test_fps_temp_contract(ops, oracle):
     """the wrapper-level entry point takes the caller's temp (pre-filled 1e10) and leaves the
     final running min-distance in it, like the reference kernel does (sampling_gpu.cu:134-135)."""

@@ -329,7 +329,12 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
         row[pos] = (uint16_t)id;
         ++cnt;
     };
+#ifdef WS3D_BQS_NO_SEARCH
+    if (active && w == 0) { for (int q = 0; q < 20; ++q) insert((mi * 7 + q * 13) % n); }
+    if (false) {
+#else
     if (active && cx == cx) {
+#endif
         // cells overlapping |x - cx| < r: x_cell is monotone, one extra cell each side absorbs the
         // rounding of cx -+ r (cell width >> 1 ulp of x)
         const int c_lo = max(0, x_cell(cx - rabs, hdr.xmin, hdr.inv_w) - 1);
@@ -382,8 +387,12 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
         cnt_s[lane] = active ? total : 0;
     }
     __syncthreads();
+#ifndef WS3D_BQS_NO_EMIT
     bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows,
                                       rstride, cnt_s, cen);
+#else
+    if (tid == 0 && out) out[((size_t)b * m + m0)] = (float)rows[0] + (float)cnt_s[0];
+#endif
 }
 
 static size_t bq_smem(int nsample, size_t idx_bytes) {

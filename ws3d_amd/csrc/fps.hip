@@ -337,6 +337,125 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
     }
 }
 
+// ---- two scenes per CU (throughput mode).  fps_reg_kernel<32,512> needs 234 VGPRs: one workgroup
+// per CU, two waves per SIMD that run in lock-step, so the SIMD idles through every reduction
+// chain (~45 % of a step).  Here z lives in LDS (64 KB per scene, read-only in the loop, 16-byte
+// conflict-free reads) and x, y and the running min-distance stay in VGPRs: <= 128 VGPRs, i.e. two
+// workgroups = two independent scenes per CU whose sweeps fill each other's chains (measured:
+// 0.98 us per scene-step at 512 scenes vs 1.17; a start-up phase offset between the two scenes
+// of a CU changes nothing).  Same arithmetic, same position order, same tie rules as fps_reg_kernel.
+template <int PPT, int NT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void fps_zlds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
+                     float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
+    constexpr int NW = NT / WS3D_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem_z[];
+    float4 *zs4 = reinterpret_cast<float4 *>(smem_z);   // [PPT/4][NT] float4: slots 4c..4c+3 of thread u at zs4[c*NT+u]
+    __shared__ float4 s_cand[2][16];
+    __shared__ int s_k[2][16];
+
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    if (temp) temp += (size_t)b * n;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+    const int u = threadIdx.x, lane = u & 63, w = u >> 6;
+
+    vecf<PPT> px, py;
+    float t[PPT];
+#pragma unroll
+    for (int c = 0; c < PPT / 4; ++c) {
+        float z4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * c + q;
+            const int p = u * PPT + s;
+            const int rb = p / S, sl = p - rb * S;
+            const int k = bitrev_bits(rb, log2bs) + sl * bs;
+            const bool valid = (rb < bs) && (k < n);
+            vec_set<PPT>(px, s, valid ? xyz[k * 3 + 0] : 0.f);
+            vec_set<PPT>(py, s, valid ? xyz[k * 3 + 1] : 0.f);
+            z4[q] = valid ? xyz[k * 3 + 2] : 0.f;
+            t[s] = valid ? (temp ? temp[k] : 1e10f) : -1.0f;
+        }
+        zs4[c * NT + u] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+    }
+    int old = 0;
+    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    if (u == 0) {
+        idx[0] = 0;
+        if (new_xyz) { new_xyz[0] = ox; new_xyz[1] = oy; new_xyz[2] = oz; }
+    }
+    __syncthreads();
+    const float *zs = reinterpret_cast<const float *>(smem_z);
+    for (int j = 1; j < m; ++j) {
+        float best = -1.0f;
+        int bslot = 0;
+        float4 zn = zs4[u];                          // software pipeline: chunk c+1 is in flight while c is consumed
+#pragma unroll
+        for (int c = 0; c < PPT / 4; ++c) {
+            const float4 z4 = zn;
+            if (c + 1 < PPT / 4) zn = zs4[(c + 1) * NT + u];
+            const float zz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int s = 4 * c + q;
+                const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, zz[q] - oz);
+                const float d2 = min_f32(d, t[s]);
+                t[s] = d2;
+                const bool gt = d2 > best;
+                bslot = gt ? s : bslot;
+                best = gt ? d2 : best;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep two z chunks live at most: 128-VGPR budget
+        }
+        const float wmax = wave_max(best);
+        const uint64_t eq = __ballot(best == wmax);
+        const int wl = (int)__builtin_ctzll(eq);
+        const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+        const float cz = zs[(((wslot >> 2) * NT) + (w * 64 + wl)) * 4 + (wslot & 3)];   // wave-uniform address: broadcast
+        const float cx = readlane_f(vec_get<PPT>(px, wslot), wl);
+        const float cy = readlane_f(vec_get<PPT>(py, wslot), wl);
+        const int kw = (w * 64 + wl) * PPT + wslot;
+        const int buf = j & 1;
+        if (lane == 0) {
+            s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
+            s_k[buf][w] = kw;
+        }
+        lds_barrier();
+        const int e = lane & 15;
+        const float4 c4 = s_cand[buf][e];
+        const int kc = s_k[buf][e];
+        const float v = e < NW ? c4.x : -2.0f;
+        const float vm = row16_max(v);
+        const uint64_t eq2 = __ballot(v == vm);
+        const int sel = (int)__builtin_ctzll(eq2);
+        ox = readlane_f(c4.y, sel);
+        oy = readlane_f(c4.z, sel);
+        oz = readlane_f(c4.w, sel);
+        old = __builtin_amdgcn_readlane(kc, sel);
+        if (u == 0) {
+            idx[j] = old;
+            if (new_xyz) { new_xyz[j * 3 + 0] = ox; new_xyz[j * 3 + 1] = oy; new_xyz[j * 3 + 2] = oz; }
+        }
+    }
+    __syncthreads();
+    for (int j = 1 + u; j < m; j += NT) {
+        const int p = idx[j];
+        const int rb = p / S, sl = p - rb * S;
+        idx[j] = bitrev_bits(rb, log2bs) + sl * bs;
+    }
+    if (temp) {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int p = u * PPT + s;
+            const int rb = p / S, sl = p - rb * S;
+            const int k = bitrev_bits(rb, log2bs) + sl * bs;
+            if ((rb < bs) && (k < n)) temp[k] = t[s];
+        }
+    }
+}
+
 // ---- streaming fallback for scenes that do not fit the register file (n > 16384).
 // Natural strided ownership (thread tid owns k = tid, tid+1024, ...: coalesced),
 // min-distance in the caller's temp buffer, explicit tie key = bitrev10(tid).
@@ -438,6 +557,19 @@ static void launch_reg(int b, int n, int m, const float *xyz, float *temp, int32
 int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
                       int bs, int log2bs, int S, hipStream_t st);  // fps_bucket.hip
 
+// WS3D_FPS_PAIR: 0 = never, 1 = always, unset = when the batch exceeds the number of CUs
+static bool fps_pair_mode(int b) {
+    static const int env = getenv("WS3D_FPS_PAIR") ? atoi(getenv("WS3D_FPS_PAIR")) : -1;
+    if (env >= 0) return env != 0;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    return b > cus;
+}
+
 static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx,
                         float *new_xyz, hipStream_t st) {
     if (b < 0 || n <= 0 || m < 0 || !xyz || (!idx && m > 0)) {
@@ -466,6 +598,15 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
         const int ppt = (int)((R + 255) / 256);
         if (ppt <= 8) launch_reg<8, 256>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
         else launch_reg<16, 256>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else if (R <= 1024L * 16 && R > 512L * 16 && fps_pair_mode(b)) {
+        // two scenes per CU: only pays when there are more scenes than CUs
+        constexpr size_t lds = (size_t)32 * 512 * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void *)fps_zlds_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL((fps_zlds_kernel<32, 512>), dim3(b), dim3(512), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
     } else if (R <= 1024L * 16) {
         const int ppt = (int)((R + 1023) / 1024);
         // Fewer, fatter waves win: the cross-lane reduction chain (DPP/readlane/ballot) does not
