@@ -67,8 +67,15 @@ def dist_setup(gpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        # WS3D_DIST_BACKEND=gloo: control-flow test of the multi-rank path on a box with fewer GPUs
+        # than ranks (ranks then share devices); the driver's runs use nccl (= RCCL over xGMI)
+        backend = os.environ.get("WS3D_DIST_BACKEND", "nccl")
+        local = local % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     if world != gpus and rank == 0:
