@@ -70,6 +70,7 @@ class C3:
         """HIP-event timers around every C-ABI launch family (only while a timed step runs)."""
         from ws3d_amd import compat
         fam = {"furthest_point_sampling_gather": "fps", "query_and_group": "ball_query+group",
+               "query_and_group_nlc": "ball_query+group", "three_interpolate_nlc": "three_interpolate",
                "three_nn_wrapper": "three_nn", "three_interpolate_wrapper": "three_interpolate",
                "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
         for fn_name, key in fam.items():
@@ -182,7 +183,7 @@ class C3:
                          "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None})
         fwd = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         custom_in_fwd = sum(r["ms_per_step"] for r in rows if r["name"] in ("fps", "ball_query+group", "three_nn", "three_interpolate"))
-        rows.append({"name": "torch (SharedMLP GEMMs, BN-folded, max-pool, cat, heads) [rocBLAS, not ours]",
+        rows.append({"name": "torch (SharedMLP GEMMs with fused epilogues, BN-folded, cat, heads) [hipBLASLt/rocBLAS] + pool kernels",
                      "ms_per_step": max(fwd - custom_in_fwd, 0.0), "launches_per_step": 0, "alg_bytes_per_step": 0,
                      "traffic_key": None})
         self.breakdown = {"rpn_forward_ms": fwd,

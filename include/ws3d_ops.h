@@ -161,6 +161,20 @@ WS3D_API int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, 
 WS3D_API int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, const float *y, const float *bias,
                                   float *out, ws3d_stream_t stream);
 
+/* Channels-last ("nlc") variants for a row-major SharedMLP chain (ws3d extension, ws3d_amd/fastpath.py):
+ * features are (b, points, C) instead of the reference's (b, C, points); idx / xyz arguments and
+ * every index result are identical to the channels-first entry points.
+ *   ws3d_query_and_group_nlc : out (b, m, nsample, 3*use_xyz + c), row = [dx, dy, dz, features...]
+ *   ws3d_three_interpolate_nlc: out row p = sum_k weight[p,k] * feats[idx[p,k], :], row stride out_stride
+ *   ws3d_rowmax_rows          : out row r = max over rows r*ns .. r*ns+ns-1 of y (rows, o_ch)        */
+WS3D_API int ws3d_query_and_group_nlc(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
+                                      const float *xyz, const float *new_xyz, const float *features_nlc,
+                                      int32_t *idx_out, float *out_nlc, const void *sorted, ws3d_stream_t stream);
+WS3D_API int ws3d_three_interpolate_nlc(int b, int c, int m, int n, const float *feats_nlc, const int32_t *idx,
+                                        const float *weight, float *out_nlc, int out_stride, ws3d_stream_t stream);
+WS3D_API int ws3d_rowmax_rows(long rows_out, int ns, int o_ch, const float *y, float *out, int out_stride,
+                              ws3d_stream_t stream);
+
 /* -------------------------------------------------------------------- iou3d_cuda */
 
 /* boxes_overlap_bev_gpu(boxes_a,boxes_b,ans)   iou3d.cpp:31-50 -> iou3d_kernel.cu:

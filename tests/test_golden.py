@@ -163,11 +163,13 @@ def test_gpu_iou3d_and_roipool_wrappers_match_reference_harness(fx):
 
 
 @pytest.mark.gpu
-def test_gpu_stage1_forward_matches_reference_harness(meta):
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     """Full 16384-point Stage-1 forward: FPS indices of all four SA
     layers and all eight ball-query tensors exact; the four outputs within 1e-4 abs of the
-    reference harness (conv/BN reduction order differs between CPU and MIOpen/rocBLAS)."""
-    from ws3d_amd import pn2_ops
+    reference harness (conv/BN reduction order differs between CPU and MIOpen/rocBLAS).  Both
+    inference pipelines: the reference-layout one and the channels-last one (ws3d_amd/fastpath.py)."""
+    from ws3d_amd import compat, pn2_ops, stage1
     from ws3d_amd.stage1 import Stage1Net, decode_center_target
     ref_keys = json.load(open(os.path.join(G, "stage1_state_dict.json")))["keys"]
     gold = np.load(os.path.join(G, "stage1_forward.npz"))
@@ -189,12 +191,26 @@ def test_gpu_stage1_forward_matches_reference_harness(meta):
         bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
         return (out, idx) if return_idx else out
 
+    orig_nlc = compat.query_and_group_nlc
+
+    def nlc_tap(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=True, sorted_xyz=None, idx_out=None):
+        idx = torch.empty((xyz.size(0), new_xyz.size(1), nsample), dtype=torch.int32, device=xyz.device)
+        out = orig_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz, sorted_xyz, idx)
+        bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
+        return out
+
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
+    compat.query_and_group_nlc = nlc_tap
+    prev = stage1.CHANNELS_LAST_FASTPATH
+    stage1.CHANNELS_LAST_FASTPATH = channels_last
     try:
         with torch.no_grad():
             out = model.rpn_forward({'pts_input': pts})
     finally:
         pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = orig_fps, orig_qg
+        compat.query_and_group_nlc = orig_nlc
+        stage1.CHANNELS_LAST_FASTPATH = prev
+    assert ("backbone_features_nlc" in out) == channels_last
     assert len(fps_log) == 4 and len(bq_log) == 8
     for i in range(4):
         np.testing.assert_array_equal(fps_log[i], gold[f"fps_idx_{i}"])

@@ -797,3 +797,69 @@ def test_trainer_learns_resumes_and_is_reproducible(ops, tmp_path):
     # bit-reproducible; MIOpen's weight-gradient reductions are not, hence a tolerance)
     res3 = train(ds, total_iters=24, batch_size=4, seed=3, net_cfg=cfg)
     np.testing.assert_allclose(res3["history"][:6], h[:6], rtol=2e-3)
+
+
+# ------------------------------------------------------------------------------- channels-last variants / fast path
+@pytest.mark.parametrize("B,N,M,C,r,ns,srt", [(2, 4096, 512, 1, 0.5, 16, True), (2, 4096, 500, 96, 1.0, 32, True),
+                                               (1, 1000, 77, 8, 2.0, 16, False), (1, 600, 40, 5, 2.0, 8, False),
+                                               (2, 2048, 256, 0, 1.0, 16, True), (1, 64, 16, 512, 4.0, 32, False),
+                                               (3, 70, 5, 12, 100.0, 64, False)])
+def test_channels_last_query_and_group(ops, B, N, M, C, r, ns, srt):
+    """ws3d_query_and_group_nlc == the channels-first fused kernel, transposed (bit for bit)"""
+    pc = synth.make_batch("lidar", B, N, 41)
+    xyz = dev(pc[:, :, :3].copy())
+    feat = torch.randn((B, C, N), generator=torch.Generator().manual_seed(C)).cuda() if C else None
+    _, new_xyz = ops.pn.furthest_point_sample_gather(xyz, M)
+    sorted_xyz = ops.c.sort_points_x(xyz) if srt else None
+    ref = ops.pn.query_and_group(r, ns, xyz, new_xyz, feat, use_xyz=True, sorted_xyz=sorted_xyz)      # (B,3+C,M,ns)
+    got = ops.c.query_and_group_nlc(r, ns, xyz, new_xyz, None if feat is None else feat.transpose(1, 2).contiguous(),
+                                    True, sorted_xyz)                                                  # (B,M,ns,3+C)
+    assert tuple(got.shape) == (B, M, ns, 3 + C)
+    assert torch.equal(got.permute(0, 3, 1, 2), ref)
+
+
+def test_channels_last_interpolate_and_rowmax(ops, oracle):
+    rng = np.random.default_rng(2)
+    B, C, M, N = 2, 20, 90, 700
+    feat = rng.standard_normal((B, C, M)).astype(np.float32)
+    idx = rng.integers(0, M, (B, N, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)
+    ref = oracle.three_interpolate(feat, idx, w)                                  # (B,C,N)
+    got = ops.c.three_interpolate_nlc(dev(np.ascontiguousarray(feat.transpose(0, 2, 1))), dev(idx), dev(w))
+    np.testing.assert_array_equal(host(got), ref.transpose(0, 2, 1))
+    buf = torch.full((B, N, C + 8), -7.0, device="cuda")                          # into the left part of a wider buffer
+    ops.c.three_interpolate_nlc(dev(np.ascontiguousarray(feat.transpose(0, 2, 1))), dev(idx), dev(w), buf)
+    np.testing.assert_array_equal(host(buf[:, :, :C]), ref.transpose(0, 2, 1))
+    assert (buf[:, :, C:] == -7.0).all()
+    y = torch.randn((50 * 16, 24), generator=torch.Generator().manual_seed(1)).cuda()
+    y[3, 5] = float("nan")
+    out = torch.zeros((50, 40), device="cuda")
+    ops.c.rowmax_rows(y, 16, out, 8)
+    np.testing.assert_array_equal(host(out[:, 8:32]), host(y.view(50, 16, 24).amax(dim=1)))
+    assert (out[:, :8] == 0).all() and (out[:, 32:] == 0).all()
+
+
+def test_channels_last_fast_path_equals_reference_layout_path(ops):
+    """the eval-mode (B,N,C) pipeline and the reference-layout pipeline run the same weights through
+    the same operators: identical sampling / neighbour decisions, outputs equal to GEMM rounding"""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.seeded import seeded_state_dict
+    model = stage1.Stage1Net(mode="TEST").eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    model = model.cuda()
+    assert fastpath.supported(model)
+    pts = dev(synth.make_batch("lidar", 2, 16384, 3))
+    fast = model.rpn_forward({"pts_input": pts})
+    assert "backbone_features_nlc" in fast
+    stage1.CHANNELS_LAST_FASTPATH = False
+    try:
+        slow = model.rpn_forward({"pts_input": pts})
+    finally:
+        stage1.CHANNELS_LAST_FASTPATH = True
+    assert "backbone_features_nlc" not in slow
+    for k in ("rpn_cls", "rpn_reg", "backbone_xyz", "backbone_features"):
+        assert fast[k].shape == slow[k].shape, k
+        scale = float(slow[k].abs().max())
+        np.testing.assert_allclose(host(fast[k]), host(slow[k]), atol=2e-5 * max(scale, 1.0), rtol=0, err_msg=k)
+    f = fast["backbone_features"].transpose(1, 2).contiguous()
+    assert f.data_ptr() == fast["backbone_features_nlc"].data_ptr()          # the (B,C,N) view costs nothing to undo

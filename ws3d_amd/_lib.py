@@ -37,6 +37,9 @@ SIGNATURES = {
     "ws3d_scatter_workspace_bytes": (C.c_size_t, [_i, _i, C.c_long]),
     "ws3d_group_points_grad_det": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_three_interpolate_grad_det": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ws3d_query_and_group_nlc": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_interpolate_nlc": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ws3d_rowmax_rows": (_i, [C.c_long, _i, _i, _vp, _vp, _i, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_rowmax_bias_act": (_i, [_i, _i, C.c_long, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

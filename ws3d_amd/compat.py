@@ -164,6 +164,54 @@ def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features
     return 1
 
 
+def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=True, sorted_xyz=None, idx_out=None):
+    """channels-last fused QueryAndGroup: xyz (B,N,3), new_xyz (B,M,3), features_nlc (B,N,C) or None
+    -> (B, M, nsample, 3*use_xyz + C) rows [dx,dy,dz, features...] (ws3d extension)"""
+    dev = _dev(xyz, new_xyz, features_nlc, sorted_xyz)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+    C = 0 if features_nlc is None else features_nlc.size(2)
+    if features_nlc is not None:
+        _f32(features_nlc, "features")
+    out = torch.empty((B, M, nsample, (3 if use_xyz else 0) + C), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_query_and_group_nlc(B, N, M, C, float(radius), nsample, int(bool(use_xyz)), _p(xyz),
+                                                   _p(new_xyz), _p(features_nlc), _p(idx_out), _p(out),
+                                                   _p(sorted_xyz), _stream()), "query_and_group_nlc")
+    return out
+
+
+def three_interpolate_nlc(feats_nlc, idx, weight, out=None):
+    """feats_nlc (B,M,C), idx/weight (B,N,3) -> (B,N,C); `out` may be a (B,N,>=C) buffer whose first
+    C columns are written (row stride = out.size(2)).  ws3d extension."""
+    dev = _dev(feats_nlc, idx, weight)
+    _f32(feats_nlc, "feats"); _i32(idx, "idx"); _f32(weight, "weight")
+    B, M, C = feats_nlc.shape
+    N = idx.size(1)
+    if out is None:
+        out = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+    _f32(out, "out")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_three_interpolate_nlc(B, C, M, N, _p(feats_nlc), _p(idx), _p(weight), _p(out),
+                                                     out.size(2), _stream()), "three_interpolate_nlc")
+    return out
+
+
+def rowmax_rows(y, ns, out=None, col0=0):
+    """y (R*ns, O) contiguous -> max over each group of ns consecutive rows; written into
+    out[:, col0:col0+O] of a (R, >=O) buffer when given.  ws3d extension."""
+    dev = _dev(y)
+    _f32(y, "y")
+    rows, O = y.shape
+    R = rows // ns
+    if out is None:
+        out = torch.empty((R, O), dtype=torch.float32, device=dev)
+    view = out[:, col0:col0 + O]
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_rowmax_rows(R, ns, O, _p(y), view.data_ptr(), out.size(1), _stream()), "rowmax_rows")
+    return out
+
+
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor, sorted_known=None):
     """interpolate.cpp:14-23 (+ optional x-binned copy of `known` from sort_points_x: same result)"""
     dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)

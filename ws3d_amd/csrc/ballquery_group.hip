@@ -59,6 +59,76 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
             if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
         }
     }
+    if (use_xyz & 2) {
+        // channels-LAST output (b, m, nsample, 3 + C) from channels-last features (b, n, C): one
+        // contiguous row per (centre, sample) -- the layout the row-major SharedMLP GEMMs consume
+        // without a transpose (ws3d_query_and_group_nlc).  32 lanes move one feature row with
+        // aligned 16-byte loads and 4-byte-aligned 16-byte stores; lanes 0-2 add the centred xyz.
+        const int cx3 = (use_xyz & 1) ? 3 : 0;
+        const int row = cx3 + c_feat;
+        float *ob = out + ((size_t)b * m + m0) * nsample * row;
+        const float *fb = features ? features + (size_t)b * n * c_feat : nullptr;
+        // gridDim.z workgroups share a tile of centres (each repeats the cheap search) and emit
+        // disjoint slices of its (centre, sample) rows: wide rows at few centres still fill the chip
+        const int e_chunk = ((total_e + (int)gridDim.z - 1) / (int)gridDim.z + 1) & ~1;
+        const int e_lo = (int)blockIdx.z * e_chunk, e_hi = min(total_e, e_lo + e_chunk);
+        if (c_feat == 1 && cx3 == 3) {
+            for (int e = e_lo + tid; e < e_hi; e += NT) {
+                const int c = e / nsample, s = e - c * nsample;
+                if (m0 + c >= m) continue;
+                const int id = (int)rows[(size_t)c * rstride + s];
+                const float4 ce = cen[c];
+                const float *p = xyz + (size_t)id * 3;
+                *reinterpret_cast<float4 *>(ob + (size_t)e * 4) = make_float4(p[0] - ce.x, p[1] - ce.y, p[2] - ce.z, fb[id]);
+            }
+        } else if ((c_feat & 3) == 0 && c_feat > 0 && (reinterpret_cast<uintptr_t>(fb) & 15) == 0) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            typedef f4v f4u __attribute__((aligned(4)));
+            const int l32 = tid & 31, f4 = c_feat >> 2;
+            for (int e0 = e_lo + (tid >> 5) * 2; e0 < e_hi; e0 += (NT >> 5) * 2) {
+                int id[2];
+                bool ok[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int e = min(e0 + q, total_e - 1);
+                    const int c = e / nsample;
+                    ok[q] = e0 + q < e_hi && m0 + c < m;
+                    id[q] = ok[q] ? (int)rows[(size_t)c * rstride + (e - c * nsample)] : 0;   // rows of absent centres are uninitialised
+                }
+                for (int c4 = l32; c4 < f4; c4 += 32) {
+                    f4v v[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) v[q] = reinterpret_cast<const f4v *>(fb + (size_t)id[q] * c_feat)[c4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (ok[q]) *reinterpret_cast<f4u *>(ob + (size_t)(e0 + q) * row + cx3 + 4 * c4) = v[q];
+                }
+                if (cx3 && l32 < 3) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (ok[q]) {
+                            const int c = (e0 + q) / nsample;
+                            const float cv = l32 == 0 ? cen[c].x : (l32 == 1 ? cen[c].y : cen[c].z);
+                            ob[(size_t)(e0 + q) * row + l32] = xyz[(size_t)id[q] * 3 + l32] - cv;
+                        }
+                }
+            }
+        } else {
+            for (int e = e_lo + tid; e < e_hi; e += NT) {
+                const int c = e / nsample, s = e - c * nsample;
+                if (m0 + c >= m) continue;
+                const int id = (int)rows[(size_t)c * rstride + s];
+                float *o = ob + (size_t)e * row;
+                if (cx3) {
+                    const float4 ce = cen[c];
+                    const float *p = xyz + (size_t)id * 3;
+                    o[0] = p[0] - ce.x; o[1] = p[1] - ce.y; o[2] = p[2] - ce.z;
+                }
+                for (int ch = 0; ch < c_feat; ++ch) o[cx3 + ch] = fb[(size_t)id * c_feat + ch];
+            }
+        }
+        return;
+    }
     const int c_xyz = use_xyz ? 3 : 0;
     const int c_out = c_xyz + c_feat;
     const size_t plane = (size_t)m * nsample;
@@ -403,7 +473,7 @@ static size_t bq_smem(int nsample, size_t idx_bytes) {
 template <bool FUSED>
 static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
                      const float *xyz, const float *new_xyz, const float *features, int32_t *idx,
-                     float *out, const void *sorted, hipStream_t st, const char *what) {
+                     float *out, const void *sorted, hipStream_t st, const char *what, int nlc = 0) {
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0 || !xyz || !new_xyz) {
         set_error("%s: invalid argument (b=%d n=%d m=%d nsample=%d c=%d)", what, b, n, m, nsample, c);
         return WS3D_E_INVALID;
@@ -416,9 +486,14 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     if (b == 0 || m == 0) return WS3D_OK;
     // channel split (fused only): enough workgroups to fill 256 CUs, at least 8 channels each
     int gz = 1;
-    if (FUSED && c >= 16) {
+    use_xyz = (use_xyz ? 1 : 0) | (nlc ? 2 : 0);   // bit 1 selects the channels-last epilogue (row-wise, no channel split)
+    if (FUSED && c >= 16 && !nlc) {
         const long tiles = (long)b * ((m + 63) / 64);
         while (gz < 64 && tiles * gz < 1024 && c / (gz * 2) >= 8) gz *= 2;
+    }
+    if (FUSED && nlc && c >= 16) {   // row slices: at least 64 rows per workgroup
+        const long tiles = (long)b * ((m + 63) / 64);
+        while (gz < 64 && tiles * gz < 1024 && (64L * nsample) / (gz * 2) >= 64) gz *= 2;
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535) {
         const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
@@ -577,6 +652,13 @@ extern "C" int ws3d_query_and_group(int b, int n, int m, int c, float radius, in
                                     const void *sorted, ws3d_stream_t stream) {
     return ws3d::bq_launch<true>(b, n, m, features ? c : 0, radius, nsample, use_xyz, xyz, new_xyz,
                                  features, idx_out, out, sorted, ws3d::as_stream(stream), "ws3d_query_and_group");
+}
+
+extern "C" int ws3d_query_and_group_nlc(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
+                                        const float *xyz, const float *new_xyz, const float *features_nlc,
+                                        int32_t *idx_out, float *out_nlc, const void *sorted, ws3d_stream_t stream) {
+    return ws3d::bq_launch<true>(b, n, m, features_nlc ? c : 0, radius, nsample, use_xyz, xyz, new_xyz, features_nlc,
+                                 idx_out, out_nlc, sorted, ws3d::as_stream(stream), "ws3d_query_and_group_nlc", 1);
 }
 
 extern "C" int ws3d_group_points(int b, int c, int n, int npoints, int nsample, const float *points,

@@ -369,6 +369,56 @@ __global__ __launch_bounds__(256) void rowmax_bias_act_generic_kernel(int o_ch, 
     out[row] = relu ? relu_f(v) : v;
 }
 
+// ---- channels-last variants (features (b, points, C) row-major): the layout of the row-major
+// SharedMLP GEMM chain (ws3d_amd/fastpath.py).  Lanes run along the channels, so every gather is a
+// contiguous row read and every store is coalesced.
+
+// out[b, p, 0:C] = w0*f[i0] + w1*f[i1] + w2*f[i2] (same fmaf expression as three_interpolate_kernel)
+// written with row stride out_stride >= C, i.e. straight into the left part of the FP module's
+// concatenated [interpolated | skip] buffer.
+__global__ __launch_bounds__(256) void three_interpolate_nlc_kernel(int c, int m, int n, long total4,
+                                                                    const float *__restrict__ feats,
+                                                                    const int32_t *__restrict__ idx,
+                                                                    const float *__restrict__ weight,
+                                                                    float *__restrict__ out, int out_stride) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int c4n = c >> 2;
+    const long row = t / c4n;            // b * n + p
+    const int c4 = (int)(t - row * c4n);
+    const int b = (int)(row / n);
+    const int32_t *id = idx + row * 3;
+    const float *w = weight + row * 3;
+    const float4 *f = reinterpret_cast<const float4 *>(feats + (size_t)b * m * c);
+    const float4 p0 = f[(size_t)id[0] * c4n + c4], p1 = f[(size_t)id[1] * c4n + c4], p2 = f[(size_t)id[2] * c4n + c4];
+    const float w0 = w[0], w1 = w[1], w2 = w[2];
+    float4 r;
+    r.x = __builtin_fmaf(w2, p2.x, __builtin_fmaf(w0, p0.x, w1 * p1.x));
+    r.y = __builtin_fmaf(w2, p2.y, __builtin_fmaf(w0, p0.y, w1 * p1.y));
+    r.z = __builtin_fmaf(w2, p2.z, __builtin_fmaf(w0, p0.z, w1 * p1.z));
+    r.w = __builtin_fmaf(w2, p2.w, __builtin_fmaf(w0, p0.w, w1 * p1.w));
+    *reinterpret_cast<float4 *>(out + (size_t)row * out_stride + 4 * c4) = r;
+}
+
+// out[r, 0:O] = max over the ns consecutive rows y[r*ns .. r*ns+ns-1, 0:O] (the SA pool on a
+// channels-last tensor), written with row stride out_stride (into a slice of the MSG concat buffer).
+__global__ __launch_bounds__(256) void rowmax_rows_kernel(long total4, int o_ch, int ns,
+                                                          const float *__restrict__ y, float *__restrict__ out,
+                                                          int out_stride) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total4) return;
+    const int o4n = o_ch >> 2;
+    const long r = t / o4n;
+    const int o4 = (int)(t - r * o4n);
+    const float4 *src = reinterpret_cast<const float4 *>(y + (size_t)r * ns * o_ch) + o4;
+    float4 v = src[0];
+    for (int i = 1; i < ns; ++i) {
+        const float4 q = src[(size_t)i * o4n];
+        v.x = nanmax(v.x, q.x); v.y = nanmax(v.y, q.y); v.z = nanmax(v.z, q.z); v.w = nanmax(v.w, q.w);
+    }
+    *reinterpret_cast<float4 *>(out + (size_t)r * out_stride + 4 * o4) = v;
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,
@@ -416,6 +466,40 @@ extern "C" int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, co
     }
 #undef WS3D_RM
     return check_launch("ws3d_rowmax_bias_act");
+}
+
+extern "C" int ws3d_three_interpolate_nlc(int b, int c, int m, int n, const float *feats_nlc, const int32_t *idx,
+                                          const float *weight, float *out_nlc, int out_stride, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(feats_nlc) | reinterpret_cast<uintptr_t>(out_nlc);
+    if (b < 0 || c <= 0 || m <= 0 || n < 0 || !feats_nlc || !idx || !weight || !out_nlc || out_stride < c ||
+        (c & 3) || (out_stride & 3) || (al & 15)) {
+        set_error("ws3d_three_interpolate_nlc: invalid argument (b=%d c=%d m=%d n=%d stride=%d; c, stride %% 4, 16-byte bases)",
+                  b, c, m, n, out_stride);
+        return WS3D_E_INVALID;
+    }
+    const long total4 = (long)b * n * (c / 4);
+    if (total4 == 0) return WS3D_OK;
+    if ((total4 + 255) / 256 > 0x7fffffffL) { set_error("ws3d_three_interpolate_nlc: too large"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(three_interpolate_nlc_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       c, m, n, total4, feats_nlc, idx, weight, out_nlc, out_stride);
+    return check_launch("ws3d_three_interpolate_nlc");
+}
+
+extern "C" int ws3d_rowmax_rows(long rows_out, int ns, int o_ch, const float *y, float *out, int out_stride,
+                                ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out);
+    if (rows_out < 0 || ns <= 0 || o_ch <= 0 || !y || !out || out_stride < o_ch || (o_ch & 3) || (out_stride & 3) || (al & 15)) {
+        set_error("ws3d_rowmax_rows: invalid argument (rows=%ld ns=%d o=%d stride=%d)", rows_out, ns, o_ch, out_stride);
+        return WS3D_E_INVALID;
+    }
+    const long total4 = rows_out * (o_ch / 4);
+    if (total4 == 0) return WS3D_OK;
+    if ((total4 + 255) / 256 > 0x7fffffffL) { set_error("ws3d_rowmax_rows: too large"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(rowmax_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), total4,
+                       o_ch, ns, y, out, out_stride);
+    return check_launch("ws3d_rowmax_rows");
 }
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
