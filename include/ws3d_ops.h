@@ -175,6 +175,16 @@ WS3D_API int ws3d_three_interpolate_nlc(int b, int c, int m, int n, const float 
 WS3D_API int ws3d_rowmax_rows(long rows_out, int ns, int o_ch, const float *y, float *out, int out_stride,
                               ws3d_stream_t stream);
 
+/* First SA level fused: x_rows4 (rows, 4) grouped columns [dx,dy,dz,f] -> three pointwise layers
+ * (W^T row-major (in, out), BN folded; ReLU after layers 1, 2 and, if relu3, 3) -> max over each
+ * group of nsample consecutive rows -> out (rows/nsample, c3) with row stride out_stride.  Widths
+ * (c1,c2,c3) x nsample in {(16,16,32),(32,32,64)} x {16,32}; WS3D_E_UNSUPPORTED otherwise (the
+ * caller then runs the GEMM chain).  ws3d extension, used by ws3d_amd/fastpath.py.               */
+WS3D_API int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, const float *x_rows4,
+                               const float *w1t, const float *b1, const float *w2t, const float *b2,
+                               const float *w3t, const float *b3, int relu3, float *out, int out_stride,
+                               ws3d_stream_t stream);
+
 /* -------------------------------------------------------------------- iou3d_cuda */
 
 /* boxes_overlap_bev_gpu(boxes_a,boxes_b,ans)   iou3d.cpp:31-50 -> iou3d_kernel.cu:

@@ -7,7 +7,7 @@ src=$1; out=$2; shift 2
 mkdir -p scratch
 python -c "import ws3d_amd.build as b; b.build()"
 objs=""
-for s in core fps fps_bucket ballquery_group interpolate roipool3d iou3d scatter_det; do
+for s in core fps fps_bucket ballquery_group interpolate roipool3d iou3d scatter_det sa_mlp; do
   [ "$s.hip" = "$src" ] || objs="$objs ws3d_amd/csrc/build/$s.o"
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden \

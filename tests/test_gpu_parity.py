@@ -863,3 +863,30 @@ def test_channels_last_fast_path_equals_reference_layout_path(ops):
         np.testing.assert_allclose(host(fast[k]), host(slow[k]), atol=2e-5 * max(scale, 1.0), rtol=0, err_msg=k)
     f = fast["backbone_features"].transpose(1, 2).contiguous()
     assert f.data_ptr() == fast["backbone_features_nlc"].data_ptr()          # the (B,C,N) view costs nothing to undo
+
+
+@pytest.mark.parametrize("c1,c2,c3,ns,R", [(16, 16, 32, 16, 777), (32, 32, 64, 32, 300), (16, 16, 32, 32, 64), (32, 32, 64, 16, 1)])
+def test_fused_sa_mlp_pool_matches_gemm_chain(ops, c1, c2, c3, ns, R):
+    """ws3d_sa_mlp3_pool == three (row GEMM + bias + ReLU) layers + max over nsample, to fp32
+    summation-order rounding (a float64 evaluation sits between the two)"""
+    g = torch.Generator().manual_seed(c3 + ns)
+    x = (torch.randn((R * ns, 4), generator=g) * 2).cuda()
+    layers = []
+    cin = 4
+    for cout in (c1, c2, c3):
+        layers.append((torch.randn((cin, cout), generator=g).mul_(cin ** -0.5).cuda().contiguous(),
+                       torch.randn(cout, generator=g).mul_(0.3).cuda(), True))
+        cin = cout
+    out = torch.full((R, c3 + 8), -3.0, device="cuda")
+    assert ops.c.sa_mlp3_pool(x, ns, layers, out, 4)
+    h = x.double()
+    for w, b, _ in layers:
+        h = torch.relu(h @ w.double() + b.double())
+    ref = h.view(R, ns, c3).amax(dim=1)
+    np.testing.assert_allclose(host(out[:, 4:4 + c3]), host(ref), rtol=2e-5, atol=2e-5)
+    assert (out[:, :4] == -3.0).all() and (out[:, 4 + c3:] == -3.0).all()
+    # unsupported widths: the caller is told to take the GEMM chain
+    bad = [(torch.zeros((4, 8), device="cuda"), torch.zeros(8, device="cuda"), True),
+           (torch.zeros((8, 8), device="cuda"), torch.zeros(8, device="cuda"), True),
+           (torch.zeros((8, 16), device="cuda"), torch.zeros(16, device="cuda"), True)]
+    assert ops.c.sa_mlp3_pool(x, ns, bad, out, 0) is False

@@ -212,6 +212,26 @@ def rowmax_rows(y, ns, out=None, col0=0):
     return out
 
 
+SA_MLP3_SHAPES = {(16, 16, 32), (32, 32, 64)}
+
+
+def sa_mlp3_pool(x_rows4, nsample, layers, out, col0=0):
+    """x_rows4 (R*nsample, 4); layers = [(W^T (in,out), bias, relu)] * 3 -> out[:, col0:col0+c3] of the
+    (R, >=c3) buffer `out`; returns False when there is no fused kernel for these widths."""
+    (w1, b1, r1), (w2, b2, r2), (w3, b3, r3) = layers
+    widths = (w1.size(1), w2.size(1), w3.size(1))
+    if (x_rows4.size(1) != 4 or widths not in SA_MLP3_SHAPES or nsample not in (16, 32) or not (r1 and r2)
+            or b1 is None or b2 is None or b3 is None):
+        return False
+    dev = _dev(x_rows4, out)
+    view = out[:, col0:col0 + widths[2]]
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_sa_mlp3_pool(x_rows4.size(0), nsample, widths[0], widths[1], widths[2], _p(x_rows4),
+                                            _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), int(bool(r3)),
+                                            view.data_ptr(), out.size(1), _stream()), "sa_mlp3_pool")
+    return True
+
+
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor, sorted_known=None):
     """interpolate.cpp:14-23 (+ optional x-binned copy of `known` from sort_points_x: same result)"""
     dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)

@@ -1,0 +1,129 @@
+// sa_mlp.hip -- the first set-abstraction level's SharedMLP + pool as ONE kernel.
+//
+// At SA level 1 the grouped tensor has 4 channels (dx, dy, dz, intensity) and 0.5-1 M columns per
+// batch, the MLP widths are 16-64.  As three GEMMs + pool that is ~2 GB of intermediate traffic
+// for ~8 GFLOP (0.55 ms per 8 scenes); here one lane carries one (centre, sample) column through
+// all three layers in registers (weights broadcast from LDS, W^T layout so that one 16-byte LDS
+// read feeds four outputs), the nsample lanes of a centre are max-reduced with DPP, and only the
+// pooled (centre, C3) rows leave the chip.  bias + ReLU of the last layer are applied after the
+// pool (they commute with max exactly, nn_blocks.forward_then_max).  fp32 FMA chains in a fixed
+// order: same math as the GEMM path up to summation order (both are within ~1e-6 relative of the
+// exact value; the network-level tests hold the 1e-4 tolerance of the GEMM path).
+//
+// Not a reference entry point: ws3d_amd/fastpath.py uses it when the shapes match
+// (C0 = 4, C1, C2 <= 32, C3 <= 64, nsample in {16, 32}); anything else takes the GEMM chain.
+#include "common.h"
+
+namespace ws3d {
+
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(256) void sa_mlp3_pool_kernel(long rows, const float *__restrict__ x,
+                                                           const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                           const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                           const float *__restrict__ w3t, const float *__restrict__ b3,
+                                                           int relu3, float *__restrict__ out, int out_stride) {
+    static_assert(C1 % 4 == 0 && C2 % 4 == 0 && C3 % 16 == 0 && (NS == 16 || NS == 32), "shape");
+    __shared__ __attribute__((aligned(16))) float s_w1[4 * C1], s_w2[C1 * C2], s_w3[C2 * C3], s_b1[C1], s_b2[C2], s_b3[C3];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4 * C1; i += 256) s_w1[i] = w1t[i];
+    for (int i = tid; i < C1 * C2; i += 256) s_w2[i] = w2t[i];
+    for (int i = tid; i < C2 * C3; i += 256) s_w3[i] = w3t[i];
+    if (tid < C1) s_b1[tid] = b1[tid];
+    if (tid < C2) s_b2[tid] = b2[tid];
+    if (tid < C3) s_b3[tid] = b3[tid];
+    __syncthreads();
+
+    const long r = (long)blockIdx.x * 256 + tid;          // rows is a multiple of NS; a group never straddles the end
+    const bool live = r < rows;
+    const float4 xin = live ? reinterpret_cast<const float4 *>(x)[r] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xi[4] = {xin.x, xin.y, xin.z, xin.w};
+
+    float h1[C1];
+#pragma unroll
+    for (int o = 0; o < C1; o += 4) {
+        float4 a = *reinterpret_cast<const float4 *>(s_b1 + o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 w = *reinterpret_cast<const float4 *>(s_w1 + i * C1 + o);
+            a.x = __builtin_fmaf(xi[i], w.x, a.x); a.y = __builtin_fmaf(xi[i], w.y, a.y);
+            a.z = __builtin_fmaf(xi[i], w.z, a.z); a.w = __builtin_fmaf(xi[i], w.w, a.w);
+        }
+        h1[o] = fmaxf(a.x, 0.f); h1[o + 1] = fmaxf(a.y, 0.f); h1[o + 2] = fmaxf(a.z, 0.f); h1[o + 3] = fmaxf(a.w, 0.f);
+    }
+    float h2[C2];
+#pragma unroll
+    for (int o = 0; o < C2; o += 4) {
+        float4 a = *reinterpret_cast<const float4 *>(s_b2 + o);
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const float4 w = *reinterpret_cast<const float4 *>(s_w2 + i * C2 + o);
+            a.x = __builtin_fmaf(h1[i], w.x, a.x); a.y = __builtin_fmaf(h1[i], w.y, a.y);
+            a.z = __builtin_fmaf(h1[i], w.z, a.z); a.w = __builtin_fmaf(h1[i], w.w, a.w);
+        }
+        h2[o] = fmaxf(a.x, 0.f); h2[o + 1] = fmaxf(a.y, 0.f); h2[o + 2] = fmaxf(a.z, 0.f); h2[o + 3] = fmaxf(a.w, 0.f);
+    }
+    const int lane = tid & 63;
+    const bool writer = live && (NS == 16 ? (lane & 15) == 0 : (lane & 31) == 16);
+    float *orow = out + (r / NS) * (long)out_stride;
+#pragma unroll 1
+    for (int o0 = 0; o0 < C3; o0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) {
+                const float4 w = *reinterpret_cast<const float4 *>(s_w3 + i * C3 + o0 + q);
+                acc[q] = __builtin_fmaf(h2[i], w.x, acc[q]); acc[q + 1] = __builtin_fmaf(h2[i], w.y, acc[q + 1]);
+                acc[q + 2] = __builtin_fmaf(h2[i], w.z, acc[q + 2]); acc[q + 3] = __builtin_fmaf(h2[i], w.w, acc[q + 3]);
+            }
+        }
+        // max over the NS lanes of the centre (a dead lane contributes its own finite garbage only
+        // to dead groups: rows % NS == 0)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            float v = row16_max(acc[q]);
+            if (NS == 32) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+            v += s_b3[o0 + q];
+            acc[q] = relu3 ? fmaxf(v, 0.f) : v;
+        }
+        if (writer) {
+#pragma unroll
+            for (int q = 0; q < 16; q += 4)
+                *reinterpret_cast<float4 *>(orow + o0 + q) = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
+        }
+    }
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, const float *x_rows4,
+                                 const float *w1t, const float *b1, const float *w2t, const float *b2,
+                                 const float *w3t, const float *b3, int relu3, float *out, int out_stride,
+                                 ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows4) | reinterpret_cast<uintptr_t>(out);
+    if (rows < 0 || !x_rows4 || !w1t || !b1 || !w2t || !b2 || !w3t || !b3 || !out || out_stride < c3 || (out_stride & 3) ||
+        (al & 15) || nsample <= 0 || rows % nsample) {
+        set_error("ws3d_sa_mlp3_pool: invalid argument (rows=%ld nsample=%d stride=%d)", rows, nsample, out_stride);
+        return WS3D_E_INVALID;
+    }
+    if (rows == 0) return WS3D_OK;
+    const long blocks = (rows + 255) / 256;
+    if (blocks > 0x7fffffffL) { set_error("ws3d_sa_mlp3_pool: too many rows"); return WS3D_E_UNSUPPORTED; }
+    hipStream_t st = as_stream(stream);
+#define WS3D_SA_MLP(A, B, C, N)                                                                                          \
+    if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                                 \
+        hipLaunchKernelGGL((sa_mlp3_pool_kernel<A, B, C, N>), dim3((unsigned)blocks), dim3(256), 0, st, rows, x_rows4,   \
+                           w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride);                                           \
+        return check_launch("ws3d_sa_mlp3_pool");                                                                        \
+    }
+    WS3D_SA_MLP(16, 16, 32, 16)
+    WS3D_SA_MLP(32, 32, 64, 32)
+    WS3D_SA_MLP(16, 16, 32, 32)
+    WS3D_SA_MLP(32, 32, 64, 16)
+#undef WS3D_SA_MLP
+    set_error("ws3d_sa_mlp3_pool: no kernel for widths (%d, %d, %d) x nsample %d", c1, c2, c3, nsample);
+    return WS3D_E_UNSUPPORTED;
+}

@@ -26,6 +26,9 @@ from . import compat as _C
 from . import nn_blocks, pn2_ops
 
 
+FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
+
+
 def _row_weights(block):
     """(W^T (C,O) contiguous, bias (O,) or None, relu?) of a Conv+BN+ReLU block, cached on the block"""
     w, shift, act = block._folded()
@@ -87,8 +90,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
     col = 0
     for grouper, mlp, width in zip(sa.groupers, sa.mlps, widths):
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
-        y = mlp_rows(g.view(-1, g.size(3)), mlp)                       # (B*M*ns, O), bias + ReLU applied
-        _C.rowmax_rows(y, grouper.nsample, out, col)                   # pool over nsample into its column slice
+        rows = g.view(-1, g.size(3))
+        blocks = _blocks(mlp)
+        # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
+        # pooled rows leaves the chip; otherwise the GEMM chain + pool kernel
+        if not (FUSED_SA_MLP and rows.size(1) == 4 and len(blocks) == 3 and
+                _C.sa_mlp3_pool(rows, grouper.nsample, [_row_weights(b) for b in blocks], out, col)):
+            y = mlp_rows(rows, mlp)                                    # (B*M*ns, O), bias + ReLU applied
+            _C.rowmax_rows(y, grouper.nsample, out, col)               # pool over nsample into its column slice
         col += width
     return new_xyz, out.view(B, sa.npoint, -1)
 
