@@ -233,6 +233,14 @@ WS3D_API int ws3d_radius_nms_batched(int batch, int n, const float *centers, flo
                                      void *workspace, size_t workspace_bytes, int64_t *keep,
                                      int32_t *num_keep, ws3d_stream_t stream);
 
+/* Proposal decode (ws3d extension): xyz (b,n,3), rpn_reg (b,n,4*bins) -> boxes (b,n,7)
+ * = [x + dx, y + h/2, z + dz, h, w, l, ry] with (dx, dz) = decode_center_target
+ * (lib/utils/bbox_transform.py:24-61) and ry the per-index synthetic heading of
+ * ws3d_amd.stage1.synthetic_orientation; bit-identical to the torch composition.          */
+WS3D_API int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope, float loc_bin_size, float h, float w,
+                                      float l, const float *xyz, const float *rpn_reg, float *boxes,
+                                      ws3d_stream_t stream);
+
 /* ---------------------------------------------------------------- roipool3d_cuda */
 
 /* forward(xyz,boxes3d,pts_feature,pooled_features,pooled_empty_flag)

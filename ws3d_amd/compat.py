@@ -290,6 +290,22 @@ def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_t
     return 1
 
 
+def decode_center_boxes(xyz, rpn_reg, loc_scope, loc_bin_size, mean_size):
+    """xyz (B,N,3), rpn_reg (B,N,4*bins) -> proposal rows (B,N,7) (ws3d extension, see ws3d_ops.h)"""
+    dev = _dev(xyz, rpn_reg)
+    _f32(xyz, "xyz"); _f32(rpn_reg, "rpn_reg")
+    B, N = xyz.size(0), xyz.size(1)
+    bins = int(loc_scope / loc_bin_size) * 2
+    if rpn_reg.size(2) != 4 * bins or not rpn_reg.is_contiguous() or not xyz.is_contiguous():
+        raise ValueError("decode_center_boxes: rpn_reg must be contiguous (B,N,%d)" % (4 * bins))
+    boxes = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
+    h, w, l = mean_size
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_decode_center_boxes(B, N, bins, float(loc_scope), float(loc_bin_size), float(h), float(w),
+                                                   float(l), _p(xyz), _p(rpn_reg), _p(boxes), _stream()), "decode_center_boxes")
+    return boxes
+
+
 def bias_act_inplace(y, bias, relu=True):
     """y (B,O,L...) contiguous: y = relu?(y + bias[o]) in place, one pass (ws3d extension)"""
     dev = _dev(y, bias)

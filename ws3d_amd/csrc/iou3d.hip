@@ -506,6 +506,49 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(int boxes_num, int max_k
     }
 }
 
+
+// Proposal decode: per point, decode_center_target (lib/utils/bbox_transform.py:24-61:
+// argmax over the x / z bins -- first maximum, NaN counts as maximum like torch.argmax -- plus the
+// residual of the chosen bin) and the (x, y + h/2, z, h, w, l, ry) proposal row with the class mean
+// size.  Every float operation is a separate fp32 op in the order of the torch composition
+// (ws3d_amd/stage1.py), so the result is bit-identical to it; ~25 tiny launches become one.
+__global__ __launch_bounds__(256) void decode_center_boxes_kernel(long total, int n, int bins, float loc_scope,
+                                                                  float bin_size, float h, float w, float l,
+                                                                  const float *__restrict__ xyz,
+                                                                  const float *__restrict__ reg,
+                                                                  float *__restrict__ boxes) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const float *r = reg + t * 4 * bins;
+    const float half = bin_size / 2;
+    float pos[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float *bl = r + a * bins;
+        int best = 0;
+        float bv = bl[0];
+        for (int i = 1; i < bins; ++i) {
+            const float v = bl[i];
+            if (v > bv || (v != v && bv == bv)) { bv = v; best = i; }
+        }
+        float p = (float)best * bin_size;
+        p = p + half;
+        p = p - loc_scope;
+        const float res = r[(2 + a) * bins + best] * half;
+        pos[a] = p + res;
+    }
+    const float *q = xyz + t * 3;
+    const unsigned long long k = (unsigned long long)(t % n);
+    const double hk = (double)((k * 2654435761ull) % 4294967296ull);
+    const float ry = (float)(hk / 4294967296.0 * (2.0 * 3.141592653589793) - 3.141592653589793);
+    float *o = boxes + t * 7;
+    o[0] = pos[0] + q[0];
+    o[1] = q[1] + h / 2;
+    o[2] = pos[1] + q[2];
+    o[3] = h; o[4] = w; o[5] = l;
+    o[6] = ry;
+}
+
 template <int MODE>
 static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
                        hipStream_t st, const char *what) {
@@ -605,6 +648,21 @@ extern "C" int ws3d_boxes_iou_bev(int num_a, const float *boxes_a, int num_b, co
                                   float *ans, ws3d_stream_t stream) {
     return ws3d::pair_launch<1>(num_a, boxes_a, num_b, boxes_b, ans, ws3d::as_stream(stream),
                                 "ws3d_boxes_iou_bev");
+}
+
+extern "C" int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope, float loc_bin_size, float h, float w,
+                                        float l, const float *xyz, const float *rpn_reg, float *boxes,
+                                        ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n < 0 || bins <= 0 || !xyz || !rpn_reg || !boxes) {
+        set_error("ws3d_decode_center_boxes: invalid argument (b=%d n=%d bins=%d)", b, n, bins);
+        return WS3D_E_INVALID;
+    }
+    const long total = (long)b * n;
+    if (total == 0) return WS3D_OK;
+    hipLaunchKernelGGL(decode_center_boxes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       total, n, bins, loc_scope, loc_bin_size, h, w, l, xyz, rpn_reg, boxes);
+    return check_launch("ws3d_decode_center_boxes");
 }
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,

@@ -202,11 +202,15 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
     K = cfg.rpn_post_nms_top_n
     h, w, l = cfg.cls_mean_size
     score = torch.sigmoid(cls[:, :, 0])                                                   # (B,N)
-    centre = decode_center_target(xyz.reshape(B * N, 3), reg.reshape(B * N, -1), cfg.loc_scope,
-                                  cfg.loc_bin_size).view(B, N, 3)
-    ry = synthetic_orientation(N, xyz.device).unsqueeze(0).expand(B, N)
-    box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h),
-                       torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
+    if xyz.is_cuda:
+        from . import compat as _C        # one kernel instead of ~25 tiny torch launches; bit-identical
+        box = _C.decode_center_boxes(xyz.contiguous(), reg.contiguous(), cfg.loc_scope, cfg.loc_bin_size, (h, w, l))
+    else:
+        centre = decode_center_target(xyz.reshape(B * N, 3), reg.reshape(B * N, -1), cfg.loc_scope,
+                                      cfg.loc_bin_size).view(B, N, 3)
+        ry = synthetic_orientation(N, xyz.device).unsqueeze(0).expand(B, N)
+        box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h),
+                           torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
     top = min(cfg.rpn_pre_nms_top_n, N)
     sc, order = torch.topk(score, top, dim=1, sorted=True)                                # (B,top)
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
