@@ -111,19 +111,10 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + u * 64 + lane;   // loads are clamped, never branched; a lane past the
             const float *p = xyz + (size_t)min(k, pts_num - 1) * 3;  // wave's range gets x = NaN = "outside"
-#ifdef WS3D_ROI_NO_LOAD   // ablation: synthetic coordinates, no memory traffic in the scan
-            nx[u] = k < end ? (float)(k & 1023) * 0.07f - 35.f : __builtin_nanf(""); ny[u] = 1.5f; nz[u] = (float)(k >> 10) + (p == nullptr ? 1.f : 0.f);
-#else
             nx[u] = k < end ? p[0] : __builtin_nanf(""); ny[u] = p[1]; nz[u] = p[2];
-#endif
         }
     };
-#ifdef WS3D_ROI_MIXED     // ablation: odd workgroups skip the scan, even ones skip the copy
-    const bool skip_scan = (blockIdx.x >> 3) & 1;
-    if (skip_scan) for (int g = 0; g < BG; ++g) { if (lane < 40) lists[(g * 4 + w) * S + lane] = start + lane * 7; wcnt[g] = g < nb ? 40 : S; }
-    if (!skip_scan) load_trip(start);
-    for (int k0 = skip_scan ? end : start; k0 < end; k0 += 256) {
-#elif defined(WS3D_ROI_NO_SCAN)   // ablation: pretend every wave found 40 points
+#if defined(WS3D_ROI_NO_SCAN)   // ablation: pretend every wave found 40 points
     for (int g = 0; g < BG; ++g) { if (lane < 40) lists[(g * 4 + w) * S + lane] = start + lane * 7; wcnt[g] = g < nb ? 40 : S; }
     for (int k0 = end; k0 < end; k0 += 256) {
 #else
@@ -194,9 +185,6 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
         __syncthreads();
 #ifdef WS3D_ROI_NO_COPY
         if (pts_num >= 0) continue;
-#endif
-#ifdef WS3D_ROI_MIXED
-        if (!((blockIdx.x >> 3) & 1)) continue;
 #endif
         float *out = pooled + bm * (size_t)S * row;
         auto fetch = [&](int sr, int j) -> float {
