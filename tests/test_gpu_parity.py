@@ -890,3 +890,67 @@ def test_fused_sa_mlp_pool_matches_gemm_chain(ops, c1, c2, c3, ns, R):
            (torch.zeros((8, 8), device="cuda"), torch.zeros(8, device="cuda"), True),
            (torch.zeros((8, 16), device="cuda"), torch.zeros(16, device="cuda"), True)]
     assert ops.c.sa_mlp3_pool(x, ns, bad, out, 0) is False
+
+
+# ------------------------------------------------------------------------------- non-finite inputs
+def _poison(a, rng, k=4):
+    """a few NaN / +inf / -inf coordinates at random places (in place)"""
+    flat = a.reshape(-1, a.shape[-1])
+    rows = rng.choice(flat.shape[0], 3 * k, replace=False)
+    for j, r in enumerate(rows):
+        flat[r, rng.integers(0, min(3, a.shape[-1]))] = (np.nan, np.inf, -np.inf)[j % 3]
+    return a
+
+
+def test_nonfinite_coordinates_follow_the_reference_semantics(ops, oracle):
+    """NaN / inf coordinates take whatever path the reference's comparisons send them down (the
+    oracle restates those comparisons literally): FPS, ball query (both searches), 3-NN (both
+    searches), roipool3d and the NMS mask must agree with it bit for bit"""
+    rng = np.random.default_rng(77)
+    pc = synth.make_batch("lidar", 2, 3000, 5)[:, :, :3].copy()
+    _poison(pc, rng)
+    # FPS (register kernel) + gathered centres
+    ref_idx = oracle.furthest_point_sample(pc, 200)
+    idx, new_xyz = ops.pn.furthest_point_sample_gather(dev(pc), 200)
+    np.testing.assert_array_equal(host(idx), ref_idx)
+    centres = np.stack([pc[b][ref_idx[b]] for b in range(2)])
+    np.testing.assert_array_equal(host(new_xyz), centres)                      # NaN == NaN position-wise
+    # ball query: brute force and x-binned
+    big = synth.make_batch("lidar", 2, 4096, 6)[:, :, :3].copy()
+    _poison(big, rng)
+    cen = _poison(big[:, :512].copy(), rng, k=2)
+    ref_bq = oracle.ball_query(1.0, 16, big, cen)
+    np.testing.assert_array_equal(host(ops.pn.ball_query(1.0, 16, dev(big), dev(cen))), ref_bq)
+    srt = ops.c.sort_points_x(dev(big))
+    got = torch.zeros((2, 512, 16), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(2, 4096, 512, 1.0, 16, dev(cen), dev(big), got, srt)
+    np.testing.assert_array_equal(host(got), ref_bq)
+    # three_nn: full scan and binned
+    kn = _poison(big[:, :2048].copy(), rng, k=2)
+    unk = _poison(big[:, 1000:3500].copy(), rng, k=2)
+    d2_ref, i_ref = oracle.three_nn_dist2(unk, kn)
+    for sorted_known in (None, ops.c.sort_points_x(dev(kn))):
+        d2 = torch.empty((2, 2500, 3), device="cuda"); i3 = torch.empty((2, 2500, 3), dtype=torch.int32, device="cuda")
+        ops.c.three_nn_wrapper(2, 2500, 2048, dev(unk), dev(kn), d2, i3, sorted_known)
+        np.testing.assert_array_equal(host(i3), i_ref)
+        np.testing.assert_array_equal(host(d2), d2_ref)
+    # roipool3d: poisoned points and boxes (NaN heading, infinite extent, NaN centre)
+    boxes = synth.proposal_boxes(2, 24, 9)
+    boxes[0, 1, 6] = np.nan; boxes[0, 2, 5] = np.inf; boxes[1, 3, 0] = np.nan; boxes[1, 4, 3] = -np.inf
+    feat = rng.standard_normal((2, 3000, 8)).astype(np.float32)
+    ref_p, ref_e = oracle.roipool3d(pc, boxes, feat, 64)
+    pooled = torch.zeros((2, 24, 64, 11), device="cuda"); empty = torch.zeros((2, 24), dtype=torch.int32, device="cuda")
+    ops.c.roipool3d_forward(dev(pc), dev(boxes), dev(feat), pooled, empty)
+    np.testing.assert_array_equal(host(empty), ref_e)
+    np.testing.assert_array_equal(host(pooled), ref_p)
+    # NMS mask with a NaN box and an infinite one
+    bev = np.ascontiguousarray(synth.boxes3d_to_bev(synth.proposal_boxes(1, 200, 4)[0]))
+    bev[5, 0] = np.nan; bev[9, 2] = np.inf; bev[11, 4] = np.nan
+    for normal in (False, True):
+        ref_mask = oracle.nms_mask(bev, 0.3, normal)
+        got_mask = host(ops.c.nms_mask(dev(bev), 0.3, normal, full_grid=True)).view(np.uint64)
+        np.testing.assert_array_equal(got_mask, ref_mask)
+        ref_keep = oracle.nms_sorted(bev, 0.3, normal)
+        keep, num = ops.c.nms_device(dev(bev), 0.3, normal)
+        assert int(num.item()) == len(ref_keep)
+        np.testing.assert_array_equal(host(keep)[:len(ref_keep)], ref_keep)

@@ -11,7 +11,8 @@ def __getattr__(name):
     """Lazy aliases under the reference's module names (``ws3d_amd.pointnet2_utils`` ...)."""
     import importlib
     alias = {"pointnet2_utils": "pn2_ops", "pointnet2_modules": "pn2_modules", "pytorch_utils": "nn_blocks",
-             "iou3d_utils": "iou3d_ops", "roipool3d_utils": "roipool3d_ops"}
+             "iou3d_utils": "iou3d_ops", "roipool3d_utils": "roipool3d_ops", "calibration": "kitti_io",
+             "loss_utils": "losses"}
     if name in alias:
         return importlib.import_module("." + alias[name], __name__)
     raise AttributeError(name)
