@@ -299,6 +299,9 @@ __global__ __launch_bounds__(64 * BQ_NW) void ball_query_kernel(int n, int m, in
 // brute-force scan (and independent of the order inside a cell).  Slabs longer than
 // BQS_MAX_SLAB (pathological density) fall back to the ordered full scan for that lane.
 constexpr int BQS_MAX_SLAB = 3072;
+#ifndef BQS_UNROLL
+#define BQS_UNROLL 8
+#endif
 // one workgroup per scene: min/max of x, LDS histogram, exclusive scan, scatter
 __global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *__restrict__ xyz,
                                                             char *__restrict__ ws) {
@@ -414,12 +417,19 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
             const int q = (kend - k0 + 3) >> 2;               // this wave's quarter of the slab
             int k = min(kend, k0 + w * q);
             const int ke = min(kend, k + q);
-            for (; k < ke; ++k) {
-                const float4 p = sorted[k];
-                const float dx = cx - p.x;
-                if (fabsf(dx) < rabs) {
-                    const float d2 = sqdist3(dx, cy - p.y, cz - p.z);
-                    if (d2 < radius2) insert(__float_as_int(p.w));
+            // BQS_UNROLL slab entries per trip: the loads are independent of the tests, so the walk pays one
+            // memory round trip per 4 candidates (clamped loads past the end are ignored)
+            for (; k < ke; k += BQS_UNROLL) {
+                float4 p[BQS_UNROLL];
+#pragma unroll
+                for (int u = 0; u < BQS_UNROLL; ++u) p[u] = sorted[min(k + u, ke - 1)];
+#pragma unroll
+                for (int u = 0; u < BQS_UNROLL; ++u) {
+                    const float dx = cx - p[u].x;
+                    if (k + u < ke && fabsf(dx) < rabs) {
+                        const float d2 = sqdist3(dx, cy - p[u].y, cz - p[u].z);
+                        if (d2 < radius2) insert(__float_as_int(p[u].w));
+                    }
                 }
             }
         } else if (w == 0) {
