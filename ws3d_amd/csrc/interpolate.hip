@@ -18,6 +18,9 @@
 namespace ws3d {
 
 constexpr int NN_TILE = 1024;
+#ifndef NN_UNROLL
+#define NN_UNROLL 4   // candidates per side and trip in the binned 3-NN walk
+#endif
 
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float *__restrict__ unknown,
@@ -139,14 +142,14 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
     // on R / L), so the walk pays one memory round trip per 8 candidates instead of per candidate;
     // loads past the stopping point or the array ends are clamped and their results unused
     while (go_r || go_l) {
-        float4 pr[4], pl[4];
+        float4 pr[NN_UNROLL], pl[NN_UNROLL];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NN_UNROLL; ++q) {
             pr[q] = sorted[min(R + q, m - 1)];
             pl[q] = sorted[max(L - q, 0)];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NN_UNROLL; ++q) {
             if (go_r) {
                 const float lb = (pr[q].x - ux) - slack;   // every point further right has dx > lb
                 if (lb > 0.f && lb * lb > b3 && pr[q].x < INFINITY) { go_r = false; } else { visit(pr[q]); go_r = ++R < m; }
