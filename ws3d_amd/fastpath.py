@@ -105,7 +105,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
 def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
     B, n = unknown.size(0), unknown.size(1)
-    dist, idx = pn2_ops.three_nn(unknown, known, pn2_ops.sort_points_x(known, min_n=512))
+    dist, idx = pn2_ops.three_nn(unknown, known, pn2_ops.sort_points_x(known, min_n=256))
     dist_recip = 1.0 / (dist + 1e-8)
     weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
     c2 = known_feats.size(2)
