@@ -144,7 +144,10 @@ class C2:
             {"name": ("fps_zlds_kernel<32,512>" if self.B > 256 else "fps_reg_kernel<32,512>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
              "launches_per_step": 1, "alg_bytes_per_step": a_model_fps() * self.B,
              "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_zlds_kernel" if self.B > 256 else "fps_reg_kernel",
-             "comment": "A_model re-reads xyz every step; this design keeps the scene on chip (VGPRs, z in LDS when two scenes share a CU), so the kernel is "
+             "valu_floor_ms": self.B * (M_PTS - 1) * (N_PTS / 64) * 10 * 2.3 / (1024 * 2.4e9) * 1e3,
+             "comment": "valu_floor_ms = the sweep alone at the measured wave64 issue rate (10 VALU instructions per point and step, "
+                        "2.3 clk per instruction and SIMD, 1024 SIMDs at 2.4 GHz): what actually bounds this kernel. "
+                        "A_model re-reads xyz every step; this design keeps the scene on chip (VGPRs, z in LDS when two scenes share a CU), so the kernel is "
                         "latency/ALU-bound and its real HBM traffic is ~A_min (see traffic_bytes_per_launch)"},
             {"name": "bin_points_x + ball_query_sorted_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
              "launches_per_step": 2, "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_sorted_kernel",
@@ -475,6 +478,7 @@ def main():
                          "traffic": (dom["traffic_bytes_per_launch"] or {}).get("hbm_bytes")
                          if isinstance(dom["traffic_bytes_per_launch"], dict) else None,
                          "ms_per_launch": dom["ms_per_step"] / max(dom["launches_per_step"], 1),
+                         "valu_floor_frac": (dom["valu_floor_ms"] / dom["ms_per_step"]) if dom.get("valu_floor_ms") else None,
                          "alg_bytes_per_launch": dom["alg_bytes_per_step"] / max(dom["launches_per_step"], 1),
                          "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic "
                                  "bytes (SURVEY.md 8d byte model, DESIGN.md section 6) / measured duration; "
