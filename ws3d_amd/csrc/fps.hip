@@ -389,8 +389,12 @@ void fps_zlds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, in
     __syncthreads();
     const float *zs = reinterpret_cast<const float *>(smem_z);
     for (int j = 1; j < m; ++j) {
-        float best = -1.0f;
-        int bslot = 0;
+        // Two scenes share the CU, so the SIMD is issue-bound and only the instruction COUNT of a
+        // step matters (the chain's latency is covered by the other scene): the sweep keeps 4 group
+        // maxima per lane (one v_max per point instead of v_cmp + 2 v_cndmask) and the winner's
+        // slot is looked up afterwards -- lowest slot first, same (slot, lane, wave) tie order.
+        constexpr int GS = PPT / 4;
+        float gm[4] = {-1.0f, -1.0f, -1.0f, -1.0f};
         float4 zn = zs4[u];                          // software pipeline: chunk c+1 is in flight while c is consumed
 #pragma unroll
         for (int c = 0; c < PPT / 4; ++c) {
@@ -403,16 +407,31 @@ void fps_zlds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, in
                 const float d = sqdist3(vec_get<PPT>(px, s) - ox, vec_get<PPT>(py, s) - oy, zz[q] - oz);
                 const float d2 = min_f32(d, t[s]);
                 t[s] = d2;
-                const bool gt = d2 > best;
-                bslot = gt ? s : bslot;
-                best = gt ? d2 : best;
+                gm[s / GS] = max_f32(gm[s / GS], d2);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep two z chunks live at most: 128-VGPR budget
         }
+        const float best = max_f32(max_f32(gm[0], gm[1]), max_f32(gm[2], gm[3]));
         const float wmax = wave_max(best);
         const uint64_t eq = __ballot(best == wmax);
         const int wl = (int)__builtin_ctzll(eq);
-        const int wslot = __builtin_amdgcn_readlane(bslot, wl);
+        int gsel = 3;
+        gsel = gm[2] == wmax ? 2 : gsel;
+        gsel = gm[1] == wmax ? 1 : gsel;
+        gsel = gm[0] == wmax ? 0 : gsel;
+        const int gw = __builtin_amdgcn_readlane(gsel, wl);
+        int ls = GS - 1;
+        auto find = [&](auto G) {
+#pragma unroll
+            for (int q = GS - 2; q >= 0; --q) ls = t[decltype(G)::value * GS + q] == wmax ? q : ls;
+        };
+        switch (gw) {   // wave-uniform
+            case 0: find(std::integral_constant<int, 0>{}); break;
+            case 1: find(std::integral_constant<int, 1>{}); break;
+            case 2: find(std::integral_constant<int, 2>{}); break;
+            default: find(std::integral_constant<int, 3>{}); break;
+        }
+        const int wslot = gw * GS + __builtin_amdgcn_readlane(ls, wl);
         const float cz = zs[(((wslot >> 2) * NT) + (w * 64 + wl)) * 4 + (wslot & 3)];   // wave-uniform address: broadcast
         const float cx = readlane_f(vec_get<PPT>(px, wslot), wl);
         const float cy = readlane_f(vec_get<PPT>(py, wslot), wl);
