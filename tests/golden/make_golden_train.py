@@ -101,6 +101,16 @@ def main():
                          "val": [float(v) for v in val_gr] + [float(v) for v in g_reg.reshape(-1)[nz]]},
         }
         print(case["name"], "loss", ret.loss.item(), ret.tb_dict)
+    # scene augmentation (rotation / scaling / flip) with the reference's random stream
+    aug = []
+    for seed in (0, 1, 2, 3):
+        pts = synth.lidar_cloud(512, 900 + seed)[:, :3].astype(np.float64)
+        boxes = synth.random_boxes3d(6, 77 + seed).astype(np.float64)
+        np.random.seed(seed)
+        a_pts, a_box, methods = KittiRCNNDataset.data_augmentation(None, pts.copy(), boxes.copy())
+        aug.append({"seed": seed, "pts_sha256": mg.sha(np.ascontiguousarray(a_pts)), "box_sha256": mg.sha(np.ascontiguousarray(a_box)),
+                    "methods": [m if isinstance(m, str) else [m[0], float(m[1])] for m in methods]})
+    out["augmentation"] = aug
     with open(os.path.join(HERE, "train_losses.json"), "w") as f:
         json.dump(out, f, indent=1)
 

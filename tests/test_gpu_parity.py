@@ -793,6 +793,16 @@ def test_trainer_learns_resumes_and_is_reproducible(ops, tmp_path):
     score = torch.sigmoid(out["rpn_cls"][0, :, 0])
     lab = torch.from_numpy(ds[0]["rpn_cls_label"]).cuda()
     assert score[lab > 0.5].mean() > score[lab < 0.05].mean()          # it learnt where the centres are
+    # evaluation pass (Trainer.eval_epoch_rpn): the trained net finds the annotated centres
+    from ws3d_amd.train_rpn import evaluate
+    ev = evaluate(res["model"], ds, cfg, max_scenes=3)
+    assert set(ev) == {"val_loss", "point_precision", "gt_recall", "mean_offset"} and np.isfinite(ev["val_loss"])
+    fresh = evaluate(stage1.Stage1Net(mode="TRAIN", cfg=cfg).cuda(), ds, cfg, max_scenes=3)
+    assert ev["val_loss"] < fresh["val_loss"]
+    # augmented training data (rotation / scaling / flip) runs through the same loop
+    aug = train(SyntheticCenters(8, npoints=4096, augment=True, rng=np.random.RandomState(1)), total_iters=3, batch_size=4,
+                seed=3, net_cfg=cfg)
+    assert np.isfinite(aug["history"]).all()
     # same seed, same data order, same schedule: the loss curve repeats (our backward kernels are
     # bit-reproducible; MIOpen's weight-gradient reductions are not, hence a tolerance)
     res3 = train(ds, total_iters=24, batch_size=4, seed=3, net_cfg=cfg)

@@ -142,3 +142,21 @@ def test_checkpoint_format_and_reference_keys(tmp_path):
         assert torch.equal(v, other.state_dict()[k])
     with pytest.raises(FileNotFoundError):
         load_checkpoint(other, None, str(tmp_path / "missing.pth"))
+
+
+def test_scene_augmentation_matches_reference_stream(fx):
+    """same numpy seed -> same rotation angle, scale and flip decision, bit-identical points and boxes"""
+    import hashlib
+    from ws3d_amd import synth
+    for ref in fx["augmentation"]:
+        pts = synth.lidar_cloud(512, 900 + ref["seed"])[:, :3].astype(np.float64)
+        boxes = synth.random_boxes3d(6, 77 + ref["seed"]).astype(np.float64)
+        np.random.seed(ref["seed"])
+        a_pts, a_box, methods = losses.scene_augmentation(pts, boxes)
+        assert [m if isinstance(m, str) else [m[0], float(m[1])] for m in methods] == ref["methods"]
+        assert hashlib.sha256(np.ascontiguousarray(a_pts).tobytes()).hexdigest() == ref["pts_sha256"]
+        assert hashlib.sha256(np.ascontiguousarray(a_box).tobytes()).hexdigest() == ref["box_sha256"]
+    # inputs are not modified; centre-only annotations (K,3) are accepted
+    pts = np.ones((4, 3)); c = np.ones((2, 3))
+    losses.scene_augmentation(pts, c, np.random.RandomState(0))
+    assert (pts == 1).all() and (c == 1).all()

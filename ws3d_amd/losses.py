@@ -49,6 +49,35 @@ def gaussian_center_labels(pts_rect: np.ndarray, gt_centers: np.ndarray, gauss_h
     return cls, reg_label
 
 
+def scene_augmentation(pts_rect: np.ndarray, gt_boxes3d: np.ndarray, rng=np.random, method_prob=(1.0, 1.0, 0.5),
+                       rot_range: float = 18.0):
+    """global rotation about y / scaling / x-flip of one scene and its annotations
+    (KittiRCNNDataset.data_augmentation, lib/datasets/kitti_rcnn_dataset.py:223-255; AUG_METHOD_LIST,
+    AUG_METHOD_PROB, AUG_ROT_RANGE of weaklyRPN.yaml:7-9).  Draws from `rng` in the reference's
+    order: rand(3), then uniform(angle), uniform(scale) for the enabled methods.  Works on copies;
+    returns (pts (N,3), boxes (K,>=3), [applied methods])."""
+    pts = np.array(pts_rect, copy=True)
+    boxes = np.array(gt_boxes3d, copy=True)
+    enable = 1 - rng.rand(3)
+    applied = []
+    if enable[0] < method_prob[0]:
+        angle = rng.uniform(-np.pi / rot_range, np.pi / rot_range)
+        rot = np.array([[np.cos(angle), -np.sin(angle)], [np.sin(angle), np.cos(angle)]])
+        pts[:, [0, 2]] = np.dot(pts[:, [0, 2]], rot.T)
+        boxes[:, [0, 2]] = np.dot(boxes[:, [0, 2]], rot.T)
+        applied.append(["rotation", angle])
+    if enable[1] < method_prob[1]:
+        scale = rng.uniform(0.95, 1.05)
+        pts = pts * scale
+        boxes[:, 0:6] = boxes[:, 0:6] * scale
+        applied.append(["scaling", scale])
+    if enable[2] < method_prob[2]:
+        pts[:, 0] = -pts[:, 0]
+        boxes[:, 0] = -boxes[:, 0]
+        applied.append("flip")
+    return pts, boxes, applied
+
+
 def _sigmoid_cross_entropy_with_logits(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     loss = torch.clamp(logits, min=0) - logits * labels.type_as(logits)
     return loss + torch.log1p(torch.exp(-torch.abs(logits)))

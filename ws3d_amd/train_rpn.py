@@ -15,8 +15,10 @@ accepted for command-line compatibility: the weaklyRPN.yaml values live in ``sta
   * the loss (``ws3d_amd.losses.rpn_loss``) on Gaussian centre labels;
   * checkpoints ``ckpt/checkpoint_iter_%05d.pth`` = {'it', 'model_state', 'optimizer_state'}
     (train_utils.py:67-99) -- ``model_state`` interchanges with the reference (identical keys).
-Not reproduced: the reference's data augmentation and GT-sampling database (its data loader),
-tensorboard, the periodic evaluation pass.  ``--mgpus`` maps to one process per GPU
+  * scene augmentation (rotation / scaling / flip, ``losses.scene_augmentation``) and the evaluation
+    pass of ``Trainer.eval_epoch_rpn`` (``evaluate``: loss, point precision, centre recall).
+Not reproduced: the reference's GT-sampling database (it needs the KITTI object crops) and
+tensorboard.  ``--mgpus`` maps to one process per GPU
 (``torchrun``, DistributedDataParallel over RCCL) instead of ``nn.DataParallel``.
 """
 from __future__ import annotations
@@ -149,9 +151,10 @@ class SyntheticCenters:
     """`count` seeded KITTI-shaped scenes with car-centre annotations (the weak labels of WS3D are
     BEV centre clicks): {'pts_input' (N,4), 'gt_centers' (K,3), 'rpn_cls_label', 'rpn_reg_label'}"""
 
-    def __init__(self, count: int, npoints: int = 16384, config_id: int = 8):
+    def __init__(self, count: int, npoints: int = 16384, config_id: int = 8, augment: bool = False, rng=np.random):
         from . import synth
         self.synth, self.count, self.npoints, self.config_id = synth, count, npoints, config_id
+        self.augment, self.rng = augment, rng
 
     def __len__(self):
         return self.count
@@ -160,6 +163,10 @@ class SyntheticCenters:
         seed = 1000 * self.config_id + i
         pc = self.synth.lidar_cloud(self.npoints, seed)
         centres = self.synth.random_boxes3d(15, seed * 7919 + 13)[:, :3].astype(np.float32)
+        if self.augment:   # AUG_DATA (rotation / scaling / flip), like the reference's TRAIN loader
+            xyz, centres, _ = losses.scene_augmentation(pc[:, :3], centres, self.rng)
+            pc = np.concatenate((xyz.astype(np.float32), pc[:, 3:]), axis=1)
+            centres = centres.astype(np.float32)
         cls, reg = losses.gaussian_center_labels(pc[:, :3], centres)
         return {"sample_id": i, "pts_input": pc, "gt_centers": centres, "rpn_cls_label": cls.astype(np.float32),
                 "rpn_reg_label": reg}
@@ -171,7 +178,8 @@ class KittiCenters:
     first ``weakly_num`` scenes that contain a Car/Van"""
 
     def __init__(self, root: str, split: str = "train", npoints: int = 16384, noise_kind: Optional[str] = None,
-                 weakly_num: int = 500, rng=np.random):
+                 weakly_num: int = 500, rng=np.random, augment: bool = False):
+        self.augment = augment
         self.scenes = kitti_io.KittiScenes(root, split, npoints=npoints, rng=rng)
         self.label_sub = noise_kind or "label_2"
         keep = []
@@ -194,6 +202,10 @@ class KittiCenters:
         pts = kitti_io.rpn_input_from_scan(self.scenes.get_lidar(sid), self.scenes.get_calib(sid),
                                            self.scenes.get_image_shape(sid), self.scenes.npoints, True, self.scenes.rng)
         centres = np.array([o.pos for o in self._objects(sid) if o.cls_type in ("Car", "Van")], dtype=np.float32).reshape(-1, 3)
+        if self.augment:
+            xyz, centres, _ = losses.scene_augmentation(pts[:, :3], centres, self.scenes.rng)
+            pts = np.concatenate((xyz, pts[:, 3:]), axis=1)
+            centres = centres.astype(np.float32)
         cls, reg = losses.gaussian_center_labels(pts[:, :3], centres)
         return {"sample_id": sid, "pts_input": pts.astype(np.float32), "gt_centers": centres,
                 "rpn_cls_label": cls.astype(np.float32), "rpn_reg_label": reg}
@@ -234,6 +246,43 @@ def train_step(model: nn.Module, optimizer: AdamOneCycle, batch: dict, it: int, 
     optimizer.step()
     tb["lr"], tb["loss"] = optimizer.lr, float(loss.item())
     return tb
+
+
+@torch.no_grad()
+def evaluate(model: nn.Module, dataset, net_cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, device="cuda:0",
+             max_scenes: Optional[int] = None) -> dict:
+    """Trainer.eval_epoch_rpn (train_utils.py:149-249), batch size 1 like the reference: mean loss,
+    point precision = P(label > 0.3 | sigmoid(cls) > 0.3), centre recall = annotated centres with a
+    decoded foreground centre within 1.4 m (BEV), and the mean BEV offset of matched predictions."""
+    dev = torch.device(device)
+    was_training = model.training
+    model.eval()
+    tot_loss, n, pt_hit, pt_fg, gt_hit, gt_cnt, offs = 0.0, 0, 0.0, 0.0, 0, 0, []
+    for i in range(len(dataset) if max_scenes is None else min(max_scenes, len(dataset))):
+        s = dataset[i]
+        pts = torch.from_numpy(s["pts_input"][None].astype(np.float32)).to(dev)
+        out = model({"pts_input": pts})
+        label = torch.from_numpy(s["rpn_cls_label"][None]).to(dev).float()
+        loss, _ = losses.rpn_loss(out["rpn_cls"], out["rpn_reg"], label, torch.from_numpy(s["rpn_reg_label"][None]).to(dev).float(),
+                                  net_cfg.loc_scope, net_cfg.loc_bin_size)
+        tot_loss += float(loss.item()); n += 1
+        score = torch.sigmoid(out["rpn_cls"]).view(-1)
+        fg = score > 0.3
+        pt_hit += float((fg & (label.view(-1) > 0.3)).sum()); pt_fg += float(fg.sum())
+        gt = torch.from_numpy(np.asarray(s["gt_centers"], dtype=np.float32).reshape(-1, 3)).to(dev)
+        if int(fg.sum()) and gt.shape[0]:
+            xyz = pts[0, :, :3][fg]
+            pred = stage1.decode_center_target(torch.zeros_like(xyz), out["rpn_reg"][0][fg], net_cfg.loc_scope,
+                                               net_cfg.loc_bin_size) + xyz
+            d = torch.cdist(pred[:, [0, 2]], gt[:, [0, 2]])                  # (P, K)
+            dmin, arg = d.min(dim=1)
+            gt_hit += len(set(arg[dmin < 1.4].tolist())); gt_cnt += gt.shape[0]
+            if bool((dmin < 2.0).any()):
+                offs.append(dmin[dmin < 2.0])
+    if was_training:
+        model.train()
+    return {"val_loss": tot_loss / max(n, 1), "point_precision": pt_hit / max(pt_fg, 1.0),
+            "gt_recall": gt_hit / max(gt_cnt, 1), "mean_offset": float(torch.cat(offs).mean()) if offs else float("nan")}
 
 
 def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] = None, ckpt: Optional[str] = None,
