@@ -233,6 +233,12 @@ WS3D_API int ws3d_radius_nms_batched(int batch, int n, const float *centers, flo
                                      void *workspace, size_t workspace_bytes, int64_t *keep,
                                      int32_t *num_keep, ws3d_stream_t stream);
 
+/* Sorted top-k per scene (ws3d extension): scores (b, n), n <= 16384 -> the k largest in
+ * descending order, out_scores (b, k) and out_idx (b, k) int64; equal scores in ascending index
+ * order, NaN first (torch.topk's convention).                                                       */
+WS3D_API int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx,
+                              ws3d_stream_t stream);
+
 /* Proposal decode (ws3d extension): xyz (b,n,3), rpn_reg (b,n,4*bins) -> boxes (b,n,7)
  * = [x + dx, y + h/2, z + dz, h, w, l, ry] with (dx, dz) = decode_center_target
  * (lib/utils/bbox_transform.py:24-61) and ry the per-index synthetic heading of

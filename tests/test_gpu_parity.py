@@ -964,3 +964,16 @@ def test_nonfinite_coordinates_follow_the_reference_semantics(ops, oracle):
         keep, num = ops.c.nms_device(dev(bev), 0.3, normal)
         assert int(num.item()) == len(ref_keep)
         np.testing.assert_array_equal(host(keep)[:len(ref_keep)], ref_keep)
+
+
+@pytest.mark.parametrize("B,n,k", [(3, 16384, 9000), (2, 5000, 5000), (1, 1, 1), (4, 700, 10), (2, 4096, 0)])
+def test_topk_sorted_kernel(ops, B, n, k):
+    g = torch.Generator().manual_seed(n)
+    s = torch.randn((B, n), generator=g).cuda()
+    if n > 300:
+        s[0, 100:200] = s[0, 7]                      # ties: ascending index order
+        s[-1, 5] = float("inf"); s[-1, 9] = float("-inf"); s[0, 3] = -0.0; s[0, 4] = 0.0
+    vals, idx = ops.c.topk_sorted(s, k)
+    ref_v, ref_i = torch.sort(s, dim=1, descending=True, stable=True)
+    assert torch.equal(idx, ref_i[:, :k])
+    assert torch.equal(vals, ref_v[:, :k])

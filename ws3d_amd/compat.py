@@ -290,6 +290,19 @@ def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_t
     return 1
 
 
+def topk_sorted(scores, k):
+    """scores (B,N) float32, N <= 16384 -> (values (B,k) descending, indices (B,k) int64); ties in
+    ascending index order (ws3d extension)"""
+    dev = _dev(scores)
+    _f32(scores, "scores")
+    B, N = scores.shape
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, k), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_topk_sorted(B, N, k, _p(scores), _p(vals), _p(idx), _stream()), "topk_sorted")
+    return vals, idx
+
+
 def decode_center_boxes(xyz, rpn_reg, loc_scope, loc_bin_size, mean_size):
     """xyz (B,N,3), rpn_reg (B,N,4*bins) -> proposal rows (B,N,7) (ws3d extension, see ws3d_ops.h)"""
     dev = _dev(xyz, rpn_reg)

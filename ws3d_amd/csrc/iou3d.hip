@@ -549,6 +549,49 @@ __global__ __launch_bounds__(256) void decode_center_boxes_kernel(long total, in
     o[6] = ry;
 }
 
+
+// Per-scene top-k of the proposal scores, sorted (replaces torch.topk(sorted=True):
+// select + gather + merge-sort launches, 0.2 ms per 8 scenes).  One workgroup per scene: the n <=
+// 16384 scores become 64-bit keys (order-preserving float bits << 32 | ~index) in 128 KB of LDS and
+// are bitonic-sorted descending -- equal scores keep ascending index order, NaN sorts first like
+// torch.topk -- then the first k are written out.
+__global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow2, const float *__restrict__ scores,
+                                                           float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+    uint64_t *key = reinterpret_cast<uint64_t *>(smem_tk);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float *sc = scores + (size_t)b * n;
+    for (int i = tid; i < pow2; i += 1024) {
+        uint64_t v = 0;                                    // padding: below every real key
+        if (i < n) {
+            const float f = sc[i];
+            uint32_t u = f == 0.0f ? 0u : __float_as_uint(f);   // -0.0 ties with +0.0 (torch's comparison)
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending unsigned order == ascending float order
+            v = ((uint64_t)u << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+        }
+        key[i] = v;
+    }
+    __syncthreads();
+    for (int len = 2; len <= pow2; len <<= 1) {
+        for (int j = len >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (pow2 >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // insert a 0 bit at position log2(j)
+                const int hi = lo | j;
+                const bool desc = (lo & len) == 0;                        // descending blocks first => final order descending
+                const uint64_t a = key[lo], c = key[hi];
+                if ((a < c) == desc) { key[lo] = c; key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 1024) {
+        const uint64_t v = key[i];
+        const uint32_t id = 0xffffffffu - (uint32_t)(v & 0xffffffffu);
+        out_idx[(size_t)b * k + i] = (int64_t)id;
+        out_scores[(size_t)b * k + i] = sc[id];
+    }
+}
+
 template <int MODE>
 static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
                        hipStream_t st, const char *what) {
@@ -663,6 +706,27 @@ extern "C" int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope,
     hipLaunchKernelGGL(decode_center_boxes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        total, n, bins, loc_scope, loc_bin_size, h, w, l, xyz, rpn_reg, boxes);
     return check_launch("ws3d_decode_center_boxes");
+}
+
+extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx,
+                                ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || k < 0 || k > n || !scores || (k > 0 && (!out_scores || !out_idx))) {
+        set_error("ws3d_topk_sorted: invalid argument (b=%d n=%d k=%d)", b, n, k);
+        return WS3D_E_INVALID;
+    }
+    if (n > 16384 || b > 65535) { set_error("ws3d_topk_sorted: n > 16384 (LDS-resident sort)"); return WS3D_E_UNSUPPORTED; }
+    if (b == 0 || k == 0) return WS3D_OK;
+    int pow2 = 2;
+    while (pow2 < n) pow2 <<= 1;
+    const size_t smem = (size_t)pow2 * sizeof(uint64_t);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)topk_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(topk_sorted_kernel, dim3(b), dim3(1024), smem, as_stream(stream), n, k, pow2, scores, out_scores, out_idx);
+    return check_launch("ws3d_topk_sorted");
 }
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,

@@ -212,7 +212,10 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
         box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h),
                            torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
     top = min(cfg.rpn_pre_nms_top_n, N)
-    sc, order = torch.topk(score, top, dim=1, sorted=True)                                # (B,top)
+    if xyz.is_cuda and N <= 16384:     # one LDS-resident sort per scene instead of topk's select + gather + merge sort
+        sc, order = _C.topk_sorted(score.contiguous(), top)
+    else:
+        sc, order = torch.topk(score, top, dim=1, sorted=True)                            # (B,top)
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
     bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
     keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K, scores_sorted=True)   # (B,K), (B,)
