@@ -71,7 +71,7 @@ class C3:
         from ws3d_amd import compat
         fam = {"furthest_point_sampling_gather": "fps", "query_and_group": "ball_query+group",
                "query_and_group_nlc": "ball_query+group", "three_interpolate_nlc": "three_interpolate",
-               "three_nn_wrapper": "three_nn", "three_interpolate_wrapper": "three_interpolate",
+               "three_nn_wrapper": "three_nn", "three_nn_with_weights": "three_nn", "three_interpolate_wrapper": "three_interpolate",
                "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
         for fn_name, key in fam.items():
             orig = getattr(compat, fn_name)

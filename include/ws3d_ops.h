@@ -123,6 +123,10 @@ WS3D_API int ws3d_query_and_group(int b, int n, int m, int c, float radius, int 
 WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                   int32_t *idx, const void *sorted_known, ws3d_stream_t stream);
 
+/* dist2 (rows,3) SQUARED distances from ws3d_three_nn -> weight (rows,3): the FP module's normalised
+ * inverse-distance weights (pointnet2_modules.py:139-142) in one launch.  ws3d extension.            */
+WS3D_API int ws3d_three_nn_weights(long rows, const float *dist2, float *weight, ws3d_stream_t stream);
+
 /* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   interpolate.cpp:26-39 ->
  * interpolate_gpu.cu:77-117.  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n).    */
 WS3D_API int ws3d_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,

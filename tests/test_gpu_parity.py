@@ -977,3 +977,16 @@ def test_topk_sorted_kernel(ops, B, n, k):
     ref_v, ref_i = torch.sort(s, dim=1, descending=True, stable=True)
     assert torch.equal(idx, ref_i[:, :k])
     assert torch.equal(vals, ref_v[:, :k])
+
+
+def test_three_nn_weights_kernel_equals_torch_composition(ops):
+    pc = synth.make_batch("lidar", 2, 3000, 12)[:, :, :3].copy()
+    kn = pc[:, :700].copy()
+    kn[0, 5] = pc[0, 1000]                                  # a zero distance: weight ~ 1e8 / norm
+    idx, w = ops.c.three_nn_with_weights(dev(pc), dev(kn))
+    dist, ref_idx = ops.pn.three_nn(dev(pc), dev(kn))
+    r = 1.0 / (dist + 1e-8)
+    ref_w = r / torch.sum(r, dim=2, keepdim=True)
+    assert torch.equal(idx, ref_idx)
+    np.testing.assert_allclose(host(w), host(ref_w), rtol=3e-7, atol=0)
+    np.testing.assert_allclose(host(w.sum(dim=2)), 1.0, rtol=1e-6)

@@ -181,6 +181,23 @@ def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=Tru
     return out
 
 
+def three_nn_with_weights(unknown, known, sorted_known=None):
+    """unknown (B,N,3), known (B,M,3) -> (idx (B,N,3) int32, weight (B,N,3)): three_nn + the FP module's
+    normalised inverse-distance weights, two launches (ws3d extension)"""
+    dev = _dev(unknown, known)
+    _f32(unknown, "unknown"); _f32(known, "known")
+    B, N, M = unknown.size(0), unknown.size(1), known.size(1)
+    d2 = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, N, 3), dtype=torch.int32, device=dev)
+    w = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        check(lib.ws3d_three_nn(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx),
+                                _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn")
+        check(lib.ws3d_three_nn_weights(B * N, _p(d2), _p(w), _stream()), "three_nn_weights")
+    return idx, w
+
+
 def three_interpolate_nlc(feats_nlc, idx, weight, out=None):
     """feats_nlc (B,M,C), idx/weight (B,N,3) -> (B,N,C); `out` may be a (B,N,>=C) buffer whose first
     C columns are written (row stride = out.size(2)).  ws3d extension."""

@@ -422,6 +422,19 @@ __global__ __launch_bounds__(256) void rowmax_rows_kernel(long total4, int o_ch,
     *reinterpret_cast<float4 *>(out + (size_t)r * out_stride + 4 * o4) = v;
 }
 
+// inverse-distance weights of the FP module (pointnet2_modules.py:139-142) from three_nn's SQUARED
+// distances: w_k = (1 / (sqrt(d2_k) + 1e-8)) / sum_j (1 / (sqrt(d2_j) + 1e-8)), every operation a
+// separate correctly rounded fp32 op like the torch composition sqrt / add / reciprocal / sum / div.
+__global__ __launch_bounds__(256) void nn_weights_kernel(long rows, const float *__restrict__ dist2, float *__restrict__ weight) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float *d = dist2 + r * 3;
+    const float r0 = 1.0f / (sqrtf(d[0]) + 1e-8f), r1 = 1.0f / (sqrtf(d[1]) + 1e-8f), r2 = 1.0f / (sqrtf(d[2]) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    float *w = weight + r * 3;
+    w[0] = r0 / norm; w[1] = r1 / norm; w[2] = r2 / norm;
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_bias_act_inplace(int b, int o_ch, long l, int relu, float *y, const float *bias,
@@ -503,6 +516,15 @@ extern "C" int ws3d_rowmax_rows(long rows_out, int ns, int o_ch, const float *y,
     hipLaunchKernelGGL(rowmax_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), total4,
                        o_ch, ns, y, out, out_stride);
     return check_launch("ws3d_rowmax_rows");
+}
+
+extern "C" int ws3d_three_nn_weights(long rows, const float *dist2, float *weight, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (rows < 0 || !dist2 || !weight) { set_error("ws3d_three_nn_weights: invalid argument"); return WS3D_E_INVALID; }
+    if (rows == 0) return WS3D_OK;
+    if ((rows + 255) / 256 > 0x7fffffffL) { set_error("ws3d_three_nn_weights: too large"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(nn_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, as_stream(stream), rows, dist2, weight);
+    return check_launch("ws3d_three_nn_weights");
 }
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,

@@ -105,18 +105,16 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
 def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
     B, n = unknown.size(0), unknown.size(1)
-    dist, idx = pn2_ops.three_nn(unknown, known, pn2_ops.sort_points_x(known, min_n=256))
-    dist_recip = 1.0 / (dist + 1e-8)
-    weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
+    idx, weight = _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_x(known, min_n=256))
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
     if c1 % 4 == 0:
         cat = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=unknown.device)
-        _C.three_interpolate_nlc(known_feats, idx, weight.contiguous(), cat)     # left columns
+        _C.three_interpolate_nlc(known_feats, idx, weight, cat)     # left columns
         if c1:
             cat[:, :, c2:] = unknown_feats
     else:   # row stride must stay a multiple of 4 floats for the 16-byte stores
-        interp = _C.three_interpolate_nlc(known_feats, idx, weight.contiguous())
+        interp = _C.three_interpolate_nlc(known_feats, idx, weight)
         cat = torch.cat([interp, unknown_feats], dim=2)
     return mlp_rows(cat.view(B * n, c2 + c1), fp.mlp).view(B, n, -1)
 
