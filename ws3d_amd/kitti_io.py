@@ -21,7 +21,7 @@ from __future__ import annotations
 import os
 import struct
 from dataclasses import dataclass
-from typing import Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 

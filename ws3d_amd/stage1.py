@@ -15,8 +15,7 @@ proposal stage used by the data-parallel driver (score -> boxes -> rotated NMS -
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import List
+from dataclasses import dataclass
 
 import numpy as np
 import torch
