@@ -94,6 +94,26 @@ def one_round(rng):
     ov = torch.zeros((na, n), device="cuda")
     c.boxes_overlap_bev_gpu(dev(bev[:na]), dev(bev), ov)
     assert np.array_equal(host(ov), oracle.boxes_overlap_bev(bev[:na], bev)), ("overlap", n)
+    # proposal-stage kernels against their torch compositions
+    from ws3d_amd import stage1
+    Bp, Np = int(rng.integers(1, 4)), int(rng.choice([1, 64, 1000, 4096, 16384]))
+    sc = torch.from_numpy(rng.standard_normal((Bp, Np)).astype(np.float32)).cuda()
+    if Np > 10:
+        sc[0, 3:8] = sc[0, 1]
+    kk = int(rng.integers(0, Np + 1))
+    v, i = c.topk_sorted(sc, kk)
+    rv, ri = torch.sort(sc, dim=1, descending=True, stable=True)
+    assert torch.equal(v, rv[:, :kk]) and torch.equal(i, ri[:, :kk]), ("topk", Bp, Np, kk)
+    xyz_t = torch.from_numpy(rng.uniform(-40, 40, (Bp, Np, 3)).astype(np.float32)).cuda()
+    reg_t = torch.from_numpy(rng.standard_normal((Bp, Np, 40)).astype(np.float32)).cuda()
+    if rng.random() < 0.3:
+        reg_t[:, :, :20] = torch.round(reg_t[:, :, :20])           # ties in the bin argmax
+    h, w, l = stage1.DEFAULT_CFG.cls_mean_size
+    box = c.decode_center_boxes(xyz_t, reg_t, 4.0, 0.8, (h, w, l))
+    ctr = stage1.decode_center_target(xyz_t.view(-1, 3), reg_t.view(-1, 40), 4.0, 0.8).view(Bp, Np, 3)
+    ref_box = torch.stack((ctr[..., 0], xyz_t[..., 1] + h / 2, ctr[..., 2], torch.full_like(ctr[..., 0], h), torch.full_like(ctr[..., 0], w),
+                           torch.full_like(ctr[..., 0], l), stage1.synthetic_orientation(Np, xyz_t.device).unsqueeze(0).expand(Bp, Np)), dim=2)
+    assert torch.equal(box, ref_box), ("decode", Bp, Np)
     cxz = np.ascontiguousarray(b3[None, :, [0, 2]])
     rr = float(rng.choice([0.05, 0.3, 1.0]))
     kr, nr = c.radius_nms_device_batched(dev(cxz), rr)
