@@ -387,6 +387,17 @@ class S2:
                           f"oracle/ws3d_oracle.c with OpenMP, wall {dt:.2f} s", "gpu_matches_oracle_on_sample": ok}
 
 
+def step_percentiles(wl):
+    """p10 / p50 / p90 of the per-step device time (first to last HIP event of a step) of the timed
+    steps, when the workload records per-step events (SURVEY 8d timing method)"""
+    ev = getattr(wl, "ev", None)
+    if not ev:
+        return None
+    t = np.array([e[0].elapsed_time(e[-1]) for e in ev])
+    return {"p10": float(np.percentile(t, 10)), "p50": float(np.percentile(t, 50)), "p90": float(np.percentile(t, 90)),
+            "n": int(t.size)}
+
+
 def traffic_batch():
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -485,6 +496,7 @@ def main():
                                  "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic.json "
                                  "(c2 workload at the batch recorded there) or null"},
             "kernels": kernels,
+            "step_ms_percentiles": step_percentiles(wl),
             "path_gbps_per_gpu": wl.path_gbps(per_gpu),
         }
         if not args.no_cpu_baseline and world == 1:
