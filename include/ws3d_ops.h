@@ -127,6 +127,16 @@ WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const floa
  * inverse-distance weights (pointnet2_modules.py:139-142) in one launch.  ws3d extension.            */
 WS3D_API int ws3d_three_nn_weights(long rows, const float *dist2, float *weight, ws3d_stream_t stream);
 
+/* The SA module's pool over nsample (pointnet2_modules.py:50, F.max_pool2d(kernel_size=[1, nsample]))
+ * with the position of the maximum kept for the backward pass.  x (rows, nsample) -- the contiguous
+ * (B,C,npoint,nsample) activation with rows = B*C*npoint -- -> out (rows), arg (rows) u8.  Window
+ * scan rule `v > best || isnan(v)`: first position of the maximum, NaN propagates.  nsample <= 255.
+ * _grad: grad_x (rows, nsample) = grad_out at arg, 0 elsewhere (every element written).
+ * ws3d extension (replaces the library max-pool kernels in the training step).                  */
+WS3D_API int ws3d_pool_nsample(long rows, int nsample, const float *x, float *out, uint8_t *arg, ws3d_stream_t stream);
+WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_out, const uint8_t *arg, float *grad_x,
+                                    ws3d_stream_t stream);
+
 /* three_interpolate_wrapper(b,c,m,n,points,idx,weight,out)   interpolate.cpp:26-39 ->
  * interpolate_gpu.cu:77-117.  points (b,c,m), idx/weight (b,n,3) -> out (b,c,n).    */
 WS3D_API int ws3d_three_interpolate(int b, int c, int m, int n, const float *points, const int32_t *idx,
@@ -143,10 +153,10 @@ WS3D_API int ws3d_three_interpolate_grad(int b, int c, int n, int m, const float
  * ascending slot order (slot = m*nsample+s, or point*3+k), i.e. bit-identical to the sequential
  * loop `for slot: dst[idx[slot]] += v[slot]` and to itself from run to run (the reference's float
  * atomicAdd scatter is neither).  grad_points is fully written (no pre-zeroing needed).
- * workspace: ws3d_scatter_workspace_bytes(b, n_targets, slots_per_scene) bytes of device memory,
+ * workspace: ws3d_scatter_workspace_bytes(b, c, n_targets, slots_per_scene) bytes of device memory,
  * n_targets = n (group/gather) or m (three_interpolate), slots_per_scene = npoints*nsample or n*3.
  * gather_points_grad == group_points_grad_det with nsample = 1.                                  */
-WS3D_API size_t ws3d_scatter_workspace_bytes(int b, int n_targets, long slots_per_scene);
+WS3D_API size_t ws3d_scatter_workspace_bytes(int b, int c, int n_targets, long slots_per_scene);
 WS3D_API int ws3d_group_points_grad_det(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                                         const int32_t *idx, float *grad_points, void *workspace,
                                         size_t workspace_bytes, ws3d_stream_t stream);

@@ -139,15 +139,48 @@ if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("
         nn_case(B, N, M)
 
 
-def grad_case(B, C, N, M, ns):
-    idx = torch.randint(0, N, (B, M, ns), dtype=torch.int32, device="cuda")
+def grad_case(B, C, N, M, ns, radius=None):
+    """backward of group_points at the training shapes; idx from a real ball query on scan-like
+    scenes when radius is given (padding repeats the first neighbour: very uneven segments)"""
+    if radius is None:
+        idx = torch.randint(0, N, (B, M, ns), dtype=torch.int32, device="cuda")
+    else:
+        from ws3d_amd import synth, pn2_ops
+        pts = torch.from_numpy(np.stack([synth.velodyne_scan(16384, seed=i)[:, :3] for i in range(B)])).cuda()
+        lvl = pts
+        while lvl.size(1) > N:
+            _, lvl = pn2_ops.furthest_point_sample_gather(lvl, lvl.size(1) // 4)
+        _, ctr = pn2_ops.furthest_point_sample_gather(lvl, M)
+        idx = pn2_ops.ball_query(radius, ns, lvl, ctr)
     g = torch.randn((B, C, M, ns), device="cuda")
     out = torch.zeros((B, C, N), device="cuda")
     ta = timeit(lambda: (out.zero_(), c.group_points_grad_wrapper(B, C, N, M, ns, g, idx, out)))[0]
+    ref = out.clone()
     td = timeit(lambda: c.group_points_grad_det(B, C, N, M, ns, g, idx, out))[0]
-    print(f"group_points_grad B={B} C={C} N={N} M={M} ns={ns}: atomic {ta:.3f} ms, deterministic {td:.3f} ms")
+    print(f"group_points_grad B={B} C={C} N={N} M={M} ns={ns} r={radius}: atomic {ta:.3f} ms, deterministic {td:.3f} ms"
+          f"  (max |diff| {float((ref - out).abs().max()):.2e})")
+
+
+def interp_grad_case(B, C, n, m):
+    from ws3d_amd import pn2_ops
+    pts = torch.from_numpy(np.stack([synth.velodyne_scan(16384, seed=i)[:, :3] for i in range(B)])).cuda()
+    unk = pts
+    while unk.size(1) > n:
+        _, unk = pn2_ops.furthest_point_sample_gather(unk, unk.size(1) // 4)
+    _, kn = pn2_ops.furthest_point_sample_gather(unk, m)
+    dist, idx = pn2_ops.three_nn(unk, kn)
+    w = 1.0 / (dist + 1e-8); w = (w / w.sum(2, keepdim=True)).contiguous()
+    g = torch.randn((B, C, n), device="cuda")
+    out = torch.zeros((B, C, m), device="cuda")
+    ta = timeit(lambda: (out.zero_(), c.three_interpolate_grad_wrapper(B, C, n, m, g, idx, w, out)))[0]
+    td = timeit(lambda: c.three_interpolate_grad_det(B, C, n, m, g, idx, w, out))[0]
+    print(f"three_interpolate_grad B={B} C={C} n={n} m={m}: atomic {ta:.3f} ms, deterministic {td:.3f} ms")
 
 
 if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "grad":
-    for shp in [(16, 32, 16384, 4096, 16), (16, 64, 16384, 4096, 32), (16, 128, 4096, 1024, 32), (16, 512, 256, 64, 32)]:
+    for shp in [(8, 256, 16384, 4096), (8, 512, 4096, 1024), (8, 512, 1024, 256), (8, 512, 256, 64)]:
+        interp_grad_case(*shp)
+    for shp in [(8, 96, 4096, 1024, 16, 0.5), (8, 96, 4096, 1024, 32, 1.0), (8, 256, 1024, 256, 16, 1.0),
+                (8, 256, 1024, 256, 32, 2.0), (8, 512, 256, 64, 16, 2.0), (8, 512, 256, 64, 32, 4.0),
+                (16, 64, 16384, 4096, 32, None), (16, 128, 4096, 1024, 32, None)]:
         grad_case(*shp)

@@ -990,3 +990,91 @@ def test_three_nn_weights_kernel_equals_torch_composition(ops):
     assert torch.equal(idx, ref_idx)
     np.testing.assert_allclose(host(w), host(ref_w), rtol=3e-7, atol=0)
     np.testing.assert_allclose(host(w.sum(dim=2)), 1.0, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------- SA pool (training path)
+@pytest.mark.parametrize("ns", [1, 4, 5, 12, 16, 32, 64, 100])
+def test_pool_nsample_equals_max_pool2d_forward_and_backward(ops, ns):
+    """pool_nsample is the SA module's F.max_pool2d(kernel=[1, nsample]) (pointnet2_modules.py:50):
+    values, the argmax the gradient goes to (first maximum; ties, +-inf and NaN rows included) and
+    the gradient itself bit-equal to the library op"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(ns)
+    x = torch.randn((3, 7, 33, ns), generator=g)
+    x = torch.round(x * 2) / 2                     # many exact ties
+    x[0, 0, 0, :] = -float("inf")                  # nothing is ever taken: position 0
+    x[0, 0, 1, :] = 1.25                           # all equal: first position
+    if ns > 2:
+        x[0, 1, 2, ns // 2] = float("nan")         # NaN wins ...
+        x[0, 1, 3, 1] = float("nan"); x[0, 1, 3, ns - 1] = float("nan")   # ... and the last NaN is recorded
+        x[0, 1, 4, ns - 1] = float("inf")
+    xa = x.cuda().requires_grad_(True)
+    xb = x.cuda().requires_grad_(True)
+    ya = ops.pn.pool_nsample(xa)
+    yb = F.max_pool2d(xb, kernel_size=[1, ns]).squeeze(-1)
+    assert ya.shape == yb.shape
+    assert torch.equal(torch.nan_to_num(ya, nan=1e30), torch.nan_to_num(yb, nan=1e30))
+    assert torch.equal(torch.isnan(ya), torch.isnan(yb))
+    go = torch.randn(ya.shape, generator=g).cuda()
+    ya.backward(go)
+    yb.backward(go)
+    assert torch.equal(xa.grad, xb.grad)
+
+
+def test_pool_nsample_rejects_wide_windows_and_cpu_tensors(ops):
+    with pytest.raises(Exception):
+        ops.c.pool_nsample(torch.zeros((4, 300), device="cuda"))
+    with pytest.raises(Exception):
+        ops.c.pool_nsample(torch.zeros((4, 16)))
+
+
+# ------------------------------------------------------------------------------- sampling one step ahead
+def test_sampling_plan_equals_sampling_inside_the_modules(ops):
+    """the FPS chain computed ahead of time (train_rpn.DevicePrefetcher) and handed to the SA
+    modules through new_xyz gives the same network output as sampling inside the modules"""
+    from ws3d_amd import stage1
+    cfg = stage1.RPNConfig(num_points=4096, npoints=(1024, 256, 64, 16))
+    torch.manual_seed(0)
+    net = stage1.Stage1Net(mode="TRAIN", cfg=cfg).cuda().train()
+    pts = torch.from_numpy(np.stack([synth.velodyne_scan(4096, seed=s) for s in (1, 2)])).cuda()
+    plan = ops.pn.sampling_plan(pts[..., 0:3].contiguous(), cfg.npoints)
+    assert [tuple(p.shape) for p in plan] == [(2, m, 3) for m in cfg.npoints]
+    cur = pts[..., 0:3].contiguous()
+    for lvl in plan:
+        _, cur = ops.pn.furthest_point_sample_gather(cur, lvl.size(1))
+        assert torch.equal(cur, lvl)
+    torch.manual_seed(1)                                     # the heads' Dropout draws from the global generator
+    a = net({"pts_input": pts})
+    torch.manual_seed(1)
+    b = net({"pts_input": pts, "sampling_plan": plan})
+    assert torch.equal(a["rpn_cls"], b["rpn_cls"]) and torch.equal(a["rpn_reg"], b["rpn_reg"])
+
+
+def test_prefetching_trainer_matches_the_inline_loop(ops):
+    from ws3d_amd import stage1
+    from ws3d_amd.train_rpn import DevicePrefetcher, SyntheticCenters, batches, train
+    cfg = stage1.RPNConfig(num_points=4096, npoints=(1024, 256, 64, 16))
+    ds = SyntheticCenters(8, npoints=4096)
+    on = train(ds, total_iters=8, batch_size=4, seed=5, net_cfg=cfg, prefetch=True)
+    off = train(ds, total_iters=8, batch_size=4, seed=5, net_cfg=cfg, prefetch=False)
+    np.testing.assert_allclose(on["history"][:4], off["history"][:4], rtol=2e-3)
+    # the prefetcher hands out device tensors in the source's order and surfaces its errors
+    pf = DevicePrefetcher(batches(ds, 4, np.random.RandomState(5)), "cuda:0", cfg.npoints)
+    ref = batches(ds, 4, np.random.RandomState(5))
+    for _ in range(3):
+        got, want = next(pf), next(ref)
+        assert got["sample_id"] == want["sample_id"]
+        assert torch.equal(got["pts_input"].cpu(), torch.from_numpy(want["pts_input"]))
+        assert got["sampling_plan"][0].shape == (4, 1024, 3) and got["rpn_cls_label"].dtype == torch.float32
+    pf.close()
+
+    def broken():
+        yield next(batches(ds, 4, np.random.RandomState(5)))
+        raise RuntimeError("loader failed")
+    pf = DevicePrefetcher(broken(), "cuda:0", cfg.npoints)
+    next(pf)
+    pf.advance()                                   # the failure is held until the batch is asked for
+    with pytest.raises(RuntimeError, match="loader failed"):
+        next(pf)
+    finite = DevicePrefetcher(iter([next(batches(ds, 4, np.random.RandomState(5)))]), "cuda:0", cfg.npoints)
+    assert len(list(finite)) == 1

@@ -34,7 +34,9 @@ SIGNATURES = {
     "ws3d_three_nn": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_interpolate_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "ws3d_scatter_workspace_bytes": (C.c_size_t, [_i, _i, C.c_long]),
+    "ws3d_pool_nsample": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_pool_nsample_grad": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_scatter_workspace_bytes": (C.c_size_t, [_i, _i, _i, C.c_long]),
     "ws3d_group_points_grad_det": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_three_interpolate_grad_det": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_query_and_group_nlc": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -229,6 +229,32 @@ def rowmax_rows(y, ns, out=None, col0=0):
     return out
 
 
+def pool_nsample(x):
+    """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
+    F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""
+    dev = _dev(x)
+    _f32(x, "x")
+    ns = x.size(-1)
+    out = torch.empty(x.shape[:-1], dtype=torch.float32, device=dev)
+    arg = torch.empty(x.shape[:-1], dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pool_nsample(out.numel(), ns, _p(x), _p(out), _p(arg), _stream()), "pool_nsample")
+    return out, arg
+
+
+def pool_nsample_grad(grad_out, arg, nsample):
+    """grad_out (...), arg (...) u8 -> grad_x (..., nsample): grad_out at arg, zero elsewhere.  ws3d extension."""
+    dev = _dev(grad_out, arg)
+    _f32(grad_out, "grad_out")
+    if arg.dtype != torch.uint8 or not arg.is_contiguous():
+        raise TypeError("arg must be a contiguous uint8 tensor")
+    grad_x = torch.empty(tuple(grad_out.shape) + (nsample,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pool_nsample_grad(grad_out.numel(), nsample, _p(grad_out), _p(arg), _p(grad_x), _stream()),
+              "pool_nsample_grad")
+    return grad_x
+
+
 SA_MLP3_SHAPES = {(16, 16, 32), (32, 32, 64)}
 
 
@@ -285,7 +311,7 @@ def group_points_grad_det(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor
     dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
     _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(grad_points_tensor, "grad_points")
     lib = _lib.load()
-    nbytes = lib.ws3d_scatter_workspace_bytes(b, n, npoints * nsample)
+    nbytes = lib.ws3d_scatter_workspace_bytes(b, c, n, npoints * nsample)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib.ws3d_group_points_grad_det(b, c, n, npoints, nsample, _p(grad_out_tensor), _p(idx_tensor),
@@ -298,7 +324,7 @@ def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_t
     dev = _dev(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
     _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
     lib = _lib.load()
-    nbytes = lib.ws3d_scatter_workspace_bytes(b, m, n * 3)
+    nbytes = lib.ws3d_scatter_workspace_bytes(b, c, m, n * 3)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         check(lib.ws3d_three_interpolate_grad_det(b, c, n, m, _p(grad_out_tensor), _p(idx_tensor), _p(weight_tensor),

@@ -422,6 +422,75 @@ __global__ __launch_bounds__(256) void rowmax_rows_kernel(long total4, int o_ch,
     *reinterpret_cast<float4 *>(out + (size_t)r * out_stride + 4 * o4) = v;
 }
 
+// ---- pooling over nsample with the position of the maximum (training path of the SA module) ----
+// The scan rule of a max-pool window, `if (v > best || isnan(v)) take v` from best = -inf at position
+// 0 (the reference pools with F.max_pool2d(kernel=[1, nsample]), pointnet2_modules.py:50): first
+// position of the maximum, a NaN wins and the LAST NaN is the recorded position.  Summaries of
+// adjacent blocks combine with the same rule (later block wins iff its value is greater or NaN),
+// so L = nsample/4 lanes scan one float4 each and merge by butterfly -- loads stay fully coalesced.
+struct PoolBest { float v; int i; };
+__device__ __forceinline__ PoolBest pool_take(PoolBest a, float v, int i) {
+    if (v > a.v || v != v) { a.v = v; a.i = i; }
+    return a;
+}
+
+template <int L>
+__global__ __launch_bounds__(256) void pool_nsample_kernel(long rows, const float *__restrict__ x, float *__restrict__ out,
+                                                           uint8_t *__restrict__ arg) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t / L;
+    const int part = (int)(t - row * L);
+    const bool live = row < rows;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) q = reinterpret_cast<const float4 *>(x)[t];
+    PoolBest best{-INFINITY, 4 * part};
+    best = pool_take(best, q.x, 4 * part); best = pool_take(best, q.y, 4 * part + 1);
+    best = pool_take(best, q.z, 4 * part + 2); best = pool_take(best, q.w, 4 * part + 3);
+    // a block that never took anything reports (-inf, its first position); merged with an earlier
+    // block it loses (-inf > x is false), so position 0 survives for an all -inf row like the scan
+#pragma unroll
+    for (int off = 1; off < L; off <<= 1) {
+        PoolBest o;
+        o.v = __shfl_xor(best.v, off);
+        o.i = __shfl_xor(best.i, off);
+        const bool mine_first = (part & off) == 0;
+        const PoolBest first = mine_first ? best : o, second = mine_first ? o : best;
+        best = (second.v > first.v || second.v != second.v) ? second : first;
+    }
+    if (live && part == 0) { out[row] = best.v; arg[row] = (uint8_t)best.i; }
+}
+
+__global__ __launch_bounds__(256) void pool_nsample_any_kernel(long rows, int ns, const float *__restrict__ x,
+                                                               float *__restrict__ out, uint8_t *__restrict__ arg) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    PoolBest best{-INFINITY, 0};
+    for (int i = 0; i < ns; ++i) best = pool_take(best, x[row * ns + i], i);
+    out[row] = best.v; arg[row] = (uint8_t)best.i;
+}
+
+// grad_x[r, s] = (s == arg[r]) ? grad_out[r] : 0, every element written
+template <int L>
+__global__ __launch_bounds__(256) void pool_nsample_grad_kernel(long rows, const float *__restrict__ grad_out,
+                                                                const uint8_t *__restrict__ arg, float *__restrict__ grad_x) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long row = t / L;
+    if (row >= rows) return;
+    const int part = (int)(t - row * L);
+    const int a = (int)arg[row] - 4 * part;
+    const float g = grad_out[row];
+    reinterpret_cast<float4 *>(grad_x)[t] = make_float4(a == 0 ? g : 0.f, a == 1 ? g : 0.f, a == 2 ? g : 0.f, a == 3 ? g : 0.f);
+}
+
+__global__ __launch_bounds__(256) void pool_nsample_grad_any_kernel(long rows, int ns, const float *__restrict__ grad_out,
+                                                                    const uint8_t *__restrict__ arg, float *__restrict__ grad_x) {
+    const long row = (long)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const int a = arg[row];
+    const float g = grad_out[row];
+    for (int i = 0; i < ns; ++i) grad_x[row * ns + i] = i == a ? g : 0.f;
+}
+
 // inverse-distance weights of the FP module (pointnet2_modules.py:139-142) from three_nn's SQUARED
 // distances: w_k = (1 / (sqrt(d2_k) + 1e-8)) / sum_j (1 / (sqrt(d2_j) + 1e-8)), every operation a
 // separate correctly rounded fp32 op like the torch composition sqrt / add / reciprocal / sum / div.
@@ -516,6 +585,59 @@ extern "C" int ws3d_rowmax_rows(long rows_out, int ns, int o_ch, const float *y,
     hipLaunchKernelGGL(rowmax_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, as_stream(stream), total4,
                        o_ch, ns, y, out, out_stride);
     return check_launch("ws3d_rowmax_rows");
+}
+
+static int pool_lanes(int ns, const void *p) {   // lanes per row of the float4 kernels, 0 = generic kernel
+    if ((ns & 3) || (reinterpret_cast<uintptr_t>(p) & 15)) return 0;
+    const int l = ns >> 2;
+    return (l == 1 || l == 2 || l == 4 || l == 8 || l == 16) ? l : 0;
+}
+
+extern "C" int ws3d_pool_nsample(long rows, int nsample, const float *x, float *out, uint8_t *arg, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (rows < 0 || nsample <= 0 || nsample > 255 || !x || !out || !arg) {
+        set_error("ws3d_pool_nsample: invalid argument (rows=%ld nsample=%d)", rows, nsample);
+        return WS3D_E_INVALID;
+    }
+    if (rows == 0) return WS3D_OK;
+    const int l = pool_lanes(nsample, x);
+    const long threads = l ? rows * l : rows;
+    if ((threads + 255) / 256 > 0x7fffffffL) { set_error("ws3d_pool_nsample: too large"); return WS3D_E_UNSUPPORTED; }
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t st = as_stream(stream);
+    switch (l) {
+    case 1: hipLaunchKernelGGL(pool_nsample_kernel<1>, grid, block, 0, st, rows, x, out, arg); break;
+    case 2: hipLaunchKernelGGL(pool_nsample_kernel<2>, grid, block, 0, st, rows, x, out, arg); break;
+    case 4: hipLaunchKernelGGL(pool_nsample_kernel<4>, grid, block, 0, st, rows, x, out, arg); break;
+    case 8: hipLaunchKernelGGL(pool_nsample_kernel<8>, grid, block, 0, st, rows, x, out, arg); break;
+    case 16: hipLaunchKernelGGL(pool_nsample_kernel<16>, grid, block, 0, st, rows, x, out, arg); break;
+    default: hipLaunchKernelGGL(pool_nsample_any_kernel, grid, block, 0, st, rows, nsample, x, out, arg);
+    }
+    return check_launch("ws3d_pool_nsample");
+}
+
+extern "C" int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_out, const uint8_t *arg, float *grad_x,
+                                      ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (rows < 0 || nsample <= 0 || nsample > 255 || !grad_out || !arg || !grad_x) {
+        set_error("ws3d_pool_nsample_grad: invalid argument (rows=%ld nsample=%d)", rows, nsample);
+        return WS3D_E_INVALID;
+    }
+    if (rows == 0) return WS3D_OK;
+    const int l = pool_lanes(nsample, grad_x);
+    const long threads = l ? rows * l : rows;
+    if ((threads + 255) / 256 > 0x7fffffffL) { set_error("ws3d_pool_nsample_grad: too large"); return WS3D_E_UNSUPPORTED; }
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipStream_t st = as_stream(stream);
+    switch (l) {
+    case 1: hipLaunchKernelGGL(pool_nsample_grad_kernel<1>, grid, block, 0, st, rows, grad_out, arg, grad_x); break;
+    case 2: hipLaunchKernelGGL(pool_nsample_grad_kernel<2>, grid, block, 0, st, rows, grad_out, arg, grad_x); break;
+    case 4: hipLaunchKernelGGL(pool_nsample_grad_kernel<4>, grid, block, 0, st, rows, grad_out, arg, grad_x); break;
+    case 8: hipLaunchKernelGGL(pool_nsample_grad_kernel<8>, grid, block, 0, st, rows, grad_out, arg, grad_x); break;
+    case 16: hipLaunchKernelGGL(pool_nsample_grad_kernel<16>, grid, block, 0, st, rows, grad_out, arg, grad_x); break;
+    default: hipLaunchKernelGGL(pool_nsample_grad_any_kernel, grid, block, 0, st, rows, nsample, grad_out, arg, grad_x);
+    }
+    return check_launch("ws3d_pool_nsample_grad");
 }
 
 extern "C" int ws3d_three_nn_weights(long rows, const float *dist2, float *weight, ws3d_stream_t stream) {

@@ -49,6 +49,9 @@ class _PointnetSAModuleBase(nn.Module):
                 continue
             grouped = mlp(grouped)                              # (B, mlp[-1], npoint, nsample)
             if self.pool_method == 'max_pool':
+                if grouped.size(3) <= 255:
+                    pooled.append(pointnet2_utils.pool_nsample(grouped))   # (B, mlp[-1], npoint), fwd + bwd kernels
+                    continue
                 grouped = F.max_pool2d(grouped, kernel_size=[1, grouped.size(3)])
             elif self.pool_method == 'avg_pool':
                 grouped = F.avg_pool2d(grouped, kernel_size=[1, grouped.size(3)])

@@ -67,6 +67,19 @@ def furthest_point_sample_gather(xyz: torch.Tensor, npoint: int) -> Tuple[torch.
     return idx, new_xyz
 
 
+def sampling_plan(xyz: torch.Tensor, npoints) -> list:
+    """The backbone's chain of furthest-point samplings, ``[new_xyz_1 (B,npoints[0],3), new_xyz_2, ...]``
+    with level k sampled from level k-1.  It depends on the coordinates only -- not on any weight --
+    so a trainer can run it for the NEXT batch on a side HIP stream while the current step computes
+    (train_rpn.DevicePrefetcher) and hand it to the SA modules through their ``new_xyz`` argument
+    (pointnet2_modules.py:19-29 accepts it).  Same result as sampling inside the modules."""
+    plan, cur = [], xyz
+    for m in npoints:
+        _, cur = furthest_point_sample_gather(cur, int(m))
+        plan.append(cur)
+    return plan
+
+
 class GatherOperation(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
@@ -234,6 +247,28 @@ class _QueryAndGroupFused(Function):
                 grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
                 _C.group_points_grad_wrapper(B, C, N, M, ns, g, idx, grad_features)
         return None, None, None, None, None, grad_features, None
+
+
+class PoolNsample(Function):
+    """max over the nsample axis of the grouped activation (B,C,npoint,nsample) -> (B,C,npoint):
+    the reference's ``F.max_pool2d(x, kernel_size=[1, nsample]).squeeze(-1)``
+    (pointnet2_modules.py:50-54) as one coalesced pass each way, same values / argmax / NaN rule."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor) -> torch.Tensor:
+        x = x.contiguous()
+        out, arg = _C.pool_nsample(x)
+        ctx.save_for_backward(arg)
+        ctx.nsample = x.size(-1)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        return _C.pool_nsample_grad(grad_out.contiguous(), arg, ctx.nsample)
+
+
+pool_nsample = PoolNsample.apply
 
 
 def sort_points_x(xyz: torch.Tensor, min_n=None):

@@ -88,11 +88,13 @@ class Pointnet2MSG(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud: torch.Tensor):
+    def forward(self, pointcloud: torch.Tensor, sampling_plan=None):
+        """sampling_plan: optional ``pointnet2_utils.sampling_plan(xyz, npoints)`` computed ahead of time
+        (the SA modules then skip their own furthest point sampling)"""
         xyz, features = self._break_up_pc(pointcloud)
         l_xyz, l_features = [xyz], [features]
-        for sa in self.SA_modules:
-            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+        for k, sa in enumerate(self.SA_modules):
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1], sampling_plan[k] if sampling_plan else None)
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
@@ -132,7 +134,7 @@ class RPN(nn.Module):
 
     def forward(self, input_data):
         pts_input = input_data['pts_input']
-        backbone_xyz, backbone_features = self.backbone_net(pts_input)                # (B,N,3), (B,C,N)
+        backbone_xyz, backbone_features = self.backbone_net(pts_input, input_data.get('sampling_plan'))  # (B,N,3), (B,C,N)
         rpn_cls = self.rpn_cls_layer(backbone_features).transpose(1, 2).contiguous()   # (B,N,1)
         rpn_reg = self.rpn_reg_layer(backbone_features).transpose(1, 2).contiguous()   # (B,N,40)
         return {'rpn_cls': rpn_cls, 'rpn_reg': rpn_reg,

@@ -27,6 +27,7 @@ import argparse
 import logging
 import math
 import os
+import time
 from dataclasses import dataclass
 from typing import Iterator, Optional
 
@@ -35,7 +36,7 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import clip_grad_norm_
 
-from . import kitti_io, losses, stage1
+from . import kitti_io, losses, pn2_ops, stage1
 
 
 @dataclass(frozen=True)
@@ -155,21 +156,29 @@ class SyntheticCenters:
         from . import synth
         self.synth, self.count, self.npoints, self.config_id = synth, count, npoints, config_id
         self.augment, self.rng = augment, rng
+        self._scenes, self._items = {}, {}   # generated scans (and, without augmentation, their labels) are kept
 
     def __len__(self):
         return self.count
 
     def __getitem__(self, i: int) -> dict:
-        seed = 1000 * self.config_id + i
-        pc = self.synth.lidar_cloud(self.npoints, seed)
-        centres = self.synth.random_boxes3d(15, seed * 7919 + 13)[:, :3].astype(np.float32)
+        if not self.augment and i in self._items:
+            return self._items[i]
+        if i not in self._scenes:
+            seed = 1000 * self.config_id + i
+            self._scenes[i] = (self.synth.lidar_cloud(self.npoints, seed),
+                               self.synth.random_boxes3d(15, seed * 7919 + 13)[:, :3].astype(np.float32))
+        pc, centres = self._scenes[i]
         if self.augment:   # AUG_DATA (rotation / scaling / flip), like the reference's TRAIN loader
             xyz, centres, _ = losses.scene_augmentation(pc[:, :3], centres, self.rng)
             pc = np.concatenate((xyz.astype(np.float32), pc[:, 3:]), axis=1)
             centres = centres.astype(np.float32)
         cls, reg = losses.gaussian_center_labels(pc[:, :3], centres)
-        return {"sample_id": i, "pts_input": pc, "gt_centers": centres, "rpn_cls_label": cls.astype(np.float32),
+        item = {"sample_id": i, "pts_input": pc, "gt_centers": centres, "rpn_cls_label": cls.astype(np.float32),
                 "rpn_reg_label": reg}
+        if not self.augment:
+            self._items[i] = item
+        return item
 
 
 class KittiCenters:
@@ -228,20 +237,92 @@ def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0,
                    "sample_id": [s["sample_id"] for s in items]}
 
 
+class DevicePrefetcher:
+    """Keeps one mini-batch ahead of the training step, on a side HIP stream.
+
+    ``advance()`` takes the next host batch from `source`, uploads it on the side stream and runs the
+    backbone's furthest-point-sampling chain there (``pointnet2_utils.sampling_plan``).  FPS is the one long serial kernel of the step -- 4095
+    dependent rounds, one workgroup per scene, 5.5 ms at batch 8 with 8 of 256 CUs busy -- and it
+    needs nothing but the input coordinates, so it runs beside the previous step's backward GEMM /
+    BN kernels instead of heading the critical path.  ``train_step`` calls ``advance`` right after
+    it has enqueued the backward pass (the host is otherwise idle until the gradient norm is read
+    back), so building the next batch on the host overlaps device work too.  Everything happens on
+    the calling thread: a worker thread was measured 30 % SLOWER than no prefetching at all (it
+    competes with the kernel-launching thread for the interpreter lock).
+    ``next()`` yields dicts of DEVICE tensors: ``pts_input``, ``rpn_cls_label`` / ``rpn_reg_label``
+    (float32), ``sampling_plan``, plus ``sample_id``; the current stream is made to wait for the
+    upload + sampling first."""
+
+    KEYS = ("pts_input", "rpn_cls_label", "rpn_reg_label")
+
+    def __init__(self, source: Iterator[dict], device, npoints):
+        self.source, self.device, self.npoints = iter(source), torch.device(device), tuple(npoints)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.pending = None                # (batch, ready event) | exception raised by the source
+
+    def advance(self) -> None:
+        """start the next batch (no-op if one is already pending)"""
+        if self.pending is not None:
+            return
+        try:
+            batch = next(self.source)
+        except BaseException as exc:       # StopIteration included: re-raised by __next__
+            self.pending = exc
+            return
+        with torch.no_grad(), torch.cuda.stream(self.side):
+            out = {"sample_id": batch.get("sample_id")}
+            for key in self.KEYS:
+                # plain pageable upload: staging through pinned buffers + non_blocking copies was measured
+                # slower here (36 vs 23 ms per iteration at batch 8)
+                out[key] = torch.from_numpy(np.ascontiguousarray(batch[key], dtype=np.float32)).to(self.device)
+            out["sampling_plan"] = pn2_ops.sampling_plan(out["pts_input"][..., 0:3].contiguous(), self.npoints)
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        self.pending = (out, ready)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> dict:
+        self.advance()
+        pending, self.pending = self.pending, None
+        if isinstance(pending, BaseException):
+            raise pending
+        out, ready = pending
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ready)
+        for v in list(out.values()) + list(out["sampling_plan"]):
+            if torch.is_tensor(v):
+                v.record_stream(cur)          # allocated on the side stream, consumed on this one
+        return out
+
+    def close(self):
+        self.pending = None
+
+
+def _on_device(x, device) -> torch.Tensor:
+    t = x if torch.is_tensor(x) else torch.from_numpy(x)
+    return t.to(device).float()
+
+
 # ----------------------------------------------------------------------------- training
 def train_step(model: nn.Module, optimizer: AdamOneCycle, batch: dict, it: int, net_cfg: stage1.RPNConfig,
-               train_cfg: TrainConfig, device) -> dict:
-    """one iteration of Trainer._train_it (train_utils.py:137-147) with the per-iteration schedules"""
+               train_cfg: TrainConfig, device, overlap=None) -> dict:
+    """one iteration of Trainer._train_it (train_utils.py:137-147) with the per-iteration schedules.
+    overlap: host work to do once the backward pass is enqueued (DevicePrefetcher.advance)"""
     set_bn_momentum(model, bn_momentum_at(it, train_cfg))
     optimizer.schedule(it)
     model.train()
     optimizer.zero_grad()
-    pts = torch.from_numpy(batch["pts_input"]).to(device)
-    out = model({"pts_input": pts})
-    loss, tb = losses.rpn_loss(out["rpn_cls"], out["rpn_reg"], torch.from_numpy(batch["rpn_cls_label"]).to(device).float(),
-                               torch.from_numpy(batch["rpn_reg_label"]).to(device).float(), net_cfg.loc_scope,
-                               net_cfg.loc_bin_size)
+    inputs = {"pts_input": _on_device(batch["pts_input"], device)}
+    if batch.get("sampling_plan") is not None:
+        inputs["sampling_plan"] = batch["sampling_plan"]
+    out = model(inputs)
+    loss, tb = losses.rpn_loss(out["rpn_cls"], out["rpn_reg"], _on_device(batch["rpn_cls_label"], device),
+                               _on_device(batch["rpn_reg_label"], device), net_cfg.loc_scope, net_cfg.loc_bin_size)
     loss.backward()
+    if overlap is not None:
+        overlap()
     tb["grad_norm"] = float(clip_grad_norm_(model.parameters(), train_cfg.grad_norm_clip))
     optimizer.step()
     tb["lr"], tb["loss"] = optimizer.lr, float(loss.item())
@@ -288,8 +369,10 @@ def evaluate(model: nn.Module, dataset, net_cfg: stage1.RPNConfig = stage1.DEFAU
 def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] = None, ckpt: Optional[str] = None,
           pretrain_ckpt: Optional[str] = None, ckpt_save_interval: int = 20, seed: int = 0, device: str = "cuda:0",
           net_cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, train_cfg: TrainConfig = TrainConfig(), logger=None,
-          distributed: bool = False) -> dict:
-    """-> {'model', 'optimizer', 'it', 'history' (loss per iteration), 'checkpoints'}"""
+          distributed: bool = False, prefetch: bool = True) -> dict:
+    """-> {'model', 'optimizer', 'it', 'history' (loss per iteration), 'checkpoints'}
+    prefetch: build / upload the next batch and run its furthest point sampling on a side stream
+    while the current step computes (DevicePrefetcher); same losses either way."""
     log = logger or logging.getLogger("ws3d_amd.train_rpn")
     rank, world = 0, 1
     if distributed:
@@ -314,18 +397,36 @@ def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] 
     n_epochs = max(int(total_iters / per_epoch), 1)
     save_every = max(int(n_epochs / min(n_epochs, ckpt_save_interval)), 1) * per_epoch
     stream = batches(dataset, batch_size, np.random.RandomState(seed), rank, world)
+    if prefetch and dev.type == "cuda":
+        stream = DevicePrefetcher(stream, dev, net_cfg.npoints)
     history, saved = [], []
+    try:
+        return _train_loop(net, model, optimizer, stream, it, total_iters, net_cfg, train_cfg, dev, rank, log, ckpt_dir,
+                           save_every, history, saved)
+    finally:
+        if isinstance(stream, DevicePrefetcher):
+            stream.close()
+
+
+def _train_loop(net, model, optimizer, stream, it, total_iters, net_cfg, train_cfg, dev, rank, log, ckpt_dir, save_every,
+                history, saved) -> dict:
+    t_mark, it_mark, step_ms = time.perf_counter(), it, []
     while it < total_iters:
-        tb = train_step(net, optimizer, next(stream), it, net_cfg, train_cfg, dev)
+        ahead = stream.advance if isinstance(stream, DevicePrefetcher) and it + 1 < total_iters else None
+        tb = train_step(net, optimizer, next(stream), it, net_cfg, train_cfg, dev, overlap=ahead)
         it += 1
         history.append(tb["loss"])
         if rank == 0 and (it % 10 == 0 or it == total_iters):
-            log.info("it %5d  loss %.4f  cls %.4f  reg %.4f  fg %d  lr %.2e", it, tb["loss"], tb["rpn_loss_cls"],
-                     tb["rpn_loss_reg"], tb["rpn_fg_sum"], tb["lr"])
+            now = time.perf_counter()            # train_step ends on loss.item(): the device is idle here
+            step_ms.append((now - t_mark) * 1e3 / max(it - it_mark, 1))
+            t_mark, it_mark = now, it
+            log.info("it %5d  loss %.4f  cls %.4f  reg %.4f  fg %d  lr %.2e  %.1f ms/it", it, tb["loss"], tb["rpn_loss_cls"],
+                     tb["rpn_loss_reg"], tb["rpn_fg_sum"], tb["lr"], step_ms[-1])
         if ckpt_dir and rank == 0 and (it % save_every == 0 or it == total_iters):
             saved.append(save_checkpoint(checkpoint_state(model, optimizer, it),
                                          os.path.join(ckpt_dir, "checkpoint_iter_%05d" % it)))
-    return {"model": model, "optimizer": optimizer, "it": it, "history": history, "checkpoints": saved}
+    return {"model": model, "optimizer": optimizer, "it": it, "history": history, "checkpoints": saved,
+            "step_ms": step_ms}
 
 
 def main():
@@ -342,6 +443,8 @@ def main():
     ap.add_argument("--noise_kind", type=str, default="label_noise")
     ap.add_argument("--weakly_num", type=int, default=500)
     ap.add_argument("--data_root", type=str, default=None, help="KITTI object directory (ImageSets/, training/)")
+    ap.add_argument("--no_prefetch", action="store_true", default=False,
+                    help="build / upload / sample the next batch inside the step instead of one step ahead")
     ap.add_argument("--synthetic", type=int, default=0, help="train on this many seeded synthetic scenes instead")
     a = ap.parse_args()
     logging.basicConfig(level=logging.INFO, format="%(asctime)s  %(levelname)5s  %(message)s")
@@ -359,9 +462,10 @@ def main():
     else:
         ap.error("give --data_root or --synthetic N")
     res = train(ds, a.total_iters, a.batch_size, out_dir, a.ckpt, a.pretrain_ckpt, a.ckpt_save_interval,
-                device=f"cuda:{local}", distributed=distributed)
-    logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s", res["it"],
-                                                 res["checkpoints"][-1] if res["checkpoints"] else None)
+                device=f"cuda:{local}", distributed=distributed, prefetch=not a.no_prefetch)
+    logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s, median %.1f ms/it", res["it"],
+                                                 res["checkpoints"][-1] if res["checkpoints"] else None,
+                                                 float(np.median(res["step_ms"])) if res["step_ms"] else float("nan"))
 
 
 if __name__ == "__main__":
