@@ -1078,3 +1078,71 @@ def test_prefetching_trainer_matches_the_inline_loop(ops):
         next(pf)
     finite = DevicePrefetcher(iter([next(batches(ds, 4, np.random.RandomState(5)))]), "cuda:0", cfg.npoints)
     assert len(list(finite)) == 1
+
+
+# ------------------------------------------------------------------------------- BatchNorm + ReLU (training step)
+@pytest.mark.parametrize("shape,relu", [((2, 16, 64, 16), True), ((3, 5, 1000), True), ((2, 7, 333), True),
+                                         ((2, 3, 5), False), ((4, 32, 4096, 8), True), ((2, 64, 20000), False)])
+def test_bn_relu_train_kernels_match_the_library_pair(ops, shape, relu):
+    """ws3d_bn_relu_train_fwd/bwd against nn.BatchNorm(train) + ReLU (pytorch_utils.py:35-101): outputs,
+    running statistics and all three gradients to fp32 round-off, and bit-identical run to run"""
+    import torch.nn as nn
+    from ws3d_amd import nn_blocks
+    g = torch.Generator().manual_seed(len(shape) * 100 + shape[1])
+    c = shape[1]
+    x = (torch.randn(shape, generator=g) * 2.0 + 0.7).cuda()
+    go = torch.randn(shape, generator=g).cuda()
+    cls = nn.BatchNorm2d if len(shape) == 4 else nn.BatchNorm1d
+    ref, own = cls(c, momentum=0.3).cuda().train(), cls(c, momentum=0.3).cuda().train()
+    with torch.no_grad():
+        for m in (ref, own):
+            m.weight.copy_(torch.linspace(0.5, 1.5, c)); m.bias.copy_(torch.linspace(-0.3, 0.3, c))
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ref(xa)
+    ya = torch.relu(ya) if relu else ya
+    yb = nn_blocks.bn_relu_train(xb, own, relu)
+    scale = float(ya.detach().abs().max()) + 1e-6
+    assert float((ya - yb).detach().abs().max()) <= 2e-6 * scale + 1e-6
+    np.testing.assert_allclose(host(own.running_mean), host(ref.running_mean), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(own.running_var), host(ref.running_var), rtol=1e-5, atol=1e-6)
+    assert int(own.num_batches_tracked) == 1
+    ya.backward(go); yb.backward(go)
+    for a, b in ((xa.grad, xb.grad), (ref.weight.grad, own.weight.grad), (ref.bias.grad, own.bias.grad)):
+        tol = 2e-5 * (float(a.abs().max()) + 1e-6)
+        # an element whose pre-activation rounds to the other side of 0 flips its ReLU mask: allow a handful
+        bad = int(((a - b).abs() > tol).sum())
+        assert bad <= max(2, a.numel() // 100000), (bad, a.numel())
+    own2 = cls(c, momentum=0.3).cuda().train()
+    own2.load_state_dict(ref.state_dict() | {"running_mean": torch.zeros(c), "running_var": torch.ones(c),
+                                              "num_batches_tracked": torch.tensor(0)})
+    own2.weight.data.copy_(own.weight.data); own2.bias.data.copy_(own.bias.data)
+    xc = x.clone().requires_grad_(True)
+    yc = nn_blocks.bn_relu_train(xc, own2, relu)
+    yc.backward(go)
+    assert torch.equal(yc, yb) and torch.equal(xc.grad, xb.grad) and torch.equal(own2.weight.grad, own.weight.grad)
+
+
+def test_conv_block_training_path_uses_the_fused_norm(ops):
+    import torch.nn as nn
+    from ws3d_amd import nn_blocks
+    torch.manual_seed(4)
+    blk = nn_blocks.Conv2d(12, 24, bn=True).cuda().train()
+    x = torch.randn(2, 12, 50, 16, device="cuda")
+    outs = []
+    for fused in (True, False):
+        nn_blocks.FUSED_BN_TRAIN = fused
+        try:
+            blk.zero_grad()
+            blk.bn[0].running_mean.zero_(); blk.bn[0].running_var.fill_(1.0)
+            xi = x.clone().requires_grad_(True)
+            y = blk(xi)
+            y.square().sum().backward()
+            outs.append((y.detach(), xi.grad, blk.conv.weight.grad.clone(), blk.bn[0].weight.grad.clone(),
+                         blk.bn[0].running_var.clone()))
+        finally:
+            nn_blocks.FUSED_BN_TRAIN = True
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(host(a), host(b), rtol=2e-4, atol=2e-5 * float(b.abs().max()))
+    with pytest.raises(Exception):
+        ops.c.bn_relu_train_fwd(torch.zeros((1, 4, 1), device="cuda"), torch.ones(4, device="cuda"), torch.zeros(4, device="cuda"),
+                                None, None, 0.1, 1e-5)

@@ -229,6 +229,45 @@ def rowmax_rows(y, ns, out=None, col0=0):
     return out
 
 
+def bn_relu_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu=True):
+    """x (B,C,...) contiguous fp32 -> (y, save_mean (C), save_invstd (C)): training-mode BatchNorm
+    (+ReLU), running stats (or None) updated in place.  ws3d extension."""
+    dev = _dev(x, gamma, beta, running_mean, running_var)
+    _f32(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
+    b, c = x.size(0), x.size(1)
+    l = x.numel() // max(b * c, 1)
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=dev)
+    invstd = torch.empty((c,), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.ws3d_bn_workspace_bytes(b, c, l)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_bn_relu_train_fwd(b, c, l, _p(x), _p(gamma), _p(beta), float(eps), float(momentum), int(bool(relu)),
+                                         _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws), nbytes,
+                                         _stream()), "bn_relu_train_fwd")
+    return y, mean, invstd
+
+
+def bn_relu_train_bwd(x, dy, gamma, beta, save_mean, save_invstd, relu=True):
+    """-> (dx like x, dgamma (C), dbeta (C)).  ws3d extension."""
+    dev = _dev(x, dy, gamma, beta, save_mean, save_invstd)
+    _f32(x, "x"); _f32(dy, "dy")
+    b, c = x.size(0), x.size(1)
+    l = x.numel() // max(b * c, 1)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    nbytes = lib.ws3d_bn_workspace_bytes(b, c, l)
+    ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_bn_relu_train_bwd(b, c, l, _p(x), _p(dy), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+                                         int(bool(relu)), _p(dx), _p(dgamma), _p(dbeta), _p(ws), nbytes, _stream()),
+              "bn_relu_train_bwd")
+    return dx, dgamma, dbeta
+
+
 def pool_nsample(x):
     """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
     F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""

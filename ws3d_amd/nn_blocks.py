@@ -9,6 +9,41 @@ from typing import List, Tuple
 
 import torch
 import torch.nn as nn
+from torch.autograd import Function
+
+FUSED_BN_TRAIN = True   # training step: BatchNorm + ReLU through ws3d_bn_relu_train_* (clear to use the library pair)
+
+
+class _BnReluTrain(Function):
+    """training-mode BatchNorm (+ReLU) of a channels-first tensor in 3 + 5 HBM passes (bn_relu.hip)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+        from . import compat as _C
+        x = x.contiguous()
+        y, mean, invstd = _C.bn_relu_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, relu)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import compat as _C
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = _C.bn_relu_train_bwd(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_train(x: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm, relu: bool) -> torch.Tensor:
+    """``relu(bn(x))`` for a BatchNorm module in train() mode, with the module's bookkeeping
+    (running statistics, num_batches_tracked, momentum=None -> cumulative average)"""
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    stats = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return _BnReluTrain.apply(x, bn.weight, bn.bias, stats[0], stats[1], momentum, bn.eps, relu)
 
 
 class _BN(nn.Sequential):
@@ -123,6 +158,12 @@ class _ConvBlock(nn.Sequential):
         NCHW fp32 shapes to its naive direct-convolution kernel on gfx950 (56 % of a Stage-1
         forward in the round-1 profile); training keeps the stock module path."""
         if not self.fast_path_ok(x):
+            bn = getattr(self, "bn", None)
+            act = getattr(self, "activation", None)
+            if (FUSED_BN_TRAIN and self.training and self._pointwise and bn is not None and x.is_cuda
+                    and x.dtype == torch.float32 and bn[0].affine and isinstance(act, (nn.ReLU, type(None)))):
+                # training: conv on the library GEMMs, BatchNorm + ReLU in one forward and one backward op
+                return bn_relu_train(self.conv(x), bn[0], act is not None)
             return super().forward(x)
         w, shift, act = self._folded()
         y = torch.matmul(w, x.reshape(x.shape[0], x.shape[1], -1))
