@@ -107,9 +107,8 @@ class AdamOneCycle:
 
     @torch.no_grad()
     def step(self) -> None:
-        for g in self.opt.param_groups:
-            for p in g["params"]:
-                p.mul_(1 - self.cfg.weight_decay * g["lr"])
+        for g in self.opt.param_groups:     # decoupled weight decay, one multi-tensor launch per group
+            torch._foreach_mul_([p for p in g["params"]], 1 - self.cfg.weight_decay * g["lr"])
         self.opt.step()
 
     def state_dict(self):
