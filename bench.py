@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- WS3D hot-path benchmark on MI355X (driver contract: one JSON line on rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|s2|t1] [--batch B]
 
 N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...``
 (one rank per GPU, RCCL).  Scenes are independent, so the path shards with NO data-path
@@ -17,6 +17,7 @@ already resident in HBM:
   c5 : N=65536, 512 proposals: roipool3d + rotated NMS, batch 8    [BASELINE.json configs[4]]
   s2 : the Stage-2 (RCNN) set-abstraction shapes of the same ops: 800 RoI clouds of 512 points,
        128 channels
+  t1 : one Stage-1 RPN training iteration, batch 8 (bench_t1.py)
 
 Extra objects on the JSON line (tier contract): "roofline" for the dominant kernel (FPS:
 algorithmic bytes A_model = (M-1)*N*12 + M*4 per scene) with the per-launch
@@ -423,11 +424,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "s2"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "s2", "t1"])
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 512, c3/c5 default 8, s2 default 800)")
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-prefetch", action="store_true", help="t1: sample inside the step instead of one step ahead")
     ap.add_argument("--pipeline-depth", type=int, default=3, help="c3: batches in flight (one HIP stream + graph each)")
     args = ap.parse_args()
 
@@ -442,6 +444,9 @@ def main():
         wl = C5(args.batch or 8, rank, args.kind)
     elif args.workload == "s2":
         wl = S2(args.batch or 800, rank, args.kind)
+    elif args.workload == "t1":
+        from bench_t1 import T1
+        wl = T1(args.batch or 8, rank, world, args.kind, prefetch=not args.no_prefetch)
     else:
         wl = C2(args.batch or 512, rank, args.kind)
 

@@ -89,7 +89,7 @@ class C3:
 
     def config(self):
         c = self.cfg
-        return {"model": "Pointnet2MSG+RPN (weaklyRPN.yaml), 3,046,201 params, random-init (seeded)",
+        return {"network": "Pointnet2MSG+RPN (weaklyRPN.yaml), 3,046,201 params, random-init (seeded)",
                 "pre_nms": c.rpn_pre_nms_top_n, "nms_thresh": c.rpn_nms_thresh, "post_nms": c.rpn_post_nms_top_n,
                 "roipool": {"sampled": c.roi_sampled_pts, "channels": 128, "extra_width": c.roi_extra_width},
                 "exchange": "all_gather of (B,100,8) proposals" if self.world > 1 else "none (1 GPU)",

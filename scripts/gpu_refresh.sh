@@ -15,6 +15,8 @@ python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 >
 python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
 python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
 python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
+python bench.py --workload t1               2>$OUT/bench_t1_b8.err   | tail -1 > $OUT/bench_t1_b8.json
+python bench.py --workload t1 --batch 25 --no-cpu-baseline 2>$OUT/bench_t1_b25.err | tail -1 > $OUT/bench_t1_b25.json
 for w in c2 c3 c5 s2; do
   extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph"
   rm -rf /tmp/prof_$w
@@ -28,4 +30,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python scripts/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \
   $OUT/traffic.json "c2 batch 512, bytes per launch, rocprofv3 --pmc in separate passes" 512 > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
+bash scripts/prof_train.sh > $OUT/prof_train.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $OUT/train_b8_kernel_stats.csv
 ls -la $OUT

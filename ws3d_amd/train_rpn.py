@@ -258,6 +258,7 @@ class DevicePrefetcher:
         self.source, self.device, self.npoints = iter(source), torch.device(device), tuple(npoints)
         self.side = torch.cuda.Stream(device=self.device)
         self.pending = None                # (batch, ready event) | exception raised by the source
+        self.timing = None                 # set to a list to collect (start, end) HIP events of the sampling chain
 
     def advance(self) -> None:
         """start the next batch (no-op if one is already pending)"""
@@ -274,7 +275,14 @@ class DevicePrefetcher:
                 # plain pageable upload: staging through pinned buffers + non_blocking copies was measured
                 # slower here (36 vs 23 ms per iteration at batch 8)
                 out[key] = torch.from_numpy(np.ascontiguousarray(batch[key], dtype=np.float32)).to(self.device)
-            out["sampling_plan"] = pn2_ops.sampling_plan(out["pts_input"][..., 0:3].contiguous(), self.npoints)
+            xyz = out["pts_input"][..., 0:3].contiguous()
+            if self.timing is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(self.side)
+            out["sampling_plan"] = pn2_ops.sampling_plan(xyz, self.npoints)
+            if self.timing is not None:
+                t1.record(self.side)
+                self.timing.append((t0, t1))
             ready = torch.cuda.Event()
             ready.record(self.side)
         self.pending = (out, ready)
