@@ -141,16 +141,17 @@ WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_ou
  * of every conv -> BatchNorm -> ReLU block of the reference (pytorch_utils.py:35-101, nn.BatchNorm1d/2d
  * in train() mode followed by nn.ReLU).  fwd: batch statistics per channel over b*l values (biased
  * variance for the normalisation, unbiased for running_var), y = relu(((x-mean)*invstd)*gamma+beta),
- * running_mean/var (nullable) updated with `momentum`, save_mean/save_invstd (c) kept for bwd.
+ * running_mean/var (nullable) updated with `momentum`, *num_batches_tracked (nullable, one int64 on
+ * the device) incremented, save_mean/save_invstd (c) kept for bwd.
  * bwd: dx (b,c,l), dgamma (c), dbeta (c) from dy; the ReLU mask is re-derived from x.  relu = 0: plain
  * BatchNorm.  Reductions run in a fixed order (fp64 partials): bit-reproducible run to run.
  * workspace: ws3d_bn_workspace_bytes(b, c, l) bytes, 8-byte aligned.  ws3d extension (replaces the
  * library BatchNorm + ReLU kernels in the training step).                                        */
 WS3D_API size_t ws3d_bn_workspace_bytes(int b, int c, long l);
 WS3D_API int ws3d_bn_relu_train_fwd(int b, int c, long l, const float *x, const float *gamma, const float *beta, float eps,
-                                    float momentum, int relu, float *running_mean, float *running_var, float *y,
-                                    float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
-                                    ws3d_stream_t stream);
+                                    float momentum, int relu, float *running_mean, float *running_var,
+                                    int64_t *num_batches_tracked, float *y, float *save_mean, float *save_invstd,
+                                    void *workspace, size_t workspace_bytes, ws3d_stream_t stream);
 WS3D_API int ws3d_bn_relu_train_bwd(int b, int c, long l, const float *x, const float *dy, const float *gamma,
                                     const float *beta, const float *save_mean, const float *save_invstd, int relu, float *dx,
                                     float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, ws3d_stream_t stream);

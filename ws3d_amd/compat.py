@@ -229,10 +229,13 @@ def rowmax_rows(y, ns, out=None, col0=0):
     return out
 
 
-def bn_relu_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu=True):
+def bn_relu_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, relu=True, num_batches_tracked=None):
     """x (B,C,...) contiguous fp32 -> (y, save_mean (C), save_invstd (C)): training-mode BatchNorm
-    (+ReLU), running stats (or None) updated in place.  ws3d extension."""
-    dev = _dev(x, gamma, beta, running_mean, running_var)
+    (+ReLU), running stats (or None) updated in place, the int64 scalar num_batches_tracked (or None)
+    incremented on the device.  ws3d extension."""
+    dev = _dev(x, gamma, beta, running_mean, running_var, num_batches_tracked)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise TypeError("num_batches_tracked must be int64")
     _f32(x, "x"); _f32(gamma, "gamma"); _f32(beta, "beta")
     b, c = x.size(0), x.size(1)
     l = x.numel() // max(b * c, 1)
@@ -244,7 +247,7 @@ def bn_relu_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, 
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
     with torch.cuda.device(dev):
         check(lib.ws3d_bn_relu_train_fwd(b, c, l, _p(x), _p(gamma), _p(beta), float(eps), float(momentum), int(bool(relu)),
-                                         _p(running_mean), _p(running_var), _p(y), _p(mean), _p(invstd), _p(ws), nbytes,
+                                         _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(y), _p(mean), _p(invstd), _p(ws), nbytes,
                                          _stream()), "bn_relu_train_fwd")
     return y, mean, invstd
 

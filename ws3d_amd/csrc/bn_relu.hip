@@ -112,7 +112,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int c, long l, int relu, 
                                                        const float *__restrict__ beta, float *__restrict__ mean,
                                                        float *__restrict__ invstd, float *__restrict__ running_mean,
                                                        float *__restrict__ running_var, float *__restrict__ dgamma,
-                                                       float *__restrict__ dbeta, float *__restrict__ out) {
+                                                       float *__restrict__ dbeta, long long *__restrict__ batches_tracked,
+                                                       float *__restrict__ out) {
     const BnRow r = bn_row(c, l);
     const int ch = blockIdx.y;
     const bool scribe = blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0;   // writes the per-channel results
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(int c, long l, int relu, 
             invstd[ch] = is;
             if (running_mean) running_mean[ch] = (1.0f - momentum) * running_mean[ch] + momentum * mu;
             if (running_var) running_var[ch] = (1.0f - momentum) * running_var[ch] + momentum * (float)(var * (count / (count - 1.0)));
+            if (batches_tracked && ch == 0) *batches_tracked += 1;
         }
     } else {
         mu = mean[ch]; is = invstd[ch];
@@ -185,9 +187,9 @@ extern "C" size_t ws3d_bn_workspace_bytes(int b, int c, long l) {
 }
 
 extern "C" int ws3d_bn_relu_train_fwd(int b, int c, long l, const float *x, const float *gamma, const float *beta, float eps,
-                                      float momentum, int relu, float *running_mean, float *running_var, float *y,
-                                      float *save_mean, float *save_invstd, void *workspace, size_t workspace_bytes,
-                                      ws3d_stream_t stream) {
+                                      float momentum, int relu, float *running_mean, float *running_var,
+                                      int64_t *num_batches_tracked, float *y, float *save_mean, float *save_invstd,
+                                      void *workspace, size_t workspace_bytes, ws3d_stream_t stream) {
     using namespace ws3d;
     if (!bn_shape_ok(b, c, l, "ws3d_bn_relu_train_fwd")) return WS3D_E_INVALID;
     if (!x || !gamma || !beta || !y || !save_mean || !save_invstd || !workspace || workspace_bytes < bn_ws_bytes(b, c, l) ||
@@ -203,8 +205,8 @@ extern "C" int ws3d_bn_relu_train_fwd(int b, int c, long l, const float *x, cons
     if (vec) hipLaunchKernelGGL((bn_partial_kernel<0, true>), grid, block, 0, st, c, l, relu, x, nullptr, gamma, beta, nullptr, nullptr, partial);
     else hipLaunchKernelGGL((bn_partial_kernel<0, false>), grid, block, 0, st, c, l, relu, x, nullptr, gamma, beta, nullptr, nullptr, partial);
     const double count = (double)b * (double)l;
-    if (vec) hipLaunchKernelGGL((bn_apply_kernel<0, true>), grid, block, 0, st, c, l, relu, count, eps, momentum, partial, x, nullptr, gamma, beta, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, y);
-    else hipLaunchKernelGGL((bn_apply_kernel<0, false>), grid, block, 0, st, c, l, relu, count, eps, momentum, partial, x, nullptr, gamma, beta, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, y);
+    if (vec) hipLaunchKernelGGL((bn_apply_kernel<0, true>), grid, block, 0, st, c, l, relu, count, eps, momentum, partial, x, nullptr, gamma, beta, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, reinterpret_cast<long long *>(num_batches_tracked), y);
+    else hipLaunchKernelGGL((bn_apply_kernel<0, false>), grid, block, 0, st, c, l, relu, count, eps, momentum, partial, x, nullptr, gamma, beta, save_mean, save_invstd, running_mean, running_var, nullptr, nullptr, reinterpret_cast<long long *>(num_batches_tracked), y);
     return check_launch("ws3d_bn_relu_train_fwd");
 }
 
@@ -227,7 +229,7 @@ extern "C" int ws3d_bn_relu_train_bwd(int b, int c, long l, const float *x, cons
     else hipLaunchKernelGGL((bn_partial_kernel<1, false>), grid, block, 0, st, c, l, relu, x, dy, gamma, beta, save_mean, save_invstd, partial);
     const double count = (double)b * (double)l;
     float *mean_rw = const_cast<float *>(save_mean), *invstd_rw = const_cast<float *>(save_invstd);   // read only in this mode
-    if (vec) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, block, 0, st, c, l, relu, count, 0.f, 0.f, partial, x, dy, gamma, beta, mean_rw, invstd_rw, nullptr, nullptr, dgamma, dbeta, dx);
-    else hipLaunchKernelGGL((bn_apply_kernel<1, false>), grid, block, 0, st, c, l, relu, count, 0.f, 0.f, partial, x, dy, gamma, beta, mean_rw, invstd_rw, nullptr, nullptr, dgamma, dbeta, dx);
+    if (vec) hipLaunchKernelGGL((bn_apply_kernel<1, true>), grid, block, 0, st, c, l, relu, count, 0.f, 0.f, partial, x, dy, gamma, beta, mean_rw, invstd_rw, nullptr, nullptr, dgamma, dbeta, nullptr, dx);
+    else hipLaunchKernelGGL((bn_apply_kernel<1, false>), grid, block, 0, st, c, l, relu, count, 0.f, 0.f, partial, x, dy, gamma, beta, mean_rw, invstd_rw, nullptr, nullptr, dgamma, dbeta, nullptr, dx);
     return check_launch("ws3d_bn_relu_train_bwd");
 }

@@ -94,9 +94,10 @@ def sigmoid_focal_loss(logits: torch.Tensor, targets: torch.Tensor, weights: tor
     return mod * a * ce * weights
 
 
-def rpn_reg_loss(pred_reg: torch.Tensor, reg_label: torch.Tensor, loc_scope: float, loc_bin_size: float):
+def rpn_reg_loss(pred_reg: torch.Tensor, reg_label: torch.Tensor, loc_scope: float, loc_bin_size: float, lazy: bool = False):
     """pred_reg (F, 4*bins), reg_label (F,3) [dx, 0, dz] -> (loss, {name: float}); bins for x and z
-    (cross entropy) + smooth-L1 on the normalised in-bin residual of the labelled bin"""
+    (cross entropy) + smooth-L1 on the normalised in-bin residual of the labelled bin.
+    lazy: the dict holds detached 0-dim tensors instead of floats (no host sync per entry)"""
     bins = int((loc_scope + 1e-3) / loc_bin_size) * 2
     assert pred_reg.shape[1] == 4 * bins, "%d vs %d" % (pred_reg.shape[1], 4 * bins)
     parts = {}
@@ -112,15 +113,19 @@ def rpn_reg_loss(pred_reg: torch.Tensor, reg_label: torch.Tensor, loc_scope: flo
         parts["loss_%s_bin" % name], parts["loss_%s_res" % name] = loss_bin, loss_res
     # the reference adds x_bin + z_bin first, then x_res + z_res
     total = (parts["loss_x_bin"] + parts["loss_z_bin"]) + (parts["loss_x_res"] + parts["loss_z_res"])
-    return total, {k: v.item() for k, v in parts.items()}
+    return total, {k: (v.detach() if lazy else v.item()) for k, v in parts.items()}
 
 
 def rpn_loss(rpn_cls: torch.Tensor, rpn_reg: torch.Tensor, cls_label: torch.Tensor, reg_label: torch.Tensor,
              loc_scope: float, loc_bin_size: float, gaussian_center: bool = True,
-             loss_weight=LOSS_WEIGHT) -> Tuple[torch.Tensor, Dict[str, float]]:
+             loss_weight=LOSS_WEIGHT, lazy: bool = False) -> Tuple[torch.Tensor, Dict[str, float]]:
     """rpn_cls (B,N,1), rpn_reg (B,N,4*bins), cls_label (B,N) (soft if gaussian_center), reg_label
-    (B,N,3) -> (loss, tb_dict) as get_rpn_loss with LOSS_CLS = SigmoidFocalLoss"""
+    (B,N,3) -> (loss, tb_dict) as get_rpn_loss with LOSS_CLS = SigmoidFocalLoss.
+    lazy: the scalar entries of tb_dict stay on the device as detached 0-dim tensors (the reference
+    reads every one back with .item(): five host syncs in the middle of the step); resolve them
+    with ``resolve_scalars`` once the step is enqueued."""
     tb = {}
+    read = (lambda t: t.detach()) if lazy else (lambda t: t.item())
     label = cls_label.reshape(-1)
     logits = rpn_cls.reshape(-1)
     fg_mask = label > 0
@@ -132,16 +137,25 @@ def rpn_loss(rpn_cls: torch.Tensor, rpn_reg: torch.Tensor, cls_label: torch.Tens
         pos, neg = (label > 0.5).float(), (label < 0.5).float()
     weights = (pos + neg) / torch.clamp(pos.sum(), min=1.0)
     per_point = sigmoid_focal_loss(logits, target, weights)
-    tb["rpn_loss_cls_pos"] = (per_point * pos).sum().item()
-    tb["rpn_loss_cls_neg"] = (per_point * neg).sum().item()
+    tb["rpn_loss_cls_pos"] = read((per_point * pos).sum())
+    tb["rpn_loss_cls_neg"] = read((per_point * neg).sum())
     loss_cls = per_point.sum()
     point_num = rpn_reg.size(0) * rpn_reg.size(1)
     fg_sum = int(fg_mask.long().sum().item())
     if fg_sum != 0:
         loss_reg, _ = rpn_reg_loss(rpn_reg.reshape(point_num, -1)[fg_mask], reg_label.reshape(point_num, 3)[fg_mask],
-                                   loc_scope, loc_bin_size)
+                                   loc_scope, loc_bin_size, lazy=True)
     else:
         loss_reg = loss_cls * 0
     loss = loss_cls * loss_weight[0] + loss_reg * loss_weight[1]
-    tb.update({"rpn_loss_cls": loss_cls.item(), "rpn_loss_reg": loss_reg.item(), "rpn_loss": loss.item(), "rpn_fg_sum": fg_sum})
+    tb.update({"rpn_loss_cls": read(loss_cls), "rpn_loss_reg": read(loss_reg), "rpn_loss": read(loss), "rpn_fg_sum": fg_sum})
     return loss, tb
+
+
+def resolve_scalars(tb: dict) -> dict:
+    """read every 0-dim device tensor of a (lazy) tb_dict back with ONE host sync"""
+    keys = [k for k, v in tb.items() if torch.is_tensor(v)]
+    if keys:
+        vals = torch.stack([tb[k].detach().float().reshape(()) for k in keys]).tolist()
+        tb.update(zip(keys, vals))
+    return tb

@@ -18,10 +18,11 @@ class _BnReluTrain(Function):
     """training-mode BatchNorm (+ReLU) of a channels-first tensor in 3 + 5 HBM passes (bn_relu.hip)"""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, tracked):
         from . import compat as _C
         x = x.contiguous()
-        y, mean, invstd = _C.bn_relu_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, relu)
+        y, mean, invstd = _C.bn_relu_train_fwd(x, gamma.detach(), beta.detach(), running_mean, running_var, momentum, eps, relu,
+                                               tracked)
         ctx.save_for_backward(x, gamma, beta, mean, invstd)
         ctx.relu = relu
         return y
@@ -31,19 +32,19 @@ class _BnReluTrain(Function):
         from . import compat as _C
         x, gamma, beta, mean, invstd = ctx.saved_tensors
         dx, dgamma, dbeta = _C.bn_relu_train_bwd(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bn_relu_train(x: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm, relu: bool) -> torch.Tensor:
     """``relu(bn(x))`` for a BatchNorm module in train() mode, with the module's bookkeeping
     (running statistics, num_batches_tracked, momentum=None -> cumulative average)"""
     momentum = 0.0 if bn.momentum is None else bn.momentum
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
-            momentum = 1.0 / float(bn.num_batches_tracked)
+    tracked = bn.num_batches_tracked if bn.track_running_stats else None
+    if tracked is not None and bn.momentum is None:      # cumulative average: the count is needed on the host
+        tracked.add_(1)
+        momentum, tracked = 1.0 / float(tracked), None
     stats = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return _BnReluTrain.apply(x, bn.weight, bn.bias, stats[0], stats[1], momentum, bn.eps, relu)
+    return _BnReluTrain.apply(x, bn.weight, bn.bias, stats[0], stats[1], momentum, bn.eps, relu, tracked)   # counts in-kernel
 
 
 class _BN(nn.Sequential):

@@ -82,9 +82,15 @@ def bn_momentum_at(it: int, cfg: TrainConfig) -> float:
 
 
 def set_bn_momentum(model: nn.Module, momentum: float) -> None:
-    for m in model.modules():
-        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
-            m.momentum = momentum
+    """(the walk over ~400 modules is skipped while the value does not change: it changes at the
+    few BN_DECAY steps only, and the step is launch-bound on the host)"""
+    cache = model.__dict__.get("_ws3d_bn_momentum")
+    if cache is not None and cache[0] == momentum and all(m.momentum == momentum for m in cache[1][:1]):
+        return
+    norms = [m for m in model.modules() if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d))]
+    for m in norms:
+        m.momentum = momentum
+    model.__dict__["_ws3d_bn_momentum"] = (momentum, norms)
 
 
 class AdamOneCycle:
@@ -319,20 +325,23 @@ def train_step(model: nn.Module, optimizer: AdamOneCycle, batch: dict, it: int, 
     overlap: host work to do once the backward pass is enqueued (DevicePrefetcher.advance)"""
     set_bn_momentum(model, bn_momentum_at(it, train_cfg))
     optimizer.schedule(it)
-    model.train()
+    if not model.training:
+        model.train()
     optimizer.zero_grad()
     inputs = {"pts_input": _on_device(batch["pts_input"], device)}
     if batch.get("sampling_plan") is not None:
         inputs["sampling_plan"] = batch["sampling_plan"]
     out = model(inputs)
     loss, tb = losses.rpn_loss(out["rpn_cls"], out["rpn_reg"], _on_device(batch["rpn_cls_label"], device),
-                               _on_device(batch["rpn_reg_label"], device), net_cfg.loc_scope, net_cfg.loc_bin_size)
+                               _on_device(batch["rpn_reg_label"], device), net_cfg.loc_scope, net_cfg.loc_bin_size, lazy=True)
     loss.backward()
     if overlap is not None:
         overlap()
-    tb["grad_norm"] = float(clip_grad_norm_(model.parameters(), train_cfg.grad_norm_clip))
+    tb["grad_norm"] = clip_grad_norm_(model.parameters(), train_cfg.grad_norm_clip)    # stays on the device ...
     optimizer.step()
-    tb["lr"], tb["loss"] = optimizer.lr, float(loss.item())
+    tb["loss"] = loss
+    losses.resolve_scalars(tb)                       # ... the step's scalars are read back once, at its end
+    tb["lr"] = optimizer.lr
     return tb
 
 
