@@ -592,6 +592,89 @@ __global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow
     }
 }
 
+// The same sort for 1024 <= pow2 <= 16384 with the keys in REGISTERS: thread t owns the E = pow2/1024
+// consecutive elements t*E .. t*E+E-1.  A bitonic pass of distance j is then
+//   j < E        : inside the thread (no data movement),
+//   E <= j < 64E : between lanes of one wave (lane ^ j/E, 64-bit shuffles, no barrier),
+//   j >= 64E     : between waves, through LDS in an element-major layout (conflict-free both ways).
+// Of the 105 passes of a 16384-key sort only 10 touch LDS behind a workgroup barrier; the LDS-only
+// kernel above spends 158 us per launch on LDS bandwidth (8 x 4 64-bit LDS ops per thread and pass).
+__device__ __forceinline__ uint64_t topk_key(float f, int i) {
+    uint32_t u = f == 0.0f ? 0u : __float_as_uint(f);       // -0.0 ties with +0.0 (torch's comparison)
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);         // ascending unsigned order == ascending float order
+    return ((uint64_t)u << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, const float *__restrict__ scores,
+                                                               float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
+    constexpr int POW2 = 1024 * E;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *sc = scores + (size_t)b * n;
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = t * E + r;
+        v[r] = i < n ? topk_key(sc[i], i) : 0ull;            // padding: below every real key
+    }
+    // compare-exchange of a register pair; desc: the larger key goes to the lower position
+    auto cx = [](uint64_t &lo, uint64_t &hi, bool desc) {
+        const uint64_t a = lo, c = hi;
+        const bool swap = (a < c) == desc;
+        lo = swap ? c : a;
+        hi = swap ? a : c;
+    };
+    for (int len = 2; len <= POW2; len <<= 1) {
+        // ---- distances that cross waves: element-major LDS exchange ----
+        for (int j = len >> 1; j >= 64 * E; j >>= 1) {
+            const int m = j / E;                              // partner thread = t ^ m
+            const bool is_lo = (t & m) == 0, desc = ((t * E) & len) == 0;
+            __syncthreads();                                  // previous readers are done
+#pragma unroll
+            for (int r = 0; r < E; ++r) lds[r * 1024 + t] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint64_t o = lds[r * 1024 + (t ^ m)];
+                v[r] = ((v[r] > o) == (is_lo == desc)) ? v[r] : o;      // keys are distinct (index in the low word)
+            }
+        }
+        // ---- distances inside a wave: lane shuffles ----
+        for (int j = min(len >> 1, 32 * E); j >= E; j >>= 1) {
+            const int m = j / E;
+            const bool is_lo = (t & m) == 0, desc = ((t * E) & len) == 0;
+            const bool take_max = is_lo == desc;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint64_t o = __shfl_xor(v[r], m);
+                v[r] = ((v[r] > o) == take_max) ? v[r] : o;
+            }
+        }
+        // ---- distances inside the thread ----
+#pragma unroll
+        for (int j = E >> 1; j >= 1; j >>= 1) {
+            if (j < len) {
+#pragma unroll
+                for (int r = 0; r < E; ++r)
+                    if ((r & j) == 0) cx(v[r], v[r | j], ((t * E + r) & len) == 0);
+            }
+        }
+    }
+    // sorted descending; through LDS once more so that the output is written coalesced
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) lds[t * E + r] = v[r];
+    __syncthreads();
+    for (int i = t; i < k; i += 1024) {
+        const uint64_t w = lds[i];
+        const uint32_t id = 0xffffffffu - (uint32_t)(w & 0xffffffffu);
+        out_idx[(size_t)b * k + i] = (int64_t)id;
+        out_scores[(size_t)b * k + i] = sc[id];
+    }
+}
+
 template <int MODE>
 static int pair_launch(int num_a, const float *boxes_a, int num_b, const float *boxes_b, float *ans,
                        hipStream_t st, const char *what) {
@@ -725,7 +808,26 @@ extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float 
         (void)hipFuncSetAttribute((const void *)topk_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr = true;
     }
-    hipLaunchKernelGGL(topk_sorted_kernel, dim3(b), dim3(1024), smem, as_stream(stream), n, k, pow2, scores, out_scores, out_idx);
+    hipStream_t st = as_stream(stream);
+#define WS3D_TOPK_REG(E)                                                                                                  \
+    do {                                                                                                                  \
+        static bool attr_reg = false;                                                                                     \
+        if (!attr_reg) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void *)topk_sorted_reg_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      128 * 1024);                                                                        \
+            attr_reg = true;                                                                                              \
+        }                                                                                                                 \
+        hipLaunchKernelGGL(topk_sorted_reg_kernel<E>, dim3(b), dim3(1024), smem, st, n, k, scores, out_scores, out_idx);   \
+    } while (0)
+    switch (pow2) {
+    case 16384: WS3D_TOPK_REG(16); break;
+    case 8192: WS3D_TOPK_REG(8); break;
+    case 4096: WS3D_TOPK_REG(4); break;
+    case 2048: WS3D_TOPK_REG(2); break;
+    case 1024: WS3D_TOPK_REG(1); break;
+    default: hipLaunchKernelGGL(topk_sorted_kernel, dim3(b), dim3(1024), smem, st, n, k, pow2, scores, out_scores, out_idx);
+    }
+#undef WS3D_TOPK_REG
     return check_launch("ws3d_topk_sorted");
 }
 
