@@ -114,6 +114,30 @@ def one_round(rng):
     ref_box = torch.stack((ctr[..., 0], xyz_t[..., 1] + h / 2, ctr[..., 2], torch.full_like(ctr[..., 0], h), torch.full_like(ctr[..., 0], w),
                            torch.full_like(ctr[..., 0], l), stage1.synthetic_orientation(Np, xyz_t.device).unsqueeze(0).expand(Bp, Np)), dim=2)
     assert torch.equal(box, ref_box), ("decode", Bp, Np)
+    # training-step kernels: deterministic scatter (bit-equal to the sequential loop), pool (bit-equal to F.max_pool2d)
+    Bg, Cg = int(rng.integers(1, 4)), int(rng.choice([1, 7, 31, 32, 33, 64, 96, 129, 256, 300, 513]))
+    Ng, Mg, nsg = int(rng.integers(1, 600)), int(rng.integers(0, 80)), int(rng.choice([1, 3, 16, 32]))
+    gi = rng.integers(0, max(Ng // int(rng.choice([1, 3, 50])), 1), (Bg, Mg, nsg)).astype(np.int32)
+    gg = (rng.standard_normal((Bg, Cg, Mg, nsg)) * 10 ** rng.uniform(-2, 2, (Bg, Cg, Mg, nsg))).astype(np.float32)
+    og = torch.full((Bg, Cg, Ng), float("nan"), device="cuda")
+    c.group_points_grad_det(Bg, Cg, Ng, Mg, nsg, dev(gg), dev(gi), og)
+    assert np.array_equal(host(og), oracle.grouping_operation_grad(gg, gi, Ng)), ("group_grad_det", Bg, Cg, Ng, Mg, nsg)
+    nu, mk = int(rng.integers(1, 700)), int(rng.integers(1, 90))
+    ii = rng.integers(0, mk, (Bg, nu, 3)).astype(np.int32)
+    ww = rng.uniform(0, 1, (Bg, nu, 3)).astype(np.float32)
+    gu = rng.standard_normal((Bg, Cg, nu)).astype(np.float32)
+    oi = torch.full((Bg, Cg, mk), float("nan"), device="cuda")
+    c.three_interpolate_grad_det(Bg, Cg, nu, mk, dev(gu), dev(ii), dev(ww), oi)
+    assert np.array_equal(host(oi), oracle.three_interpolate_grad(gu, ii, ww, mk)), ("interp_grad_det", Bg, Cg, nu, mk)
+    nsp = int(rng.choice([1, 2, 4, 7, 8, 16, 32, 33, 64, 128, 255]))
+    xp = torch.from_numpy(np.round(rng.standard_normal((int(rng.integers(1, 4)), int(rng.integers(1, 9)), int(rng.integers(1, 200)), nsp)) * 2).astype(np.float32) / 2).cuda()
+    if rng.random() < 0.3 and xp.numel() > 4:
+        flat = xp.view(-1)
+        flat[int(rng.integers(0, flat.numel()))] = float("nan"); flat[int(rng.integers(0, flat.numel()))] = float("-inf")
+    pv, pa = c.pool_nsample(xp)
+    rvp, rip = torch.nn.functional.max_pool2d(xp, kernel_size=[1, nsp], return_indices=True)
+    same = torch.equal(torch.nan_to_num(pv, nan=7e30), torch.nan_to_num(rvp.squeeze(-1), nan=7e30))
+    assert same and torch.equal(pa.long(), rip.squeeze(-1) % nsp), ("pool_nsample", tuple(xp.shape))
     cxz = np.ascontiguousarray(b3[None, :, [0, 2]])
     rr = float(rng.choice([0.05, 0.3, 1.0]))
     kr, nr = c.radius_nms_device_batched(dev(cxz), rr)

@@ -696,7 +696,10 @@ def test_stage2_sa_shapes_bit_exact(ops, oracle, B):
 
 
 # ------------------------------------------------------------------------------- deterministic backward, SURVEY 8f.2
-@pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 300, 40, 16), (1, 19, 4096, 1024, 32), (3, 8, 64, 64, 1), (1, 3, 10, 0, 4)])
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 5, 300, 40, 16), (1, 19, 4096, 1024, 32), (3, 8, 64, 64, 1), (1, 3, 10, 0, 4),
+                                        # c >= 32: rows copy + 1 / 2 / 4 / 8 channel chunks per lane, c > 512: two passes
+                                        (2, 32, 64, 64, 1), (2, 96, 500, 64, 16), (1, 130, 777, 100, 5), (1, 256, 300, 50, 8),
+                                        (1, 515, 100, 30, 4), (1, 700, 50, 20, 3), (1, 64, 9, 100, 32)])
 def test_group_and_gather_grad_deterministic_bit_exact(ops, oracle, B, C, N, M, ns):
     """sorted-segment accumulation == the sequential loop `dst[idx[slot]] += g[slot]` (oracle),
     bit for bit, and identical across repeated launches (the atomic kernel is neither)"""
@@ -717,9 +720,9 @@ def test_group_and_gather_grad_deterministic_bit_exact(ops, oracle, B, C, N, M, 
         np.testing.assert_allclose(host(at), ref, rtol=1e-4, atol=1e-3 * np.abs(g).max())
 
 
-def test_three_interpolate_grad_deterministic_bit_exact(ops, oracle):
-    rng = np.random.default_rng(4)
-    B, C, n, m = 2, 21, 1500, 90
+@pytest.mark.parametrize("B,C,n,m", [(2, 21, 1500, 90), (2, 64, 1500, 90), (1, 130, 333, 7), (1, 600, 200, 50), (3, 256, 64, 64)])
+def test_three_interpolate_grad_deterministic_bit_exact(ops, oracle, B, C, n, m):
+    rng = np.random.default_rng(4 + C)
     idx = rng.integers(0, m, (B, n, 3)).astype(np.int32)
     w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
     g = rng.standard_normal((B, C, n)).astype(np.float32)
