@@ -1,4 +1,5 @@
-"""1x1 convolution fwd+bwd on the Stage-1 shapes: nn.Conv2d (MIOpen) vs W @ x.view(B,C,L) (hipBLASLt/rocBLAS)."""
+"""1x1 convolution fwd+bwd on the Stage-1 shapes: nn.Conv2d (MIOpen) vs W @ x.view(B,C,L) (rocBLAS batched)
+vs F.linear on a rows (B*L, C) tensor."""
 import torch, torch.nn as nn
 dev = "cuda"
 LAYERS = [(4, 16, 4096 * 16), (16, 16, 4096 * 16), (16, 32, 4096 * 16), (4, 32, 4096 * 32), (32, 32, 4096 * 32), (32, 64, 4096 * 32),
@@ -21,10 +22,11 @@ for ci, co, L in LAYERS:
         conv(x).backward(g)
     def fm():
         torch.matmul(w, x.view(8, ci, L)).backward(g.view(8, co, L))
-    def fr():   # rows: one (8L, ci) x (ci, co) GEMM on a channels-last copy (for reference)
-        xr = x.detach().view(8, ci, L).transpose(1, 2).reshape(8 * L, ci).requires_grad_(True)
-        (xr @ w.t()).backward(g.view(8, co, L).transpose(1, 2).reshape(8 * L, co))
-    tc, tm = timeit(fc), timeit(fm)
-    tot[0] += tc; tot[1] += tm
-    print(f"{ci:5d}->{co:4d} L={L:7d}: conv2d {tc:.3f} ms  matmul {tm:.3f} ms", flush=True)
-print("total conv2d %.2f ms, matmul %.2f ms" % (tot[0], tot[1]))
+    xr = torch.randn(8 * L, ci, device=dev, requires_grad=True)     # rows layout: one (8L, ci) x (ci, co) GEMM
+    gr = torch.randn(8 * L, co, device=dev)
+    def fr():
+        torch.nn.functional.linear(xr, w).backward(gr)
+    tc, tm, tr = timeit(fc), timeit(fm), timeit(fr)
+    tot[0] += tc; tot[1] += tm; tot[2] += tr
+    print(f"{ci:5d}->{co:4d} L={L:7d}: conv2d {tc:.3f} ms  matmul {tm:.3f} ms  rows-linear {tr:.3f} ms", flush=True)
+print("total conv2d %.2f ms, matmul %.2f ms, rows-linear %.2f ms" % tuple(tot))
