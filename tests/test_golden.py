@@ -223,3 +223,47 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     dec = decode_center_target(out["backbone_xyz"][0], out["rpn_reg"][0], 4.0, 0.8).cpu().numpy()
     d = np.abs(dec.reshape(-1)[gold["decode_pos"]] - gold["decode_val"])
     assert (d < 1e-3).mean() > 0.97  # a bin argmax may flip where two logits are within 1e-4
+
+
+# ------------------------------------------------------------------------------- BASELINE configs[0] ("C1")
+def _c1():
+    case = json.load(open(os.path.join(G, "c1_sa_layer.json")))
+    gold = np.load(os.path.join(G, "c1_sa_layer.npz"))
+    pc = synth.make_batch("lidar", 1, case["n"], case["config_id"])
+    return case, gold, pc[:, :, :3].copy(), np.ascontiguousarray(pc[:, :, 3:].transpose(0, 2, 1))
+
+
+def test_c1_oracle_leaf_ops_reproduce_the_reference_sa_layer(oracle):
+    """BASELINE configs[0]: one 16384 x 4 cloud through the reference's SA layer on CPU -- the sampling
+    and both neighbour searches the reference harness recorded are what the oracle computes"""
+    case, gold, xyz, _ = _c1()
+    idx = oracle.furthest_point_sample(xyz, case["npoint"])
+    np.testing.assert_array_equal(idx[0], gold["fps_idx"][0] if gold["fps_idx"].ndim == 2 else gold["fps_idx"])
+    new_xyz = xyz[:, idx[0]]
+    assert _sha(new_xyz) == case["new_xyz_sha256"]
+    for r, ns, want in zip(case["radii"], case["nsamples"], case["ball_query_sha256"]):
+        assert _sha(oracle.ball_query(r, ns, xyz, new_xyz).astype(np.int32)) == want
+
+
+@pytest.mark.gpu
+def test_c1_gpu_sa_layer_matches_reference_harness():
+    """the same layer through ws3d_amd's PointnetSAModuleMSG on the HIP kernels: sampled points and
+    neighbour indices exact, the (1, 96, 4096) features within 1e-4 of the reference harness"""
+    from ws3d_amd import pn2_modules, pn2_ops
+    case, gold, xyz, feats = _c1()
+    sa = pn2_modules.PointnetSAModuleMSG(npoint=case["npoint"], radii=case["radii"], nsamples=case["nsamples"],
+                                         mlps=[list(m) for m in case["mlps"]], use_xyz=True, bn=True).eval()
+    sa.load_state_dict(seeded_state_dict({k: tuple(v) for k, v in case["keys"].items()}, case["seed"]))
+    sa.cuda()
+    x = dev(xyz)
+    with torch.no_grad():
+        new_xyz, new_feat = sa(x, dev(feats))
+    assert list(new_feat.shape) == case["features_shape"]
+    assert _sha(new_xyz.cpu().numpy()) == case["new_xyz_sha256"]
+    idx, _ = pn2_ops.furthest_point_sample_gather(x, case["npoint"])
+    np.testing.assert_array_equal(idx.cpu().numpy().reshape(-1), gold["fps_idx"].reshape(-1))
+    for r, ns, want in zip(case["radii"], case["nsamples"], case["ball_query_sha256"]):
+        assert _sha(pn2_ops.ball_query(r, ns, x, new_xyz).cpu().numpy().astype(np.int32)) == want
+    got = new_feat.cpu().numpy().reshape(-1)[gold["feat_pos"]]
+    np.testing.assert_allclose(got, gold["feat_val"], atol=1e-4, rtol=1e-4)
+    assert abs(float(np.abs(new_feat.cpu().numpy()).mean()) - case["features_abs_mean"]) < 1e-4
