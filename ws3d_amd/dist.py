@@ -26,12 +26,18 @@ def init(backend: str = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # WS3D_DIST_BACKEND=gloo: control-flow runs of the multi-rank paths on a box with fewer GPUs than
+        # ranks (ranks then share devices); production is nccl (= RCCL over xGMI)
+        backend = backend or os.environ.get("WS3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
-        if backend == "nccl":
+        if torch.cuda.is_available():
+            local = local % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", local)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    elif torch.cuda.is_available():
+        local = local % max(torch.cuda.device_count(), 1)
     return world, rank, local
 
 

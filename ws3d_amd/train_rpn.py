@@ -479,9 +479,10 @@ def main():
         ap.error("give --data_root or --synthetic N")
     res = train(ds, a.total_iters, a.batch_size, out_dir, a.ckpt, a.pretrain_ckpt, a.ckpt_save_interval,
                 device=f"cuda:{local}", distributed=distributed, prefetch=not a.no_prefetch)
-    logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s, median %.1f ms/it", res["it"],
-                                                 res["checkpoints"][-1] if res["checkpoints"] else None,
-                                                 float(np.median(res["step_ms"])) if res["step_ms"] else float("nan"))
+    if int(os.environ.get("RANK", "0")) == 0:
+        logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s, median %.1f ms/it", res["it"],
+                                                     res["checkpoints"][-1] if res["checkpoints"] else None,
+                                                     float(np.median(res["step_ms"])) if res["step_ms"] else float("nan"))
 
 
 if __name__ == "__main__":
