@@ -95,7 +95,8 @@ class C3:
                 "exchange": "all_gather of (B,100,8) proposals" if self.world > 1 else "none (1 GPU)",
                 "launch": ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth)
                 if getattr(self, "_graph", None) is not None
-                else "eager (graph capture failed: %s)" % getattr(self, "_graph_err", "not attempted")}
+                else "eager (graph capture failed: %s)" % getattr(self, "_graph_err", "not attempted"),
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}
 
     @torch.no_grad()
     def _body(self, pts=None):
