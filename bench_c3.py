@@ -108,45 +108,29 @@ class C3:
         return out, boxes, scores, count, pooled, empty
 
     def capture(self):
-        """Record the whole step (all torch ops + every C-ABI launch: no entry point allocates or
-        synchronises) into hipGraphs, one per pipeline slot; returns True on success.  Replay
-        removes the launch gaps of ~450 small kernels, and `depth` batches are kept in flight on
-        separate HIP streams: FPS of the next batch (8 workgroups = 8 of 256 CUs for 4.8 ms) runs
-        under the MLP / NMS / roipool work of the previous one."""
-        try:
-            self._slots = []
-            for d in range(self.depth):
-                stream = torch.cuda.Stream()
-                pts = self.pts.clone()
-                stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(stream):
-                    for _ in range(2):
-                        self._body(pts)
-                torch.cuda.current_stream().wait_stream(stream)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
-                    outs = self._body(pts)
-                self._slots.append((stream, g, outs, pts))
-            torch.cuda.synchronize()
-            self._graph = True
-            return True
-        except Exception as e:  # pragma: no cover - depends on the runtime
-            self._graph = None
-            self._graph_err = repr(e)
-            return False
+        """Throughput mode = the product's ``ws3d_amd.pipeline.Stage1Pipeline``: the whole step (all
+        torch ops + every C-ABI launch: no entry point allocates or synchronises) captured into one
+        hipGraph per slot, `depth` batches in flight on separate HIP streams; returns True on success."""
+        from ws3d_amd.pipeline import Stage1Pipeline
+        self.pipe = Stage1Pipeline(self.model, self.cfg, batch=self.B, n_points=self.pts.size(1), depth=self.depth,
+                                   roipool=True, device=self.pts.device)
+        for slot in self.pipe.slots:
+            slot["inp"].copy_(self.pts)
+        ok = self.pipe.capture_all()
+        self._graph = True if ok else None
+        self._graph_err = self.pipe.graph_error
+        return ok
 
     @torch.no_grad()
     def step(self, timed=False):
         if getattr(self, "_graph", None) is not None and not timed:
-            stream, g, outs, _ = self._slots[self._i % self.depth]
-            self._i += 1
-            with torch.cuda.stream(stream):
-                g.replay()
-                out, boxes, scores, count, pooled, empty = outs
-                gathered = wdist.all_gather_proposals(wdist.pack_proposals(boxes, scores), count,
+            ticket = self.pipe.submit()                    # inputs already resident in the slot's buffer
+            slot = self.pipe.slots[ticket % self.depth]
+            res = slot["out"]
+            with torch.cuda.stream(slot["stream"]):
+                gathered = wdist.all_gather_proposals(wdist.pack_proposals(res["boxes"], res["scores"]), res["count"],
                                                       self.B * self.world)
-            self.last = (out, boxes, scores, count, pooled, empty, gathered)
+            self.last = (res["rpn"], res["boxes"], res["scores"], res["count"], res["pooled"], res["empty"], gathered)
             return
         self._timed = timed
         e = None

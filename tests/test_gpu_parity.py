@@ -1149,3 +1149,38 @@ def test_conv_block_training_path_uses_the_fused_norm(ops):
     with pytest.raises(Exception):
         ops.c.bn_relu_train_fwd(torch.zeros((1, 4, 1), device="cuda"), torch.ones(4, device="cuda"), torch.zeros(4, device="cuda"),
                                 None, None, 0.1, 1e-5)
+
+
+# ------------------------------------------------------------------------------- batches in flight
+def test_stage1_pipeline_equals_the_plain_step(ops):
+    """ws3d_amd.pipeline.Stage1Pipeline (hipGraph per slot, several batches in flight, padded last
+    batch) returns what the plain forward + proposal stage returns for every batch"""
+    from ws3d_amd import stage1
+    from ws3d_amd.pipeline import Stage1Pipeline
+    from ws3d_amd.seeded import seeded_state_dict
+    cfg = stage1.RPNConfig(num_points=4096, npoints=(1024, 256, 64, 16), rpn_pre_nms_top_n=1000, rpn_post_nms_top_n=20)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg)
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 3))
+    model = model.cuda().eval()
+    batches = [np.stack([synth.velodyne_scan(4096, seed=10 * i + j) for j in range(n)]) for i, n in enumerate((3, 3, 3, 3, 2))]
+    want = []
+    with torch.no_grad():
+        for b in batches:
+            out = model.rpn_forward({"pts_input": dev(b)})
+            boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
+            want.append((host(boxes), host(scores), host(count)))
+    for use_graph, depth in ((True, 3), (False, 2), (True, 1)):
+        pipe = Stage1Pipeline(model, cfg, batch=3, n_points=4096, depth=depth, use_graph=use_graph)
+        got = [(f0, nv, host(o["boxes"]), host(o["scores"]), host(o["count"])) for f0, nv, o in pipe.map(batches)]
+        assert pipe.graph_error is None
+        assert [g[0] for g in got] == [0, 3, 6, 9, 12] and [g[1] for g in got] == [3, 3, 3, 3, 2]
+        for (f0, nv, boxes, scores, count), (wb, ws, wc) in zip(got, want):
+            np.testing.assert_array_equal(count[:nv], wc)
+            for j in range(nv):
+                k = int(wc[j])
+                np.testing.assert_allclose(boxes[j, :k], wb[j, :k], atol=1e-4)
+                np.testing.assert_allclose(scores[j, :k], ws[j, :k], atol=1e-4)
+    with pytest.raises(ValueError):
+        pipe.submit(np.zeros((4, 4096, 4), dtype=np.float32))
+    with pytest.raises(ValueError):
+        pipe.result(99)

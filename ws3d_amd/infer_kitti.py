@@ -17,10 +17,11 @@ import numpy as np
 import torch
 
 from . import kitti_io, stage1
+from .pipeline import Stage1Pipeline, ensure_hw_queues
 
 
 def run(root: str, split: str, out_dir: str, batch: int = 8, ckpt: str | None = None, npoints: int = 16384,
-        seed: int = 666, device: str = "cuda:0", cfg: stage1.RPNConfig = stage1.DEFAULT_CFG) -> list:
+        seed: int = 666, device: str = "cuda:0", cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, depth: int = 4) -> list:
     """returns the list of result files written (one per scene, possibly empty)"""
     dev = torch.device(device)
     model = stage1.Stage1Net(mode="TEST", cfg=cfg).to(dev).eval()
@@ -34,17 +35,22 @@ def run(root: str, split: str, out_dir: str, batch: int = 8, ckpt: str | None = 
     scenes = kitti_io.KittiScenes(root, split, npoints=npoints, rng=rng)
     os.makedirs(out_dir, exist_ok=True)
     written = []
-    with torch.no_grad():
-        for i0 in range(0, len(scenes), batch):
-            samples = [scenes[i] for i in range(i0, min(i0 + batch, len(scenes)))]
-            pts = torch.from_numpy(kitti_io.collate_scenes(samples)["pts_input"]).to(dev)
-            out = model.rpn_forward({"pts_input": pts})
-            boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
-            boxes, scores, count = boxes.cpu().numpy(), scores.cpu().numpy(), count.cpu().numpy()
-            for j, s in enumerate(samples):
-                sid, k = s["sample_id"], int(count[j])
-                written.append(kitti_io.save_kitti_format(sid, scenes.get_calib(sid), boxes[j, :k], out_dir,
-                                                          scores[j, :k], scenes.get_image_shape(sid), "Car"))
+    starts = list(range(0, len(scenes), batch))
+    loaded = {}
+
+    def batches():
+        for i0 in starts:
+            loaded[i0] = [scenes[i] for i in range(i0, min(i0 + batch, len(scenes)))]
+            yield kitti_io.collate_scenes(loaded[i0])["pts_input"]
+
+    # `depth` batches in flight (ws3d_amd.pipeline): the next scans are read and sampled on the host while the device works
+    pipe = Stage1Pipeline(model, cfg, batch=batch, n_points=npoints, depth=depth, device=dev)
+    for i0, n_valid, out in pipe.map(batches()):
+        boxes, scores, count = out["boxes"].cpu().numpy(), out["scores"].cpu().numpy(), out["count"].cpu().numpy()
+        for j, s in enumerate(loaded.pop(i0)[:n_valid]):
+            sid, k = s["sample_id"], int(count[j])
+            written.append(kitti_io.save_kitti_format(sid, scenes.get_calib(sid), boxes[j, :k], out_dir,
+                                                      scores[j, :k], scenes.get_image_shape(sid), "Car"))
     return written
 
 
@@ -56,8 +62,10 @@ def main():
     ap.add_argument("--ckpt", default=None)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--npoints", type=int, default=16384)
+    ap.add_argument("--pipeline_depth", type=int, default=4, help="batches in flight on separate HIP streams")
     a = ap.parse_args()
-    files = run(a.root, a.split, a.out, a.batch, a.ckpt, a.npoints)
+    ensure_hw_queues()
+    files = run(a.root, a.split, a.out, a.batch, a.ckpt, a.npoints, depth=a.pipeline_depth)
     print(f"{len(files)} result files in {a.out}")
 
 

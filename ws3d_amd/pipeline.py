@@ -1,0 +1,147 @@
+"""Throughput mode of the Stage-1 inference step: several batches in flight.
+
+One batch of 8 scenes cannot fill an MI355X: furthest point sampling is one workgroup per scene
+(8 of 256 CUs for 4.8 ms) and most of the ~60 kernels after it are small.  ``Stage1Pipeline``
+captures the whole step -- ``Stage1Net.rpn_forward`` + ``proposals_from_rpn`` (+ ``roipool3d``) --
+into one hipGraph per slot, each slot on its own HIP stream with its own input buffer, and keeps
+``depth`` batches in flight, so the sampling of one batch runs under the GEMMs / NMS / pooling of the
+others.  Nothing in the C ABI allocates or synchronises, which is what makes the capture possible.
+
+HIP multiplexes streams onto at most ``GPU_MAX_HW_QUEUES`` hardware queues (default 4) and streams
+that share a queue serialise; the variable is read when the runtime starts, so set it (e.g. 24)
+before the first device call of the process -- ``ensure_hw_queues()`` does it when still possible.
+Measured (batch 8 x 16384 points, bench.py c3): 942 scenes/s with one batch in flight, 2,037 with 3
+on the default 4 queues, 3,468 with 12 on 24 queues.
+
+    pipe = Stage1Pipeline(model, cfg, batch=8, depth=6)
+    for first_scene, n_valid, out in pipe.map(batches):      # batches: iterable of (<=B, N, 4) arrays / tensors
+        boxes, scores, count = out["boxes"], out["scores"], out["count"]   # device tensors, valid until the slot is reused
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Iterator, Tuple
+
+import numpy as np
+import torch
+
+from . import roipool3d_ops, stage1
+
+
+def ensure_hw_queues(n: int = 24) -> bool:
+    """raise the runtime's hardware-queue cap unless the user set it; True if the value can still
+    take effect (no device context yet in this process)"""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(n))
+    return not torch.cuda.is_initialized()
+
+
+class Stage1Pipeline:
+    def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
+                 n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
+                 channels: int = 4):
+        self.model, self.cfg, self.B, self.depth, self.roipool = model.eval(), cfg, int(batch), max(1, int(depth)), roipool
+        self.device = torch.device(device)
+        self.hw_queues_raised = ensure_hw_queues()      # False: the runtime already started with its own cap
+        self.submitted = 0
+        self.graph_error = None
+        self.slots = []
+        with torch.cuda.device(self.device):
+            for _ in range(self.depth):
+                stream = torch.cuda.Stream(device=self.device)
+                inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
+                self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
+                                   "done": torch.cuda.Event(), "primed": False})
+        self.use_graph = use_graph
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def body(self, pts: torch.Tensor) -> dict:
+        out = self.model.rpn_forward({"pts_input": pts})
+        boxes, scores, count = stage1.proposals_from_rpn(out, self.cfg)
+        res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count}
+        if self.roipool:
+            feats = out["backbone_features"].transpose(1, 2).contiguous()
+            res["pooled"], res["empty"] = roipool3d_ops.roipool3d_gpu(out["backbone_xyz"], feats, boxes, self.cfg.roi_extra_width,
+                                                                      sampled_pt_num=self.cfg.roi_sampled_pts)
+        return res
+
+    def _prime(self, slot: dict) -> None:
+        """first use of a slot: two eager runs (library workspaces, weight caches), then the capture"""
+        slot["primed"] = True
+        if not self.use_graph or self.graph_error is not None:
+            return
+        try:
+            stream = slot["stream"]
+            stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(stream):
+                for _ in range(2):
+                    self.body(slot["inp"])
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                slot["out"] = self.body(slot["inp"])
+            slot["graph"] = graph
+        except Exception as exc:      # capture is an optimisation: fall back to eager launches on the slot streams
+            self.graph_error = repr(exc)
+            slot["graph"] = None
+
+    def capture_all(self) -> bool:
+        """prime every slot now (otherwise each is primed on first use); True if the graphs were captured"""
+        for slot in self.slots:
+            if not slot["primed"]:
+                slot["inp"].copy_(self.slots[0]["inp"])
+                self._prime(slot)
+        torch.cuda.synchronize(self.device)
+        return self.use_graph and self.graph_error is None
+
+    # ------------------------------------------------------------------ submit / collect
+    @torch.no_grad()
+    def submit(self, pts=None) -> int:
+        """start one batch on the next slot -> ticket.  pts (<=B, N, C) host or device (None: reuse the
+        slot's input buffer); a short batch is padded by repeating its last scene.  The results of the
+        batch submitted `depth` tickets ago become invalid."""
+        slot = self.slots[self.submitted % self.depth]
+        with torch.cuda.device(self.device):
+            if pts is not None:
+                t = torch.from_numpy(np.ascontiguousarray(pts, dtype=np.float32)) if not torch.is_tensor(pts) else pts
+                if t.size(0) > self.B or tuple(t.shape[1:]) != tuple(slot["inp"].shape[1:]):
+                    raise ValueError(f"batch of shape {tuple(t.shape)} does not fit the pipeline's {tuple(slot['inp'].shape)}")
+            if not slot["primed"]:
+                if pts is not None:
+                    slot["inp"][:t.size(0)].copy_(t)
+                self._prime(slot)
+            with torch.cuda.stream(slot["stream"]):
+                if pts is not None:
+                    slot["inp"][:t.size(0)].copy_(t, non_blocking=True)
+                    if t.size(0) < self.B:
+                        slot["inp"][t.size(0):] = slot["inp"][t.size(0) - 1]
+                if slot["graph"] is not None:
+                    slot["graph"].replay()
+                else:
+                    slot["out"] = self.body(slot["inp"])
+                slot["done"].record(slot["stream"])
+        self.submitted += 1
+        return self.submitted - 1
+
+    def result(self, ticket: int) -> dict:
+        """wait for a ticket -> its output dict (device tensors owned by the slot)"""
+        if not (self.submitted - self.depth <= ticket < self.submitted):
+            raise ValueError(f"ticket {ticket} is not in flight (submitted {self.submitted}, depth {self.depth})")
+        slot = self.slots[ticket % self.depth]
+        slot["done"].synchronize()
+        return slot["out"]
+
+    def map(self, batches: Iterable) -> Iterator[Tuple[int, int, dict]]:
+        """run every batch of an iterable, `depth` in flight -> (index of its first scene, number of valid
+        scenes, output dict) in submission order"""
+        pending = []          # (ticket, first scene, valid scenes)
+        first = 0
+        for pts in batches:
+            n = int(pts.shape[0])
+            pending.append((self.submit(pts), first, n))
+            first += n
+            if len(pending) == self.depth:
+                ticket, f0, nv = pending.pop(0)
+                yield f0, nv, self.result(ticket)
+        for ticket, f0, nv in pending:
+            yield f0, nv, self.result(ticket)
