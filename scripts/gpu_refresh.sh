@@ -13,6 +13,8 @@ python bench.py --batch 256 --no-cpu-baseline 2>$OUT/bench_c2_b256.err | tail -1
 python bench.py --batch 8 --no-cpu-baseline 2>$OUT/bench_c2_b8.err   | tail -1 > $OUT/bench_c2_b8.json
 python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 > $OUT/bench_c3_b8.json
 python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
+python bench.py --workload c3 --steps 60 --no-cpu-baseline 2>>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_steps60.json
+GPU_MAX_HW_QUEUES=4 python bench.py --workload c3 --pipeline-depth 3 --no-cpu-baseline 2>>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
 python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
 python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
 python bench.py --workload t1               2>$OUT/bench_t1_b8.err   | tail -1 > $OUT/bench_t1_b8.json
