@@ -160,3 +160,28 @@ def test_scene_augmentation_matches_reference_stream(fx):
     pts = np.ones((4, 3)); c = np.ones((2, 3))
     losses.scene_augmentation(pts, c, np.random.RandomState(0))
     assert (pts == 1).all() and (c == 1).all()
+
+
+def test_loader_processes_deliver_the_same_batches():
+    """batches(workers=2): forked loader processes prepare the scenes; composition and order of the
+    mini-batches equal the in-process loader's (a dataset without random draws gives equal data)"""
+    from ws3d_amd.train_rpn import SyntheticCenters, batches
+    ds = SyntheticCenters(10, npoints=512)
+    a = batches(ds, 3, np.random.RandomState(4))
+    b = batches(ds, 3, np.random.RandomState(4), workers=2, ahead=2)
+    try:
+        for _ in range(7):                      # crosses an epoch boundary (3 batches per epoch, drop_last)
+            x, y = next(a), next(b)
+            assert x["sample_id"] == y["sample_id"]
+            for k in ("pts_input", "rpn_cls_label", "rpn_reg_label"):
+                np.testing.assert_array_equal(x[k], y[k])
+    finally:
+        a.close(); b.close()
+    # two ranks take disjoint slices of each global batch, also with loader processes
+    r0 = batches(ds, 2, np.random.RandomState(1), rank=0, world=2, workers=1)
+    r1 = batches(ds, 2, np.random.RandomState(1), rank=1, world=2, workers=1)
+    try:
+        for _ in range(3):
+            assert not set(next(r0)["sample_id"]) & set(next(r1)["sample_id"])
+    finally:
+        r0.close(); r1.close()

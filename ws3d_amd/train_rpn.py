@@ -225,21 +225,67 @@ class KittiCenters:
                 "rpn_cls_label": cls.astype(np.float32), "rpn_reg_label": reg}
 
 
-def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0, world: int = 1) -> Iterator[dict]:
+def _collate(items) -> dict:
+    return {"pts_input": np.stack([s["pts_input"] for s in items]).astype(np.float32),
+            "rpn_cls_label": np.stack([s["rpn_cls_label"] for s in items]),
+            "rpn_reg_label": np.stack([s["rpn_reg_label"] for s in items]),
+            "sample_id": [s["sample_id"] for s in items]}
+
+
+_WORKER_DATASET = None      # inherited by the forked loader processes
+
+
+def _worker_init(seed: int) -> None:
+    """every loader process gets its own random stream (sampling / augmentation draw from numpy)"""
+    seed = (seed + os.getpid()) % (2 ** 31)
+    np.random.seed(seed)
+    rng = getattr(_WORKER_DATASET, "rng", None)
+    if isinstance(rng, np.random.RandomState):
+        rng.seed(seed)
+
+
+def _worker_item(i: int) -> dict:
+    return _WORKER_DATASET[i]
+
+
+def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0, world: int = 1, workers: int = 0,
+            ahead: int = 3) -> Iterator[dict]:
     """endless shuffled mini-batches (drop_last, like the reference's DataLoader); with world > 1
-    every rank takes its own slice of each global batch"""
+    every rank takes its own slice of each global batch.  workers > 0 (the reference's --workers):
+    the scenes of the next `ahead` batches are read / sampled / labelled by that many forked
+    processes -- same batch composition and order as workers = 0; scenes whose preparation draws
+    random numbers (the 16384-point sampler, augmentation) then use per-process streams."""
     n = len(dataset)
     if n < batch_size * world:
         raise ValueError(f"{n} scenes < global batch {batch_size * world}")
-    while True:
-        order = rng.permutation(n)
-        for i0 in range(0, n - batch_size * world + 1, batch_size * world):
-            ids = order[i0 + rank * batch_size:i0 + (rank + 1) * batch_size]
-            items = [dataset[int(i)] for i in ids]
-            yield {"pts_input": np.stack([s["pts_input"] for s in items]).astype(np.float32),
-                   "rpn_cls_label": np.stack([s["rpn_cls_label"] for s in items]),
-                   "rpn_reg_label": np.stack([s["rpn_reg_label"] for s in items]),
-                   "sample_id": [s["sample_id"] for s in items]}
+
+    def id_batches():
+        while True:
+            order = rng.permutation(n)
+            for i0 in range(0, n - batch_size * world + 1, batch_size * world):
+                yield [int(i) for i in order[i0 + rank * batch_size:i0 + (rank + 1) * batch_size]]
+
+    if workers <= 0:
+        for ids in id_batches():
+            yield _collate([dataset[i] for i in ids])
+        return
+    import collections
+    import concurrent.futures
+    import multiprocessing
+    global _WORKER_DATASET
+    _WORKER_DATASET = dataset
+    pool = concurrent.futures.ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("fork"),
+                                                  initializer=_worker_init, initargs=(int(rng.randint(2 ** 31 - 1)),))
+    try:
+        ids_gen, queue = id_batches(), collections.deque()
+        for _ in range(max(1, ahead)):
+            queue.append([pool.submit(_worker_item, i) for i in next(ids_gen)])
+        while True:
+            futures = queue.popleft()
+            queue.append([pool.submit(_worker_item, i) for i in next(ids_gen)])
+            yield _collate([f.result() for f in futures])
+    finally:
+        pool.shutdown(wait=False, cancel_futures=True)
 
 
 class DevicePrefetcher:
@@ -385,7 +431,7 @@ def evaluate(model: nn.Module, dataset, net_cfg: stage1.RPNConfig = stage1.DEFAU
 def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] = None, ckpt: Optional[str] = None,
           pretrain_ckpt: Optional[str] = None, ckpt_save_interval: int = 20, seed: int = 0, device: str = "cuda:0",
           net_cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, train_cfg: TrainConfig = TrainConfig(), logger=None,
-          distributed: bool = False, prefetch: bool = True) -> dict:
+          distributed: bool = False, prefetch: bool = True, workers: int = 0) -> dict:
     """-> {'model', 'optimizer', 'it', 'history' (loss per iteration), 'checkpoints'}
     prefetch: build / upload the next batch and run its furthest point sampling on a side stream
     while the current step computes (DevicePrefetcher); same losses either way."""
@@ -412,9 +458,8 @@ def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] 
     per_epoch = max(len(dataset) // (batch_size * world), 1)
     n_epochs = max(int(total_iters / per_epoch), 1)
     save_every = max(int(n_epochs / min(n_epochs, ckpt_save_interval)), 1) * per_epoch
-    stream = batches(dataset, batch_size, np.random.RandomState(seed), rank, world)
-    if prefetch and dev.type == "cuda":
-        stream = DevicePrefetcher(stream, dev, net_cfg.npoints)
+    source = batches(dataset, batch_size, np.random.RandomState(seed), rank, world, workers=workers)
+    stream = DevicePrefetcher(source, dev, net_cfg.npoints) if prefetch and dev.type == "cuda" else source
     history, saved = [], []
     try:
         return _train_loop(net, model, optimizer, stream, it, total_iters, net_cfg, train_cfg, dev, rank, log, ckpt_dir,
@@ -422,6 +467,7 @@ def train(dataset, total_iters: int, batch_size: int, output_dir: Optional[str] 
     finally:
         if isinstance(stream, DevicePrefetcher):
             stream.close()
+        source.close()                      # stops the loader processes
 
 
 def _train_loop(net, model, optimizer, stream, it, total_iters, net_cfg, train_cfg, dev, rank, log, ckpt_dir, save_every,
@@ -451,7 +497,7 @@ def main():
     ap.add_argument("--batch_size", type=int, default=25)
     ap.add_argument("--total_iters", type=int, default=8000)
     ap.add_argument("--ckpt_save_interval", type=int, default=20)
-    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=0, help="loader processes preparing the next batches (0: in the training process)")
     ap.add_argument("--output_dir", type=str, default=None)
     ap.add_argument("--mgpus", action="store_true", default=False, help="one process per GPU under torchrun (DDP over RCCL)")
     ap.add_argument("--ckpt", type=str, default=None)
@@ -478,7 +524,7 @@ def main():
     else:
         ap.error("give --data_root or --synthetic N")
     res = train(ds, a.total_iters, a.batch_size, out_dir, a.ckpt, a.pretrain_ckpt, a.ckpt_save_interval,
-                device=f"cuda:{local}", distributed=distributed, prefetch=not a.no_prefetch)
+                device=f"cuda:{local}", distributed=distributed, prefetch=not a.no_prefetch, workers=a.workers)
     if int(os.environ.get("RANK", "0")) == 0:
         logging.getLogger("ws3d_amd.train_rpn").info("done: it %d, last checkpoint %s, median %.1f ms/it", res["it"],
                                                      res["checkpoints"][-1] if res["checkpoints"] else None,
