@@ -654,6 +654,13 @@ def test_kitti_directory_to_result_files(ops, tmp_path):
         for x, y in zip(oa, ob):
             np.testing.assert_allclose(x.box3d(), y.box3d(), atol=2e-3)
             np.testing.assert_allclose(x.box2d, y.box2d, atol=5e-2)
+    # loader processes + a deeper pipeline: every scene still gets its file (the 16384-point sampler then
+    # draws from per-process random streams, so the proposals are those of another sampling of the scan)
+    par = infer_kitti.run(root, "val", str(tmp_path / "res3"), batch=1, depth=3, workers=2)
+    assert [os.path.basename(f) for f in par] == ["000007.txt", "000008.txt", "000011.txt"]
+    for f in par:
+        objs = kitti_io.read_label_file(f)
+        assert 0 < len(objs) <= 100 and all(np.isfinite(o.box3d()).all() for o in objs)
 
 
 # ------------------------------------------------------------------------------- Stage-2 (RCNN) shapes, SURVEY 8f.3

@@ -16,12 +16,13 @@ import os
 import numpy as np
 import torch
 
-from . import kitti_io, stage1
+from . import kitti_io, loader, stage1
 from .pipeline import Stage1Pipeline, ensure_hw_queues
 
 
 def run(root: str, split: str, out_dir: str, batch: int = 8, ckpt: str | None = None, npoints: int = 16384,
-        seed: int = 666, device: str = "cuda:0", cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, depth: int = 4) -> list:
+        seed: int = 666, device: str = "cuda:0", cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, depth: int = 4,
+        workers: int = 0) -> list:
     """returns the list of result files written (one per scene, possibly empty)"""
     dev = torch.device(device)
     model = stage1.Stage1Net(mode="TEST", cfg=cfg).to(dev).eval()
@@ -38,10 +39,11 @@ def run(root: str, split: str, out_dir: str, batch: int = 8, ckpt: str | None = 
     starts = list(range(0, len(scenes), batch))
     loaded = {}
 
-    def batches():
-        for i0 in starts:
-            loaded[i0] = [scenes[i] for i in range(i0, min(i0 + batch, len(scenes)))]
-            yield kitti_io.collate_scenes(loaded[i0])["pts_input"]
+    def batches():      # scans read + sampled in `workers` loader processes when asked for (ws3d_amd.loader)
+        ids = [list(range(i0, min(i0 + batch, len(scenes)))) for i0 in starts]
+        for i0, items in zip(starts, loader.item_batches(scenes, ids, workers, ahead=depth + 1, seed=seed)):
+            loaded[i0] = items
+            yield kitti_io.collate_scenes(items)["pts_input"]
 
     # `depth` batches in flight (ws3d_amd.pipeline): the next scans are read and sampled on the host while the device works
     pipe = Stage1Pipeline(model, cfg, batch=batch, n_points=npoints, depth=depth, device=dev)
@@ -63,9 +65,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--npoints", type=int, default=16384)
     ap.add_argument("--pipeline_depth", type=int, default=4, help="batches in flight on separate HIP streams")
+    ap.add_argument("--workers", type=int, default=0, help="loader processes reading / sampling the next scans")
     a = ap.parse_args()
     ensure_hw_queues()
-    files = run(a.root, a.split, a.out, a.batch, a.ckpt, a.npoints, depth=a.pipeline_depth)
+    files = run(a.root, a.split, a.out, a.batch, a.ckpt, a.npoints, depth=a.pipeline_depth, workers=a.workers)
     print(f"{len(files)} result files in {a.out}")
 
 

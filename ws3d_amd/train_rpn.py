@@ -36,7 +36,7 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import clip_grad_norm_
 
-from . import kitti_io, losses, pn2_ops, stage1
+from . import kitti_io, loader, losses, pn2_ops, stage1
 
 
 @dataclass(frozen=True)
@@ -232,22 +232,6 @@ def _collate(items) -> dict:
             "sample_id": [s["sample_id"] for s in items]}
 
 
-_WORKER_DATASET = None      # inherited by the forked loader processes
-
-
-def _worker_init(seed: int) -> None:
-    """every loader process gets its own random stream (sampling / augmentation draw from numpy)"""
-    seed = (seed + os.getpid()) % (2 ** 31)
-    np.random.seed(seed)
-    rng = getattr(_WORKER_DATASET, "rng", None)
-    if isinstance(rng, np.random.RandomState):
-        rng.seed(seed)
-
-
-def _worker_item(i: int) -> dict:
-    return _WORKER_DATASET[i]
-
-
 def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0, world: int = 1, workers: int = 0,
             ahead: int = 3) -> Iterator[dict]:
     """endless shuffled mini-batches (drop_last, like the reference's DataLoader); with world > 1
@@ -265,27 +249,9 @@ def batches(dataset, batch_size: int, rng: np.random.RandomState, rank: int = 0,
             for i0 in range(0, n - batch_size * world + 1, batch_size * world):
                 yield [int(i) for i in order[i0 + rank * batch_size:i0 + (rank + 1) * batch_size]]
 
-    if workers <= 0:
-        for ids in id_batches():
-            yield _collate([dataset[i] for i in ids])
-        return
-    import collections
-    import concurrent.futures
-    import multiprocessing
-    global _WORKER_DATASET
-    _WORKER_DATASET = dataset
-    pool = concurrent.futures.ProcessPoolExecutor(workers, mp_context=multiprocessing.get_context("fork"),
-                                                  initializer=_worker_init, initargs=(int(rng.randint(2 ** 31 - 1)),))
-    try:
-        ids_gen, queue = id_batches(), collections.deque()
-        for _ in range(max(1, ahead)):
-            queue.append([pool.submit(_worker_item, i) for i in next(ids_gen)])
-        while True:
-            futures = queue.popleft()
-            queue.append([pool.submit(_worker_item, i) for i in next(ids_gen)])
-            yield _collate([f.result() for f in futures])
-    finally:
-        pool.shutdown(wait=False, cancel_futures=True)
+    worker_seed = int(rng.get_state()[1][0]) % (2 ** 31)      # derived without drawing: the batch order must not depend on `workers`
+    for items in loader.item_batches(dataset, id_batches(), workers, ahead, seed=worker_seed):
+        yield _collate(items)
 
 
 class DevicePrefetcher:
