@@ -95,6 +95,10 @@ WS3D_API int ws3d_ball_query(int b, int n, int m, float radius, int nsample, con
  * against the same xyz.                                                                        */
 WS3D_API size_t ws3d_sorted_points_bytes(int b, int n);
 WS3D_API int ws3d_sort_points_x(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream);
+/* Same buffer size and layout, but the points are binned into a near-square (x, z) grid (~2 points per
+ * cell) instead of x slabs: for ws3d_three_nn ONLY (its search then visits square rings of cells around
+ * the query, ~20 candidates instead of an x slab of ~100); not accepted by the ball-query entries.   */
+WS3D_API int ws3d_sort_points_xz(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream);
 
 /* group_points_wrapper(b,c,n,npoints,nsample,points,idx,out)   group_points.cpp:25-36
  * -> group_points_gpu.cu:47-86.  points (b,c,n), idx (b,npoints,nsample) ->
@@ -118,7 +122,7 @@ WS3D_API int ws3d_query_and_group(int b, int n, int m, int c, float radius, int 
 /* three_nn_wrapper(b,n,m,unknown,known,dist2,idx)   interpolate.cpp:14-23 ->
  * interpolate_gpu.cu:9-67.  unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3)
  * SQUARED distances, idx (b,n,3).  sorted_known: NULL (full scan) or the x-binned copy of
- * `known` from ws3d_sort_points_x(b, m, known, ...) -- same result, the search then only visits
+ * `known` from ws3d_sort_points_x / ws3d_sort_points_xz(b, m, known, ...) -- same result, the search then only visits
  * the known points whose x is closer than the running third-best distance.            */
 WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
                   int32_t *idx, const void *sorted_known, ws3d_stream_t stream);

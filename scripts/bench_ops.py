@@ -131,7 +131,12 @@ def nn_case(B, N, M):
         return
     t_sort = timeit(lambda: c.sort_points_x(kn, min_n=64))[0]
     t_s = timeit(lambda: c.three_nn_wrapper(B, N, M, unk, kn, d2, i2, srt))[0]
-    print(f"three_nn B={B} N={N} M={M}: brute {t_b:.3f} ms, binned {t_s:.3f} ms + sort {t_sort:.3f} ms")
+    ref = i2.clone()
+    grid = c.sort_points_xz(kn, min_n=1)
+    t_gsort = timeit(lambda: c.sort_points_xz(kn, min_n=1))[0]
+    t_g = timeit(lambda: c.three_nn_wrapper(B, N, M, unk, kn, d2, i2, grid))[0]
+    print(f"three_nn B={B} N={N} M={M}: brute {t_b:.3f} ms, x-binned {t_s:.3f} ms + sort {t_sort:.3f} ms, "
+          f"xz-grid {t_g:.3f} ms + sort {t_gsort:.3f} ms (same idx: {bool(torch.equal(ref, i2))})")
 
 
 if __name__ == "__main__" and "--what" in sys.argv and sys.argv[sys.argv.index("--what") + 1] == "nn":

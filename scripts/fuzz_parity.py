@@ -53,7 +53,7 @@ def one_round(rng):
     if M >= 1:
         d2r, ir = oracle.three_nn_dist2(pc, cen)
         sk = c.sort_points_x(dev(cen), min_n=64)
-        for s in ([None, sk] if sk is not None else [None]):
+        for s in ([None, sk, c.sort_points_xz(dev(cen), min_n=1)] if sk is not None else [None, c.sort_points_xz(dev(cen), min_n=1)]):
             d2 = torch.empty((B, N, 3), device="cuda"); i3 = torch.empty((B, N, 3), dtype=torch.int32, device="cuda")
             c.three_nn_wrapper(B, N, M, dev(pc), dev(cen), d2, i3, s)
             assert np.array_equal(host(i3), ir) and np.array_equal(host(d2), d2r), ("three_nn", B, N, M, s is not None)

@@ -296,7 +296,9 @@ def test_three_nn_bit_exact(ops, oracle, B, n, m, seed):
 
 @pytest.mark.parametrize("B,n,m,kind,seed", [(2, 4096, 2048, "lidar", 1), (1, 16384, 4096, "lidar", 2), (2, 3000, 2500, "uniform", 3),
                                              (1, 5000, 2048, "dups", 4), (1, 4096, 2100, "line", 5), (1, 2500, 2048, "outside", 6),
-                                             (1, 2048, 2048, "samex", 7), (1, 7000, 6000, "lidar", 8)])
+                                             (1, 2048, 2048, "samex", 7), (1, 7000, 6000, "lidar", 8),
+                                             (1, 500, 3, "uniform", 9), (2, 700, 64, "lidar", 10), (1, 3000, 300, "lattice", 11),
+                                             (1, 2048, 2048, "samez", 12), (1, 300, 40, "point", 13), (1, 1200, 1000, "lattice", 14)])
 def test_three_nn_binned_search_bit_exact(ops, oracle, B, n, m, kind, seed):
     """the x-binned 3-NN == the full ascending scan, including equal-distance tie-breaks (duplicated
     known points), unknown points outside the known x range (clamped cells), a degenerate x
@@ -317,14 +319,23 @@ def test_three_nn_binned_search_bit_exact(ops, oracle, B, n, m, kind, seed):
         unk[:, :, 0] *= 3.0
     if kind == "samex":     # all known points share one x: zero-width binning
         kn[:, :, 0] = 1.25
+    if kind == "samez":     # ... or one z: a one-row grid
+        kn[:, :, 2] = 30.0
+    if kind == "point":     # every known point at the same place: a 1 x 1 grid, all distances tie
+        kn[:] = kn[:, :1]
+    if kind == "lattice":   # integer lattice in (x, z): exact ties between cells of the grid, queries on lattice points too
+        kn[:, :, 0] = rng.integers(-20, 20, (B, m)); kn[:, :, 2] = rng.integers(0, 40, (B, m)); kn[:, :, 1] = rng.integers(0, 2, (B, m))
+        unk[:, :, 0] = rng.integers(-25, 25, (B, n)) * 0.5; unk[:, :, 2] = rng.integers(-5, 90, (B, n)) * 0.5; unk[:, :, 1] = 0.5
     kn = np.ascontiguousarray(kn.astype(np.float32)); unk = np.ascontiguousarray(unk.astype(np.float32))
     d2_ref, idx_ref = oracle.three_nn_dist2(unk, kn)
-    srt = ops.c.sort_points_x(dev(kn))
-    assert srt is not None
-    d2 = torch.empty((B, n, 3), device="cuda"); i2 = torch.empty((B, n, 3), dtype=torch.int32, device="cuda")
-    ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2, i2, srt)
-    np.testing.assert_array_equal(host(i2), idx_ref)
-    np.testing.assert_array_equal(host(d2), d2_ref)
+    srt = ops.c.sort_points_x(dev(kn), min_n=1)
+    grid = ops.c.sort_points_xz(dev(kn), min_n=1)           # the (x, z) grid flavour of the binned known set
+    assert srt is not None and grid is not None
+    for binned in (srt, grid):
+        d2 = torch.full((B, n, 3), float("nan"), device="cuda"); i2 = torch.full((B, n, 3), -7, dtype=torch.int32, device="cuda")
+        ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2, i2, binned)
+        np.testing.assert_array_equal(host(i2), idx_ref)
+        np.testing.assert_array_equal(host(d2), d2_ref)
     d2b = torch.empty_like(d2); i2b = torch.empty_like(i2)
     ops.c.three_nn_wrapper(B, n, m, dev(unk), dev(kn), d2b, i2b)          # full scan kernel
     np.testing.assert_array_equal(host(i2b), host(i2))
@@ -949,7 +960,7 @@ def test_nonfinite_coordinates_follow_the_reference_semantics(ops, oracle):
     kn = _poison(big[:, :2048].copy(), rng, k=2)
     unk = _poison(big[:, 1000:3500].copy(), rng, k=2)
     d2_ref, i_ref = oracle.three_nn_dist2(unk, kn)
-    for sorted_known in (None, ops.c.sort_points_x(dev(kn))):
+    for sorted_known in (None, ops.c.sort_points_x(dev(kn)), ops.c.sort_points_xz(dev(kn))):
         d2 = torch.empty((2, 2500, 3), device="cuda"); i3 = torch.empty((2, 2500, 3), dtype=torch.int32, device="cuda")
         ops.c.three_nn_wrapper(2, 2500, 2048, dev(unk), dev(kn), d2, i3, sorted_known)
         np.testing.assert_array_equal(host(i3), i_ref)

@@ -122,6 +122,22 @@ def sort_points_x(xyz, min_n=None):
     return out
 
 
+def sort_points_xz(xyz, min_n=256):
+    """(B,N,3) -> the same kind of buffer as sort_points_x, binned into an (x, z) grid: for three_nn's
+    ``sorted_known`` only (NOT for the ball query).  None when N < min_n or N > 16384.  ws3d extension."""
+    dev = _dev(xyz)
+    _f32(xyz, "xyz")
+    b, n = xyz.size(0), xyz.size(1)
+    lib = _lib.load()
+    nbytes = lib.ws3d_sorted_points_bytes(b, n)
+    if n < min_n or nbytes == 0:
+        return None
+    out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.ws3d_sort_points_xz(b, n, _p(xyz), _p(out), _stream()), "sort_points_xz")
+    return out
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz=None):
     """ball_query.cpp:14-25 (sorted_xyz: optional output of sort_points_x for this xyz)"""
     dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz)

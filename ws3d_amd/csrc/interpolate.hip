@@ -83,6 +83,83 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     }
 }
 
+// ---- (x, z) grid flavour of the binned known set (binning.h), for the 3-NN search only ----
+// One workgroup per scene: bounding box of the finite (x, z), a gx x gz grid of near-square cells with
+// ~2 points each (gx * gz <= BQS_CELLS), LDS histogram, exclusive scan, scatter.
+__global__ __launch_bounds__(1024) void bin_points_xz_kernel(int n, const float *__restrict__ xyz, char *__restrict__ ws) {
+    __shared__ int hist[BQS_CELLS];
+    __shared__ int wsum[16];
+    __shared__ float red[4][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    xyz += (size_t)b * n * 3;
+    char *base = ws + (size_t)b * bin_scene_stride(n);
+    float4 *sorted = reinterpret_cast<float4 *>(base);
+    BinHeader *hdr = reinterpret_cast<BinHeader *>(base + (size_t)n * 16);
+    int *start = reinterpret_cast<int *>(base + (size_t)n * 16 + sizeof(BinHeader));
+
+    float lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float x = xyz[(size_t)i * 3], z = xyz[(size_t)i * 3 + 2];
+        if (fabsf(x) < INFINITY) { lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); }
+        if (fabsf(z) < INFINITY) { lo_z = fminf(lo_z, z); hi_z = fmaxf(hi_z, z); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, o)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+        lo_z = fminf(lo_z, __shfl_xor(lo_z, o)); hi_z = fmaxf(hi_z, __shfl_xor(hi_z, o));
+    }
+    if (lane == 0) { red[0][w] = lo_x; red[1][w] = hi_x; red[2][w] = lo_z; red[3][w] = hi_z; }
+    for (int i = tid; i < BQS_CELLS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    lo_x = red[0][0]; hi_x = red[1][0]; lo_z = red[2][0]; hi_z = red[3][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        lo_x = fminf(lo_x, red[0][i]); hi_x = fmaxf(hi_x, red[1][i]);
+        lo_z = fminf(lo_z, red[2][i]); hi_z = fmaxf(hi_z, red[3][i]);
+    }
+    const float xmin = lo_x <= hi_x ? lo_x : 0.f, wx = lo_x <= hi_x ? hi_x - lo_x : 0.f;
+    const float zmin = lo_z <= hi_z ? lo_z : 0.f, wz = lo_z <= hi_z ? hi_z - lo_z : 0.f;
+    // near-square cells, about two points each; a degenerate extent gets one cell along that axis
+    int gx = 1, gz = 1;
+    const int target = max(1, min(BQS_CELLS, n / 2));
+    if (wx > 0.f && wz > 0.f) {
+        const float h = sqrtf(wx * wz / (float)target);
+        gx = max(1, min(BQS_CELLS, (int)ceilf(wx / h)));
+        gz = max(1, min(BQS_CELLS / gx, (int)ceilf(wz / h)));
+    } else if (wx > 0.f) {
+        gx = target;
+    } else if (wz > 0.f) {
+        gz = target;
+    }
+    const float inv_wx = wx > 0.f ? (float)gx / wx : 0.f, inv_wz = wz > 0.f ? (float)gz / wz : 0.f;
+    auto cell_of = [&](const float *p) { return grid_coord(p[2], zmin, inv_wz, gz) * gx + grid_coord(p[0], xmin, inv_wx, gx); };
+    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[cell_of(xyz + (size_t)i * 3)], 1);
+    __syncthreads();
+    const int a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
+    int v = a0 + a1;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    const int excl = off + v - (a0 + a1);
+    __syncthreads();
+    hist[2 * tid] = excl;
+    hist[2 * tid + 1] = excl + a0;
+    start[2 * tid] = excl;
+    start[2 * tid + 1] = excl + a0;
+    if (tid == 0) {
+        start[BQS_CELLS] = n;
+        hdr->xmin = xmin; hdr->inv_w = inv_wx; hdr->n = n; hdr->pad = gx;
+        start[GRID_ZMIN] = __float_as_int(zmin); start[GRID_INV_WZ] = __float_as_int(inv_wz); start[GRID_GZ] = gz;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float *p = xyz + (size_t)i * 3;
+        const int pos = atomicAdd(&hist[cell_of(p)], 1);
+        sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+    }
+}
+
 // Exact 3-NN against an x-binned copy of the known set (binning.h; built once per FP layer by
 // ws3d_sort_points_x).  The reference's ascending scan with strict '<' keeps, among equal
 // distances, the smaller index in front: its result is the 3 smallest (d2, index) pairs in
@@ -107,15 +184,20 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
     const int pi = blockIdx.x * 512 + threadIdx.x;
     const char *base = ws + (size_t)b * bin_scene_stride(m);
     const float4 *sorted = reinterpret_cast<const float4 *>(base);
+    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)m * 16);
+    const int *start = reinterpret_cast<const int *>(base + (size_t)m * 16 + sizeof(BinHeader));
     if (LDS) {
         float4 *stage = reinterpret_cast<float4 *>(smem_nn);
         for (int i = threadIdx.x; i < m; i += 512) stage[i] = sorted[i];
-        __syncthreads();
         sorted = stage;
+        if (hdr.pad > 0) {          // grid flavour: the cell table is read several times per query
+            int *tab = reinterpret_cast<int *>(stage + m);
+            for (int i = threadIdx.x; i < BQS_CELLS + 4; i += 512) tab[i] = start[i];
+            start = tab;
+        }
+        __syncthreads();
     }
     if (pi >= n) return;
-    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)m * 16);
-    const int *start = reinterpret_cast<const int *>(base + (size_t)m * 16 + sizeof(BinHeader));
     const float *u = unknown + ((size_t)b * n + pi) * 3;
     const float ux = u[0], uy = u[1], uz = u[2];
     const float slack = hdr.inv_w > 0.f ? 2.0f / hdr.inv_w : INFINITY;   // two cell widths, see above
@@ -135,6 +217,47 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
             }
         }
     };
+    if (hdr.pad > 0) {
+        // ---- (x, z) grid: square rings of cells around the query's cell ----
+        // After the rings 0..r every unvisited known point lies in a cell whose x or z coordinate
+        // differs from the query's by more than r cells, so its distance exceeds r cell sizes (minus
+        // the fp32 error of the cell coordinates, <= 1e-3 cell): stop once that bound exceeds the third
+        // best.  The query's cell is clamped into the grid; for a query outside the bounding box the
+        // bound only gets more conservative.  Rows of a ring are contiguous ranges of the cell table.
+        const int gx = hdr.pad, gz = start[GRID_GZ];
+        const float inv_wx = hdr.inv_w, inv_wz = __int_as_float(start[GRID_INV_WZ]);
+        const int cx = grid_coord(ux, hdr.xmin, inv_wx, gx), cz = grid_coord(uz, __int_as_float(start[GRID_ZMIN]), inv_wz, gz);
+        float hmin = INFINITY;                        // the smaller cell size of the axes that have more than one cell
+        if (gx > 1) hmin = fminf(hmin, 1.0f / inv_wx);
+        if (gz > 1) hmin = fminf(hmin, 1.0f / inv_wz);
+        auto scan = [&](int z, int x_lo, int x_hi) {  // cells (x_lo..x_hi, z), clipped to the grid
+            if (z < 0 || z >= gz) return;
+            x_lo = max(x_lo, 0); x_hi = min(x_hi, gx - 1);
+            if (x_lo > x_hi) return;
+            int i = start[z * gx + x_lo];
+            const int e = start[z * gx + x_hi + 1];
+            for (; i + 1 < e; i += 2) {               // two independent loads per trip
+                const float4 p0 = sorted[i], p1 = sorted[i + 1];
+                visit(p0); visit(p1);
+            }
+            if (i < e) visit(sorted[i]);
+        };
+        for (int dz = -1; dz <= 1; ++dz) scan(cz + dz, cx - 1, cx + 1);          // rings 0 and 1 as one 3 x 3 block
+        const int reach = max(max(cx, gx - 1 - cx), max(cz, gz - 1 - cz));       // last ring that still holds cells
+        for (int r = 1; r < reach; ) {
+            const float lb = (float)r * hmin * 0.999f;
+            if (lb * lb > b3) break;
+            ++r;
+            scan(cz - r, cx - r, cx + r);
+            scan(cz + r, cx - r, cx + r);
+            for (int z = cz - r + 1; z <= cz + r - 1; ++z) { scan(z, cx - r, cx - r); scan(z, cx + r, cx + r); }
+        }
+        float *odg = dist2 + ((size_t)b * n + pi) * 3;
+        int32_t *oig = idx + ((size_t)b * n + pi) * 3;
+        odg[0] = b1; odg[1] = b2; odg[2] = b3;
+        oig[0] = i1; oig[1] = i2; oig[2] = i3;
+        return;
+    }
     const int c0 = x_cell(ux, hdr.xmin, hdr.inv_w);
     int R = start[c0], L = R - 1;
     bool go_r = R < m, go_l = L >= 0;
@@ -649,6 +772,17 @@ extern "C" int ws3d_three_nn_weights(long rows, const float *dist2, float *weigh
     return check_launch("ws3d_three_nn_weights");
 }
 
+extern "C" int ws3d_sort_points_xz(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || n > SORT_MAX_N || !xyz || !sorted) {
+        set_error("ws3d_sort_points_xz: invalid argument (b=%d n=%d, n <= %d)", b, n, SORT_MAX_N);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0) return WS3D_OK;
+    hipLaunchKernelGGL(bin_points_xz_kernel, dim3(b), dim3(1024), 0, as_stream(stream), n, xyz, reinterpret_cast<char *>(sorted));
+    return check_launch("ws3d_sort_points_xz");
+}
+
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
                              float *dist2, int32_t *idx, const void *sorted_known, ws3d_stream_t stream) {
     using namespace ws3d;
@@ -658,10 +792,17 @@ extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const fl
     }
     if (b == 0 || n == 0) return WS3D_OK;
     if (sorted_known && m >= 3 && m <= SORT_MAX_N) {
-        const size_t lds = (size_t)m * sizeof(float4);
-        if (lds <= 64 * 1024)
+        const size_t lds = (size_t)m * sizeof(float4) + (size_t)(BQS_CELLS + 4) * sizeof(int);
+        if ((size_t)m * sizeof(float4) <= 64 * 1024) {
+            static bool attr = false;
+            if (!attr) {
+                (void)hipFuncSetAttribute((const void *)three_nn_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          80 * 1024);
+                attr = true;
+            }
             hipLaunchKernelGGL(three_nn_sorted_kernel<true>, dim3((n + 511) / 512, b), dim3(512), lds, as_stream(stream),
                                n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);
+        }
         else
             hipLaunchKernelGGL(three_nn_sorted_kernel<false>, dim3((n + 511) / 512, b), dim3(512), 0, as_stream(stream),
                                n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);

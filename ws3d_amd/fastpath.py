@@ -105,7 +105,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
 def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
     B, n = unknown.size(0), unknown.size(1)
-    idx, weight = _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_x(known, min_n=256))
+    idx, weight = _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
     if c1 % 4 == 0:

@@ -101,7 +101,7 @@ class PointnetFPModule(nn.Module):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n), known_feats (B,C2,m) -> (B,mlp[-1],n)"""
         if known is not None:
             # x-binned copy of the known set (None below 256 points): exact pruned 3-NN search
-            dist, idx = pointnet2_utils.three_nn(unknown, known, pointnet2_utils.sort_points_x(known, min_n=256))
+            dist, idx = pointnet2_utils.three_nn(unknown, known, pointnet2_utils.sort_points_xz(known))
             dist_recip = 1.0 / (dist + 1e-8)
             norm = torch.sum(dist_recip, dim=2, keepdim=True)
             weight = dist_recip / norm

@@ -278,6 +278,12 @@ def sort_points_x(xyz: torch.Tensor, min_n=None):
     return _C.sort_points_x(xyz, min_n)
 
 
+def sort_points_xz(xyz: torch.Tensor, min_n: int = 256):
+    """Per-scene copy of xyz binned into an (x, z) grid (or None for small sets): the ``sorted_known``
+    of ``three_nn`` -- same neighbours, the search visits ~20 candidates per query.  Not for the ball query."""
+    return _C.sort_points_xz(xyz, min_n)
+
+
 def query_and_group(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor,
                     features: torch.Tensor = None, use_xyz: bool = True, return_idx: bool = False,
                     sorted_xyz: torch.Tensor = None):
