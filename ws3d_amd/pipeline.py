@@ -38,7 +38,7 @@ def ensure_hw_queues(n: int = 24) -> bool:
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
-                 channels: int = 4):
+                 channels: int = 4, tune_gemms: bool = True):
         self.model, self.cfg, self.B, self.depth, self.roipool = model.eval(), cfg, int(batch), max(1, int(depth)), roipool
         self.device = torch.device(device)
         self.hw_queues_raised = ensure_hw_queues()      # False: the runtime already started with its own cap
@@ -51,7 +51,7 @@ class Stage1Pipeline:
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
                                    "done": torch.cuda.Event(), "primed": False})
-        self.use_graph = use_graph
+        self.use_graph, self.tune_gemms = use_graph, tune_gemms
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
@@ -65,11 +65,40 @@ class Stage1Pipeline:
                                                                       sampled_pt_num=self.cfg.roi_sampled_pts)
         return res
 
+    def _tunable(self, on: bool):
+        """the GEMMs between our kernels run on hipBLASLt through torch; its TunableOp times the candidate
+        solutions of each (m, n, k) once -- during the eager priming runs, so the captured graph replays
+        the winners (measured +3 % on c3).  Process-wide switches: restored after the capture."""
+        tun = getattr(torch.cuda, "tunable", None)
+        if not self.tune_gemms or tun is None:
+            return None
+        try:
+            if on:
+                prev = (tun.is_enabled(), tun.tuning_is_enabled())
+                tun.enable(True)
+                tun.tuning_enable(True)
+                if not os.environ.get("PYTORCH_TUNABLEOP_FILENAME"):      # results file: not into the working directory
+                    import tempfile
+                    tun.set_filename(os.path.join(tempfile.gettempdir(), "ws3d_amd_tunableop.csv"), True)
+                return prev
+            return None
+        except Exception:           # an optimisation only
+            return None
+
     def _prime(self, slot: dict) -> None:
         """first use of a slot: two eager runs (library workspaces, weight caches), then the capture"""
         slot["primed"] = True
         if not self.use_graph or self.graph_error is not None:
             return
+        prev = self._tunable(True)
+        try:
+            self._prime_capture(slot)
+        finally:
+            if prev is not None:
+                torch.cuda.tunable.enable(prev[0])
+                torch.cuda.tunable.tuning_enable(prev[1])
+
+    def _prime_capture(self, slot: dict) -> None:
         try:
             stream = slot["stream"]
             stream.wait_stream(torch.cuda.current_stream(self.device))
