@@ -4,7 +4,6 @@ GPU, plus the one all-gather of proposals when world > 1 (BASELINE.json configs[
 from __future__ import annotations
 
 import os
-import time
 
 import numpy as np
 import torch
