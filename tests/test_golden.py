@@ -267,3 +267,45 @@ def test_c1_gpu_sa_layer_matches_reference_harness():
     got = new_feat.cpu().numpy().reshape(-1)[gold["feat_pos"]]
     np.testing.assert_allclose(got, gold["feat_val"], atol=1e-4, rtol=1e-4)
     assert abs(float(np.abs(new_feat.cpu().numpy()).mean()) - case["features_abs_mean"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------- BASELINE configs[4] ("C5")
+def _c5():
+    case = json.load(open(os.path.join(G, "c5_roipool_nms.json")))
+    gold = np.load(os.path.join(G, "c5_roipool_nms.npz"))
+    pc = synth.make_batch("lidar", 1, case["n"], case["config_id"])
+    boxes = synth.proposal_boxes(1, case["boxes"], case["config_id"])
+    boxes[0, 100:108, 0] += 500.0
+    feat = np.random.default_rng(case["feat_seed"]).standard_normal((1, case["n"], case["channels"])).astype(np.float32)
+    return case, gold, pc[:, :, :3].copy(), boxes, feat, synth.distinct_scores(case["boxes"], case["config_id"])
+
+
+def _enlarge(boxes, e):
+    out = boxes.copy()
+    out[..., 3:6] += 2 * e
+    out[..., 1] += e
+    return out
+
+
+def test_c5_oracle_reproduces_the_reference_cpu_roipool_and_nms(oracle):
+    """BASELINE configs[4]: 65536 points x 512 proposals.  The pooled tensor recorded from the reference's
+    own COMPILED roipool3d C++ and the keep list of its nms_gpu wrapper are what the oracle computes"""
+    case, gold, xyz, boxes, feat, scores = _c5()
+    pooled, empty = oracle.roipool3d(xyz, _enlarge(boxes, case["extra_width"]), feat, case["sampled"])
+    np.testing.assert_array_equal(empty[0], gold["empty"])
+    assert list(pooled[0].shape) == case["pooled_shape"] and _sha(pooled[0]) == case["pooled_sha256"]
+    assert int((gold["empty"] == 0).sum()) == case["non_empty"] < case["boxes"]
+    np.testing.assert_array_equal(oracle.nms(synth.boxes3d_to_bev(boxes[0]), scores, case["nms_thresh"], False), gold["nms_keep"])
+
+
+@pytest.mark.gpu
+def test_c5_gpu_roipool_and_nms_match_the_reference():
+    from ws3d_amd import iou3d_ops, roipool3d_ops
+    case, gold, xyz, boxes, feat, scores = _c5()
+    pooled, empty = roipool3d_ops.roipool3d_gpu(dev(xyz), dev(feat), dev(boxes), case["extra_width"], sampled_pt_num=case["sampled"])
+    np.testing.assert_array_equal(empty.cpu().numpy()[0], gold["empty"])
+    got = pooled.cpu().numpy()[0]
+    np.testing.assert_array_equal(got.reshape(-1)[gold["pooled_pos"]], gold["pooled_val"])
+    assert _sha(got) == case["pooled_sha256"]
+    keep = iou3d_ops.nms_gpu(dev(synth.boxes3d_to_bev(boxes[0])), dev(scores), case["nms_thresh"])
+    np.testing.assert_array_equal(keep.cpu().numpy(), gold["nms_keep"])
