@@ -33,9 +33,9 @@ import sys
 import time
 
 # HIP maps streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4): streams that share a
-# queue serialise.  The c3 pipeline keeps 12 batches in flight on 12 streams, so the cap is raised
-# BEFORE the runtime starts (measured: 2,037 scenes/s with 4 queues / 3 in flight, 3,468 with 24 / 12).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# queue serialise.  The c3 pipeline keeps 20 batches in flight on 20 streams, so the cap is raised
+# BEFORE the runtime starts (measured: 2,106 scenes/s with 4 queues / 3 in flight, 3,850 with 32 / 20).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np
 import torch
@@ -468,7 +468,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-prefetch", action="store_true", help="t1: sample inside the step instead of one step ahead")
-    ap.add_argument("--pipeline-depth", type=int, default=12, help="c3: batches in flight (one HIP stream + graph each)")
+    ap.add_argument("--pipeline-depth", type=int, default=20, help="c3: batches in flight (one HIP stream + graph each)")
     args = ap.parse_args()
 
     from ws3d_amd import _lib

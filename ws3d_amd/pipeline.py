@@ -8,10 +8,10 @@ into one hipGraph per slot, each slot on its own HIP stream with its own input b
 others.  Nothing in the C ABI allocates or synchronises, which is what makes the capture possible.
 
 HIP multiplexes streams onto at most ``GPU_MAX_HW_QUEUES`` hardware queues (default 4) and streams
-that share a queue serialise; the variable is read when the runtime starts, so set it (e.g. 24)
+that share a queue serialise; the variable is read when the runtime starts, so set it (e.g. 32)
 before the first device call of the process -- ``ensure_hw_queues()`` does it when still possible.
-Measured (batch 8 x 16384 points, bench.py c3): 942 scenes/s with one batch in flight, 2,037 with 3
-on the default 4 queues, 3,468 with 12 on 24 queues.
+Measured (batch 8 x 16384 points, bench.py c3): 969 scenes/s with one batch in flight, 2,106 with 3
+on the default 4 queues, 3,599 with 12 and 3,850 with 20 on 32 queues (24 in flight: slower again).
 
     pipe = Stage1Pipeline(model, cfg, batch=8, depth=6)
     for first_scene, n_valid, out in pipe.map(batches):      # batches: iterable of (<=B, N, 4) arrays / tensors
@@ -28,7 +28,7 @@ import torch
 from . import roipool3d_ops, stage1
 
 
-def ensure_hw_queues(n: int = 24) -> bool:
+def ensure_hw_queues(n: int = 32) -> bool:
     """raise the runtime's hardware-queue cap unless the user set it; True if the value can still
     take effect (no device context yet in this process)"""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(n))
