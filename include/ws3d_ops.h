@@ -300,6 +300,13 @@ WS3D_API int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int feat
                    int sampled_pts_num, const float *xyz, const float *boxes3d,
                    const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
                    int32_t *pts_idx, ws3d_stream_t stream);
+/* Same result, but EVERY element of pooled_features / pooled_empty_flag (/ pts_idx) is written: no
+ * pre-zeroing by the caller (the wrapper's zero-fill is a 214 MB memset per 8 scenes at the C3 shapes;
+ * here only the rows of empty boxes are zeroed, by the workgroup that found the box empty).        */
+WS3D_API int ws3d_roipool3d_fill(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                   int sampled_pts_num, const float *xyz, const float *boxes3d,
+                   const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
+                   int32_t *pts_idx, ws3d_stream_t stream);
 
 /* Device twin of pts_in_boxes3d_cpu (roipool3d.cpp:97-124): pts (N,3), boxes3d (M,7)
  * -> flag (M,N) int64 in {0,1}.                                                      */

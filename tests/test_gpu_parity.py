@@ -1202,3 +1202,21 @@ def test_stage1_pipeline_equals_the_plain_step(ops):
         pipe.submit(np.zeros((4, 4096, 4), dtype=np.float32))
     with pytest.raises(ValueError):
         pipe.result(99)
+
+
+def test_roipool3d_fill_writes_every_element(ops, oracle):
+    """ws3d_roipool3d_fill: outputs poisoned with NaN / garbage beforehand come out equal to the oracle,
+    empty boxes included (zeros), for row widths that are and are not multiples of 16 bytes"""
+    pc = synth.make_batch("lidar", 2, 3000, 21)[:, :, :3].copy()
+    for C, S in ((8, 64), (5, 33), (0, 16), (128, 512)):
+        boxes = synth.proposal_boxes(2, 24, 21)
+        boxes[0, 3:7, 0] += 400.0; boxes[1, 0, 2] -= 300.0          # empty boxes
+        feat = np.random.default_rng(C + S).standard_normal((2, 3000, C)).astype(np.float32)
+        ref_p, ref_e = oracle.roipool3d(pc, boxes, feat, S)
+        pooled = torch.full((2, 24, S, 3 + C), float("nan"), device="cuda")
+        empty = torch.full((2, 24), 77, dtype=torch.int32, device="cuda")
+        pidx = torch.full((2, 24, S), -5, dtype=torch.int32, device="cuda")
+        ops.c.roipool3d_forward_fill(dev(pc), dev(boxes), dev(feat), pooled, empty, pidx)
+        np.testing.assert_array_equal(host(empty), ref_e)
+        np.testing.assert_array_equal(host(pooled), ref_p)
+        assert (ref_e == 1).sum() >= 5 and (host(pidx)[ref_e == 1] == 0).all() and (host(pidx) >= 0).all()

@@ -61,6 +61,7 @@ SIGNATURES = {
     "ws3d_nms_batched": (_i, [_i, _i, _vp, _f, _i, _i, _vp, _sz, _vp, _vp, _vp]),
     "ws3d_radius_nms_batched": (_i, [_i, _i, _vp, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_roipool3d_fill": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_pts_in_boxes3d": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
 }
 

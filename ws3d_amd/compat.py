@@ -563,6 +563,19 @@ def roipool3d_forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_f
     return 1
 
 
+def roipool3d_forward_fill(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx=None):
+    """roipool3d_forward that writes every output element (outputs need not be pre-zeroed).  ws3d extension."""
+    dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
+    _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
+    _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_roipool3d_fill(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
+                                               pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
+                                               _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
+              "roipool3d_fill")
+    return 1
+
+
 def pts_in_boxes3d_device(pts, boxes3d):
     """device twin of pts_in_boxes3d_cpu: (N,3),(M,7) -> (M,N) int64 on the device"""
     dev = _dev(pts, boxes3d)

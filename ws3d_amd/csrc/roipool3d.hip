@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
                                                         const float *__restrict__ pts_feature,
                                                         float *__restrict__ pooled,
                                                         int32_t *__restrict__ empty_flag,
-                                                        int32_t *__restrict__ pts_idx) {
+                                                        int32_t *__restrict__ pts_idx, int fill) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lists = reinterpret_cast<int *>(smem);  // BG * 4 * S
     int *sel = lists + BG * 4 * S;               // S
@@ -170,8 +170,15 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
             if (tid == 0) empty_flag[bm] = 1;
             if (pts_idx)
                 for (int q = tid; q < S; q += 256) pts_idx[bm * S + q] = 0;
+            if (fill) {  // ws3d_roipool3d_fill: the caller did not pre-zero, write the zeros of an empty box here
+                float *o = pooled + bm * (size_t)total;
+                const float4v zero = {0.f, 0.f, 0.f, 0.f};
+                for (int q = tid * 4; q + 3 < total; q += 1024) *reinterpret_cast<float4u *>(o + q) = zero;
+                for (int q = (total & ~3) + tid; q < total; q += 256) o[q] = 0.f;
+            }
             continue;  // wave-uniform for the whole workgroup
         }
+        if (fill && tid == 0) empty_flag[bm] = 0;
         for (int q = tid; q < S; q += 256) {
             int t = q < cnt ? q : q % cnt;  // duplicate_idx = k % cnt (roipool3d_kernel.cu:153-157)
             int v;
@@ -263,10 +270,10 @@ __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int 
 
 }  // namespace ws3d
 
-extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
-                              int sampled_pts_num, const float *xyz, const float *boxes3d,
-                              const float *pts_feature, float *pooled_features,
-                              int32_t *pooled_empty_flag, int32_t *pts_idx, ws3d_stream_t stream) {
+static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                            int sampled_pts_num, const float *xyz, const float *boxes3d,
+                            const float *pts_feature, float *pooled_features,
+                            int32_t *pooled_empty_flag, int32_t *pts_idx, int fill, ws3d_stream_t stream) {
     using namespace ws3d;
     if (batch_size < 0 || pts_num < 0 || boxes_num < 0 || feature_in_len < 0 || sampled_pts_num <= 0 ||
         !xyz || !boxes3d || (!pts_feature && feature_in_len > 0) || !pooled_features || !pooled_empty_flag) {
@@ -292,11 +299,27 @@ extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int fe
                                       (int)smem);                                                                  \
         hipLaunchKernelGGL(roipool3d_kernel<BGV>, dim3((boxes_num + BGV - 1) / BGV, batch_size), dim3(256), smem, \
                            as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,   \
-                           pts_feature, pooled_features, pooled_empty_flag, pts_idx);                              \
+                           pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill);                        \
     }
     if (bg == 4) WS3D_ROI_LAUNCH(4) else if (bg == 2) WS3D_ROI_LAUNCH(2) else WS3D_ROI_LAUNCH(1)
 #undef WS3D_ROI_LAUNCH
     return check_launch("ws3d_roipool3d");
+}
+
+extern "C" int ws3d_roipool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                              int sampled_pts_num, const float *xyz, const float *boxes3d,
+                              const float *pts_feature, float *pooled_features,
+                              int32_t *pooled_empty_flag, int32_t *pts_idx, ws3d_stream_t stream) {
+    return roipool3d_launch(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
+                            pooled_features, pooled_empty_flag, pts_idx, 0, stream);
+}
+
+extern "C" int ws3d_roipool3d_fill(int batch_size, int pts_num, int boxes_num, int feature_in_len,
+                                   int sampled_pts_num, const float *xyz, const float *boxes3d,
+                                   const float *pts_feature, float *pooled_features,
+                                   int32_t *pooled_empty_flag, int32_t *pts_idx, ws3d_stream_t stream) {
+    return roipool3d_launch(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
+                            pooled_features, pooled_empty_flag, pts_idx, 1, stream);
 }
 
 extern "C" int ws3d_pts_in_boxes3d(int boxes_num, int pts_num, const float *pts, const float *boxes3d,

@@ -11,11 +11,12 @@ from . import kitti_utils
 
 def _pool(pts, pts_feature, pooled_boxes3d, sampled_pt_num):
     batch_size, boxes_num, feature_len = pts.shape[0], pooled_boxes3d.shape[1], pts_feature.shape[2]
-    pooled_features = torch.zeros((batch_size, boxes_num, sampled_pt_num, 3 + feature_len),
+    # the kernel writes every element (zeros for empty boxes): no 214 MB memset per 8 scenes at S=512, C=128
+    pooled_features = torch.empty((batch_size, boxes_num, sampled_pt_num, 3 + feature_len),
                                   dtype=torch.float32, device=pts.device)
-    pooled_empty_flag = torch.zeros((batch_size, boxes_num), dtype=torch.int32, device=pts.device)
-    _C.roipool3d_forward(pts.contiguous(), pooled_boxes3d.contiguous(), pts_feature.contiguous(),
-                         pooled_features, pooled_empty_flag)
+    pooled_empty_flag = torch.empty((batch_size, boxes_num), dtype=torch.int32, device=pts.device)
+    _C.roipool3d_forward_fill(pts.contiguous(), pooled_boxes3d.contiguous(), pts_feature.contiguous(),
+                              pooled_features, pooled_empty_flag)
     return pooled_features, pooled_empty_flag
 
 
