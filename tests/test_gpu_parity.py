@@ -1220,3 +1220,19 @@ def test_roipool3d_fill_writes_every_element(ops, oracle):
         np.testing.assert_array_equal(host(empty), ref_e)
         np.testing.assert_array_equal(host(pooled), ref_p)
         assert (ref_e == 1).sum() >= 5 and (host(pidx)[ref_e == 1] == 0).all() and (host(pidx) >= 0).all()
+
+
+def test_three_interpolate_nlc_into_an_odd_stride_buffer(ops, oracle):
+    """the FP concat buffer [interpolated | skip] may be 257 floats wide: the left columns are written with
+    4-byte-aligned 16-byte stores and the skip column stays untouched"""
+    rng = np.random.default_rng(3)
+    B, n, m, C = 2, 700, 90, 8
+    idx = rng.integers(0, m, (B, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (B, n, 3)).astype(np.float32)
+    feats = rng.standard_normal((B, C, m)).astype(np.float32)
+    ref = oracle.three_interpolate(feats, idx, w)                                  # (B, C, n)
+    for extra in (1, 2, 3):
+        buf = torch.full((B, n, C + extra), 9.5, device="cuda")
+        ops.c.three_interpolate_nlc(dev(np.ascontiguousarray(feats.transpose(0, 2, 1))), dev(idx), dev(w), buf)
+        np.testing.assert_array_equal(host(buf[:, :, :C]), ref.transpose(0, 2, 1))
+        assert bool((buf[:, :, C:] == 9.5).all())

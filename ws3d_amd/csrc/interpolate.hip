@@ -523,7 +523,11 @@ __global__ __launch_bounds__(256) void three_interpolate_nlc_kernel(int c, int m
     r.y = __builtin_fmaf(w2, p2.y, __builtin_fmaf(w0, p0.y, w1 * p1.y));
     r.z = __builtin_fmaf(w2, p2.z, __builtin_fmaf(w0, p0.z, w1 * p1.z));
     r.w = __builtin_fmaf(w2, p2.w, __builtin_fmaf(w0, p0.w, w1 * p1.w));
-    *reinterpret_cast<float4 *>(out + (size_t)row * out_stride + 4 * c4) = r;
+    // 16-byte store that only needs 4-byte alignment: the row stride may be odd (257 = 256 interpolated + 1 skip channel)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef f4v f4u __attribute__((aligned(4)));
+    const f4v rv = {r.x, r.y, r.z, r.w};
+    *reinterpret_cast<f4u *>(out + (size_t)row * out_stride + 4 * c4) = rv;
 }
 
 // out[r, 0:O] = max over the ns consecutive rows y[r*ns .. r*ns+ns-1, 0:O] (the SA pool on a
@@ -679,10 +683,9 @@ extern "C" int ws3d_rowmax_bias_act(int b, int o_ch, long m, int s, int relu, co
 extern "C" int ws3d_three_interpolate_nlc(int b, int c, int m, int n, const float *feats_nlc, const int32_t *idx,
                                           const float *weight, float *out_nlc, int out_stride, ws3d_stream_t stream) {
     using namespace ws3d;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(feats_nlc) | reinterpret_cast<uintptr_t>(out_nlc);
     if (b < 0 || c <= 0 || m <= 0 || n < 0 || !feats_nlc || !idx || !weight || !out_nlc || out_stride < c ||
-        (c & 3) || (out_stride & 3) || (al & 15)) {
-        set_error("ws3d_three_interpolate_nlc: invalid argument (b=%d c=%d m=%d n=%d stride=%d; c, stride %% 4, 16-byte bases)",
+        (c & 3) || (reinterpret_cast<uintptr_t>(feats_nlc) & 15) || (reinterpret_cast<uintptr_t>(out_nlc) & 3)) {
+        set_error("ws3d_three_interpolate_nlc: invalid argument (b=%d c=%d m=%d n=%d stride=%d; c %% 4, 16-byte feature base)",
                   b, c, m, n, out_stride);
         return WS3D_E_INVALID;
     }

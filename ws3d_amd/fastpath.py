@@ -108,14 +108,10 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
     idx, weight = _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
-    if c1 % 4 == 0:
-        cat = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=unknown.device)
-        _C.three_interpolate_nlc(known_feats, idx, weight, cat)     # left columns
-        if c1:
-            cat[:, :, c2:] = unknown_feats
-    else:   # row stride must stay a multiple of 4 floats for the 16-byte stores
-        interp = _C.three_interpolate_nlc(known_feats, idx, weight)
-        cat = torch.cat([interp, unknown_feats], dim=2)
+    cat = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=unknown.device)
+    _C.three_interpolate_nlc(known_feats, idx, weight, cat)         # left columns, any row stride (4-byte-aligned 16-byte stores)
+    if c1:
+        cat[:, :, c2:] = unknown_feats
     return mlp_rows(cat.view(B * n, c2 + c1), fp.mlp).view(B, n, -1)
 
 
