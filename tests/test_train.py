@@ -185,3 +185,23 @@ def test_loader_processes_deliver_the_same_batches():
             assert not set(next(r0)["sample_id"]) & set(next(r1)["sample_id"])
     finally:
         r0.close(); r1.close()
+
+
+def test_item_batches_finite_source_and_worker_errors():
+    """ws3d_amd.loader: a finite list of index batches is served completely and in order by the loader
+    processes; an exception raised inside a loader process surfaces in the consumer"""
+    from ws3d_amd import loader
+
+    class Squares:
+        def __getitem__(self, i):
+            if i == 13:
+                raise ValueError("bad scene 13")
+            return {"i": i, "sq": np.full((4,), i * i)}
+
+    ids = [[0, 1, 2], [3], [4, 5], [], [6]]
+    for workers in (0, 2):
+        got = list(loader.item_batches(Squares(), ids, workers=workers, ahead=2, seed=1))
+        assert [[it["i"] for it in b] for b in got] == ids
+        assert all(int(it["sq"][0]) == it["i"] ** 2 for b in got for it in b)
+        with pytest.raises(ValueError, match="bad scene 13"):
+            list(loader.item_batches(Squares(), [[1], [13], [2]], workers=workers, ahead=2, seed=1))
