@@ -282,7 +282,7 @@ class C5:
         roi_bytes = (self.M * self.S * (3 + self.C) * 4 + self.N * (3 + self.C) * 4) * self.B
         return [
             {"name": "roipool3d_kernel (select + wrap-pad + copy, fused)", "ms_per_step": roi, "launches_per_step": 1,
-             "alg_bytes_per_step": roi_bytes, "traffic_key": None,
+             "alg_bytes_per_step": roi_bytes, "traffic_key": "c5:roipool3d_kernel",
              "comment": "A_min of SURVEY 8d (171,720,704 B/scene) assumes every RoI is non-empty; rows of empty "
                         "RoIs are left untouched by contract: non-empty fraction here = %.2f" % nonempty},
             {"name": "nms_rot_mask_kernel + nms_sweep_kernel (n=512)", "ms_per_step": nms, "launches_per_step": 2,
@@ -437,21 +437,28 @@ def step_percentiles(wl):
             "n": int(t.size)}
 
 
-def traffic_batch():
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+def _traffic_file(kernel_key):
+    """'fps_zlds_kernel' -> (profiles/traffic.json, key); 'c5:roipool3d_kernel' -> (profiles/traffic_c5.json, key)"""
+    if kernel_key and ":" in kernel_key:
+        tag, key = kernel_key.split(":", 1)
+        return os.path.join(ROOT, "profiles", "traffic_%s.json" % tag), key
+    return os.path.join(ROOT, "profiles", "traffic.json"), kernel_key
+
+
+def traffic_batch(kernel_key=None):
     try:
-        return int(json.load(open(p)).get("_scenes_per_launch", 256))
+        return int(json.load(open(_traffic_file(kernel_key)[0])).get("_scenes_per_launch", 256))
     except Exception:
         return -1
 
 
 def load_traffic(kernel_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json),
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic*.json),
     already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    if kernel_key and os.path.exists(p):
+    p, key = _traffic_file(kernel_key)
+    if key and os.path.exists(p):
         try:
-            return json.load(open(p)).get(kernel_key)
+            return json.load(open(p)).get(key)
         except Exception:
             return None
     return None
@@ -516,9 +523,10 @@ def main():
         for k in kernels:
             k["achieved_GBps"] = k["alg_bytes_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9 if k["ms_per_step"] > 0 else 0.0
             k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
-            tr = load_traffic(k.pop("traffic_key", None))
+            tkey = k.pop("traffic_key", None)
+            tr = load_traffic(tkey)
             # the committed PMC passes were taken at one batch size: only comparable at that batch
-            k["traffic_bytes_per_launch"] = tr if wl.scenes() == traffic_batch() else None
+            k["traffic_bytes_per_launch"] = tr if wl.scenes() == traffic_batch(tkey) else None
         dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
         per_gpu = value / world
         out = {

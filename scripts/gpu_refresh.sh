@@ -32,5 +32,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python scripts/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \
   $OUT/traffic.json "c2 batch 512, bytes per launch, rocprofv3 --pmc in separate passes" 512 > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
+for wl in c5:8; do
+  w=${wl%%:*}; nb=${wl##*:}
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${w}_$c
+    rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${w}_$c -o pmc -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${w}_$c.log 2>&1
+  done
+  python scripts/pmc_traffic.py "$(find /tmp/pmc_${w}_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_${w}_WRITE_SIZE -name '*.db' | head -1)" \
+    $OUT/traffic_$w.json "$w batch $nb, bytes per launch, rocprofv3 --pmc in separate passes" $nb > /dev/null 2>>$OUT/pmc_${w}_WRITE_SIZE.log
+done
 bash scripts/prof_train.sh > $OUT/prof_train.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $OUT/train_b8_kernel_stats.csv
 ls -la $OUT
