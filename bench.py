@@ -544,8 +544,8 @@ def main():
                          "alg_bytes_per_launch": dom["alg_bytes_per_step"] / max(dom["launches_per_step"], 1),
                          "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic "
                                  "bytes (SURVEY.md 8d byte model, DESIGN.md section 6) / measured duration; "
-                                 "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic.json "
-                                 "(c2 workload at the batch recorded there) or null"},
+                                 "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json "
+                                 "(this workload at the batch recorded there) or null"},
             "kernels": kernels,
             "step_ms_percentiles": step_percentiles(wl),
             "path_gbps_per_gpu": wl.path_gbps(per_gpu),
