@@ -141,6 +141,14 @@ WS3D_API int ws3d_pool_nsample(long rows, int nsample, const float *x, float *ou
 WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_out, const uint8_t *arg, float *grad_x,
                                     ws3d_stream_t stream);
 
+/* Last SharedMLP layer of a set-abstraction scale fused with the pool over nsample (ws3d extension, replaces
+ * addmm + ws3d_rowmax_rows): out[g, 0:o] = act(max over the nsample rows of group g of x_rows . wt + bias).
+ * x_rows (rows, k) row-major, wt (k, o) = W^T, rows % 64 == 0, o % 64 == 0, k % 4 == 0, nsample 16 or 32;
+ * out (rows/nsample, o) with row stride out_stride.  fp32 matrix cores, fp32 accumulate.
+ * WS3D_E_UNSUPPORTED for other shapes (the caller keeps the two-launch path).                       */
+WS3D_API int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
+                            const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream);
+
 /* Training-mode BatchNorm (+ ReLU) of a channels-first activation x (b, c, l) -- the norm + activation
  * of every conv -> BatchNorm -> ReLU block of the reference (pytorch_utils.py:35-101, nn.BatchNorm1d/2d
  * in train() mode followed by nn.ReLU).  fwd: batch statistics per channel over b*l values (biased

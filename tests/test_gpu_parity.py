@@ -1236,3 +1236,28 @@ def test_three_interpolate_nlc_into_an_odd_stride_buffer(ops, oracle):
         ops.c.three_interpolate_nlc(dev(np.ascontiguousarray(feats.transpose(0, 2, 1))), dev(idx), dev(w), buf)
         np.testing.assert_array_equal(host(buf[:, :, :C]), ref.transpose(0, 2, 1))
         assert bool((buf[:, :, C:] == 9.5).all())
+
+
+# ------------------------------------------------------------------------------- last SA layer + pool on the matrix cores
+@pytest.mark.parametrize("rows,ns,k,o,relu,bias", [(128, 16, 64, 128, True, True), (256, 32, 96, 64, True, True), (64, 16, 196, 256, False, True),
+                                                    (192, 32, 4, 64, True, False), (64, 32, 388, 512, True, True)])
+def test_gemm_pool_matches_gemm_then_rowmax(ops, rows, ns, k, o, relu, bias):
+    """ws3d_gemm_pool == addmm (+bias, +ReLU) followed by the max over each group of nsample rows, to fp32
+    round-off (matrix-core summation order differs from the library GEMM's); written into a column slice"""
+    g = torch.Generator().manual_seed(rows + k)
+    x = torch.randn((rows, k), generator=g).cuda()
+    wt = (torch.randn((k, o), generator=g) * 0.2).cuda()
+    b = torch.randn((o,), generator=g).cuda() if bias else None
+    y = x.double() @ wt.double()
+    if b is not None:
+        y = y + b.double()
+    if relu:
+        y = torch.relu(y)
+    ref = y.view(rows // ns, ns, o).amax(dim=1)
+    out = torch.full((rows // ns, o + 64), 7.0, device="cuda")
+    assert ops.c.gemm_pool(x, wt, b, relu, ns, out, 64)
+    assert bool((out[:, :64] == 7.0).all())
+    np.testing.assert_allclose(host(out[:, 64:]), host(ref.float()), rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    # shapes the kernel does not cover are declined, not mis-computed
+    assert ops.c.gemm_pool(x[:, :k], wt, b, relu, 8, out, 64) is False
+    assert ops.c.gemm_pool(x[:rows - 1], wt, b, relu, ns, out, 64) is False

@@ -287,6 +287,22 @@ def bn_relu_train_bwd(x, dy, gamma, beta, save_mean, save_invstd, relu=True):
     return dx, dgamma, dbeta
 
 
+def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0):
+    """out[:, col0:col0+O] = act(max over each group of nsample rows of x_rows @ wt + bias); False when the
+    shape is not covered by the fused kernel (rows, O multiples of 64, K of 4, nsample 16 / 32).  ws3d extension."""
+    dev = _dev(x_rows, wt, bias)
+    _f32(x_rows, "x_rows"); _f32(wt, "wt")
+    rows, k = x_rows.shape
+    o = wt.size(1)
+    if rows % 64 or o % 64 or k % 4 or nsample not in (16, 32) or wt.size(0) != k:
+        return False
+    view = out[:, col0:col0 + o]
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gemm_pool(rows, nsample, k, o, _p(x_rows), _p(wt), _p(bias), int(bool(relu)), view.data_ptr(),
+                                         out.size(1), _stream()), "gemm_pool")
+    return True
+
+
 def pool_nsample(x):
     """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
     F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""

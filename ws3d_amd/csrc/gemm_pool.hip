@@ -1,0 +1,114 @@
+// gemm_pool.hip -- last SharedMLP layer of a set-abstraction scale fused with the pool over nsample:
+//   out[g, o] = relu( max_{s < ns} ( X[g*ns + s, :] . Wt[:, o] ) + bias[o] )
+// (bias add and ReLU are monotone, so they commute with the max exactly, like nn_blocks.forward_then_max).
+// The separate launches write the (rows, O) activation with the GEMM and read it back for the pool:
+// 351 MB each way per batch of 8 scenes at SA2..SA4.  Here a 64 x 64 output tile per workgroup is
+// accumulated on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate -- same precision
+// class as the library GEMM, different summation order) and reduced over its row groups in registers;
+// only the pooled rows reach HBM.
+#include "common.h"
+
+namespace ws3d {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int GP_KT = 16;          // K step per LDS tile
+constexpr int GP_XS = 65;          // padded row length of the k-major X tile
+
+__device__ __forceinline__ float gp_nanmax(float a, float b) { return (a > b || a != a) ? a : b; }
+
+// grid (O / 64, R / 64), 256 threads = 4 waves as 2 (rows) x 2 (cols) sub-tiles of 32 x 32
+template <int NS>
+__global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, const float *__restrict__ x,
+                                                        const float *__restrict__ wt, const float *__restrict__ bias,
+                                                        int relu, float *__restrict__ out, int out_stride) {
+    __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
+    __shared__ float ws[2][GP_KT][64];        // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const long row0 = (long)blockIdx.y * 64;
+    const int col0 = blockIdx.x * 64;
+    // global -> register staging: X tile 64 rows x 16 k (one float4 per thread), W tile 16 k x 64 cols
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const float *xp = x + (row0 + xr) * (long)k_dim;
+    auto load_x = [&](int k0) {
+        const int k = k0 + xk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(xp + k) : make_float4(0.f, 0.f, 0.f, 0.f);   // k_dim % 4 == 0
+    };
+    auto load_w = [&](int k0) {
+        const int k = k0 + wk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)k * o_dim + col0 + wc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stage = [&](int buf, const float4 xv, const float4 wv) {
+        xs[buf][xk + 0][xr] = xv.x; xs[buf][xk + 1][xr] = xv.y; xs[buf][xk + 2][xr] = xv.z; xs[buf][xk + 3][xr] = xv.w;
+        *reinterpret_cast<float4 *>(&ws[buf][wk][wc]) = wv;
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 xv = load_x(0), wv = load_w(0);
+    stage(0, xv, wv);
+    __syncthreads();
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) { xv = load_x((t + 1) * GP_KT); wv = load_w((t + 1) * GP_KT); }
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[cur][k + kh][ar], ws[cur][k + kh][bc], acc, 0, 0, 0);
+        if (t + 1 < ntiles) stage(cur ^ 1, xv, wv);
+        __syncthreads();
+    }
+    // accumulator layout (32 x 32 tile): register v of lane l holds row 8*(v/4) + 4*(l/32) + v%4, column l%32
+    const int col = col0 + bc;
+    const float bv = bias ? bias[col] : 0.f;
+    if (NS == 16) {
+        float m0 = acc[0], m1 = acc[8];
+#pragma unroll
+        for (int v = 1; v < 8; ++v) { m0 = gp_nanmax(m0, acc[v]); m1 = gp_nanmax(m1, acc[8 + v]); }
+        m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+        m1 = gp_nanmax(m1, __shfl_xor(m1, 32));
+        if (lane < 32) {
+            const long g = (row0 + wm * 32) / 16;
+            float r0 = m0 + bv, r1 = m1 + bv;
+            if (relu) { r0 = r0 < 0.f ? 0.f : r0; r1 = r1 < 0.f ? 0.f : r1; }
+            out[g * out_stride + col] = r0;
+            out[(g + 1) * out_stride + col] = r1;
+        }
+    } else {   // NS == 32: the whole sub-tile is one group
+        float m0 = acc[0];
+#pragma unroll
+        for (int v = 1; v < 16; ++v) m0 = gp_nanmax(m0, acc[v]);
+        m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+        if (lane < 32) {
+            const long g = (row0 + wm * 32) / 32;
+            float r0 = m0 + bv;
+            if (relu) r0 = r0 < 0.f ? 0.f : r0;
+            out[g * out_stride + col] = r0;
+        }
+    }
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
+                              const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(wt);
+    if (rows < 0 || (nsample != 16 && nsample != 32) || k_dim <= 0 || (k_dim & 3) || o_dim <= 0 || (o_dim & 63) || (rows & 63) ||
+        !x_rows || !wt || !out || out_stride < o_dim || (al & 15)) {
+        set_error("ws3d_gemm_pool: unsupported shape (rows=%ld ns=%d k=%d o=%d; rows, o %% 64, k %% 4, ns 16|32)", rows, nsample,
+                  k_dim, o_dim);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    if (rows / 64 > 65535) { set_error("ws3d_gemm_pool: too many rows"); return WS3D_E_UNSUPPORTED; }
+    const dim3 grid(o_dim / 64, (unsigned)(rows / 64)), block(256);
+    if (nsample == 16)
+        hipLaunchKernelGGL(gemm_pool_kernel<16>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride);
+    else
+        hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride);
+    return check_launch("ws3d_gemm_pool");
+}

@@ -27,6 +27,7 @@ from . import nn_blocks, pn2_ops
 
 
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
+FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
 
 
 def _row_weights(block):
@@ -96,8 +97,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
         # pooled rows leaves the chip; otherwise the GEMM chain + pool kernel
         if not (FUSED_SA_MLP and rows.size(1) == 4 and len(blocks) == 3 and
                 _C.sa_mlp3_pool(rows, grouper.nsample, [_row_weights(b) for b in blocks], out, col)):
-            y = mlp_rows(rows, mlp)                                    # (B*M*ns, O), bias + ReLU applied
-            _C.rowmax_rows(y, grouper.nsample, out, col)               # pool over nsample into its column slice
+            y = rows
+            for blk in blocks[:-1]:
+                y = _layer(y, blk)                                     # (B*M*ns, C_k), bias + ReLU in the GEMM epilogue
+            wt, bias, relu = _row_weights(blocks[-1])
+            # last layer + pool in one matrix-core kernel (only the pooled rows reach HBM); shapes it does not
+            # cover: GEMM with fused bias + ReLU, then the pool kernel into the column slice
+            if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
+                _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
         col += width
     return new_xyz, out.view(B, sa.npoint, -1)
 
