@@ -294,7 +294,7 @@ def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0):
     _f32(x_rows, "x_rows"); _f32(wt, "wt")
     rows, k = x_rows.shape
     o = wt.size(1)
-    if rows % 64 or o % 64 or k % 4 or nsample not in (16, 32) or wt.size(0) != k:
+    if rows % 64 or rows // 64 > 65535 or o % 64 or k % 4 or nsample not in (16, 32) or wt.size(0) != k:
         return False
     view = out[:, col0:col0 + o]
     with torch.cuda.device(dev):
