@@ -149,6 +149,14 @@ WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_ou
 WS3D_API int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
                             const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream);
 
+/* Weight gradient of a 1x1 convolution on channels-first tensors (the Conv1d / Conv2d of every SharedMLP
+ * block, pytorch_utils.py:35-101): grad_w (o, c) = sum_b sum_l grad_out[b, o, l] * x[b, c, l].  fp32 matrix
+ * cores, the (scene, l-range) slices of the sum are added in a fixed order: bit-reproducible (the library's
+ * split-K kernels use atomics).  workspace: ws3d_conv1x1_wgrad_workspace_bytes(b, o, c, l) bytes.  ws3d extension. */
+WS3D_API size_t ws3d_conv1x1_wgrad_workspace_bytes(int b, int o, int c, long l);
+WS3D_API int ws3d_conv1x1_wgrad(int b, int o, int c, long l, const float *grad_out, const float *x, float *grad_w,
+                                void *workspace, size_t workspace_bytes, ws3d_stream_t stream);
+
 /* Training-mode BatchNorm (+ ReLU) of a channels-first activation x (b, c, l) -- the norm + activation
  * of every conv -> BatchNorm -> ReLU block of the reference (pytorch_utils.py:35-101, nn.BatchNorm1d/2d
  * in train() mode followed by nn.ReLU).  fwd: batch statistics per channel over b*l values (biased

@@ -39,6 +39,8 @@ SIGNATURES = {
     "ws3d_bn_relu_train_fwd": (_i, [_i, _i, C.c_long, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.c_size_t, _vp]),
     "ws3d_bn_relu_train_bwd": (_i, [_i, _i, C.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ws3d_conv1x1_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, C.c_long]),
+    "ws3d_conv1x1_wgrad": (_i, [_i, _i, _i, C.c_long, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_gemm_pool": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
     "ws3d_pool_nsample": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
     "ws3d_pool_nsample_grad": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
