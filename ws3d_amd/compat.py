@@ -287,16 +287,16 @@ def bn_relu_train_bwd(x, dy, gamma, beta, save_mean, save_invstd, relu=True):
     return dx, dgamma, dbeta
 
 
-def conv1x1_wgrad(grad_out, x):
-    """grad_out (B, O, ...), x (B, C, ...) contiguous, same trailing shape -> grad_w (O, C) of a 1x1 convolution;
-    deterministic.  ws3d extension."""
+def conv1x1_wgrad(grad_out, x, shape=None):
+    """grad_out (B, O, ...), x (B, C, ...) contiguous, same trailing shape -> grad_w (O, C) of a 1x1 convolution
+    (allocated as `shape`, e.g. (O, C, 1, 1), when given); deterministic.  ws3d extension."""
     dev = _dev(grad_out, x)
     _f32(grad_out, "grad_out"); _f32(x, "x")
     b, o, c = x.size(0), grad_out.size(1), x.size(1)
     l = x.numel() // max(b * c, 1)
     if grad_out.numel() != b * o * l:
         raise Ws3dError("conv1x1_wgrad: grad_out and x disagree in shape")
-    gw = torch.empty((o, c), dtype=torch.float32, device=dev)
+    gw = torch.empty((o, c) if shape is None else tuple(shape), dtype=torch.float32, device=dev)
     lib = _lib.load()
     nbytes = lib.ws3d_conv1x1_wgrad_workspace_bytes(b, o, c, l)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)

@@ -61,7 +61,7 @@ class _Conv1x1Train(Function):
             gx = torch.ops.aten.convolution_backward(gy, x, w, None, [1] * nd, [0] * nd, [1] * nd, False, [0] * nd, 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = _C.conv1x1_wgrad(gy, x.contiguous()).view_as(w)
+            gw = _C.conv1x1_wgrad(gy, x.contiguous(), w.shape)      # a fresh tensor in the weight's shape: autograd keeps it as .grad without a copy
         if ctx.needs_input_grad[2]:
             gb = gy.sum(dim=[0] + list(range(2, gy.dim())))
         return gx, gw, gb
