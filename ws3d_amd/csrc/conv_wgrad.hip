@@ -131,7 +131,7 @@ static int wgrad_lsplit(int b, int o, int c, long l) {
     const int rows = wgrad_rows(o, c);
     const long tiles = (long)((o + rows - 1) / rows) * ((c + rows - 1) / rows) * b;
     int sp = 1;
-    while (tiles * sp < 1024 && l / (sp * 2) >= 1024 && sp < 256) sp *= 2;   // >= 1024 l per slice, ~1024 workgroups
+    while (tiles * sp < 1024 && l / (sp * 2) >= 256 && sp < 256) sp *= 2;    // >= 256 l per slice, ~1024 workgroups
     return sp;
 }
 
