@@ -48,6 +48,7 @@ class T1:
     def config(self):
         return {"optimizer": "adam_onecycle", "backward": "deterministic (sorted-segment scatter)",
                 "norm": "ws3d_bn_relu_train (fused BatchNorm+ReLU)", "pool": "ws3d_pool_nsample",
+                "weight_gradients": "ws3d_conv1x1_wgrad (fp32 matrix cores, fixed summation order)",
                 "sampling": "one step ahead on a side HIP stream" if self.prefetch else "inside the step",
                 "primed_iterations": 6,
                 "data_parallel": "DistributedDataParallel (RCCL all-reduce)" if self.world > 1 else "single GPU"}

@@ -41,7 +41,7 @@ FUSED_CONV_WGRAD = True   # training step: weight gradient of the 1x1 convolutio
 class _Conv1x1Train(Function):
     """1x1 convolution whose WEIGHT gradient runs on ws3d_conv1x1_wgrad: channels-first operands read
     where they lie, fp32 matrix cores, slices added in a fixed order -- bit-reproducible, and faster than the
-    library's NHWC split-K kernels + their transposes (2.9 vs 3.8 ms per Stage-1 step).  Forward and the input
+    library's NHWC split-K kernels + their transposes (2.7 vs 3.8 ms per Stage-1 step).  Forward and the input
     gradient stay on the library convolution."""
 
     @staticmethod
