@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- WS3D hot-path benchmark on MI355X (driver contract: one JSON line on rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5|s2|t1] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|s2|t1] [--batch B]
+
+With no flags it measures BASELINE.json's headline: workload **c3** = configs[2], the full Stage-1 RPN
+forward + proposal NMS + roipool3d at batch 8 scenes/GPU (`value` = throughput mode, `latency_mode` =
+one batch in flight, both in the same line), and -- outside the timed region -- the **c2** block
+(configs[1]: FPS 16384->4096 + fused ball_query/group, the "FPS+group HBM GB/s" half of the metric)
+with the `roofline` of the path's dominant kernel.
 
 N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...``
 (one rank per GPU, RCCL).  Scenes are independent, so the path shards with NO data-path
@@ -45,6 +51,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md (spec)
+# VALU issue roof (MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD-32;
+# 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz) in lane-instructions per second
+VALU_PEAK = 256 * 4 * 32 * 2.4e9
+# the FPS sweep's algorithmic VALU work per point and step: 3 v_sub + v_mul + 2 v_fma (squared distance),
+# v_min (running min-distance), v_max (argmax candidate) -- DESIGN.md section 5.1
+FPS_VALU_PER_POINT = 8
+HEADLINE_METRIC = "KITTI scenes/sec (16384 pts) Stage-1 RPN fwd, 1/2/4/8 GPU; FPS+group HBM GB/s"   # = BASELINE.json "metric"
+
+
+def fps_lane_instr(n, m):
+    """algorithmic VALU lane-instructions of one scene's furthest_point_sample n -> m"""
+    return (m - 1) * n * FPS_VALU_PER_POINT
 
 # SURVEY.md 8(d) / BASELINE.md section 3: bytes per scene at config 2
 N_PTS, M_PTS, NSAMPLE, RADIUS, C_FEAT = 16384, 4096, 64, 0.1, 1
@@ -167,22 +185,22 @@ class C2:
             e[2].record()
             self.ev.append(e)
 
-    metric = "KITTI scenes/sec (16384 pts), fused FPS+ball_query+group path; FPS+group HBM GB/s"
+    metric = "KITTI scenes/sec (16384 pts), fused FPS+ball_query+group path only (BASELINE configs[1]); FPS+group HBM GB/s"
 
     def kernel_table(self):
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
         return [
             {"name": ("fps_zlds_kernel<32,512>" if self.B > 256 else "fps_reg_kernel<32,512>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
-             "launches_per_step": 1, "alg_bytes_per_step": a_model_fps() * self.B,
+             "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
+             "alg_bytes_per_step": a_model_fps() * self.B,
              "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_zlds_kernel" if self.B > 256 else "fps_reg_kernel",
-             "valu_floor_ms": self.B * (M_PTS - 1) * (N_PTS / 64) * 10 * 2.3 / (1024 * 2.4e9) * 1e3,
-             "comment": "valu_floor_ms = the sweep alone at the measured wave64 issue rate (10 VALU instructions per point and step, "
-                        "2.3 clk per instruction and SIMD, 1024 SIMDs at 2.4 GHz): what actually bounds this kernel. "
-                        "A_model re-reads xyz every step; this design keeps the scene on chip (VGPRs, z in LDS when two scenes share a CU), so the kernel is "
-                        "latency/ALU-bound and its real HBM traffic is ~A_min (see traffic_bytes_per_launch)"},
-            {"name": "bin_points_x + ball_query_sorted_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
-             "launches_per_step": 2, "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_sorted_kernel",
+             "comment": "VALU-issue-bound: (M-1) dependent argmax steps over a scene that stays on chip (x, y, min-dist in VGPRs, z in LDS "
+                        "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
+                        "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "
+                        "(traffic_bytes_per_launch)" % FPS_VALU_PER_POINT},
+            {"name": "bin_points + ball_query_sorted_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
+             "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_sorted_kernel",
              "comment": "A_model == A_min for this kernel (every input read once, every output written once)"},
         ]
 
@@ -195,7 +213,7 @@ class C2:
     def scenes(self):
         return self.B
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, min_seconds=8.0):
         """CPU oracle port (same arithmetic, OpenMP over scenes/centres) on a bounded sample."""
         import oracle
         threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
@@ -214,7 +232,7 @@ class C2:
             gx -= new_xyz.transpose(0, 2, 1)[..., None]
             gf = oracle.grouping_operation(feat, nbr)
             return idx, nbr, gx, gf
-        (idx, nbr, gx, gf), dt, reps = repeat_for(one_pass)
+        (idx, nbr, gx, gf), dt, reps = repeat_for(one_pass, min_seconds)
         oracle.set_threads(1)
         # parity spot-check of the GPU result of the last step against the same oracle run
         ok = bool(np.array_equal(self.idx[:ns].cpu().numpy(), idx) and
@@ -464,13 +482,77 @@ def load_traffic(kernel_key):
     return None
 
 
+def finish_kernel_rows(kernels, scenes):
+    """derived figures of every kernel row: algorithmic GB/s, and the PHYSICAL roofline fraction of the
+    bound that applies (VALU issue for FPS, HBM for the copy/search kernels)"""
+    for k in kernels:
+        sec = k["ms_per_step"] * 1e-3
+        k["achieved_GBps"] = k["alg_bytes_per_step"] / sec / 1e9 if sec > 0 else 0.0
+        k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
+        if k.get("bound") == "valu" and sec > 0:
+            k["valu_lane_instr_per_s"] = k["lane_instr_per_step"] / sec
+            k["valu_frac"] = k["valu_lane_instr_per_s"] / VALU_PEAK
+        tkey = k.pop("traffic_key", None)
+        tr = load_traffic(tkey)
+        # the committed PMC passes were taken at one batch size: only comparable at that batch
+        k["traffic_bytes_per_launch"] = tr if scenes == traffic_batch(tkey) else None
+    return kernels
+
+
+def roofline_of(k, where):
+    """the tier contract's roofline object for kernel row k (after finish_kernel_rows)"""
+    launches = max(k["launches_per_step"], 1)
+    traffic = k["traffic_bytes_per_launch"].get("hbm_bytes") if isinstance(k.get("traffic_bytes_per_launch"), dict) else None
+    sec = k["ms_per_step"] * 1e-3
+    r = {"kernel": k["name"], "measured_in": where, "ms_per_launch": k["ms_per_step"] / launches, "traffic": traffic}
+    if k.get("bound") == "valu":
+        r.update({"bound": "valu", "achieved": k["valu_lane_instr_per_s"] / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-instr/s",
+                  "frac": k["valu_frac"], "lane_instr_per_launch": k["lane_instr_per_step"] / launches,
+                  "valu_instr_per_point_and_step": FPS_VALU_PER_POINT,
+                  "effective_frac": k["frac_of_8TBps"], "effective_GBps_a_model": k["achieved_GBps"],
+                  "alg_bytes_per_launch_a_model": k["alg_bytes_per_step"] / launches,
+                  "hbm_frac_physical": (traffic / (sec / launches) / HBM_PEAK) if traffic else None,
+                  "note": "FPS never re-reads the scene, so HBM does not bound it: frac = algorithmic VALU lane-instructions (8 per point "
+                          "and step) / duration / the VALU issue roof of MI355X_MICROARCH.md (wave64 instruction = 2 clk on a SIMD-32). "
+                          "effective_frac = SURVEY 8d's A_model bytes / duration / 8 TB/s (the north-star's accounting; may exceed 1 "
+                          "because nothing is re-read). traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json or null"})
+    else:
+        r.update({"bound": "hbm", "achieved": k["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": k["frac_of_8TBps"],
+                  "alg_bytes_per_launch": k["alg_bytes_per_step"] / launches,
+                  "note": "achieved = algorithmic bytes (SURVEY.md 8d byte model: every input read once, every output written once) / "
+                          "measured duration; traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json or null"})
+    return r
+
+
+def c2_block(batch, rank, kind, steps=10, warmup=2):
+    """BASELINE configs[1] measured outside the timed region of the headline run: the 'FPS+group HBM GB/s'
+    half of the metric, and the chip-filling launch of the path's dominant kernel (FPS)"""
+    wl = C2(batch, rank, kind)
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step(timed=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per_gpu = batch * steps / dt
+    kernels = finish_kernel_rows(wl.kernel_table(), batch)
+    blk = {"workload": wl.name, "batch_per_gpu": batch, "steps": steps, "scenes_per_s_per_gpu": per_gpu, "ms_per_step": dt / steps * 1e3,
+           "config": wl.config(), "kernels": kernels, "path_gbps_per_gpu": wl.path_gbps(per_gpu),
+           "step_ms_percentiles": step_percentiles(wl)}
+    return wl, blk
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5", "s2", "t1"])
-    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c2 default 512, c3/c5 default 8, s2 default 800)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5", "s2", "t1"],
+                    help="c3 (default) = BASELINE.json's headline: Stage-1 RPN forward + NMS + roipool3d, batch 8/GPU, with the c2 block")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c3/c5 default 8, c2 default 512, s2 default 800)")
+    ap.add_argument("--c2-batch", type=int, default=512, help="c3: scenes per launch of the embedded c2 block (0 = skip it)")
     ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
@@ -507,57 +589,75 @@ def main():
         wl.step(timed=not use_graph)
     barrier_sync(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
+
+    # ---- everything below is outside the timed region
+    latency = None
+    if hasattr(wl, "latency_mode"):
+        # the same step with ONE batch in flight (submit, exchange, wait): what a caller that needs the
+        # proposals of this batch before it submits the next one sees
+        lat = wl.latency_mode(n=10)
+        lat_ms = max_over_ranks(lat, world)
+        latency = {"batches_in_flight": 1, "ms_per_batch": lat_ms, "value": wl.scenes() * world / (lat_ms * 1e-3),
+                   "unit": getattr(wl, "unit", "scenes/s"), "batches_timed": 10}
     if use_graph:
-        # per-kernel HIP-event table from a few EAGER steps after the timed region (events cannot be
-        # recorded inside a graph); `value` above is the graph-replay throughput
+        # per-kernel HIP-event table from a few EAGER steps (events cannot be recorded inside a graph);
+        # `value` above is the graph-replay throughput
         for _ in range(min(args.steps, 5)):
             wl.step(timed=True)
         torch.cuda.synchronize()
+    if os.environ.get("WS3D_BENCH_DUMP") and hasattr(wl, "dump"):
+        wl.dump(os.environ["WS3D_BENCH_DUMP"])
+    c2wl = c2blk = None
+    if args.workload == "c3" and args.c2_batch > 0:
+        c2wl, c2blk = c2_block(args.c2_batch, rank, args.kind)
+    barrier_sync(world)
 
     total_scenes = wl.scenes() * world * args.steps
     value = total_scenes / dt
     ms_per_step = dt / args.steps * 1e3
 
     if rank == 0:
-        kernels = wl.kernel_table()   # [{name, ms_per_step, launches_per_step, alg_bytes_per_step, traffic_key}]
-        for k in kernels:
-            k["achieved_GBps"] = k["alg_bytes_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9 if k["ms_per_step"] > 0 else 0.0
-            k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
-            tkey = k.pop("traffic_key", None)
-            tr = load_traffic(tkey)
-            # the committed PMC passes were taken at one batch size: only comparable at that batch
-            k["traffic_bytes_per_launch"] = tr if wl.scenes() == traffic_batch(tkey) else None
+        kernels = finish_kernel_rows(wl.kernel_table(), wl.scenes())
         dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
         per_gpu = value / world
         out = {
-            "metric": wl.metric, "value": value, "unit": getattr(wl, "unit", "scenes/s"), "n_gpus": world, "steps": args.steps,
+            "metric": getattr(wl, "metric", HEADLINE_METRIC), "value": value, "unit": getattr(wl, "unit", "scenes/s"),
+            "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
             "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS}, **wl.config()),  # (c5 overrides n_points)
-            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": dom["achieved_GBps"],
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": dom["frac_of_8TBps"],
-                         "traffic": (dom["traffic_bytes_per_launch"] or {}).get("hbm_bytes")
-                         if isinstance(dom["traffic_bytes_per_launch"], dict) else None,
-                         "ms_per_launch": dom["ms_per_step"] / max(dom["launches_per_step"], 1),
-                         "valu_floor_frac": (dom["valu_floor_ms"] / dom["ms_per_step"]) if dom.get("valu_floor_ms") else None,
-                         "alg_bytes_per_launch": dom["alg_bytes_per_step"] / max(dom["launches_per_step"], 1),
-                         "note": "dominant kernel of the timed region by HIP-event time; achieved = algorithmic "
-                                 "bytes (SURVEY.md 8d byte model, DESIGN.md section 6) / measured duration; "
-                                 "traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json "
-                                 "(this workload at the batch recorded there) or null"},
-            "kernels": kernels,
-            "step_ms_percentiles": step_percentiles(wl),
-            "path_gbps_per_gpu": wl.path_gbps(per_gpu),
         }
+        if latency is not None:
+            out["throughput_mode"] = {"batches_in_flight": getattr(wl, "depth", 1), "ms_per_batch": ms_per_step, "value": value,
+                                      "unit": out["unit"]}
+            out["latency_mode"] = latency
+        if c2blk is not None:
+            # the dominant kernel family of the Stage-1 forward is furthest_point_sample (kernels[] below); its
+            # roofline is quoted on the chip-filling launch of the c2 block, with the c3 launch (8 workgroups) beside it
+            c2dom = max(c2blk["kernels"], key=lambda k: k["ms_per_step"])
+            out["roofline"] = roofline_of(c2dom, "c2 block of this run (batch %d per launch)" % c2blk["batch_per_gpu"])
+            c3fps = next((k for k in kernels if k.get("bound") == "valu"), None)
+            if c3fps is not None:
+                out["roofline"]["same_kernel_family_in_the_timed_c3_step"] = {
+                    "ms_per_step_eager": c3fps["ms_per_step"], "workgroups": wl.scenes(),
+                    "valu_frac_of_chip": c3fps["valu_frac"], "valu_frac_of_occupied_CUs": c3fps["valu_frac"] * 256 / max(wl.scenes(), 1),
+                    "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs; throughput mode overlaps 20 batches"}
+            out["c2"] = c2blk
+        else:
+            out["roofline"] = roofline_of(dom, "the timed region (HIP events on the launch stream)")
+        out.update({"kernels": kernels, "step_ms_percentiles": step_percentiles(wl), "path_gbps_per_gpu": wl.path_gbps(per_gpu)})
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = wl.cpu_baseline()
+                if c2wl is not None:
+                    out["c2"]["cpu_baseline"] = c2wl.cpu_baseline(min_seconds=6.0)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
-                out["cpu_baseline"] = {"error": repr(e)}
+                out.setdefault("cpu_baseline", {"error": repr(e)})
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

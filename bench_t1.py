@@ -87,9 +87,17 @@ class T1:
             rows.append({"name": "fps_reg_kernel chain 16384->4096->1024->256->64 (side stream, beside the previous step)" if self.prefetch else
                          "fps_reg_kernel chain 16384->4096->1024->256->64",
                          "ms_per_step": fps_ms, "launches_per_step": 4, "alg_bytes_per_step": _fps_model_bytes(self.cfg) * self.B,
-                         "traffic_key": None,
+                         "traffic_key": None, "bound": "valu", "lane_instr_per_step": self._fps_lane_instr() * self.B,
                          "comment": "A_model (12 B/point re-read per sampled point); latency-bound: one workgroup per scene"})
         return rows
+
+    def _fps_lane_instr(self):
+        from bench import fps_lane_instr
+        n, tot = self.cfg.num_points, 0
+        for m in self.cfg.npoints:
+            tot += fps_lane_instr(n, m)
+            n = m
+        return tot
 
     def path_gbps(self, scenes_per_s_per_gpu):
         return {"loss_last_step": None if self.last is None else self.last["loss"]}

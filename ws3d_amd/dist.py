@@ -4,8 +4,8 @@ Scenes are independent (every kernel indexes the batch dimension and nothing cro
 the path shards with NO data-path collective: one process per GPU, rank r owns the contiguous
 scene range [r*B/W, (r+1)*B/W) of the global batch, full model replica, weights materialised
 locally.  The ONLY exchange is one fixed-shape all-gather per batch of the per-scene
-proposals ``(B/W, K, 8) f32 = [x, y, z, h, w, l, ry, score]`` plus a ``(B/W,) i64`` valid count
-(25.6 KB/rank at K=100: latency-bound on xGMI, no bucketing needed).  Backend "nccl" is RCCL on
+proposals ``(B/W, K, 8) f32 = [x, y, z, h, w, l, ry, score]`` plus the ``(B/W,)`` valid counts in the
+same buffer (25.6 KB/rank at K=100: latency-bound on xGMI, no bucketing needed).  Backend "nccl" is RCCL on
 ROCm; "gloo" is used by the CPU tests.  The reference's own multi-GPU story
 (nn.DataParallel, tools/train_rpn.py:175-176) is not reproduced.
 """
@@ -53,36 +53,41 @@ def pack_proposals(boxes: torch.Tensor, scores: torch.Tensor) -> torch.Tensor:
     return torch.cat([boxes, scores.unsqueeze(-1)], dim=-1).contiguous()
 
 
-def all_gather_proposals(packed: torch.Tensor, count: torch.Tensor, global_batch: int):
+def all_gather_proposals(packed: torch.Tensor, count: torch.Tensor, global_batch: int, force: bool = False):
     """Gather every rank's (b_r, K, 8) proposals + (b_r,) counts into (global_batch, K, 8) /
     (global_batch,) on every rank, in scene order.  Ranks may own different b_r (uneven
-    division): shards are padded to the largest shard so the collective has a fixed shape."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    division): shards are padded to the largest shard so the collective has a fixed shape.
+
+    ONE collective per batch: the counts ride in the same fp32 buffer as the proposals (one extra
+    column per scene; exact, counts are < 2**24), `all_gather_into_tensor` on the caller's current
+    stream (RCCL).  gloo has no device all-gather, so with that backend device tensors are staged
+    through host memory -- an explicit, synchronising test mode (``WS3D_DIST_BACKEND=gloo``: ranks
+    sharing one GPU), never a fallback: any failure of the collective propagates.
+    ``force`` runs the collective even at world size 1 (covers the RCCL call on a 1-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
         return packed, count
-    world, rank = dist.get_world_size(), dist.get_rank()
-    K, F = packed.shape[1], packed.shape[2]
+    world = dist.get_world_size()
+    if world == 1 and not force:
+        return packed, count
+    b, K, F = packed.shape
     bmax = -(-global_batch // world)
-    pad_p = packed.new_zeros((bmax, K, F))
-    pad_c = count.new_zeros((bmax,))
-    pad_p[:packed.shape[0]] = packed
-    pad_c[:count.shape[0]] = count
-    out_p = packed.new_empty((world * bmax, K, F))
-    out_c = count.new_empty((world * bmax,))
-    try:
-        dist.all_gather_into_tensor(out_p, pad_p)
-        dist.all_gather_into_tensor(out_c, pad_c)
-    except (RuntimeError, NotImplementedError):  # backends without the flat variant
-        lp = [torch.empty_like(pad_p) for _ in range(world)]
-        lc = [torch.empty_like(pad_c) for _ in range(world)]
-        dist.all_gather(lp, pad_p)
-        dist.all_gather(lc, pad_c)
-        out_p, out_c = torch.cat(lp), torch.cat(lc)
-    rows = []
-    for r in range(world):
-        s, e = shard_range(global_batch, world, r)
-        rows.append(torch.arange(r * bmax, r * bmax + (e - s), device=packed.device))
-    sel = torch.cat(rows)
-    return out_p[sel], out_c[sel]
+    buf = packed.new_zeros((bmax, K * F + 1))
+    buf[:b, :K * F] = packed.reshape(b, K * F)
+    buf[:b, K * F] = count.to(packed.dtype)
+    out = packed.new_empty((world * bmax, K * F + 1))
+    if packed.is_cuda and dist.get_backend() == "gloo":
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, buf.cpu())
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, buf)
+    if global_batch != world * bmax:        # uneven shards: drop the padding rows
+        rows = []
+        for r in range(world):
+            s, e = shard_range(global_batch, world, r)
+            rows.append(torch.arange(r * bmax, r * bmax + (e - s), device=packed.device))
+        out = out[torch.cat(rows)]
+    return out[:, :K * F].reshape(-1, K, F), out[:, K * F].round().to(count.dtype)
 
 
 def run_sharded(global_batch: int, compute: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]):

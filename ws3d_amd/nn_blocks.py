@@ -173,7 +173,17 @@ class _ConvBlock(nn.Sequential):
         return w, shift, getattr(self, "activation", None)
 
     def fast_path_ok(self, x):
-        return not (self.training or not self._pointwise or (torch.is_grad_enabled() and x.requires_grad))
+        """the folded-weights path is inference only: the fold runs under no_grad, so it is declined whenever autograd
+        could want a path to the input OR to the block's own parameters (eval() with grad enabled), and whenever the
+        block's BatchNorm is itself in training mode (it must then see batch statistics -- stock module path)"""
+        if self.training or not self._pointwise:
+            return False
+        bn = getattr(self, "bn", None)
+        if bn is not None and bn[0].training:
+            return False
+        if torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in self._fold_sources() if t is not None)):
+            return False
+        return True
 
     def forward_then_max(self, x):
         """y = max over the last axis of this block's output, computed as
@@ -200,7 +210,7 @@ class _ConvBlock(nn.Sequential):
         if not self.fast_path_ok(x):
             bn = getattr(self, "bn", None)
             act = getattr(self, "activation", None)
-            if (FUSED_BN_TRAIN and self.training and self._pointwise and bn is not None and x.is_cuda
+            if (FUSED_BN_TRAIN and self.training and self._pointwise and bn is not None and bn[0].training and x.is_cuda
                     and x.dtype == torch.float32 and bn[0].affine and isinstance(act, (nn.ReLU, type(None)))):
                 # training: conv on the library GEMMs, BatchNorm + ReLU in one forward and one backward op
                 return bn_relu_train(conv1x1_train(x, self.conv), bn[0], act is not None)

@@ -30,15 +30,26 @@ from . import roipool3d_ops, stage1
 
 def ensure_hw_queues(n: int = 32) -> bool:
     """raise the runtime's hardware-queue cap unless the user set it; True if the value can still
-    take effect (no device context yet in this process)"""
+    take effect (no device context yet in this process).  Once the runtime has started the variable
+    is left alone, so that it keeps saying what the runtime read."""
+    if torch.cuda.is_initialized():
+        return False
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(n))
-    return not torch.cuda.is_initialized()
+    return True
+
+
+def _hw_queue_cap() -> int:
+    """the cap the runtime reads at start-up (its own default is 4)"""
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    except ValueError:
+        return 4
 
 
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
-                 channels: int = 4, tune_gemms: bool = True):
+                 channels: int = 4, tune_gemms: bool = None):
         self.model, self.cfg, self.B, self.depth, self.roipool = model.eval(), cfg, int(batch), max(1, int(depth)), roipool
         self.device = torch.device(device)
         self.hw_queues_raised = ensure_hw_queues()      # False: the runtime already started with its own cap
@@ -51,7 +62,15 @@ class Stage1Pipeline:
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
                                    "done": torch.cuda.Event(), "primed": False})
+        if tune_gemms is None:      # WS3D_TUNE_GEMMS=0: keep the library's heuristic GEMM solutions (identical in every process)
+            tune_gemms = os.environ.get("WS3D_TUNE_GEMMS", "1") != "0"
         self.use_graph, self.tune_gemms = use_graph, tune_gemms
+        if not self.hw_queues_raised and self.depth > _hw_queue_cap():
+            import warnings
+            warnings.warn("Stage1Pipeline: depth %d but the HIP runtime of this process already started with GPU_MAX_HW_QUEUES=%d; "
+                          "streams that share a hardware queue serialise (measured: 2,106 scenes/s with 4 queues vs 3,850 with 32). "
+                          "Export GPU_MAX_HW_QUEUES=32 (or call ws3d_amd.pipeline.ensure_hw_queues()) before the first device call."
+                          % (self.depth, _hw_queue_cap()), RuntimeWarning, stacklevel=2)
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
@@ -139,6 +158,9 @@ class Stage1Pipeline:
                 if pts is not None:
                     slot["inp"][:t.size(0)].copy_(t)
                 self._prime(slot)
+            if pts is not None and t.is_cuda:       # produced on the caller's stream: order the slot's copy behind it
+                slot["stream"].wait_stream(torch.cuda.current_stream(self.device))
+                t.record_stream(slot["stream"])
             with torch.cuda.stream(slot["stream"]):
                 if pts is not None:
                     slot["inp"][:t.size(0)].copy_(t, non_blocking=True)
