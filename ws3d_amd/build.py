@@ -27,7 +27,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libws3d_hip.so")
 ARCH = "gfx950"
-SOURCES = ["core.hip", "fps.hip", "fps_bucket.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
+SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

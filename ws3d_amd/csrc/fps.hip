@@ -575,6 +575,8 @@ static void launch_reg(int b, int n, int m, const float *xyz, float *temp, int32
 
 int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
                       int bs, int log2bs, int S, hipStream_t st);  // fps_bucket.hip
+bool fps_v3_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz, int bs, int log2bs, int S,
+                   long R, bool pair, hipStream_t st);             // fps_v3.hip
 
 // WS3D_FPS_PAIR: 0 = never, 1 = always, unset = when the batch exceeds the number of CUs
 static bool fps_pair_mode(int b) {
@@ -606,6 +608,10 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : 0;
     if (use_bucket && n > 4096 && n <= 16384 && m > 1)
         return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    // round-2 kernels (fps_v3.hip: hand-scheduled sweep, winner-only lookup); WS3D_FPS_IMPL=2 keeps the round-1 ones
+    static const int impl = getenv("WS3D_FPS_IMPL") ? atoi(getenv("WS3D_FPS_IMPL")) : 3;
+    if (impl == 3 && R <= 1024L * 16 && fps_v3_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, R, fps_pair_mode(b), st))
+        return check_launch("furthest_point_sampling");
     if (R <= 64L * 16) {
         const int ppt = (int)((R + 63) / 64);
         if (ppt <= 1) launch_reg<1, 64>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
