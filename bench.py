@@ -199,8 +199,8 @@ class C2:
                         "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
                         "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "
                         "(traffic_bytes_per_launch)" % FPS_VALU_PER_POINT},
-            {"name": "bin_points + ball_query_sorted_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
-             "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_sorted_kernel",
+            {"name": "bin_points_grid + ball_query_grid_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
+             "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_grid_kernel",
              "comment": "A_model == A_min for this kernel (every input read once, every output written once)"},
         ]
 

@@ -142,6 +142,53 @@ def test_fps_two_scenes_per_cu_kernel_subprocess(ops, oracle, tmp_path):
         np.testing.assert_array_equal(np.load(tmp_path / f"tmp{i}.npy"), ref_temp)
 
 
+FPS_ENV_VARIANTS = [
+    {"WS3D_FPS_IMPL": "2"},                              # the round-1 kernels (fps.hip) for every shape
+    {"WS3D_FPS_SMALL3": "1"},                            # fps_v3 kernels also for the one-to-four-wave shapes
+    {"WS3D_FPS_ONEX": "1"},                              # one-exchange variant of the 16384-point kernel
+    {"WS3D_FPS_ONEX": "1", "WS3D_FPS_GEOM3": "1024"},
+    {"WS3D_FPS_GEOM3": "512"}, {"WS3D_FPS_GEOM3": "256"}, {"WS3D_FPS_GEOM3": "1024"},
+    {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "0"}, {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "2"},
+]
+
+
+@pytest.mark.parametrize("env", FPS_ENV_VARIANTS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()))
+def test_fps_kernel_variants_subprocess(oracle, tmp_path, env):
+    """every selectable FPS kernel / geometry (environment switches are read once per process): indices, gathered centres
+    and the final min-distance buffer against the oracle, over shapes that reach every template instance"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(2, 16384, 1500, "lidar", 0.02), (1, 12345, 400, "lidar", 0.3), (2, 8192, 300, "uniform", 0.0), (2, 4096, 500, "lidar", 0.05),
+             (2, 3000, 200, "lidar", 0.0), (2, 2048, 256, "lidar", 0.05), (2, 1025, 100, "uniform", 0.0), (2, 1000, 250, "lidar", 0.1),
+             (2, 512, 128, "lidar", 0.0), (3, 200, 60, "uniform", 0.2), (2, 100, 37, "uniform", 0.0), (2, 64, 64, "uniform", 0.0)]
+    refs = []
+    for i, (B, N, M, kind, dup) in enumerate(cases):
+        pcs = synth.make_batch(kind, B, N, 13, dup_frac=dup)[:, :, :3].copy()
+        np.save(tmp_path / f"in{i}.npy", pcs)
+        refs.append(oracle.furthest_point_sample(pcs, M, return_temp=True))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import compat
+        for i, M in enumerate({[c[2] for c in cases]!r}):
+            x = torch.from_numpy(np.load({str(tmp_path)!r} + f"/in{{i}}.npy")).cuda()
+            B, N = x.shape[0], x.shape[1]
+            idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); nx = torch.empty((B, M, 3), device="cuda")
+            temp = torch.full((B, N), 1e10, device="cuda")
+            compat.furthest_point_sampling_gather(B, N, M, x, temp, idx, nx)
+            np.save({str(tmp_path)!r} + f"/out{{i}}.npy", idx.cpu().numpy())
+            np.save({str(tmp_path)!r} + f"/xyz{{i}}.npy", nx.cpu().numpy())
+            np.save({str(tmp_path)!r} + f"/tmp{{i}}.npy", temp.cpu().numpy())
+    """)
+    r = subprocess.run([sys.executable, "-B", "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, (ref, ref_temp) in enumerate(refs):
+        np.testing.assert_array_equal(np.load(tmp_path / f"out{i}.npy"), ref, err_msg=str(cases[i]))
+        pcs = np.load(tmp_path / f"in{i}.npy")
+        np.testing.assert_array_equal(np.load(tmp_path / f"xyz{i}.npy"), np.stack([pcs[b][ref[b]] for b in range(pcs.shape[0])]))
+        np.testing.assert_array_equal(np.load(tmp_path / f"tmp{i}.npy"), ref_temp, err_msg=str(cases[i]))
+
+
 def test_fps_temp_contract(ops, oracle):
     """the wrapper-level entry point takes the caller's temp (pre-filled 1e10) and leaves the
     final running min-distance in it, like the reference kernel does (sampling_gpu.cu:134-135)."""
@@ -211,7 +258,30 @@ def test_ball_query_sorted_slab_equals_bruteforce(ops, oracle, N, M, r, ns, kind
     new_xyz = np.stack([xyz[b][cidx[b]] for b in range(2)])
     ref = oracle.ball_query(r, ns, xyz, new_xyz)
     x, c = dev(xyz), dev(new_xyz)
-    srt = ops.c.sort_points_x(x)
+    # fine (x, z) grid flavour (the default of sort_points_x): permutation of the scene, 16-bit cell starts non-decreasing
+    grid = ops.c.sort_points_x(x, grid=True)
+    assert grid is not None
+    gstride = grid.numel() // 2
+    for sc in range(2):
+        raw = host(grid[sc * gstride:(sc + 1) * gstride])
+        pts = raw[:N * 16].view(np.float32).reshape(N, 4)
+        np.testing.assert_array_equal(np.sort(pts[:, 3].view(np.int32)), np.arange(N))
+        np.testing.assert_array_equal(pts[:, :3], xyz[sc][pts[:, 3].view(np.int32)])
+        hdr = raw[N * 16:N * 16 + 16]
+        gx = -int(hdr[12:16].view(np.int32)[0])
+        gz = int(raw[N * 16 + 16 + 65540:N * 16 + 16 + 65552].view(np.int32)[2])
+        assert gx > 0 and gz > 0 and gx * gz <= 32768
+        start16 = raw[N * 16 + 16:N * 16 + 16 + 2 * (gx * gz + 1)].view(np.uint16).astype(np.int64)
+        assert start16[0] == 0 and start16[-1] == N and (np.diff(start16) >= 0).all()
+    g = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, g, grid)
+    np.testing.assert_array_equal(host(g), ref)
+    d3 = torch.empty((2, M, 3), device="cuda"); i3 = torch.empty((2, M, 3), dtype=torch.int32, device="cuda")
+    ops.c.three_nn_wrapper(2, M, N, c, x, d3, i3, grid)          # a grid-flavour buffer handed to three_nn stays exact
+    rd, ri = oracle.three_nn_dist2(new_xyz, xyz)
+    np.testing.assert_array_equal(host(i3), ri)
+    np.testing.assert_array_equal(host(d3), rd)
+    srt = ops.c.sort_points_x(x, grid=False)
     assert srt is not None
     stride = srt.numel() // 2
     for sc in range(2):  # binned copy: a permutation of the scene, cell starts non-decreasing, x grouped by cell

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ws3d_sorted_points_bytes": (_sz, [_i, _i]),
     "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_xz": (_i, [_i, _i, _vp, _vp, _vp]),
+    "ws3d_sort_points_grid": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -105,10 +105,14 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
 SORTED_MIN_N = 2048  # below this the LDS-tiled brute-force scan is already cheap
 
 
-def sort_points_x(xyz, min_n=None):
-    """(B,N,3) -> opaque uint8 buffer (per scene: N float4 {x,y,z,bits(index)} binned by x, a
-    header and a cell-start table), or None when the x-binned path does not apply (N < min_n,
-    default 2048 -- where the binned ball query starts to pay -- or N > 16384).  ws3d extension."""
+BQ_FINE_GRID = True   # sort_points_x builds the fine (x, z) grid (ws3d_sort_points_grid); False: x slabs (A/B runs)
+
+
+def sort_points_x(xyz, min_n=None, grid=None):
+    """(B,N,3) -> opaque uint8 buffer for the ball-query entries (per scene: N float4 {x,y,z,bits(index)} binned into a
+    fine (x, z) grid -- or, grid=False, into x slabs -- a header and a cell-start table), or None when the binned path
+    does not apply (N < min_n, default 2048 -- where the binned ball query starts to pay -- or N > 16384).
+    ws3d extension."""
     dev = _dev(xyz)
     _f32(xyz, "xyz")
     b, n = xyz.size(0), xyz.size(1)
@@ -118,7 +122,10 @@ def sort_points_x(xyz, min_n=None):
         return None
     out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        check(lib.ws3d_sort_points_x(b, n, _p(xyz), _p(out), _stream()), "sort_points_x")
+        if BQ_FINE_GRID if grid is None else grid:
+            check(lib.ws3d_sort_points_grid(b, n, _p(xyz), _p(out), _stream()), "sort_points_grid")
+        else:
+            check(lib.ws3d_sort_points_x(b, n, _p(xyz), _p(out), _stream()), "sort_points_x")
     return out
 
 

@@ -15,10 +15,29 @@
 // of the contract -- and leave the chip with coalesced stores.  In the fused kernel the
 // rows never go back to global memory: the same workgroup emits the centred xyz and
 // the feature channels straight into the (B, 3+C, M, ns) tensor the SharedMLP consumes.
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "binning.h"
 
 namespace ws3d {
+
+// Which flavour a binned buffer holds is written in its device-side header; the HOST picks the kernel, so the sort entry
+// points also note it per buffer address (the last sort into an address wins; unknown addresses run the kernel that
+// reads the header and handles both flavours).  Consulted at launch / graph-capture time, never synchronises.
+static std::mutex g_flavour_mu;
+static std::unordered_map<const void *, int> g_flavour;   // 1 = fine (x, z) grid, 0 = x slabs
+static void note_flavour(const void *p, int f) {
+    std::lock_guard<std::mutex> lk(g_flavour_mu);
+    if (g_flavour.size() > 8192) g_flavour.clear();
+    g_flavour[p] = f;
+}
+static bool grid_flavour(const void *p) {
+    std::lock_guard<std::mutex> lk(g_flavour_mu);
+    const auto it = g_flavour.find(p);
+    return it != g_flavour.end() && it->second == 1;
+}
 
 // 16-byte store; streaming (non-temporal) when the grouped tensor is far larger than the last-level
 // cache (stage-2 shapes: 3.4 GB per launch, 0.98 -> 0.75 ms), plain otherwise so that the SharedMLP
@@ -41,7 +60,8 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
                                         int use_xyz, const float *__restrict__ xyz /* scene base */,
                                         const float *__restrict__ features, int32_t *__restrict__ idx_out,
                                         float *__restrict__ out, const IDX *rows, int rstride,
-                                        const int *cnt_s, const float4 *cen) {
+                                        const int *cnt_s, const float4 *cen, int nbatch = -1) {
+    if (nbatch < 0) nbatch = (int)gridDim.y;      // scenes of the launch (the 1-D grid kernel passes it)
     const int total_e = NC * nsample;
     if (!FUSED) {
         // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44)
@@ -139,9 +159,45 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
     const int chunk = (c_feat + (int)gridDim.z - 1) / (int)gridDim.z;
     const int ch_lo = (int)blockIdx.z * chunk, ch_hi = min(c_feat, ch_lo + chunk);
     if ((nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        const bool stream = (size_t)gridDim.y * c_out * plane * sizeof(float) > STREAM_STORE_BYTES;
+        const bool stream = (size_t)nbatch * c_out * plane * sizeof(float) > STREAM_STORE_BYTES;
         // 4 consecutive samples of one centre per lane: 16-byte stores along (m, s), 4 independent
         // gathers per channel, two channels in flight
+        if (c_feat == 1 && use_xyz && gridDim.z == 1) {
+            // the c2 / first-SA-level shape (3 xyz + 1 feature channel): two groups of 4 samples per trip, all 16 gathers
+            // issued before the first store -- the emit is latency-bound on its gathers
+            typedef float f3v __attribute__((ext_vector_type(3)));
+            typedef f3v f3u __attribute__((aligned(4)));
+            for (int q0 = tid; q0 < total_e / 4; q0 += 2 * NT) {
+                int e[2], cc[2];
+                bool ok[2];
+                f3v p[2][4];
+                float f[2][4];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = q0 + h * NT;
+                    e[h] = 4 * min(q, total_e / 4 - 1);
+                    cc[h] = e[h] / nsample;
+                    ok[h] = q < total_e / 4 && m0 + cc[h] < m;
+                    const IDX *r = rows + (size_t)cc[h] * rstride + (e[h] - cc[h] * nsample);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int id = ok[h] ? (int)r[u] : 0;
+                        p[h][u] = *reinterpret_cast<const f3u *>(xyz + (size_t)id * 3);
+                        f[h][u] = fb[id];
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if (!ok[h]) continue;
+                    const float4 ce = cen[cc[h]];
+                    st4(ob + e[h], make_float4(p[h][0].x - ce.x, p[h][1].x - ce.x, p[h][2].x - ce.x, p[h][3].x - ce.x), stream);
+                    st4(ob + plane + e[h], make_float4(p[h][0].y - ce.y, p[h][1].y - ce.y, p[h][2].y - ce.y, p[h][3].y - ce.y), stream);
+                    st4(ob + 2 * plane + e[h], make_float4(p[h][0].z - ce.z, p[h][1].z - ce.z, p[h][2].z - ce.z, p[h][3].z - ce.z), stream);
+                    st4(ob + 3 * plane + e[h], make_float4(f[h][0], f[h][1], f[h][2], f[h][3]), stream);
+                }
+            }
+            return;
+        }
         for (int q = tid; q < total_e / 4; q += NT) {
             const int e = 4 * q;
             const int c = e / nsample, s = e - c * nsample;
@@ -150,11 +206,16 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
             const int i0 = (int)r[0], i1 = (int)r[1], i2 = (int)r[2], i3 = (int)r[3];
             if (use_xyz && blockIdx.z == 0) {
                 const float4 ce = cen[c];
-                const float *p0 = xyz + (size_t)i0 * 3, *p1 = xyz + (size_t)i1 * 3, *p2 = xyz + (size_t)i2 * 3,
-                            *p3 = xyz + (size_t)i3 * 3;   // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
-                *reinterpret_cast<float4 *>(ob + e) = make_float4(p0[0] - ce.x, p1[0] - ce.x, p2[0] - ce.x, p3[0] - ce.x);
-                *reinterpret_cast<float4 *>(ob + plane + e) = make_float4(p0[1] - ce.y, p1[1] - ce.y, p2[1] - ce.y, p3[1] - ce.y);
-                *reinterpret_cast<float4 *>(ob + 2 * plane + e) = make_float4(p0[2] - ce.z, p1[2] - ce.z, p2[2] - ce.z, p3[2] - ce.z);
+                // ONE 12-byte gather per neighbour (global_load_dwordx3, 4-byte aligned) instead of three dword gathers: the
+                // emit is bound by the rate of uncoalesced L2 accesses (~1 lane per clock and CU), not by bytes
+                typedef float f3v __attribute__((ext_vector_type(3)));
+                typedef f3v f3u __attribute__((aligned(4)));
+                const f3v p0 = *reinterpret_cast<const f3u *>(xyz + (size_t)i0 * 3), p1 = *reinterpret_cast<const f3u *>(xyz + (size_t)i1 * 3),
+                          p2 = *reinterpret_cast<const f3u *>(xyz + (size_t)i2 * 3), p3 = *reinterpret_cast<const f3u *>(xyz + (size_t)i3 * 3);
+                // grouped_xyz -= new_xyz (pointnet2_utils.py:252)
+                *reinterpret_cast<float4 *>(ob + e) = make_float4(p0.x - ce.x, p1.x - ce.x, p2.x - ce.x, p3.x - ce.x);
+                *reinterpret_cast<float4 *>(ob + plane + e) = make_float4(p0.y - ce.y, p1.y - ce.y, p2.y - ce.y, p3.y - ce.y);
+                *reinterpret_cast<float4 *>(ob + 2 * plane + e) = make_float4(p0.z - ce.z, p1.z - ce.z, p2.z - ce.z, p3.z - ce.z);
             }
             int ch = ch_lo;
             for (; ch + 4 <= ch_hi; ch += 4) {
@@ -355,6 +416,100 @@ __global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *
     }
 }
 
+// ---- fine (x, z) grid flavour (binning.h) for the ball query.  One workgroup per scene: bounding box of the finite
+// (x, z), a gx x gz grid of near-square cells (gx * gz <= GRID16_CELLS, ~0.5 points per cell), counting sort with 16-bit
+// counters packed two per LDS word (a cell holds < 65536 points, so the halves never carry into each other).
+__global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const float *__restrict__ xyz, char *__restrict__ ws) {
+    __shared__ unsigned hist[GRID16_CELLS / 2];      // 64 KB
+    __shared__ int wsum[16];
+    __shared__ float red[4][16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    xyz += (size_t)b * n * 3;
+    char *base = ws + (size_t)b * bin_scene_stride(n);
+    float4 *sorted = reinterpret_cast<float4 *>(base);
+    BinHeader *hdr = reinterpret_cast<BinHeader *>(base + (size_t)n * 16);
+    uint16_t *start = reinterpret_cast<uint16_t *>(base + (size_t)n * 16 + sizeof(BinHeader));
+    int *params = reinterpret_cast<int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
+
+    float lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float x = xyz[(size_t)i * 3], z = xyz[(size_t)i * 3 + 2];
+        if (fabsf(x) < INFINITY) { lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); }
+        if (fabsf(z) < INFINITY) { lo_z = fminf(lo_z, z); hi_z = fmaxf(hi_z, z); }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, o)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+        lo_z = fminf(lo_z, __shfl_xor(lo_z, o)); hi_z = fmaxf(hi_z, __shfl_xor(hi_z, o));
+    }
+    if (lane == 0) { red[0][w] = lo_x; red[1][w] = hi_x; red[2][w] = lo_z; red[3][w] = hi_z; }
+    for (int i = tid; i < GRID16_CELLS / 2; i += 1024) hist[i] = 0u;
+    __syncthreads();
+    lo_x = red[0][0]; hi_x = red[1][0]; lo_z = red[2][0]; hi_z = red[3][0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        lo_x = fminf(lo_x, red[0][i]); hi_x = fmaxf(hi_x, red[1][i]);
+        lo_z = fminf(lo_z, red[2][i]); hi_z = fmaxf(hi_z, red[3][i]);
+    }
+    const float xmin = lo_x <= hi_x ? lo_x : 0.f, wx = lo_x <= hi_x ? hi_x - lo_x : 0.f;
+    const float zmin = lo_z <= hi_z ? lo_z : 0.f, wz = lo_z <= hi_z ? hi_z - lo_z : 0.f;
+    int gx = 1, gz = 1;
+    const int target = max(1, min(GRID16_CELLS, 2 * n));
+    if (wx > 0.f && wz > 0.f) {
+        const float h = sqrtf(wx * wz / (float)target);
+        gx = max(1, min(GRID16_CELLS, (int)ceilf(wx / h)));
+        gz = max(1, min(GRID16_CELLS / gx, (int)ceilf(wz / h)));
+    } else if (wx > 0.f) {
+        gx = target;
+    } else if (wz > 0.f) {
+        gz = target;
+    }
+    const int ncell = gx * gz;
+    const float inv_wx = wx > 0.f ? (float)gx / wx : 0.f, inv_wz = wz > 0.f ? (float)gz / wz : 0.f;
+    auto cell_of = [&](const float *p) { return grid_coord(p[2], zmin, inv_wz, gz) * gx + grid_coord(p[0], xmin, inv_wx, gx); };
+    for (int i = tid; i < n; i += 1024) {
+        const int c = cell_of(xyz + (size_t)i * 3);
+        atomicAdd(&hist[c >> 1], 1u << (16 * (c & 1)));
+    }
+    __syncthreads();
+    // exclusive scan over 32768 16-bit counters: 16 words (32 cells) per thread
+    unsigned wd[16];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { wd[i] = hist[tid * 16 + i]; v += (int)(wd[i] & 0xffffu) + (int)(wd[i] >> 16); }
+    const int mine = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    int off = 0;
+    for (int i = 0; i < w; ++i) off += wsum[i];
+    int run = off + v - mine;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c0 = (tid * 16 + i) * 2;
+        const unsigned lo = (unsigned)run;
+        run += (int)(wd[i] & 0xffffu);
+        const unsigned hi = (unsigned)run;
+        run += (int)(wd[i] >> 16);
+        hist[tid * 16 + i] = lo | (hi << 16);           // running scatter cursors (each < 65536)
+        if (c0 <= ncell) start[c0] = (uint16_t)lo;
+        if (c0 + 1 <= ncell) start[c0 + 1] = (uint16_t)hi;
+    }
+    if (tid == 0) {
+        hdr->xmin = xmin; hdr->inv_w = inv_wx; hdr->n = n; hdr->pad = -gx;
+        params[0] = __float_as_int(zmin); params[1] = __float_as_int(inv_wz); params[2] = gz;
+    }
+    if (tid == 1023 && ncell == GRID16_CELLS) start[GRID16_CELLS] = (uint16_t)n;   // the sentinel behind a full table
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const float *p = xyz + (size_t)i * 3;
+        const int c = cell_of(p);
+        const unsigned old = atomicAdd(&hist[c >> 1], 1u << (16 * (c & 1)));
+        const int pos = (int)((old >> (16 * (c & 1))) & 0xffffu);
+        sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+    }
+}
+
 // One workgroup = 64 centres (one per lane) x 4 waves; wave j scans the j-th quarter of every
 // centre's slab and keeps its own "nsample smallest indices" row; wave 0 then 4-way merges.
 template <bool FUSED>
@@ -408,17 +563,9 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
 #else
     if (active && cx == cx) {
 #endif
-        // cells overlapping |x - cx| < r: x_cell is monotone, one extra cell each side absorbs the
-        // rounding of cx -+ r (cell width >> 1 ulp of x)
-        const int c_lo = max(0, x_cell(cx - rabs, hdr.xmin, hdr.inv_w) - 1);
-        const int c_hi = min(BQS_CELLS - 1, x_cell(cx + rabs, hdr.xmin, hdr.inv_w) + 1);
-        const int k0 = start[c_lo], kend = start[c_hi + 1];
-        if (kend - k0 <= BQS_MAX_SLAB) {
-            const int q = (kend - k0 + 3) >> 2;               // this wave's quarter of the slab
-            int k = min(kend, k0 + w * q);
-            const int ke = min(kend, k + q);
-            // BQS_UNROLL slab entries per trip: the loads are independent of the tests, so the walk pays one
-            // memory round trip per 4 candidates (clamped loads past the end are ignored)
+        auto scan = [&](int k, const int ke) {
+            // BQS_UNROLL entries per trip: the loads are independent of the tests, so the walk pays one memory round trip
+            // per BQS_UNROLL candidates (clamped loads past the end are ignored)
             for (; k < ke; k += BQS_UNROLL) {
                 float4 p[BQS_UNROLL];
 #pragma unroll
@@ -432,8 +579,44 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
                     }
                 }
             }
-        } else if (w == 0) {
-            // pathological slab: ordered full scan with early exit (the reference's own loop)
+        };
+        bool full_scan = false;
+        if (hdr.pad < 0) {
+            // fine (x, z) grid: a hit has |fl(cx - px)| < r and |fl(cz - pz)| < r (each squared term alone is <= d2 under
+            // monotone rounding), i.e. px within r (1 + 2^-23) of cx; the bounds are widened by 6e-7 (|c| + r) -- ten times
+            // the rounding of c -+ r -- and grid_coord is monotone, so no cell holding a hit is skipped.  Wave j takes
+            // the grid rows j, j + 4, ...: one contiguous range of cells per row.
+            const uint16_t *start16 = reinterpret_cast<const uint16_t *>(start);
+            const int *params = reinterpret_cast<const int *>(reinterpret_cast<const char *>(start) + GRID16_PARAMS);
+            const int gx = -hdr.pad, gz = params[2];
+            const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
+            const float sx = (fabsf(cx) + rabs) * 6e-7f, sz = (fabsf(cz) + rabs) * 6e-7f;
+            const int ix0 = grid_coord((cx - rabs) - sx, hdr.xmin, hdr.inv_w, gx), ix1 = grid_coord((cx + rabs) + sx, hdr.xmin, hdr.inv_w, gx);
+            const int iz0 = grid_coord((cz - rabs) - sz, zmin, inv_wz, gz), iz1 = grid_coord((cz + rabs) + sz, zmin, inv_wz, gz);
+            int total = 0;
+            for (int iz = iz0; iz <= iz1 && total <= BQS_MAX_SLAB; ++iz)
+                total += (int)start16[iz * gx + ix1 + 1] - (int)start16[iz * gx + ix0];
+            if (total <= BQS_MAX_SLAB) {
+                for (int iz = iz0 + w; iz <= iz1; iz += 4) scan((int)start16[iz * gx + ix0], (int)start16[iz * gx + ix1 + 1]);
+            } else {
+                full_scan = true;
+            }
+        } else {
+            // x slabs: cells overlapping |x - cx| < r: x_cell is monotone, one extra cell each side absorbs the
+            // rounding of cx -+ r (cell width >> 1 ulp of x)
+            const int c_lo = max(0, x_cell(cx - rabs, hdr.xmin, hdr.inv_w) - 1);
+            const int c_hi = min(BQS_CELLS - 1, x_cell(cx + rabs, hdr.xmin, hdr.inv_w) + 1);
+            const int k0 = start[c_lo], kend = start[c_hi + 1];
+            if (kend - k0 <= BQS_MAX_SLAB) {
+                const int q = (kend - k0 + 3) >> 2;               // this wave's quarter of the slab
+                const int k = min(kend, k0 + w * q);
+                scan(k, min(kend, k + q));
+            } else {
+                full_scan = true;
+            }
+        }
+        if (full_scan && w == 0) {
+            // pathological density: ordered full scan with early exit (the reference's own loop)
             for (int q = 0; q < n && cnt < nsample; ++q) {
                 const float d2 = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]);
                 if (d2 < radius2) { row[cnt] = (uint16_t)q; ++cnt; }
@@ -475,6 +658,105 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
 #endif
 }
 
+// ---- fine-grid flavour: 64 centres per workgroup, wave 0 searches (one lane per centre: the grid leaves ~5-30 candidates,
+// so the four-wave split and its merge are not worth their 33 KB of partial rows), then all four waves emit.  10 KB of LDS
+// per workgroup instead of 44 KB: 8 workgroups = 32 waves per CU instead of 12 -- the emit is latency-bound on its gathers,
+// and resident waves are what keeps loads in flight.  1-D grid, XCD-aware: workgroup g runs on XCD g % 8 (observed dispatch
+// order), so scene = (g / 8 / tiles) * 8 + g % 8 puts all tiles of a scene on ONE XCD -- its points and features are pulled
+// into one L2 instead of eight.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
+                                                              const float *__restrict__ xyz, const char *__restrict__ ws,
+                                                              const float *__restrict__ new_xyz, const float *__restrict__ features,
+                                                              int32_t *__restrict__ idx_out, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
+    int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
+    uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
+    const int rstride = nsample + 1;
+    const int tiles = (m + 63) / 64;
+    int b, tile;
+    if ((nb & 7) == 0) {
+        const int g = blockIdx.x, j = g >> 3;
+        b = (j / tiles) * 8 + (g & 7);
+        tile = j - (j / tiles) * tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x - b * tiles;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = tile * 64;
+    const int mi = m0 + lane;
+    const bool active = mi < m;
+    xyz += (size_t)b * n * 3;
+    const char *base = ws + (size_t)b * bin_scene_stride(n);
+    const float4 *sorted = reinterpret_cast<const float4 *>(base);
+    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)n * 16);
+    const uint16_t *start16 = reinterpret_cast<const uint16_t *>(base + (size_t)n * 16 + sizeof(BinHeader));
+    const int *params = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
+    new_xyz += (size_t)b * m * 3;
+    if (w == 0) {
+        float cx = 0.f, cy = 0.f, cz = 0.f;
+        if (active) { cx = new_xyz[mi * 3 + 0]; cy = new_xyz[mi * 3 + 1]; cz = new_xyz[mi * 3 + 2]; }
+        cen[lane] = make_float4(cx, cy, cz, 0.f);
+        const float radius2 = radius * radius;
+        const float rabs = fabsf(radius);
+        uint16_t *row = rows + (size_t)lane * rstride;
+        int cnt = 0;
+        auto insert = [&](const int id) {  // keep the nsample smallest indices, ascending
+            if (cnt == nsample) {
+                if (id >= (int)row[nsample - 1]) return;
+                --cnt;
+            }
+            int pos = cnt;
+            while (pos > 0 && (int)row[pos - 1] > id) { row[pos] = row[pos - 1]; --pos; }
+            row[pos] = (uint16_t)id;
+            ++cnt;
+        };
+        if (active && cx == cx) {
+            // see ball_query_sorted_kernel for the bounds argument (hits lie within r (1 + 2^-23) of the centre on each axis)
+            const int gx = -hdr.pad, gz = params[2];
+            const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
+            const float sx = (fabsf(cx) + rabs) * 6e-7f, sz = (fabsf(cz) + rabs) * 6e-7f;
+            const int ix0 = grid_coord((cx - rabs) - sx, hdr.xmin, hdr.inv_w, gx), ix1 = grid_coord((cx + rabs) + sx, hdr.xmin, hdr.inv_w, gx);
+            const int iz0 = grid_coord((cz - rabs) - sz, zmin, inv_wz, gz), iz1 = grid_coord((cz + rabs) + sz, zmin, inv_wz, gz);
+            int total = 0;
+            for (int iz = iz0; iz <= iz1 && total <= BQS_MAX_SLAB; ++iz)
+                total += (int)start16[iz * gx + ix1 + 1] - (int)start16[iz * gx + ix0];
+            if (total <= BQS_MAX_SLAB) {
+                for (int iz = iz0; iz <= iz1; ++iz) {
+                    int k = (int)start16[iz * gx + ix0];
+                    const int ke = (int)start16[iz * gx + ix1 + 1];
+                    for (; k < ke; k += 4) {
+                        float4 p[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) p[u] = sorted[min(k + u, ke - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float dx = cx - p[u].x;
+                            if (k + u < ke && fabsf(dx) < rabs) {
+                                const float d2 = sqdist3(dx, cy - p[u].y, cz - p[u].z);
+                                if (d2 < radius2) insert(__float_as_int(p[u].w));
+                            }
+                        }
+                    }
+                }
+            } else {
+                // pathological density: ordered full scan with early exit (the reference's own loop)
+                for (int q = 0; q < n && cnt < nsample; ++q) {
+                    const float d2 = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]);
+                    if (d2 < radius2) { row[cnt] = (uint16_t)q; ++cnt; }
+                }
+            }
+        }
+        const uint16_t first = cnt > 0 ? row[0] : (uint16_t)0;
+        for (int s2 = cnt; s2 < nsample; ++s2) row[s2] = first;
+        cnt_s[lane] = active ? cnt : 0;
+    }
+    __syncthreads();
+    bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
+}
+
 static size_t bq_smem(int nsample, size_t idx_bytes) {
     return sizeof(float4) * (BQ_NW * BQ_TILE + 64) + sizeof(int) * BQ_NW * 64 +
            idx_bytes * (size_t)BQ_NW * 64 * (nsample + 1);
@@ -504,6 +786,14 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     if (FUSED && nlc && c >= 16) {   // row slices: at least 64 rows per workgroup
         const long tiles = (long)b * ((m + 63) / 64);
         while (gz < 64 && tiles * gz < 1024 && (64L * nsample) / (gz * 2) >= 64) gz *= 2;
+    }
+    if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
+        const size_t smem_g = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)64 * (nsample + 1);
+        if (smem_g <= 64 * 1024) {
+            hipLaunchKernelGGL((ball_query_grid_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_g, st, b, n, m, c,
+                               radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out);
+            return check_launch(what);
+        }
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535) {
         const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
@@ -647,7 +937,20 @@ extern "C" int ws3d_sort_points_x(int b, int n, const float *xyz, void *sorted, 
     if (b == 0) return WS3D_OK;
     hipLaunchKernelGGL(bin_points_x_kernel, dim3(b), dim3(1024), 0, as_stream(stream), n, xyz,
                        reinterpret_cast<char *>(sorted));
+    note_flavour(sorted, 0);
     return check_launch("ws3d_sort_points_x");
+}
+
+extern "C" int ws3d_sort_points_grid(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || n > SORT_MAX_N || !xyz || !sorted) {
+        set_error("ws3d_sort_points_grid: invalid argument (b=%d n=%d, n <= %d)", b, n, SORT_MAX_N);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0) return WS3D_OK;
+    hipLaunchKernelGGL(bin_points_grid_kernel, dim3(b), dim3(1024), 0, as_stream(stream), n, xyz, reinterpret_cast<char *>(sorted));
+    note_flavour(sorted, 1);
+    return check_launch("ws3d_sort_points_grid");
 }
 
 extern "C" int ws3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,

@@ -258,6 +258,16 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
         oig[0] = i1; oig[1] = i2; oig[2] = i3;
         return;
     }
+    if (hdr.pad < 0) {
+        // fine-grid flavour of the ball query (ws3d_sort_points_grid) handed to three_nn: its table is not ours; the result
+        // is order-independent, so a full scan of the binned copy is still exact (correct, just not pruned)
+        for (int i = 0; i < m; ++i) visit(sorted[i]);
+        float *odf = dist2 + ((size_t)b * n + pi) * 3;
+        int32_t *oif = idx + ((size_t)b * n + pi) * 3;
+        odf[0] = b1; odf[1] = b2; odf[2] = b3;
+        oif[0] = i1; oif[1] = i2; oif[2] = i3;
+        return;
+    }
     const int c0 = x_cell(ux, hdr.xmin, hdr.inv_w);
     int R = start[c0], L = R - 1;
     bool go_r = R < m, go_l = L >= 0;
