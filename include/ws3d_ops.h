@@ -48,6 +48,11 @@ extern "C" {
 typedef void *ws3d_stream_t;
 
 WS3D_API int ws3d_abi_version(void);
+/* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
+ * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
+ * cannot be captured without a CUDA device): 0 = fma(dz,dz,fma(dx,dx,dy*dy)) [default], 1 = no contraction,
+ * 2 = fma(dz,dz,fma(dy,dy,dx*dx)).  libws3d_hip_dm1.so / _dm2.so are the other builds.                          */
+WS3D_API int ws3d_dist_mode(void);
 WS3D_API const char *ws3d_last_error(void);
 /* name/CU count/LDS bytes of the current device; any pointer may be NULL */
 WS3D_API int ws3d_device_info(char *name, int name_len, int *cu_count, int *lds_bytes_per_block);

@@ -21,7 +21,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libws3d_oracle.so")
+# WS3D_DIST_MODE=1|2 (the variable ws3d_amd reads too): the oracle built under the same alternative convention
+DIST_MODE = int(os.environ.get("WS3D_DIST_MODE", "0") or 0)
+_SO_NAME = "libws3d_oracle.so" if DIST_MODE == 0 else "libws3d_oracle_dm%d.so" % DIST_MODE
+_SO = os.path.join(_HERE, _SO_NAME)
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -33,9 +36,17 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (seconds).  Returns the path of the .so."""
     src = os.path.join(_HERE, "ws3d_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libws3d_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", _SO_NAME], stdout=subprocess.DEVNULL)
     return _SO
+
+
+def build_all() -> None:
+    """all three conventions (the default library plus _dm1 / _dm2): they travel to the GPU box prebuilt"""
+    src = os.path.join(_HERE, "ws3d_oracle.c")
+    for name in ("libws3d_oracle.so", "libws3d_oracle_dm1.so", "libws3d_oracle_dm2.so"):
+        so = os.path.join(_HERE, name)
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
 
 
 _lib = None

@@ -189,6 +189,45 @@ def test_fps_kernel_variants_subprocess(oracle, tmp_path, env):
         np.testing.assert_array_equal(np.load(tmp_path / f"tmp{i}.npy"), ref_temp, err_msg=str(cases[i]))
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_alternative_distance_conventions_subprocess(tmp_path, mode):
+    """libws3d_hip_dm<N>.so (WS3D_DIST_MODE=N: the squared distance spelled without / with the other FMA contraction) against
+    the oracle built under the SAME convention: FPS (every kernel family), ball query (grid, slabs, brute force), 3-NN"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        import oracle
+        from ws3d_amd import compat, synth, _lib
+        assert _lib.load().ws3d_dist_mode() == {mode} and oracle.dist_mode() == {mode}
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        for (B, N, M) in [(2, 16384, 1200), (2, 4096, 600), (2, 1000, 250), (3, 200, 60)]:
+            pcs = synth.make_batch("lidar", B, N, 21, dup_frac=0.02)[:, :, :3].copy()
+            ref = oracle.furthest_point_sample(pcs, M)
+            idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); nx = torch.empty((B, M, 3), device="cuda")
+            compat.furthest_point_sampling_gather(B, N, M, dev(pcs), None, idx, nx)
+            assert np.array_equal(idx.cpu().numpy(), ref), ("fps", N)
+            new = np.stack([pcs[b][ref[b]] for b in range(B)])
+            for r, ns in ((0.1, 16), (0.7, 32)):
+                want = oracle.ball_query(r, ns, pcs, new)
+                x, c = dev(pcs), dev(new)
+                for srt in ((compat.sort_points_x(x, grid=True), compat.sort_points_x(x, grid=False), None) if N >= 2048 else (None,)):
+                    got = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+                    compat.ball_query_wrapper(B, N, M, r, ns, c, x, got, srt)
+                    assert np.array_equal(got.cpu().numpy(), want), ("ball_query", N, r)
+            d2, i3 = oracle.three_nn_dist2(pcs, new)
+            gd = torch.empty((B, N, 3), device="cuda"); gi = torch.empty((B, N, 3), dtype=torch.int32, device="cuda")
+            for srt in (compat.sort_points_xz(dev(new)), None):
+                compat.three_nn_wrapper(B, N, M, dev(pcs), dev(new), gd, gi, srt)
+                assert np.array_equal(gi.cpu().numpy(), i3) and np.array_equal(gd.cpu().numpy(), d2), ("three_nn", N)
+        print("DIST_MODE_OK")
+    """)
+    r = subprocess.run([sys.executable, "-B", "-c", code], env=dict(os.environ, WS3D_DIST_MODE=str(mode)), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "DIST_MODE_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_fps_temp_contract(ops, oracle):
     """the wrapper-level entry point takes the caller's temp (pre-filled 1e10) and leaves the
     final running min-distance in it, like the reference kernel does (sampling_gpu.cu:134-135)."""

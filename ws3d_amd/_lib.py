@@ -9,7 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(_HERE, "libws3d_hip.so")  # env: A/B builds
+# WS3D_DIST_MODE=1|2: the library built under another squared-distance convention (csrc/common.h; built by
+# ``python -m ws3d_amd.build --dist-mode N``) -- for users whose CUDA reference outputs match that convention
+DIST_MODE = int(os.environ.get("WS3D_DIST_MODE", "0") or 0)
+LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B builds
+    _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -19,6 +23,7 @@ _sz = C.c_size_t
 # name -> (restype, argtypes); kept in the order of include/ws3d_ops.h
 SIGNATURES = {
     "ws3d_abi_version": (_i, []),
+    "ws3d_dist_mode": (_i, []),
     "ws3d_last_error": (C.c_char_p, []),
     "ws3d_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ws3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -99,6 +104,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if not os.environ.get("WS3D_HIP_LIB") and lib.ws3d_dist_mode() != DIST_MODE:
+        raise Ws3dError(f"{LIB_PATH} was built with WS3D_DIST_MODE={lib.ws3d_dist_mode()}, expected {DIST_MODE}: rebuild it")
     _lib = lib
     return lib
 

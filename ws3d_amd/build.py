@@ -26,6 +26,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libws3d_hip.so")
+DIST_MODES = (0, 1, 2)   # squared-distance conventions (csrc/common.h); 0 is the product default
+
+
+def lib_path(dist_mode: int = 0) -> str:
+    return LIB if dist_mode == 0 else os.path.join(HERE, "libws3d_hip_dm%d.so" % dist_mode)
 ARCH = "gfx950"
 SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -44,13 +49,13 @@ def _deps(src: str):
             os.path.abspath(__file__)]
 
 
-def _compile(src: str, force: bool, verbose: bool) -> str:
+def _compile(src: str, force: bool, verbose: bool, dist_mode: int = 0) -> str:
     path = os.path.join(CSRC, src)
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    obj = os.path.join(OBJ if dist_mode == 0 else OBJ + "_dm%d" % dist_mode, os.path.splitext(src)[0] + ".o")
     if not force and os.path.exists(obj) and all(
             os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(path)):
         return obj
-    cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, "-c", path, "-o", obj]
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, f"-DWS3D_DIST_MODE={dist_mode}", "-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,10 +66,13 @@ def _compile(src: str, force: bool, verbose: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, dist_mode: int = 0) -> str:
+    """dist_mode != 0 builds the same library under another squared-distance convention (csrc/common.h) into
+    libws3d_hip_dm<N>.so; ``WS3D_DIST_MODE=N`` in the environment makes ws3d_amd load it."""
+    LIB = lib_path(dist_mode)
+    os.makedirs(OBJ if dist_mode == 0 else OBJ + "_dm%d" % dist_mode, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, verbose), SOURCES))
+        objs = list(ex.map(lambda s: _compile(s, force, verbose, dist_mode), SOURCES))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         # export only the extern "C" ws3d_* symbols (-fvisibility=hidden + default below)
         cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
@@ -80,6 +88,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--dist-mode", type=int, default=0, choices=DIST_MODES)
+    ap.add_argument("--all-dist-modes", action="store_true")
     a = ap.parse_args()
-    print(build(a.force, a.verbose))
+    for dm in (DIST_MODES if a.all_dist_modes else (a.dist_mode,)):
+        print(build(a.force, a.verbose, dm))
     sys.exit(0)

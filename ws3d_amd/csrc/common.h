@@ -19,10 +19,25 @@ int check_launch(const char *what);
 static inline hipStream_t as_stream(ws3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Squared distance of the three pointnet2 search kernels: the source expression
-// dx*dx + dy*dy + dz*dz (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36)
-// under nvcc's default FMA contraction: fma(dz,dz, fma(dx,dx, dy*dy)).
+// dx*dx + dy*dy + dz*dz (sampling_gpu.cu:133, ball_query_gpu.cu:33, interpolate_gpu.cu:36).
+// WS3D_DIST_MODE (a BUILD option: python -m ws3d_amd.build --dist-mode N -> libws3d_hip_dmN.so, selected at run time with
+// the environment variable WS3D_DIST_MODE; same numbering as the oracle's WS3D_ORACLE_DIST_MODE):
+//   0 (default)  fma(dz,dz, fma(dx,dx, dy*dy))   nvcc's default contraction (--fmad=true) of the expression
+//   1            (dx*dx + dy*dy) + dz*dz          no contraction (nvcc --fmad=false; also what a CPU build computes)
+//   2            fma(dz,dz, fma(dy,dy, dx*dx))    the other contraction order (SURVEY.md appendix A's proposal)
+// No CUDA device exists here to capture which one the reference binary executes; a user holding
+// real CUDA outputs selects the matching mode.  scripts/dist_mode_sensitivity.py reports how often the choice is visible.
+#ifndef WS3D_DIST_MODE
+#define WS3D_DIST_MODE 0
+#endif
 __device__ __forceinline__ float sqdist3(float dx, float dy, float dz) {
+#if WS3D_DIST_MODE == 0
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+#elif WS3D_DIST_MODE == 1
+    return (dx * dx + dy * dy) + dz * dz;
+#else
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+#endif
 }
 
 // float trig = double libm result rounded to float (== correctly rounded float

@@ -29,6 +29,8 @@ int check_launch(const char *what) {
 
 extern "C" int ws3d_abi_version(void) { return 1; }
 
+extern "C" int ws3d_dist_mode(void) { return WS3D_DIST_MODE; }
+
 extern "C" const char *ws3d_last_error(void) { return ws3d::g_err; }
 
 extern "C" int ws3d_device_info(char *name, int name_len, int *cu_count, int *lds_bytes_per_block) {

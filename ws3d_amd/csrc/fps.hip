@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                 gm[s / GS] = max_f32(gm[s / GS], d2);
             }
             best = max_f32(max_f32(gm[0], gm[1]), max_f32(gm[2], gm[3]));
-        } else if constexpr (PPT >= 2 && NT == 64 && WS3D_FPS_PACKED) {  // pays only for the single-wave shapes (measured)
+        } else if constexpr (PPT >= 2 && NT == 64 && WS3D_FPS_PACKED && WS3D_DIST_MODE == 0) {  // pays only for the single-wave shapes (measured)
             // two points per instruction for the distance (v_pk_add/mul/fma_f32: same IEEE
             // results per element as the scalar forms)
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NT) void fps_reg_kernel(const float *__restrict__ x
                 ti[s] = gt ? 2 * s + 1 : 2 * s;
             }
             tourney<PPT / 2>(tv, ti, best, bslot);
-        } else if constexpr (PPT >= 4 && WS3D_FPS_CHAINS) {
+        } else if constexpr (PPT >= 4 && WS3D_FPS_CHAINS && WS3D_DIST_MODE == 0) {
             // CH independent argmax chains over contiguous slot ranges, advanced in lock step so
             // that CH distance computations (each a 7-deep dependent chain) and CH compare/select
             // recurrences are in flight at once; the single-chain form left one wave with no

@@ -418,9 +418,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
                 if (YLDS && c == NC - 1) { y0 = yl.x; y1 = yl.y; y2 = yl.z; y3 = yl.w; }
                 else { y0 = v3get<PPT>(py, 4 * c); y1 = v3get<PPT>(py, 4 * c + 1); y2 = v3get<PPT>(py, 4 * c + 2); y3 = v3get<PPT>(py, 4 * c + 3); }
                 if (YLDS && c == NC - 2) yl = zs4[NC * NT + u];       // in flight while chunk NC-2 is consumed
+#if WS3D_DIST_MODE == 2
+                // the asm computes (A - a)^2, then fma with (B - b), then fma with (z - oz); mode 0: A = y, B = x; mode 2: A = x, B = y
+                sweep4<SG>(y0, y1, y2, y3,
+                             v3get<PPT>(px, 4 * c), v3get<PPT>(px, 4 * c + 1), v3get<PPT>(px, 4 * c + 2), v3get<PPT>(px, 4 * c + 3),
+                             z0, z1, z2, z3, t[4 * c], t[4 * c + 1], t[4 * c + 2], t[4 * c + 3], gm[(4 * c) / GS], sy, sx, sz);
+#else
                 sweep4<SG>(v3get<PPT>(px, 4 * c), v3get<PPT>(px, 4 * c + 1), v3get<PPT>(px, 4 * c + 2), v3get<PPT>(px, 4 * c + 3),
                              y0, y1, y2, y3,
                              z0, z1, z2, z3, t[4 * c], t[4 * c + 1], t[4 * c + 2], t[4 * c + 3], gm[(4 * c) / GS], sx, sy, sz);
+#endif
                 if constexpr (ZLDS) __builtin_amdgcn_sched_barrier(0);   // keep two z chunks live at most (128-VGPR budget)
             }
         } else {
@@ -623,6 +630,9 @@ bool fps_v3_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *
                    long R, bool pair, hipStream_t st) {
     // WS3D_FPS_GEOM3: "<threads>" overrides the workgroup size of the large shapes (A/B runs)
     static const int geom = getenv("WS3D_FPS_GEOM3") ? atoi(getenv("WS3D_FPS_GEOM3")) : 0;
+#if WS3D_DIST_MODE == 1
+    return false;     // the hand-scheduled sweep spells the two contracted forms only; the un-contracted build uses fps.hip
+#endif
 #define V3(P, T, Z) launch_v3<P, T, Z>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st)
     // small clouds (<= 2048 positions: one to four waves) stay on fps.hip's kernels: with so few waves a step is a serial
     // instruction stream at ~4.2 clk per instruction, and their packed-math sweep issues fewer instructions (measured:
