@@ -146,3 +146,30 @@ def test_config3_nms_9000_boxes(ops, oracle):
     is_kept = torch.zeros(n, dtype=torch.bool, device="cuda")
     is_kept[kept] = True
     assert torch.equal(sup, ~is_kept)
+
+
+def test_dense_scan_fps_65536_to_16384_full_oracle_check(ops, oracle):
+    """SURVEY a1's dense shape: furthest_point_sample 65536 -> 16384 (fps_big_kernel: min-distance in registers, xyz streamed)
+    against the oracle over ALL 16384 indices, plus the min-distance buffer contract, on two scenes (one with duplicates)"""
+    N, M = 65536, 16384
+    pcs = np.stack([synth.lidar_cloud(N, 5100)[:, :3], synth.make_batch("lidar", 1, N, 5101, dup_frac=0.05)[0, :, :3]]).copy()
+    ref, ref_temp = oracle.furthest_point_sample(pcs, M, return_temp=True)
+    x = dev(pcs)
+    temp = torch.full((2, N), 1e10, device="cuda")
+    idx = torch.empty((2, M), dtype=torch.int32, device="cuda")
+    new_xyz = torch.empty((2, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(2, N, M, x, temp, idx, new_xyz)
+    np.testing.assert_array_equal(host(idx), ref)
+    np.testing.assert_array_equal(host(temp), ref_temp)
+    np.testing.assert_array_equal(host(new_xyz), np.stack([pcs[b][ref[b]] for b in range(2)]))
+
+
+@pytest.mark.parametrize("N,M", [(16385, 300), (20000, 500), (32768, 400), (33000, 200), (50001, 300)])
+def test_large_n_fps_ragged_sizes(ops, oracle, N, M):
+    """the register-resident-min-distance kernel at ragged sizes either side of its two instances (<= 32768, <= 65536),
+    without a temp buffer (the round-1 streaming kernel required one)"""
+    pcs = synth.make_batch("lidar", 2, N, 5200 + N % 97, dup_frac=0.02)[:, :, :3].copy()
+    ref = oracle.furthest_point_sample(pcs, M)
+    idx = torch.empty((2, M), dtype=torch.int32, device="cuda")
+    ops.c.furthest_point_sampling_wrapper(2, N, M, dev(pcs), None, idx)
+    np.testing.assert_array_equal(host(idx), ref)

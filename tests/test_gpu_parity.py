@@ -149,6 +149,7 @@ FPS_ENV_VARIANTS = [
     {"WS3D_FPS_ONEX": "1", "WS3D_FPS_GEOM3": "1024"},
     {"WS3D_FPS_GEOM3": "512"}, {"WS3D_FPS_GEOM3": "256"}, {"WS3D_FPS_GEOM3": "1024"},
     {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "0"}, {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "2"},
+    {"WS3D_FPS_STREAM": "1"},                            # the round-1 streaming kernel above 16384 points
 ]
 
 
@@ -158,7 +159,7 @@ def test_fps_kernel_variants_subprocess(oracle, tmp_path, env):
     and the final min-distance buffer against the oracle, over shapes that reach every template instance"""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cases = [(2, 16384, 1500, "lidar", 0.02), (1, 12345, 400, "lidar", 0.3), (2, 8192, 300, "uniform", 0.0), (2, 4096, 500, "lidar", 0.05),
+    cases = [(1, 40000, 150, "lidar", 0.02), (1, 20000, 100, "uniform", 0.0), (2, 16384, 1500, "lidar", 0.02), (1, 12345, 400, "lidar", 0.3), (2, 8192, 300, "uniform", 0.0), (2, 4096, 500, "lidar", 0.05),
              (2, 3000, 200, "lidar", 0.0), (2, 2048, 256, "lidar", 0.05), (2, 1025, 100, "uniform", 0.0), (2, 1000, 250, "lidar", 0.1),
              (2, 512, 128, "lidar", 0.0), (3, 200, 60, "uniform", 0.2), (2, 100, 37, "uniform", 0.0), (2, 64, 64, "uniform", 0.0)]
     refs = []

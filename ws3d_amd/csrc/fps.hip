@@ -557,6 +557,114 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(const float *__restric
     }
 }
 
+// ---- 16384 < n <= 65536 (the dense-scan shapes, SURVEY a1: 65536 -> 16384).  The scene no longer fits the register
+// file, but its running min-distance does: SPT <= 64 values per lane of a 1024-thread workgroup stay in VGPRs for the whole
+// kernel, so a step only STREAMS xyz (12 B per point, coalesced dwordx3, L2-resident: 786 KB per scene) instead of also
+// reading and writing the 4-byte min-distance of every point in global memory as fps_stream_kernel (and the reference,
+// sampling_gpu.cu:124-138) do -- 12 instead of 20 bytes per point and step, and no store->load dependence between steps.
+// Same strided ownership (k = tid + 1024 s) and tie key as fps_stream_kernel.
+template <int SPT>
+__global__ __launch_bounds__(512) void fps_big_kernel(const float *__restrict__ xyz, float *__restrict__ temp,
+                                                      int32_t *__restrict__ idx, float *__restrict__ new_xyz, int n, int m) {
+    // 512 threads x SPT <= 128 slots (256-VGPR budget: 1024 threads would leave 128 and spill).  Thread u owns
+    // k = u + 512 s, i.e. the points of the reference's threads u (even s) and u + 512 (odd s); their tie keys are
+    // bitrev10(u) and bitrev10(u) + 1, so the two are tracked separately and the even one keeps exact ties.
+    typedef float f3v __attribute__((ext_vector_type(3)));
+    typedef f3v f3u __attribute__((aligned(4)));
+    __shared__ float4 s_cand[2][8];
+    __shared__ int2 s_kk[2][8];  // {k, key}
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    if (temp) temp += (size_t)b * n;
+    idx += (size_t)b * m;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int key0 = bitrev_bits(tid, 10);
+    float t[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        const int k = tid + 512 * s;
+        t[s] = k < n ? (temp ? temp[k] : 1e10f) : -1.0f;     // -1: never beats a real candidate, min(d, -1) stays -1
+    }
+    int old = 0;
+    float ox = xyz[0], oy = xyz[1], oz = xyz[2];
+    if (tid == 0) {
+        idx[0] = 0;
+        if (new_xyz) { new_xyz[0] = ox; new_xyz[1] = oy; new_xyz[2] = oz; }
+    }
+    for (int j = 1; j < m; ++j) {
+        float bestA = -1.0f, bestB = -1.0f;
+        int iA = 0, iB = 0;
+        // 8 independent 12-byte loads in flight per lane and trip (clamped, never branched).  The byte offsets are
+        // recomputed every step from an opaque start: hoisted out of the step loop they would cost SPT registers
+        unsigned off = (unsigned)tid * 12u;
+        asm volatile("" : "+v"(off));
+        const unsigned last = (unsigned)(n - 1) * 12u;
+        const char *xb = reinterpret_cast<const char *>(xyz);
+#pragma unroll
+        for (int s0 = 0; s0 < SPT; s0 += 8) {
+            f3v p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { p[u] = *reinterpret_cast<const f3u *>(xb + min(off, last)); off += 512u * 12u; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float d = sqdist3(p[u].x - ox, p[u].y - oy, p[u].z - oz);
+                const float d2 = min_f32(d, t[s0 + u]);
+                t[s0 + u] = d2;
+                if ((u & 1) == 0) {   // reference thread u: ascending k, strict '>' keeps the smallest k among exact ties
+                    const bool gt = d2 > bestA;
+                    iA = gt ? tid + 512 * (s0 + u) : iA;
+                    bestA = gt ? d2 : bestA;
+                } else {              // reference thread u + 512
+                    const bool gt = d2 > bestB;
+                    iB = gt ? tid + 512 * (s0 + u) : iB;
+                    bestB = gt ? d2 : bestB;
+                }
+            }
+        }
+        const bool useB = bestB > bestA;                 // the lower key (A) keeps exact ties
+        const float best = useB ? bestB : bestA;
+        const int besti = useB ? iB : iA;
+        const int key = key0 + (useB ? 1 : 0);
+        const float wmax = wave_max(best);
+        const int mykey = (best == wmax) ? key : (1 << 20);
+        const int wkey = wave_min_i(mykey);
+        const uint64_t eq = __ballot(mykey == wkey);
+        const int wl = (int)__builtin_ctzll(eq);
+        const int kw = __builtin_amdgcn_readlane(besti, wl);
+        const int buf = j & 1;
+        if (lane == 0) {
+            const float cx = xyz[kw * 3 + 0], cy = xyz[kw * 3 + 1], cz = xyz[kw * 3 + 2];
+            s_cand[buf][w] = make_float4(wmax, cx, cy, cz);
+            s_kk[buf][w] = make_int2(kw, wkey);
+        }
+        __syncthreads();
+        const int e = lane & 7;
+        const float4 c = s_cand[buf][e];
+        const int2 kk = s_kk[buf][e];
+        const float vm = row16_max(c.x);
+        const int k2 = (c.x == vm) ? kk.y : (1 << 20);
+        const int kmin = row16_min_i(k2);
+        const uint64_t eq2 = __ballot(k2 == kmin);
+        const int sel = (int)__builtin_ctzll(eq2);
+        ox = readlane_f(c.y, sel);
+        oy = readlane_f(c.z, sel);
+        oz = readlane_f(c.w, sel);
+        old = __builtin_amdgcn_readlane(kk.x, sel);
+        if (tid == 0) {
+            idx[j] = old;
+            if (new_xyz) { new_xyz[j * 3 + 0] = ox; new_xyz[j * 3 + 1] = oy; new_xyz[j * 3 + 2] = oz; }
+        }
+    }
+    if (temp) {
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            const int k = tid + 512 * s;
+            if (k < n) temp[k] = t[s];
+        }
+    }
+}
+
 // host: cuda_utils.h:10-14 (same libm expression as the reference's launcher)
 static int opt_n_threads(int work_size) {
     const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
@@ -643,9 +751,13 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
         else if (ppt <= 8) launch_reg<8, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
         else if (geom != 0) launch_reg<32, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
         else launch_reg<16, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else if (n <= 65536 && bs == 1024 && !(getenv("WS3D_FPS_STREAM") && atoi(getenv("WS3D_FPS_STREAM")))) {
+        // min-distance in registers, xyz streamed from L2 (WS3D_FPS_STREAM=1 keeps the round-1 streaming kernel: A/B runs)
+        if (n <= 32768) hipLaunchKernelGGL(fps_big_kernel<64>, dim3(b), dim3(512), 0, st, xyz, temp, idx, new_xyz, n, m);
+        else hipLaunchKernelGGL(fps_big_kernel<128>, dim3(b), dim3(512), 0, st, xyz, temp, idx, new_xyz, n, m);
     } else {
         if (!temp) {
-            set_error("ws3d_furthest_point_sampling: n=%d exceeds the in-register capacity (16384); "
+            set_error("ws3d_furthest_point_sampling: n=%d exceeds the on-chip capacity (65536); "
                       "the streaming path needs the caller's temp (b,n) buffer", n);
             return WS3D_E_WORKSPACE;
         }
