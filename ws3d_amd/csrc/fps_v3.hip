@@ -373,7 +373,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
         const int slot = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
         if (lane == 0) atomicMin(&s_rank, slot);
         __syncthreads();
-        if (prio_mode != 0) sweep_prio = (s_rank == 0 && prio_mode == 1) ? 1 : 0;      // mode 2: chain priority only (A/B runs)
+        if (prio_mode != 0) sweep_prio = (s_rank == 0 && (prio_mode & 3) == 1) ? 1 : 0;      // mode 2: chain priority only (A/B runs)
+        // start-up offset of the second scene of the CU (prio_mode >> 2, units of 64 clk): A/B runs of the anti-phase start
+        if (s_rank != 0) for (int d = prio_mode >> 2; d > 0; --d) __builtin_amdgcn_s_sleep(1);
     }
     const float *zs = reinterpret_cast<const float *>(smem_z);
     // two-exchange kernel: the winning wave's stores of step j are issued at the top of step j+1 (off the chain)
