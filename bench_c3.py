@@ -141,12 +141,12 @@ class C3:
         out = self.model.rpn_forward({'pts_input': self.pts})
         if timed:
             e[1].record()
-        boxes, scores, count = proposals_from_rpn(out, self.cfg)
+        boxes, scores, count, enlarged = proposals_from_rpn(out, self.cfg, with_pool_boxes=True)
         if timed:
             e[2].record()
         feats = out['backbone_features'].transpose(1, 2).contiguous()
         pooled, empty = roipool3d_ops.roipool3d_gpu(out['backbone_xyz'], feats, boxes, self.cfg.roi_extra_width,
-                                                    sampled_pt_num=self.cfg.roi_sampled_pts)
+                                                    sampled_pt_num=self.cfg.roi_sampled_pts, enlarged=enlarged)
         if timed:
             e[3].record()
             self.ev.append(e)

@@ -311,6 +311,19 @@ WS3D_API int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope, f
                                       float l, const float *xyz, const float *rpn_reg, float *boxes,
                                       ws3d_stream_t stream);
 
+/* Glue of the on-device proposal stage (no reference counterpart: the reference does these steps in Python around its ops,
+ * kitti_utils.py:134-160, roipool3d_utils.py:19, generate_box_dataset.py:92-140).
+ * ws3d_gather_boxes_bev: box (b,n,7), order (b,top) int64 -> box_sorted (b,top,7) = box[order] and bev (b,top,5) =
+ * [x - l/2, z - w/2, x + l/2, z + w/2, ry] (boxes3d_to_bev).                                                        */
+WS3D_API int ws3d_gather_boxes_bev(int b, int n, int top, const float *box, const int64_t *order, float *box_sorted, float *bev,
+                          ws3d_stream_t stream);
+/* ws3d_select_proposals: keep (b,keep_stride) int64 / num (b) int32 from ws3d_nms_batched on score-sorted boxes -> the
+ * first min(num, k) survivors as boxes_out (b,k,7) and scores_out (b,k), zero-padded (row * 0 for the padding, as the
+ * torch composition does), count (b) int64, and (optional) pooled_boxes (b,k,7) = enlarge_box3d(boxes_out, extra_width). */
+WS3D_API int ws3d_select_proposals(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
+                          const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
+                          int64_t *count, float *pooled_boxes, ws3d_stream_t stream);
+
 /* ---------------------------------------------------------------- roipool3d_cuda */
 
 /* forward(xyz,boxes3d,pts_feature,pooled_features,pooled_empty_flag)

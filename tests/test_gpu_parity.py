@@ -623,7 +623,11 @@ def test_nms_batched_and_proposal_stage(ops, oracle):
     out = {"backbone_xyz": dev(pc[:, :, :3].copy()),
            "rpn_reg": dev(rng.standard_normal((2, N, 40)).astype(np.float32)),
            "rpn_cls": dev((rng.permutation(2 * N).reshape(2, N, 1) / (2 * N) * 8 - 4).astype(np.float32))}
-    pb, ps, pcnt = stage1.proposals_from_rpn(out, cfg)
+    pb, ps, pcnt, penl = stage1.proposals_from_rpn(out, cfg, with_pool_boxes=True)
+    # the fused glue (ws3d_gather_boxes_bev / ws3d_select_proposals) is bit-identical to the torch composition it replaces
+    tb, ts, tcnt, tenl = stage1.proposals_from_rpn(out, cfg, with_pool_boxes=True, fused=False)
+    assert torch.equal(pb, tb) and torch.equal(ps, ts) and torch.equal(pcnt, tcnt) and torch.equal(penl, tenl)
+    assert pb.view(torch.int32).eq(tb.view(torch.int32)).all()          # including the sign of the zero padding
     h, w, l = cfg.cls_mean_size
     for b in range(2):
         score = torch.sigmoid(out["rpn_cls"][b, :, 0])

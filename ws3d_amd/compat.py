@@ -461,6 +461,39 @@ def decode_center_boxes(xyz, rpn_reg, loc_scope, loc_bin_size, mean_size):
     return boxes
 
 
+def gather_boxes_bev(box, order):
+    """box (B,N,7), order (B,top) int64 -> (box[order] (B,top,7), its BEV rectangles (B,top,5)) in one launch (ws3d extension)"""
+    dev = _dev(box, order)
+    _f32(box, "box")
+    if order.dtype != torch.int64 or not order.is_contiguous() or not box.is_contiguous():
+        raise ValueError("gather_boxes_bev: box must be contiguous fp32 and order contiguous int64")
+    B, N, top = box.size(0), box.size(1), order.size(1)
+    box_sorted = torch.empty((B, top, 7), dtype=torch.float32, device=dev)
+    bev = torch.empty((B, top, 5), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gather_boxes_bev(B, N, top, _p(box), _p(order), _p(box_sorted), _p(bev), _stream()), "gather_boxes_bev")
+    return box_sorted, bev
+
+
+def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None):
+    """first min(num, k) NMS survivors of score-sorted boxes -> (boxes (B,k,7), scores (B,k), count (B,) int64,
+    boxes enlarged by extra_width for RoI pooling or None), zero padded; one launch (ws3d extension)"""
+    dev = _dev(box_sorted, scores_sorted, keep, num)
+    _f32(box_sorted, "box_sorted"); _f32(scores_sorted, "scores")
+    if keep.dtype != torch.int64 or num.dtype != torch.int32:
+        raise ValueError("select_proposals: keep must be int64 and num int32 (ws3d_nms_batched outputs)")
+    B, top = box_sorted.size(0), box_sorted.size(1)
+    boxes = torch.empty((B, k, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((B, k), dtype=torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int64, device=dev)
+    pooled = torch.empty((B, k, 7), dtype=torch.float32, device=dev) if extra_width is not None else None
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_select_proposals(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
+                                                _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
+                                                _stream()), "select_proposals")
+    return boxes, scores, count, pooled
+
+
 def bias_act_inplace(y, bias, relu=True):
     """y (B,O,L...) contiguous: y = relu?(y + bias[o]) in place, one pass (ws3d extension)"""
     dev = _dev(y, bias)

@@ -76,12 +76,12 @@ class Stage1Pipeline:
     @torch.no_grad()
     def body(self, pts: torch.Tensor) -> dict:
         out = self.model.rpn_forward({"pts_input": pts})
-        boxes, scores, count = stage1.proposals_from_rpn(out, self.cfg)
+        boxes, scores, count, enlarged = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True)
         res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count}
         if self.roipool:
             feats = out["backbone_features"].transpose(1, 2).contiguous()
             res["pooled"], res["empty"] = roipool3d_ops.roipool3d_gpu(out["backbone_xyz"], feats, boxes, self.cfg.roi_extra_width,
-                                                                      sampled_pt_num=self.cfg.roi_sampled_pts)
+                                                                      sampled_pt_num=self.cfg.roi_sampled_pts, enlarged=enlarged)
         return res
 
     def _tunable(self, on: bool):

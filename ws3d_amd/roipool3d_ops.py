@@ -20,10 +20,13 @@ def _pool(pts, pts_feature, pooled_boxes3d, sampled_pt_num):
     return pooled_features, pooled_empty_flag
 
 
-def roipool3d_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=512):
+def roipool3d_gpu(pts, pts_feature, boxes3d, pool_extra_width, sampled_pt_num=512, enlarged=None):
     """pts (B,N,3), pts_feature (B,N,C), boxes3d (B,M,7) -> pooled (B,M,S,3+C), empty (B,M)
-    (roipool3d_utils.py:7-28): boxes are enlarged by pool_extra_width first."""
+    (roipool3d_utils.py:7-28): boxes are enlarged by pool_extra_width first.  enlarged (ws3d extension): the already
+    enlarged boxes (stage1.proposals_from_rpn(with_pool_boxes=True) emits them with the proposals)."""
     batch_size = pts.shape[0]
+    if enlarged is not None:
+        return _pool(pts, pts_feature, enlarged, sampled_pt_num)
     pooled_boxes3d = kitti_utils.enlarge_box3d(boxes3d.view(-1, 7), pool_extra_width).view(batch_size, -1, 7)
     return _pool(pts, pts_feature, pooled_boxes3d, sampled_pt_num)
 

@@ -192,12 +192,14 @@ def synthetic_orientation(n: int, device) -> torch.Tensor:
 
 
 @torch.no_grad()
-def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
+def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes: bool = False, fused: bool = True):
     """On-device proposal stage for the whole batch (config 3 of BASELINE.json): score =
     sigmoid(rpn_cls), centre = decode_center_target, box = centre + CLS_MEAN_SIZE + synthetic
     heading; top RPN_PRE_NMS_TOP_N by score -> rotated NMS (thresh 0.8) -> first
     RPN_POST_NMS_TOP_N survivors.  Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed
-    shapes, zero padded, batched torch ops + ONE NMS launch pair, no host synchronisation."""
+    shapes, zero padded, batched torch ops + ONE NMS launch pair, no host synchronisation.
+    with_pool_boxes: also return the (B,K,7) rows enlarged by cfg.roi_extra_width (what roipool3d_gpu would compute);
+    fused=False keeps the torch composition of the gather / BEV / padding steps (parity tests)."""
     xyz, reg, cls = out['backbone_xyz'], out['rpn_reg'], out['rpn_cls']
     B, N, _ = xyz.shape
     K = cfg.rpn_post_nms_top_n
@@ -217,6 +219,14 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
         sc, order = _C.topk_sorted(score.contiguous(), top)
     else:
         sc, order = torch.topk(score, top, dim=1, sorted=True)                            # (B,top)
+    if xyz.is_cuda and top >= K and fused:
+        # two launches instead of ~25: rows in score order + BEV rectangles, NMS, then the padded survivors (+ the rows
+        # enlarged for RoI pooling when asked for); bit-identical to the composition below
+        box_sorted, bev = _C.gather_boxes_bev(box, order)
+        keep_dev, num = _C.nms_device_batched(bev, cfg.rpn_nms_thresh, False, max_keep=K)
+        boxes_out, scores_out, cnt, pooled = _C.select_proposals(box_sorted, sc, keep_dev, num, K,
+                                                                  cfg.roi_extra_width if with_pool_boxes else None)
+        return (boxes_out, scores_out, cnt, pooled) if with_pool_boxes else (boxes_out, scores_out, cnt)
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
     bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
     keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K, scores_sorted=True)   # (B,K), (B,)
@@ -224,6 +234,8 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG):
     safe = keep.clamp(min=0)
     boxes_out = torch.gather(box, 1, safe.unsqueeze(-1).expand(B, K, 7)) * valid.unsqueeze(-1)
     scores_out = torch.gather(sc, 1, safe) * valid
+    if with_pool_boxes:
+        return boxes_out, scores_out, cnt, kitti_utils.enlarge_box3d(boxes_out.view(-1, 7), cfg.roi_extra_width).view(B, K, 7)
     return boxes_out, scores_out, cnt
 
 
@@ -258,8 +270,8 @@ def center_proposals(out: dict, cfg: RPNConfig = DEFAULT_CFG, prop_dist: float =
 def stage1_inference(model: Stage1Net, pts_input: torch.Tensor, cfg: RPNConfig = DEFAULT_CFG):
     """Stage-1 forward + proposals + RoI pooling for a batch of scenes (B,N,4)."""
     out = model.rpn_forward({'pts_input': pts_input})
-    boxes, scores, count = proposals_from_rpn(out, cfg)
+    boxes, scores, count, enlarged = proposals_from_rpn(out, cfg, with_pool_boxes=True)
     feats = out['backbone_features'].transpose(1, 2).contiguous()  # (B,N,C)
     pooled, empty = roipool3d_ops.roipool3d_gpu(out['backbone_xyz'], feats, boxes, cfg.roi_extra_width,
-                                                sampled_pt_num=cfg.roi_sampled_pts)
+                                                sampled_pt_num=cfg.roi_sampled_pts, enlarged=enlarged)
     return {'boxes': boxes, 'scores': scores, 'count': count, 'pooled': pooled, 'empty': empty, 'rpn': out}
