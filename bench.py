@@ -191,10 +191,10 @@ class C2:
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
         return [
-            {"name": ("fps_zlds_kernel<32,512>" if self.B > 256 else "fps_reg_kernel<32,512>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
+            {"name": ("fps_v3_kernel<32,512,ZLDS> (two scenes per CU)" if self.B > 256 else "fps_v3_kernel<16,1024>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
              "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
              "alg_bytes_per_step": a_model_fps() * self.B,
-             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_zlds_kernel" if self.B > 256 else "fps_reg_kernel",
+             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_v3_pair_kernel" if self.B > 256 else "fps_v3_kernel",
              "comment": "VALU-issue-bound: (M-1) dependent argmax steps over a scene that stays on chip (x, y, min-dist in VGPRs, z in LDS "
                         "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
                         "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "

@@ -1,34 +1,41 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): full GPU test suite, the bench lines and the rocprofv3
 # evidence of one code state.  Everything lands in gpurun_out/refresh/; copy what should be
-# judged into profiles/ afterwards (see profiles/README.md).
+# judged into profiles/ afterwards (see profiles/README.md).  Round 2: the default bench line is the
+# BASELINE headline (c3 + the c2 block).
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-python bench.py                             2>$OUT/bench_c2_b512.err | tail -1 > $OUT/bench_c2_b512.json
-python bench.py --batch 256 --no-cpu-baseline 2>$OUT/bench_c2_b256.err | tail -1 > $OUT/bench_c2_b256.json
-python bench.py --batch 8 --no-cpu-baseline 2>$OUT/bench_c2_b8.err   | tail -1 > $OUT/bench_c2_b8.json
-python bench.py --workload c3               2>$OUT/bench_c3_b8.err   | tail -1 > $OUT/bench_c3_b8.json
-python bench.py --workload c3 --pipeline-depth 1 --no-cpu-baseline 2>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth1.json
-python bench.py --workload c3 --steps 60 --no-cpu-baseline 2>>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_steps60.json
-GPU_MAX_HW_QUEUES=4 python bench.py --workload c3 --pipeline-depth 3 --no-cpu-baseline 2>>$OUT/bench_c3_b8_d1.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
-python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
-python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
-python bench.py --workload t1               2>$OUT/bench_t1_b8.err   | tail -1 > $OUT/bench_t1_b8.json
-python bench.py --workload t1 --batch 25 --no-cpu-baseline 2>$OUT/bench_t1_b25.err | tail -1 > $OUT/bench_t1_b25.json
+T="timeout 900"
+$T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+$T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+$T python bench.py --steps 80 --no-cpu-baseline --c2-batch 0  2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps80.json
+$T python bench.py --pipeline-depth 1 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
+GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
+$T python bench.py --workload c2                              2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b512.json
+for b in 1 8 64 256 1024; do
+  $T python bench.py --workload c2 --batch $b --no-cpu-baseline 2>>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b$b.json
+done
+$T python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
+$T python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
+$T python bench.py --workload t1 --no-cpu-baseline 2>$OUT/bench_t1_b8.err | tail -1 > $OUT/bench_t1_b8.json
 for w in c2 c3 c5 s2; do
-  extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph"
+  extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph --c2-batch 0"
   rm -rf /tmp/prof_$w
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o $w -- python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline $extra > $OUT/prof_$w.log 2>&1
+  $T rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o $w -- python bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline $extra > $OUT/prof_$w.log 2>&1
   db=$(find /tmp/prof_$w -name '*.db' | head -1)
   python scripts/rocpd_stats.py "$db" > $OUT/${w}_kernel_stats.csv 2>>$OUT/prof_$w.log
 done
+# the default command itself (what the driver runs), kernel trace only
+rm -rf /tmp/prof_default
+$T rocprofv3 --kernel-trace --stats -d /tmp/prof_default -o d -- python bench.py --no-cpu-baseline > $OUT/prof_default.log 2>&1
+python scripts/rocpd_stats.py "$(find /tmp/prof_default -name '*.db' | head -1)" > $OUT/default_kernel_stats.csv 2>>$OUT/prof_default.log
+# HBM traffic: separate --pmc passes (MI355X_MICROARCH.md), c2 at the default batch 512 and c5
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o pmc -- python bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
+  $T rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o pmc -- python bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1
 done
 python scripts/pmc_traffic.py "$(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1)" \
   $OUT/traffic.json "c2 batch 512, bytes per launch, rocprofv3 --pmc in separate passes" 512 > /dev/null 2>>$OUT/pmc_WRITE_SIZE.log
@@ -36,10 +43,9 @@ for wl in c5:8; do
   w=${wl%%:*}; nb=${wl##*:}
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
-    rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${w}_$c -o pmc -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${w}_$c.log 2>&1
+    $T rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_${w}_$c -o pmc -- python bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${w}_$c.log 2>&1
   done
   python scripts/pmc_traffic.py "$(find /tmp/pmc_${w}_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_${w}_WRITE_SIZE -name '*.db' | head -1)" \
     $OUT/traffic_$w.json "$w batch $nb, bytes per launch, rocprofv3 --pmc in separate passes" $nb > /dev/null 2>>$OUT/pmc_${w}_WRITE_SIZE.log
 done
-bash scripts/prof_train.sh > $OUT/prof_train.log 2>&1; cp gpurun_out/train/train_kernel_stats.csv $OUT/train_b8_kernel_stats.csv
 ls -la $OUT

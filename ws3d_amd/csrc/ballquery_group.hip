@@ -420,7 +420,10 @@ __global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *
 // (x, z), a gx x gz grid of near-square cells (gx * gz <= GRID16_CELLS, ~0.5 points per cell), counting sort with 16-bit
 // counters packed two per LDS word (a cell holds < 65536 points, so the halves never carry into each other).
 __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const float *__restrict__ xyz, char *__restrict__ ws) {
-    __shared__ unsigned hist[GRID16_CELLS / 2];      // 64 KB
+    // 64 KB + one pad word per 16: thread t scans words 16 t .. 16 t + 15, stored at 17 t + i -- conflict-free (unpadded, the
+    // 64 lanes of a wave hit two banks: 16-way conflicts on every access of the scan)
+    __shared__ unsigned hist[GRID16_CELLS / 2 + GRID16_CELLS / 32];
+#define HW(wi) ((wi) + ((wi) >> 4))
     __shared__ int wsum[16];
     __shared__ float red[4][16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -431,9 +434,19 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
     uint16_t *start = reinterpret_cast<uint16_t *>(base + (size_t)n * 16 + sizeof(BinHeader));
     int *params = reinterpret_cast<int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
 
+    // the thread's <= 16 points (n <= 16384) are loaded ONCE, 16 independent 12-byte loads in flight, and stay in registers
+    // for the three passes (bounding box, histogram, scatter): with a load per pass and point the kernel was a chain of
+    // ~48 dependent memory round trips (47 us for one scene)
+    typedef float f3v __attribute__((ext_vector_type(3)));
+    typedef f3v f3u __attribute__((aligned(4)));
+    f3v pt[SORT_MAX_N / 1024];
+#pragma unroll
+    for (int s = 0; s < SORT_MAX_N / 1024; ++s) pt[s] = *reinterpret_cast<const f3u *>(xyz + (size_t)min(tid + 1024 * s, n - 1) * 3);
     float lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
-    for (int i = tid; i < n; i += 1024) {
-        const float x = xyz[(size_t)i * 3], z = xyz[(size_t)i * 3 + 2];
+#pragma unroll
+    for (int s = 0; s < SORT_MAX_N / 1024; ++s) {
+        if (tid + 1024 * s >= n) continue;
+        const float x = pt[s].x, z = pt[s].z;
         if (fabsf(x) < INFINITY) { lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); }
         if (fabsf(z) < INFINITY) { lo_z = fminf(lo_z, z); hi_z = fmaxf(hi_z, z); }
     }
@@ -442,7 +455,7 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
         lo_z = fminf(lo_z, __shfl_xor(lo_z, o)); hi_z = fmaxf(hi_z, __shfl_xor(hi_z, o));
     }
     if (lane == 0) { red[0][w] = lo_x; red[1][w] = hi_x; red[2][w] = lo_z; red[3][w] = hi_z; }
-    for (int i = tid; i < GRID16_CELLS / 2; i += 1024) hist[i] = 0u;
+    for (int i = tid; i < GRID16_CELLS / 2 + GRID16_CELLS / 32; i += 1024) hist[i] = 0u;
     __syncthreads();
     lo_x = red[0][0]; hi_x = red[1][0]; lo_z = red[2][0]; hi_z = red[3][0];
 #pragma unroll
@@ -465,17 +478,19 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
     }
     const int ncell = gx * gz;
     const float inv_wx = wx > 0.f ? (float)gx / wx : 0.f, inv_wz = wz > 0.f ? (float)gz / wz : 0.f;
-    auto cell_of = [&](const float *p) { return grid_coord(p[2], zmin, inv_wz, gz) * gx + grid_coord(p[0], xmin, inv_wx, gx); };
-    for (int i = tid; i < n; i += 1024) {
-        const int c = cell_of(xyz + (size_t)i * 3);
-        atomicAdd(&hist[c >> 1], 1u << (16 * (c & 1)));
+    auto cell_of = [&](const f3v p) { return grid_coord(p.z, zmin, inv_wz, gz) * gx + grid_coord(p.x, xmin, inv_wx, gx); };
+#pragma unroll
+    for (int s = 0; s < SORT_MAX_N / 1024; ++s) {
+        if (tid + 1024 * s >= n) continue;
+        const int c = cell_of(pt[s]);
+        atomicAdd(&hist[HW(c >> 1)], 1u << (16 * (c & 1)));
     }
     __syncthreads();
     // exclusive scan over 32768 16-bit counters: 16 words (32 cells) per thread
     unsigned wd[16];
     int v = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { wd[i] = hist[tid * 16 + i]; v += (int)(wd[i] & 0xffffu) + (int)(wd[i] >> 16); }
+    for (int i = 0; i < 16; ++i) { wd[i] = hist[tid * 17 + i]; v += (int)(wd[i] & 0xffffu) + (int)(wd[i] >> 16); }
     const int mine = v;
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
     if (lane == 63) wsum[w] = v;
@@ -491,7 +506,7 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
         run += (int)(wd[i] & 0xffffu);
         const unsigned hi = (unsigned)run;
         run += (int)(wd[i] >> 16);
-        hist[tid * 16 + i] = lo | (hi << 16);           // running scatter cursors (each < 65536)
+        hist[tid * 17 + i] = lo | (hi << 16);           // running scatter cursors (each < 65536)
         if (c0 <= ncell) start[c0] = (uint16_t)lo;
         if (c0 + 1 <= ncell) start[c0 + 1] = (uint16_t)hi;
     }
@@ -501,13 +516,16 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
     }
     if (tid == 1023 && ncell == GRID16_CELLS) start[GRID16_CELLS] = (uint16_t)n;   // the sentinel behind a full table
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float *p = xyz + (size_t)i * 3;
-        const int c = cell_of(p);
-        const unsigned old = atomicAdd(&hist[c >> 1], 1u << (16 * (c & 1)));
+#pragma unroll
+    for (int s = 0; s < SORT_MAX_N / 1024; ++s) {
+        const int i = tid + 1024 * s;
+        if (i >= n) continue;
+        const int c = cell_of(pt[s]);
+        const unsigned old = atomicAdd(&hist[HW(c >> 1)], 1u << (16 * (c & 1)));
         const int pos = (int)((old >> (16 * (c & 1))) & 0xffffu);
-        sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+        sorted[pos] = make_float4(pt[s].x, pt[s].y, pt[s].z, __int_as_float(i));
     }
+#undef HW
 }
 
 // One workgroup = 64 centres (one per lane) x 4 waves; wave j scans the j-th quarter of every
