@@ -149,6 +149,7 @@ FPS_ENV_VARIANTS = [
     {"WS3D_FPS_ONEX": "1", "WS3D_FPS_GEOM3": "1024"},
     {"WS3D_FPS_GEOM3": "512"}, {"WS3D_FPS_GEOM3": "256"}, {"WS3D_FPS_GEOM3": "1024"},
     {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "0"}, {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "2"},
+    {"WS3D_FPS_PAIR": "1", "WS3D_FPS_DUO": "1"},          # two scenes per workgroup, half a step out of phase (even batches)
     {"WS3D_FPS_STREAM": "1"},                            # the round-1 streaming kernel above 16384 points
 ]
 

@@ -307,8 +307,14 @@ __device__ __forceinline__ void wave_max_gsel2(float best, const float (&gm)[2],
 //   z, position}.  Measured SLOWER (1.12 vs 1.08 us/step at 512 x 32, 1.37 vs 1.03 at 1024 x 16): the lookup is scalar-heavy
 //   (readlanes, mask SGPRs, branches) and the CU has ONE scalar unit, so 8-16 lookups at once serialise; one lookup by the
 //   winning wave plus a second LDS exchange is cheaper.
-template <int PPT, int NT, bool ZLDS, bool ONEX = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1, ZLDS ? 4 : 8))) void fps_v3_kernel(
+//   DUO (with ZLDS): TWO scenes per 2 NT-thread workgroup (waves 0-7 / 8-15), half a step out of phase.  Two independent
+//   workgroups on one CU lock IN phase -- both sweep at half rate, then both sit through their reduction chains with the
+//   SIMDs idle; priorities and start-up offsets do not break that (measured).  Here both halves run the SAME loop, the
+//   second half merely passes ONE extra workgroup barrier before it: from then on every barrier pairs one scene's
+//   "wave maxima are in LDS" with the other scene's "winner is in LDS", so while one scene sweeps the other one reduces
+//   and looks its winner up, and a scene-step costs about one sweep instead of a sweep plus a chain.
+template <int PPT, int NT, bool ZLDS, bool ONEX = false, bool DUO = false>
+__global__ __launch_bounds__(DUO ? 2 * NT : NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1, ZLDS ? 4 : 8))) void fps_v3_kernel(
     const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx, float *__restrict__ new_xyz, int n, int m,
     int bs, int log2bs, int S, int prio_mode) {
     constexpr int NW = NT / WS3D_WAVE;
@@ -321,18 +327,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
     // otherwise one or two registers short and the allocator spills a coordinate that the sweep reloads every step)
     constexpr bool YLDS = ZLDS && PPT == 32;
     static_assert(NG <= 8, "at most 32 points per lane");
-    extern __shared__ __attribute__((aligned(16))) char smem_z[];     // ZLDS: [NC (+1: YLDS)][NT] float4
-    __shared__ float s_wmax[16];
-    __shared__ float4 s_rec[2][16];  // ONEX: {wave max, x, y, z} per wave, double-buffered by step parity (ONE barrier per
-    __shared__ int s_pos[2][16];     //       step);  two-exchange kernel: [0][0] = the winner's {x, y, z}
+    static_assert(!DUO || (ZLDS && !ONEX), "DUO is a variant of the two-exchange ZLDS kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];   // ZLDS: [DUO: 2 scenes][NC (+1: YLDS)][NT] float4
+    __shared__ float s_wmax_all[DUO ? 2 : 1][16];
+    __shared__ float4 s_rec_all[DUO ? 2 : 1][2][16];  // ONEX: {wave max, x, y, z} per wave, double-buffered by step parity (ONE
+    __shared__ int s_pos[2][16];                      //       barrier per step);  two-exchange kernel: [0][0] = the winner's {x, y, z}
     __shared__ int s_rank;
 
-    const int b = blockIdx.x;
+    // DUO: grp (which scene of the workgroup) is wave-uniform -- say so, or every per-scene pointer lives in VGPRs
+    const int grp = DUO ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT) : 0;
+    const int b = DUO ? 2 * (int)blockIdx.x + grp : (int)blockIdx.x;
     xyz += (size_t)b * n * 3;
     idx += (size_t)b * m;
     if (temp) temp += (size_t)b * n;
     if (new_xyz) new_xyz += (size_t)b * m * 3;
-    const int u = threadIdx.x, lane = u & 63, w = u >> 6;
+    const int u = DUO ? (int)threadIdx.x - grp * NT : (int)threadIdx.x, lane = u & 63, w = u >> 6;
+    char *smem_z = smem_all + (size_t)grp * (NC + (PPT == 32 ? 1 : 0)) * NT * sizeof(float4);
+    float *s_wmax = s_wmax_all[grp];
+    float4 (*s_rec)[16] = s_rec_all[grp];
 
     v3vec<PPT> px, py;
     v3vec<ZLDS ? 1 : PPT> pz;
@@ -366,7 +378,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
     // Two workgroups share the CU (ZLDS).  Issue priority: the reduction chain of either scene outranks a sweep (few
     // instructions, all latency); the scene holding the low wave slots of the CU outranks the other while both sweep.
     int sweep_prio = -1;
-    if constexpr (ZLDS) {
+    if constexpr (DUO) sweep_prio = prio_mode != 0 ? 0 : -1;      // chain priority only: the barriers fix the phase
+    if constexpr (ZLDS && !DUO) {
         if (u == 0) s_rank = 1 << 20;
         __syncthreads();
         // HW_REG_HW_ID (id 4) bits [3:0] = wave slot on its SIMD: the first workgroup of the CU holds the low slots
@@ -378,6 +391,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
         if (s_rank != 0) for (int d = prio_mode >> 2; d > 0; --d) __builtin_amdgcn_s_sleep(1);
     }
     const float *zs = reinterpret_cast<const float *>(smem_z);
+    if constexpr (DUO) {
+        __syncthreads();
+        if (grp == 1) lds_barrier();      // the second scene runs one barrier behind (paired with the first scene's barrier 1)
+    }
     // two-exchange kernel: the winning wave's stores of step j are issued at the top of step j+1 (off the chain)
     // (its coordinates are the current sample ox, oy, oz by then)
     bool pend = false;
@@ -582,6 +599,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
             ox = c4.x; oy = c4.y; oz = c4.z;
         }
     }
+    if constexpr (DUO) { if (grp == 0) lds_barrier(); }      // pairs with the second scene's last barrier
     if constexpr (!ONEX && NW > 1) {
         if (pend && lane == 0) {
             idx[m - 1] = pend_pos;
@@ -610,19 +628,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(ZLDS ? 4 : 1
     }
 }
 
-template <int PPT, int NT, bool ZLDS, bool ONEX = false>
+template <int PPT, int NT, bool ZLDS, bool ONEX = false, bool DUO = false>
 static void launch_v3(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz, int bs, int log2bs, int S,
                       hipStream_t st) {
-    constexpr size_t lds = ZLDS ? (size_t)(PPT + (PPT == 32 ? 4 : 0)) * NT * sizeof(float) : 0;   // z (+ the last y quad)
+    constexpr size_t lds = ZLDS ? (size_t)(DUO ? 2 : 1) * (PPT + (PPT == 32 ? 4 : 0)) * NT * sizeof(float) : 0;   // z (+ the last y quad)
     if constexpr (ZLDS) {
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void *)fps_v3_kernel<PPT, NT, ZLDS, ONEX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void *)fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
     }
     static const int prio_mode = getenv("WS3D_FPS_PRIO") ? atoi(getenv("WS3D_FPS_PRIO")) : 1;   // 0: no priorities (A/B runs)
-    hipLaunchKernelGGL((fps_v3_kernel<PPT, NT, ZLDS, ONEX>), dim3(b), dim3(NT), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S,
+    hipLaunchKernelGGL((fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>), dim3(DUO ? b / 2 : b), dim3(DUO ? 2 * NT : NT), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S,
                        prio_mode);
 }
 
@@ -651,9 +669,15 @@ bool fps_v3_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *
     else if (R <= 8192) { if (geom == 256) V3(32, 256, false); else if (geom == 1024) V3(8, 1024, false); else V3(16, 512, false); }
     else if (R <= 16384) {
         static const int onex = getenv("WS3D_FPS_ONEX") ? atoi(getenv("WS3D_FPS_ONEX")) : 0;
+        // WS3D_FPS_DUO=1: two scenes per workgroup, half a step out of phase (A/B runs: measured SLOWER than two independent
+        // workgroups per CU with chain priority, 6.55-6.85 vs 6.14 ms for 512 scenes -- a slot lasts ~2000 clk, not the ~1500
+        // of a sweep: the reduction stage of one scene does not hide under the sweep of the other as modelled)
+        static const int duo_mode = getenv("WS3D_FPS_DUO") ? atoi(getenv("WS3D_FPS_DUO")) : 0;
         if (onex && !pair) {
             if (geom == 1024) launch_v3<16, 1024, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
             else launch_v3<32, 512, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        } else if (pair && duo_mode && (b & 1) == 0) {
+            launch_v3<32, 512, true, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
         } else if (pair) V3(32, 512, true);
         else if (geom == 512) V3(32, 512, false);
         else V3(16, 1024, false);
