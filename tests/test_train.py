@@ -142,6 +142,16 @@ def test_checkpoint_format_and_reference_keys(tmp_path):
         assert torch.equal(v, other.state_dict()[k])
     with pytest.raises(FileNotFoundError):
         load_checkpoint(other, None, str(tmp_path / "missing.pth"))
+    # the same optimizer layout resumes; a reference-style optimizer_state (fastai OptimWrapper: two parameter groups) is
+    # skipped with a warning instead of raising, model_state and `it` are still restored
+    opt2 = AdamOneCycle(other.train().parameters(), 10)
+    assert load_checkpoint(other, opt2, path)[0] == 7
+    n = len(ck["optimizer_state"]["param_groups"][0]["params"])
+    ck["optimizer_state"]["param_groups"] = [dict(ck["optimizer_state"]["param_groups"][0], params=list(range(n // 2))),
+                                             dict(ck["optimizer_state"]["param_groups"][0], params=list(range(n // 2, n)))]
+    torch.save(ck, str(tmp_path / "ref_style.pth"))
+    with pytest.warns(UserWarning, match="parameter-group layout"):
+        assert load_checkpoint(other, AdamOneCycle(other.parameters(), 10), str(tmp_path / "ref_style.pth"))[0] == 7
 
 
 def test_scene_augmentation_matches_reference_stream(fx):

@@ -139,14 +139,26 @@ def save_checkpoint(state: dict, filename: str = "checkpoint") -> str:
 
 
 def load_checkpoint(model: Optional[nn.Module] = None, optimizer=None, filename: str = "checkpoint", logger=None):
-    """-> (it, epoch); accepts checkpoints written by the reference's train_utils.save_checkpoint"""
+    """-> (it, epoch).  ``model_state`` interchanges with the reference's train_utils.save_checkpoint (same keys).
+    ``optimizer_state`` interchanges only between runs of THIS trainer: the reference's comes from fastai's OptimWrapper
+    (two parameter groups from split_bn_bias), AdamOneCycle has one -- such a state is skipped with a warning and the
+    optimizer starts fresh at iteration ``it`` of the one-cycle schedule."""
     if not os.path.isfile(filename):
         raise FileNotFoundError(filename)
     ck = torch.load(filename, map_location="cpu")
     if model is not None and ck.get("model_state") is not None:
         model.load_state_dict(ck["model_state"])
     if optimizer is not None and ck.get("optimizer_state") is not None:
-        optimizer.load_state_dict(ck["optimizer_state"])
+        state = ck["optimizer_state"]
+        ours = optimizer.state_dict()
+        same = (isinstance(state, dict) and "param_groups" in state and len(state["param_groups"]) == len(ours["param_groups"])
+                and [len(g["params"]) for g in state["param_groups"]] == [len(g["params"]) for g in ours["param_groups"]])
+        if same:
+            optimizer.load_state_dict(state)
+        else:
+            import warnings
+            warnings.warn("load_checkpoint: optimizer_state of '%s' has another parameter-group layout (e.g. written by the "
+                          "reference's OptimWrapper); it is skipped, only model_state and `it` are restored" % filename)
     if logger:
         logger.info("==> loaded checkpoint '%s' (it %s)", filename, ck.get("it"))
     return ck.get("it", 0), ck.get("epoch", -1)
@@ -198,15 +210,21 @@ class KittiCenters:
         self.label_sub = noise_kind or "label_2"
         keep = []
         for sid in self.scenes.sample_id_list:
-            if any(o.cls_type in ("Car", "Van") for o in self._objects(sid)):
+            if self._objects(sid):
                 keep.append(sid)
             if len(keep) >= weakly_num:
                 break
         self.ids = keep
 
     def _objects(self, sid):
+        """Car / Van objects inside PC_AREA_SCOPE: the reference's TRAIN-mode filtrate_objects (kitti_rcnn_dataset.py:
+        115-135: class whitelist incl. Van, then check_pc_range on obj.pos) -- applied BEFORE the 'scene has an object'
+        test and before the centres become labels, so the weakly_num subset and the labels match the reference's"""
         path = os.path.join(self.scenes.imageset_dir, self.label_sub, "%06d.txt" % sid)
-        return kitti_io.read_label_file(path) if os.path.isfile(path) else []
+        objs = kitti_io.read_label_file(path) if os.path.isfile(path) else []
+        (x0, x1), (y0, y1), (z0, z1) = kitti_io.PC_AREA_SCOPE
+        return [o for o in objs if o.cls_type in ("Car", "Van")
+                and x0 <= o.pos[0] <= x1 and y0 <= o.pos[1] <= y1 and z0 <= o.pos[2] <= z1]
 
     def __len__(self):
         return len(self.ids)
@@ -215,7 +233,7 @@ class KittiCenters:
         sid = self.ids[i]
         pts = kitti_io.rpn_input_from_scan(self.scenes.get_lidar(sid), self.scenes.get_calib(sid),
                                            self.scenes.get_image_shape(sid), self.scenes.npoints, True, self.scenes.rng)
-        centres = np.array([o.pos for o in self._objects(sid) if o.cls_type in ("Car", "Van")], dtype=np.float32).reshape(-1, 3)
+        centres = np.array([o.pos for o in self._objects(sid)], dtype=np.float32).reshape(-1, 3)
         if self.augment:
             xyz, centres, _ = losses.scene_augmentation(pts[:, :3], centres, self.scenes.rng)
             pts = np.concatenate((xyz, pts[:, 3:]), axis=1)
