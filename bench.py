@@ -404,8 +404,9 @@ class S2:
             {"name": "ball_query_kernel<fused> SA2 (128 -> 32 x 64, 3+128 ch)", "ms_per_step": t[3], "launches_per_step": 1,
              "alg_bytes_per_step": self._bytes(self.M1, self.M2, self.C) * B, "traffic_key": None, "comment": ""},
             {"name": "fps_reg_kernel<*,64> SA1+SA2 (one wave per cloud)", "ms_per_step": t[0] + t[2], "launches_per_step": 2,
+             "bound": "valu", "lane_instr_per_step": (fps_lane_instr(self.N, self.M1) + fps_lane_instr(self.M1, self.M2)) * B,
              "alg_bytes_per_step": ((self.M1 - 1) * self.N * 12 + (self.M2 - 1) * self.M1 * 12) * B, "traffic_key": None,
-             "comment": "A_model (re-read per step); real traffic is the 6 KB cloud once"},
+             "comment": "A_model (re-read per step) in alg_bytes; real traffic is the 6 KB cloud once; the physical fraction is valu_frac"},
             {"name": "GroupAll (torch cat)", "ms_per_step": t[4], "launches_per_step": 0,
              "alg_bytes_per_step": 2 * (3 + 2 * self.C) * self.M2 * 4 * B, "traffic_key": None, "comment": "not ours"},
         ]
