@@ -160,6 +160,15 @@ WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_ou
 WS3D_API int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
                             const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream);
 
+/* First SharedMLP layer of a set-abstraction scale with the grouping fused into the GEMM's A operand (no reference
+ * counterpart; replaces QueryAndGroup -> Conv2d(1x1)+BN+ReLU, pointnet2_utils.py:241-264 + pytorch_utils.py:20-32, on
+ * channels-last tensors): out (b*m*nsample, o) = relu?([feats[nbr] | xyz[nbr] - new_xyz] @ wt + bias) with feats (b,n,c),
+ * xyz (b,n,3), new_xyz (b,m,3), nbr (b,m,nsample) int32 (ws3d_ball_query), wt (c+3, o) row-major with the three xyz rows
+ * LAST, on the fp32 matrix cores.  c % 4 == 0, o % 64 == 0, b*m*nsample % 64 == 0, else WS3D_E_UNSUPPORTED.        */
+WS3D_API int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, int o_dim, const float *feats, const float *xyz,
+                     const float *new_xyz, const int32_t *nbr, const float *wt, const float *bias, int relu, float *out,
+                     ws3d_stream_t stream);
+
 /* Weight gradient of a 1x1 convolution on channels-first tensors (the Conv1d / Conv2d of every SharedMLP
  * block, pytorch_utils.py:35-101): grad_w (o, c) = sum_b sum_l grad_out[b, o, l] * x[b, c, l].  fp32 matrix
  * cores, the (scene, l-range) slices of the sum are added in a fixed order: bit-reproducible (the library's

@@ -199,8 +199,17 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
         return out
 
+    orig_bq = compat.ball_query_wrapper
+
+    def bq_tap(b, n, m, radius, nsample, new_xyz, xyz, idx, sorted_xyz=None):     # the gather-GEMM path asks for the lists only
+        r = orig_bq(b, n, m, radius, nsample, new_xyz, xyz, idx, sorted_xyz)
+        bq_log.append(_sha(idx.cpu().numpy().astype(np.int32)))
+        return r
+
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
     compat.query_and_group_nlc = nlc_tap
+    if channels_last:
+        compat.ball_query_wrapper = bq_tap
     prev = stage1.CHANNELS_LAST_FASTPATH
     stage1.CHANNELS_LAST_FASTPATH = channels_last
     try:
@@ -209,6 +218,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     finally:
         pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = orig_fps, orig_qg
         compat.query_and_group_nlc = orig_nlc
+        compat.ball_query_wrapper = orig_bq
         stage1.CHANNELS_LAST_FASTPATH = prev
     assert ("backbone_features_nlc" in out) == channels_last
     assert len(fps_log) == 4 and len(bq_log) == 8

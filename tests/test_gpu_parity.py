@@ -1414,3 +1414,31 @@ def test_conv_block_backward_uses_our_weight_gradient(ops):
     np.testing.assert_allclose(host(grads[0][0]), host(grads[1][0]), rtol=2e-4, atol=2e-5 * float(grads[1][0].abs().max()))
     np.testing.assert_allclose(host(grads[0][1]), host(grads[1][1]), rtol=2e-4, atol=2e-5 * float(grads[1][1].abs().max()))
     assert torch.equal(grads[0][0], grads[2][0])          # our path: identical bits on the second run
+
+
+@pytest.mark.parametrize("B,N,M,ns,C,O,r", [(2, 4096, 1024, 16, 96, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 1.0), (1, 1024, 256, 16, 256, 128, 1.0),
+                                           (2, 256, 64, 32, 512, 256, 4.0)])
+def test_gather_gemm_equals_group_then_linear(ops, B, N, M, ns, C, O, r):
+    """ws3d_gather_gemm (grouping fused into the first SharedMLP layer, fp32 matrix cores) against QueryAndGroup rows @ W + b:
+    same neighbour lists (ball query, bit-exact), features within fp32 round-off of the float64 product"""
+    rng = np.random.default_rng(4)
+    pc = synth.make_batch("lidar", B, 16384, 61)[:, :N, :3].copy()
+    xyz = dev(pc)
+    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
+    wt = dev((rng.standard_normal((C + 3, O)) / np.sqrt(C)).astype(np.float32))       # rows: features, then dx dy dz
+    bias = dev(rng.standard_normal(O).astype(np.float32))
+    got = ops.c.gather_gemm(feats, xyz, new_xyz, nbr, wt, bias, True)
+    assert got is not None and tuple(got.shape) == (B * M * ns, O)
+    li = nbr.long()
+    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
+    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
+    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
+    want = torch.relu(x @ wt.double() + bias.double())
+    err = (got.double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= 4e-6 * max(scale, 1.0) * np.sqrt(C / 96), (err, scale)
+    assert ops.c.gather_gemm(feats[:, :, :C - 2].contiguous(), xyz, new_xyz, nbr, wt[:C + 1].contiguous(), bias, True) is None   # C % 4

@@ -328,6 +328,25 @@ def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0):
     return True
 
 
+def gather_gemm(feats, xyz, new_xyz, nbr, wt_feat_then_xyz, bias, relu):
+    """first SharedMLP layer with the grouping fused in: feats (B,N,C), xyz (B,N,3), new_xyz (B,M,3), nbr (B,M,ns) int32,
+    wt (C+3, O) with the xyz rows LAST -> (B*M*ns, O), or None when the shape is not covered (C % 4, O % 64, rows % 64).
+    ws3d extension."""
+    dev = _dev(feats, xyz, new_xyz, nbr, wt_feat_then_xyz)
+    _f32(feats, "feats"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(nbr, "nbr"); _f32(wt_feat_then_xyz, "wt")
+    B, N, C = feats.shape
+    M, ns = nbr.size(1), nbr.size(2)
+    O = wt_feat_then_xyz.size(1)
+    rows = B * M * ns
+    if C % 4 or O % 64 or rows % 64 or rows // 64 > 65535 or wt_feat_then_xyz.size(0) != C + 3 or not feats.is_contiguous():
+        return None
+    out = torch.empty((rows, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gather_gemm(B, N, M, ns, C, O, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(wt_feat_then_xyz), _p(bias),
+                                           int(bool(relu)), _p(out), _stream()), "gather_gemm")
+    return out
+
+
 def pool_nsample(x):
     """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
     F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""

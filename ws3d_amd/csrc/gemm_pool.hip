@@ -91,6 +91,78 @@ __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, co
     }
 }
 
+// ---- first SharedMLP layer of a set-abstraction scale with the GROUPING fused into its A operand:
+//   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, centre m, sample s),
+//   X[r, 0:C] = feats[b, nbr[b, m, s], :]   X[r, C:C+3] = xyz[b, nbr[b, m, s]] - new_xyz[b, m]
+// i.e. QueryAndGroup (pointnet2_utils.py:241-264, channels-last, the xyz block behind the features: the caller
+// permutes the weight rows once) feeding layer 1 without the (rows, 3+C) grouped tensor ever existing: 156 MB per batch
+// written by the grouping kernel and read back by the GEMM at SA2, 102 MB at SA3.  Same 64 x 64 tile / LDS / MFMA
+// structure as gemm_pool_kernel; the X tile loader follows the neighbour list instead of a row pointer (a 16-byte load
+// of 4 consecutive channels of the neighbour's feature row: C % 4 == 0 keeps it aligned and makes k == C a chunk start).
+__global__ __launch_bounds__(256) void gather_gemm_kernel(int c_feat, int o_dim, int n, int m, int ns, const float *__restrict__ feats,
+                                                          const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                          const int32_t *__restrict__ nbr, const float *__restrict__ wt,
+                                                          const float *__restrict__ bias, int relu, float *__restrict__ out) {
+    __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
+    __shared__ float ws[2][GP_KT][64];        // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const long row0 = (long)blockIdx.y * 64;
+    const int col0 = blockIdx.x * 64;
+    const int k_dim = c_feat + 3;
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    // this thread's row of the tile: (scene, centre, sample) -> neighbour
+    const long r = row0 + xr;
+    const long cm = r / ns;                                   // scene * m + centre
+    const long b = cm / m;
+    const int src = nbr[r];
+    const float *frow = feats + ((size_t)b * n + (size_t)src) * c_feat;
+    const float *prow = xyz + ((size_t)b * n + (size_t)src) * 3;
+    const float *crow = new_xyz + (size_t)cm * 3;
+    auto load_x = [&](int k0) {
+        const int k = k0 + xk;
+        if (k < c_feat) return *reinterpret_cast<const float4 *>(frow + k);
+        if (k == c_feat) return make_float4(prow[0] - crow[0], prow[1] - crow[1], prow[2] - crow[2], 0.f);   // grouped_xyz -= new_xyz
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto load_w = [&](int k0) {
+        const int k = k0 + wk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)k * o_dim + col0 + wc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stage = [&](int buf, const float4 xv, const float4 wv) {
+        xs[buf][xk + 0][xr] = xv.x; xs[buf][xk + 1][xr] = xv.y; xs[buf][xk + 2][xr] = xv.z; xs[buf][xk + 3][xr] = xv.w;
+        *reinterpret_cast<float4 *>(&ws[buf][wk][wc]) = wv;
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 xv = load_x(0), wv = load_w(0);
+    stage(0, xv, wv);
+    __syncthreads();
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) { xv = load_x((t + 1) * GP_KT); wv = load_w((t + 1) * GP_KT); }
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[cur][k + kh][ar], ws[cur][k + kh][bc], acc, 0, 0, 0);
+        if (t + 1 < ntiles) stage(cur ^ 1, xv, wv);
+        __syncthreads();
+    }
+    // accumulator layout (32 x 32 tile): register v of lane l holds row 8*(v/4) + 4*(l/32) + v%4, column l%32
+    const int col = col0 + bc;
+    const float bv = bias ? bias[col] : 0.f;
+    float *o = out + (row0 + wm * 32 + 4 * (lane >> 5)) * (long)o_dim + col;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float y = acc[v] + bv;
+        if (relu) y = y < 0.f ? 0.f : y;       // NaN stays NaN, like relu_
+        o[(long)(8 * (v / 4) + (v % 4)) * o_dim] = y;
+    }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
@@ -111,4 +183,22 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
     else
         hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride);
     return check_launch("ws3d_gemm_pool");
+}
+
+extern "C" int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, int o_dim, const float *feats, const float *xyz,
+                                const float *new_xyz, const int32_t *nbr, const float *wt, const float *bias, int relu, float *out,
+                                ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(wt);
+    if (b < 0 || n <= 0 || m <= 0 || nsample <= 0 || c_feat <= 0 || (c_feat & 3) || o_dim <= 0 || (o_dim & 63) || (rows & 63) || !feats || !xyz ||
+        !new_xyz || !nbr || !wt || !out || (al & 15)) {
+        set_error("ws3d_gather_gemm: unsupported shape (b=%d n=%d m=%d ns=%d c=%d o=%d; rows, o %% 64, c %% 4)", b, n, m, nsample, c_feat, o_dim);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    if (rows / 64 > 65535) { set_error("ws3d_gather_gemm: too many rows"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(gather_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c_feat, o_dim, n, m,
+                       nsample, feats, xyz, new_xyz, nbr, wt, bias, relu, out);
+    return check_launch("ws3d_gather_gemm");
 }

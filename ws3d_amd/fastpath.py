@@ -28,6 +28,7 @@ from . import nn_blocks, pn2_ops
 
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
 FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
+FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 
 
 def _row_weights(block):
@@ -41,6 +42,17 @@ def _row_weights(block):
         if not torch.cuda.is_current_stream_capturing():
             block.__dict__["_row_cache"] = cache
     return cache[1], shift, act is not None
+
+
+def _row_weights_xyz_last(block):
+    """_row_weights with the three xyz rows moved behind the feature rows (the K order ws3d_gather_gemm reads), cached"""
+    wt, bias, relu = _row_weights(block)
+    cache = block.__dict__.get("_row_cache_xyz_last")
+    if cache is None or cache[0] is not wt:
+        cache = (wt, torch.cat((wt[3:], wt[:3]), dim=0).contiguous())
+        if not torch.cuda.is_current_stream_capturing():
+            block.__dict__["_row_cache_xyz_last"] = cache
+    return cache[1], bias, relu
 
 
 def _layer(x2d: torch.Tensor, block) -> torch.Tensor:
@@ -90,9 +102,24 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
     out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     col = 0
     for grouper, mlp, width in zip(sa.groupers, sa.mlps, widths):
+        blocks = _blocks(mlp)
+        if (FUSED_GATHER_GEMM and feats is not None and feats.size(2) >= 16 and grouper.use_xyz and len(blocks) >= 2 and
+                blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0):
+            # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
+            nbr = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
+            _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
+            wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
+            y = _C.gather_gemm(feats, xyz, new_xyz, nbr, wt1, b1, r1)
+            if y is not None:
+                for blk in blocks[1:-1]:
+                    y = _layer(y, blk)
+                wt, bias, relu = _row_weights(blocks[-1])
+                if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
+                    _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
+                col += width
+                continue
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
-        blocks = _blocks(mlp)
         # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
         # pooled rows leaves the chip; otherwise the GEMM chain + pool kernel
         if not (FUSED_SA_MLP and rows.size(1) == 4 and len(blocks) == 3 and
