@@ -123,8 +123,8 @@ class C3:
         return ok
 
     @torch.no_grad()
-    def step(self, timed=False):
-        if getattr(self, "_graph", None) is not None and not timed:
+    def step(self, timed=False, eager=False):
+        if getattr(self, "_graph", None) is not None and not timed and not eager:
             ticket = self.pipe.submit()                    # inputs already resident in the slot's buffer
             slot = self.pipe.slots[ticket % self.depth]
             res = slot["out"]
@@ -135,10 +135,16 @@ class C3:
             return
         self._timed = timed
         e = None
-        if timed:
+        from ws3d_amd import fastpath
+        ahead = fastpath.GEOMETRY_AHEAD
+        if timed:           # per-operator timers: one stream, so that an operator's time is its own
+            fastpath.GEOMETRY_AHEAD = False
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-        out = self.model.rpn_forward({'pts_input': self.pts})
+        try:
+            out = self.model.rpn_forward({'pts_input': self.pts})
+        finally:
+            fastpath.GEOMETRY_AHEAD = ahead
         if timed:
             e[1].record()
         boxes, scores, count, enlarged = proposals_from_rpn(out, self.cfg, with_pool_boxes=True)
@@ -155,16 +161,27 @@ class C3:
         self.last = (out, boxes, scores, count, pooled, empty, gathered)
 
     def latency_mode(self, n=10):
-        """ms per batch with ONE batch in flight (submit -> exchange -> wait), graph replay when captured"""
+        """ms per batch with ONE batch in flight (submit -> exchange -> wait), two ways of launching it:
+        hipGraph replay of the whole step on one stream, and eager launches with the coordinate-only work (sampling chain of
+        levels 2-4, ball-query lists, 3-NN) on side streams beside the GEMMs (ws3d_amd/fastpath.py _Geometry; a captured graph
+        with such branches replays slower on this runtime, so the graph keeps one stream) -> (best ms, detail dict)"""
         import time
-        torch.cuda.synchronize()
-        self.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            self.step()
+
+        def run(eager):
             torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3
+            for _ in range(2):
+                self.step(eager=eager)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                self.step(eager=eager)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+        from ws3d_amd import fastpath
+        detail = {"eager_side_streams_ms" if fastpath.GEOMETRY_AHEAD else "eager_ms": run(True)}
+        if getattr(self, "_graph", None) is not None:
+            detail["graph_replay_ms"] = run(False)
+        return min(detail.values()), detail
 
     def dump(self, folder):
         """one more step, then this rank's own proposals and the gathered ones to <folder>/proposals_rank<r>.npz

@@ -169,6 +169,15 @@ WS3D_API int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, int 
                      const float *new_xyz, const int32_t *nbr, const float *wt, const float *bias, int relu, float *out,
                      ws3d_stream_t stream);
 
+/* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
+ * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
+ * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +
+ * bias) with f = known_feats (b,m,c2), u = unknown_feats (b,n,c1) or NULL (c1 = 0), idx / weight (b,n,3) from ws3d_three_nn
+ * + ws3d_three_nn_weights, wt (c2+c1, o) row-major.  c2 % 4 == 0, o % 64 == 0, b*n % 64 == 0, else WS3D_E_UNSUPPORTED. */
+WS3D_API int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, const float *known_feats, const float *unknown_feats,
+                     const int32_t *idx, const float *weight, const float *wt, const float *bias, int relu, float *out,
+                     ws3d_stream_t stream);
+
 /* Weight gradient of a 1x1 convolution on channels-first tensors (the Conv1d / Conv2d of every SharedMLP
  * block, pytorch_utils.py:35-101): grad_w (o, c) = sum_b sum_l grad_out[b, o, l] * x[b, c, l].  fp32 matrix
  * cores, the (scene, l-range) slices of the sum are added in a fixed order: bit-reproducible (the library's

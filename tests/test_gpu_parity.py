@@ -1442,3 +1442,29 @@ def test_gather_gemm_equals_group_then_linear(ops, B, N, M, ns, C, O, r):
     scale = want.abs().max().item()
     assert err <= 4e-6 * max(scale, 1.0) * np.sqrt(C / 96), (err, scale)
     assert ops.c.gather_gemm(feats[:, :, :C - 2].contiguous(), xyz, new_xyz, nbr, wt[:C + 1].contiguous(), bias, True) is None   # C % 4
+
+
+@pytest.mark.parametrize("B,N,M,C2,C1,O", [(2, 4096, 1024, 256, 96, 128), (1, 16384, 4096, 128, 1, 128), (2, 1024, 256, 512, 256, 256),
+                                           (2, 256, 64, 512, 512, 512), (2, 1024, 256, 128, 0, 64)])
+def test_interp_gemm_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
+    """ws3d_interp_gemm (three_interpolate + skip concat fused into the first FP layer, fp32 matrix cores) against the bit-exact
+    three_interpolate rows, concatenated with the skip features, @ W + b in float64"""
+    rng = np.random.default_rng(9)
+    pc = synth.make_batch("lidar", B, 16384, 62)[:, :N, :3].copy()
+    unknown = dev(pc)
+    known = unknown[:, ::N // M].contiguous()
+    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
+    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
+    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
+    wt = dev((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32))
+    bias = dev(rng.standard_normal(O).astype(np.float32))
+    got = ops.c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
+    assert got is not None and tuple(got.shape) == (B * N, O)
+    interp = torch.empty((B, N, C2), device="cuda")
+    ops.c.three_interpolate_nlc(kf, idx, weight, interp)
+    x = interp if uf is None else torch.cat((interp, uf), dim=2)
+    want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
+    err = (got.double() - want).abs().max().item()
+    scale = want.abs().max().item()
+    assert err <= 4e-6 * max(scale, 1.0) * np.sqrt((C2 + C1) / 96), (err, scale)
+    assert ops.c.interp_gemm(kf, uf, idx, weight, wt[:, :O - 8].contiguous(), bias[:O - 8], True) is None              # O % 64

@@ -347,6 +347,26 @@ def gather_gemm(feats, xyz, new_xyz, nbr, wt_feat_then_xyz, bias, relu):
     return out
 
 
+def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
+    """first FP-module layer with the interpolation + skip concat fused in: known_feats (B,M,C2), unknown_feats (B,N,C1) or
+    None, idx / weight (B,N,3), wt (C2+C1, O) -> (B*N, O), or None when the shape is not covered.  ws3d extension."""
+    dev = _dev(known_feats, idx, weight, wt)
+    _f32(known_feats, "known_feats"); _i32(idx, "idx"); _f32(weight, "weight"); _f32(wt, "wt")
+    B, M, C2 = known_feats.shape
+    N = idx.size(1)
+    C1 = 0 if unknown_feats is None else unknown_feats.size(2)
+    O = wt.size(1)
+    rows = B * N
+    if (C2 % 4 or O % 64 or rows % 64 or rows // 64 > 65535 or wt.size(0) != C2 + C1 or not known_feats.is_contiguous() or
+            (unknown_feats is not None and not unknown_feats.is_contiguous())):
+        return None
+    out = torch.empty((rows, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_interp_gemm(B, N, M, C2, C1, O, _p(known_feats), _p(unknown_feats), _p(idx), _p(weight), _p(wt), _p(bias),
+                                           int(bool(relu)), _p(out), _stream()), "interp_gemm")
+    return out
+
+
 def pool_nsample(x):
     """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
     F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""

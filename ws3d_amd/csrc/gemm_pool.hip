@@ -163,6 +163,83 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(int c_feat, int o_dim,
     }
 }
 
+// ---- first layer of a feature-propagation module with the interpolation and the concatenation fused into its A operand:
+//   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, unknown point p),
+//   X[r, 0:c2]      = w0 f[i0, :] + w1 f[i1, :] + w2 f[i2, :]   (three_interpolate, interpolate_gpu.cu:77-97, the same fmaf
+//                     expression as the stand-alone kernels)     f = known_feats (b, m, c2) channels-last
+//   X[r, c2:c2+c1]  = unknown_feats[b, p, :]                     (the skip connection, pointnet2_modules.py:147-150)
+// so neither the interpolated tensor nor the (rows, c2 + c1) concat buffer exists (135 MB per batch at FP1).
+__global__ __launch_bounds__(256) void interp_gemm_kernel(int c2, int c1, int o_dim, int n, int m, const float *__restrict__ known_feats,
+                                                          const float *__restrict__ unknown_feats, const int32_t *__restrict__ idx3,
+                                                          const float *__restrict__ w3, const float *__restrict__ wt,
+                                                          const float *__restrict__ bias, int relu, float *__restrict__ out) {
+    __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
+    __shared__ float ws[2][GP_KT][64];        // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const long row0 = (long)blockIdx.y * 64;
+    const int col0 = blockIdx.x * 64;
+    const int k_dim = c2 + c1;
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const long r = row0 + xr;
+    const long b = r / n;
+    const int i0 = idx3[r * 3 + 0], i1 = idx3[r * 3 + 1], i2 = idx3[r * 3 + 2];
+    const float w0 = w3[r * 3 + 0], w1 = w3[r * 3 + 1], w2 = w3[r * 3 + 2];
+    const float *f0 = known_feats + ((size_t)b * m + (size_t)i0) * c2, *f1 = known_feats + ((size_t)b * m + (size_t)i1) * c2,
+                *f2 = known_feats + ((size_t)b * m + (size_t)i2) * c2;
+    const float *urow = unknown_feats ? unknown_feats + (size_t)r * c1 : nullptr;
+    auto load_x = [&](int k0) {
+        const int k = k0 + xk;
+        if (k < c2) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(f0 + k), p1 = *reinterpret_cast<const float4 *>(f1 + k),
+                         p2 = *reinterpret_cast<const float4 *>(f2 + k);
+            return make_float4(__builtin_fmaf(w2, p2.x, __builtin_fmaf(w0, p0.x, w1 * p1.x)), __builtin_fmaf(w2, p2.y, __builtin_fmaf(w0, p0.y, w1 * p1.y)),
+                               __builtin_fmaf(w2, p2.z, __builtin_fmaf(w0, p0.z, w1 * p1.z)), __builtin_fmaf(w2, p2.w, __builtin_fmaf(w0, p0.w, w1 * p1.w)));
+        }
+        const int ku = k - c2;
+        if (ku + 3 < c1) return *reinterpret_cast<const float4 *>(urow + ku);          // c1 % 4 == 0: aligned
+        float v[4] = {0.f, 0.f, 0.f, 0.f};                                            // the ragged tail (c1 = 1 at FP1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (ku + q < c1) v[q] = urow[ku + q];
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    auto load_w = [&](int k0) {
+        const int k = k0 + wk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)k * o_dim + col0 + wc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stage = [&](int buf, const float4 xv, const float4 wv) {
+        xs[buf][xk + 0][xr] = xv.x; xs[buf][xk + 1][xr] = xv.y; xs[buf][xk + 2][xr] = xv.z; xs[buf][xk + 3][xr] = xv.w;
+        *reinterpret_cast<float4 *>(&ws[buf][wk][wc]) = wv;
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 xv = load_x(0), wv = load_w(0);
+    stage(0, xv, wv);
+    __syncthreads();
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) { xv = load_x((t + 1) * GP_KT); wv = load_w((t + 1) * GP_KT); }
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[cur][k + kh][ar], ws[cur][k + kh][bc], acc, 0, 0, 0);
+        if (t + 1 < ntiles) stage(cur ^ 1, xv, wv);
+        __syncthreads();
+    }
+    const int col = col0 + bc;
+    const float bv = bias ? bias[col] : 0.f;
+    float *o = out + (row0 + wm * 32 + 4 * (lane >> 5)) * (long)o_dim + col;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        float y = acc[v] + bv;
+        if (relu) y = y < 0.f ? 0.f : y;
+        o[(long)(8 * (v / 4) + (v % 4)) * o_dim] = y;
+    }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
@@ -201,4 +278,23 @@ extern "C" int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, in
     hipLaunchKernelGGL(gather_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c_feat, o_dim, n, m,
                        nsample, feats, xyz, new_xyz, nbr, wt, bias, relu, out);
     return check_launch("ws3d_gather_gemm");
+}
+
+extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, const float *known_feats, const float *unknown_feats,
+                                const int32_t *idx, const float *weight, const float *wt, const float *bias, int relu, float *out,
+                                ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * n;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(known_feats) | reinterpret_cast<uintptr_t>(wt) |
+                         ((c1 & 3) == 0 ? reinterpret_cast<uintptr_t>(unknown_feats) : 0);
+    if (b < 0 || n <= 0 || m <= 0 || c2 <= 0 || (c2 & 3) || c1 < 0 || o_dim <= 0 || (o_dim & 63) || (rows & 63) || !known_feats ||
+        (c1 > 0 && !unknown_feats) || !idx || !weight || !wt || !out || (al & 15)) {
+        set_error("ws3d_interp_gemm: unsupported shape (b=%d n=%d m=%d c2=%d c1=%d o=%d; rows, o %% 64, c2 %% 4)", b, n, m, c2, c1, o_dim);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    if (rows / 64 > 65535) { set_error("ws3d_interp_gemm: too many rows"); return WS3D_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(interp_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
+                       known_feats, unknown_feats, idx, weight, wt, bias, relu, out);
+    return check_launch("ws3d_interp_gemm");
 }

@@ -19,6 +19,8 @@ eval mode on the GPU unless ``stage1.CHANNELS_LAST_FASTPATH`` is cleared.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -28,6 +30,8 @@ from . import nn_blocks, pn2_ops
 
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
 FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
+FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
+GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 
 
@@ -93,31 +97,128 @@ def supported(model) -> bool:
         return False
 
 
-def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
+def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
+    return (FUSED_GATHER_GEMM and c_feat >= 16 and c_feat % 4 == 0 and grouper.use_xyz and len(blocks) >= 2 and
+            blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
+
+
+def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
+    """per grouper: the (B, npoint, nsample) neighbour list when its first layer gathers its own rows, else None"""
+    B = xyz.size(0)
+    lists = []
+    for grouper, mlp in zip(sa.groupers, sa.mlps):
+        if not _gather_gemm_ok(sa, grouper, _blocks(mlp), c_feat, B):
+            lists.append(None)
+            continue
+        nbr = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
+        _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
+        lists.append(nbr)
+    return lists
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(main: torch.cuda.Stream):
+    """the two side streams of a device: the sampling chain and the searches.  ONE pair per device, shared by every caller
+    stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has
+    descriptors gets time-sliced (measured: a pair per Stage1Pipeline slot, 60 streams, ran every kernel of the process
+    ~1.6x slower -- FPS of the c2 block 0.30 instead of 0.54 of the VALU peak)."""
+    key = main.device.index
+    pair = _SIDE_STREAMS.get(key)
+    if pair is None:
+        pair = _SIDE_STREAMS[key] = (torch.cuda.Stream(device=main.device), torch.cuda.Stream(device=main.device))
+    return pair
+
+
+class _Geometry:
+    """Everything of a forward pass that depends on coordinates only -- the sampling chain of levels 2.., the binned copies,
+    the neighbour lists of the gather-GEMM groupers and the 3-NN indices / weights of all FP modules -- issued on two side
+    streams right after the first level's sampling, so that it runs beside the feature path (SharedMLP GEMMs) instead of
+    in front of it: at batch 8 the sampling kernels occupy 8 of 256 CUs.  The caller's stream waits on one event per product.
+    All tensors stay referenced here until the forward pass returns (they are allocated on the side streams; the side streams'
+    first action of the next pass is to wait for the caller's stream, so their reuse is ordered; passes issued from different
+    caller streams share the side streams and are therefore ordered on them as well)."""
+
+    def __init__(self, net, xyz: torch.Tensor, c0: int):
+        sas = list(net.SA_modules)
+        main = torch.cuda.current_stream(xyz.device)
+        s_fps, s_search = _side_streams(main)
+        self.xyz = [xyz]
+        _, nx = pn2_ops.furthest_point_sample_gather(xyz, sas[0].npoint)            # everything waits for this one: caller's stream
+        self.xyz.append(nx)
+        start = torch.cuda.Event()
+        start.record(main)
+        fps_done = [start]
+        s_fps.wait_event(start)
+        with torch.cuda.stream(s_fps):
+            for sa in sas[1:]:
+                _, nx = pn2_ops.furthest_point_sample_gather(self.xyz[-1], sa.npoint)
+                self.xyz.append(nx)
+                ev = torch.cuda.Event()
+                ev.record(s_fps)
+                fps_done.append(ev)
+        self.sorted, self.nbr, self.sa_ready = [None], [None], [None]
+        self.nn, self.nn_ready = [], []
+        c_feat = [c0] + [sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) for sa in sas]
+        with torch.cuda.stream(s_search):
+            for i in range(len(sas)):
+                s_search.wait_event(fps_done[i])                                     # level i + 1 exists
+                if i >= 1:                                                           # (level 0: fused query+group on the caller's stream)
+                    srt = pn2_ops.sort_points_x(self.xyz[i])
+                    self.sorted.append(srt)
+                    self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i]))
+                    ev = torch.cuda.Event()
+                    ev.record(s_search)
+                    self.sa_ready.append(ev)
+                self.nn.append(_C.three_nn_with_weights(self.xyz[i], self.xyz[i + 1], pn2_ops.sort_points_xz(self.xyz[i + 1])))
+                ev = torch.cuda.Event()
+                ev.record(s_search)
+                self.nn_ready.append(ev)
+        self.main, self.side = main, (s_fps, s_search)
+
+    def release(self):
+        """every consumer of the side streams' tensors has been issued on the caller's stream: later side-stream work (of
+        any caller) is ordered behind them, so the allocator may hand the blocks out again"""
+        done = torch.cuda.Event()
+        done.record(self.main)
+        for s in self.side:
+            s.wait_event(done)
+
+
+def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0):
     """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O)"""
     B = xyz.size(0)
-    _, new_xyz = pn2_ops.furthest_point_sample_gather(xyz, sa.npoint)
-    sorted_xyz = pn2_ops.sort_points_x(xyz)
+    c_feat = 0 if feats is None else feats.size(2)
+    if geo is not None:
+        new_xyz = geo.xyz[level + 1]
+        if level >= 1:
+            geo.main.wait_event(geo.sa_ready[level])
+            sorted_xyz, nbrs = geo.sorted[level], geo.nbr[level]
+        else:
+            sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat)
+    else:
+        _, new_xyz = pn2_ops.furthest_point_sample_gather(xyz, sa.npoint)
+        sorted_xyz = pn2_ops.sort_points_x(xyz)
+        nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
     out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     col = 0
-    for grouper, mlp, width in zip(sa.groupers, sa.mlps, widths):
+    for grouper, mlp, width, nbr in zip(sa.groupers, sa.mlps, widths, nbrs):
         blocks = _blocks(mlp)
-        if (FUSED_GATHER_GEMM and feats is not None and feats.size(2) >= 16 and grouper.use_xyz and len(blocks) >= 2 and
-                blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0):
+        if nbr is not None:
             # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
-            nbr = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
-            _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
             wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
             y = _C.gather_gemm(feats, xyz, new_xyz, nbr, wt1, b1, r1)
-            if y is not None:
-                for blk in blocks[1:-1]:
-                    y = _layer(y, blk)
-                wt, bias, relu = _row_weights(blocks[-1])
-                if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
-                    _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
-                col += width
-                continue
+            if y is None:
+                raise RuntimeError("ws3d_gather_gemm declined a shape _gather_gemm_ok accepted")
+            for blk in blocks[1:-1]:
+                y = _layer(y, blk)
+            wt, bias, relu = _row_weights(blocks[-1])
+            if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
+                _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
+            col += width
+            continue
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
         # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
@@ -136,12 +237,20 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor):
     return new_xyz, out.view(B, sa.npoint, -1)
 
 
-def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor):
+def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
     B, n = unknown.size(0), unknown.size(1)
-    idx, weight = _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
+    idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
+    blocks = _blocks(fp.mlp)
+    if FUSED_INTERP_GEMM and blocks and blocks[0].conv.out_channels % 64 == 0:
+        wt1, b1, r1 = _row_weights(blocks[0])
+        y = _C.interp_gemm(known_feats.contiguous(), None if unknown_feats is None else unknown_feats.contiguous(), idx, weight, wt1, b1, r1)
+        if y is not None:
+            for blk in blocks[1:]:
+                y = _layer(y, blk)
+            return y.view(B, n, -1)
     cat = torch.empty((B, n, c2 + c1), dtype=torch.float32, device=unknown.device)
     _C.three_interpolate_nlc(known_feats, idx, weight, cat)         # left columns, any row stride (4-byte-aligned 16-byte stores)
     if c1:
@@ -154,13 +263,24 @@ def backbone_forward(net, pointcloud: torch.Tensor):
     """Pointnet2MSG.forward on channels-last tensors -> xyz (B,N,3), features (B,N,C)"""
     xyz = pointcloud[..., 0:3].contiguous()
     feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None
+    # (not while a hipGraph is being captured: a graph with such branches replays slower than one stream on this runtime --
+    # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
+    ahead = GEOMETRY_AHEAD and not torch.cuda.is_current_stream_capturing()
+    geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2)) if ahead else None
     l_xyz, l_feats = [xyz], [feats]
-    for sa in net.SA_modules:
-        nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1])
+    for level, sa in enumerate(net.SA_modules):
+        nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level)
         l_xyz.append(nx)
         l_feats.append(nf)
     for i in range(-1, -(len(net.FP_modules) + 1), -1):
-        l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i])
+        nn3 = None
+        if geo is not None:
+            lvl = len(l_xyz) + i - 1                                   # unknown level of this module
+            geo.main.wait_event(geo.nn_ready[lvl])
+            nn3 = geo.nn[lvl]
+        l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3)
+    if geo is not None:
+        geo.release()
     return l_xyz[0], l_feats[0]
 
 
