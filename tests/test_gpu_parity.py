@@ -524,6 +524,59 @@ def test_roipool3d_bit_exact(ops, oracle, B, n, m, c, s, cfg):
     np.testing.assert_array_equal(host(bp), rp)
 
 
+ROI_ENV_VARIANTS = [
+    {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "0"},     # round-1 copy: aligned loads, row-shifted stores
+    {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "16"}, {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "32"},
+    {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "2"}, {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "2", "WS3D_ROI_STAGE": "32"},
+    {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "1"}, {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "1", "WS3D_ROI_STAGE": "32"},
+    {"WS3D_ROI_BG": "1", "WS3D_ROI_STAGE": "16"}, {"WS3D_ROI_BG": "2"},
+]
+
+
+@pytest.mark.parametrize("env", ROI_ENV_VARIANTS, ids=lambda e: ",".join(f"{k[9:]}={v}" for k, v in e.items()))
+def test_roipool3d_kernel_variants_subprocess(oracle, tmp_path, env):
+    """every selectable roipool3d kernel (boxes per workgroup, direct / LDS-staged copy, the variant that overlaps scan and
+    copy): pooled rows, empty flags and selected indices against the oracle; scenes above and below the 16384-point switch,
+    a box count that leaves a ragged last workgroup, empty boxes, pre-zeroed and fill entry points"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(2, 20000, 37, 128, 512), (1, 40000, 9, 128, 64), (2, 3000, 24, 128, 512), (2, 20000, 18, 8, 36), (1, 17000, 6, 5, 33)]
+    refs = []
+    for i, (B, N, M, C, S) in enumerate(cases):
+        pc = synth.make_batch("lidar", B, N, 30 + i)[:, :, :3].copy()
+        boxes = synth.proposal_boxes(B, M, 30 + i)
+        boxes[0, 1:3, 0] += 400.0                                             # empty boxes
+        feat = np.random.default_rng(i).standard_normal((B, N, C)).astype(np.float32)
+        np.savez(tmp_path / f"in{i}.npz", pc=pc, boxes=boxes, feat=feat)
+        refs.append(oracle.roipool3d(pc, boxes, feat, S, return_idx=True))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import compat
+        for i, S in enumerate({[c[4] for c in cases]!r}):
+            d = np.load({str(tmp_path)!r} + f"/in{{i}}.npz")
+            pc, boxes, feat = (torch.from_numpy(d[k]).cuda() for k in ("pc", "boxes", "feat"))
+            B, M, C = boxes.shape[0], boxes.shape[1], feat.shape[2]
+            out = {{}}
+            for name, fn, init in (("z", compat.roipool3d_forward, 0.0), ("f", compat.roipool3d_forward_fill, float("nan"))):
+                pooled = torch.full((B, M, S, 3 + C), init, device="cuda")
+                empty = torch.full((B, M), 0 if name == "z" else 77, dtype=torch.int32, device="cuda")
+                sel = torch.full((B, M, S), -5, dtype=torch.int32, device="cuda")
+                fn(pc, boxes, feat, pooled, empty, sel)
+                out.update({{name + "p": pooled.cpu().numpy(), name + "e": empty.cpu().numpy(), name + "s": sel.cpu().numpy()}})
+            np.savez({str(tmp_path)!r} + f"/out{{i}}.npz", **out)
+    """)
+    r = subprocess.run([sys.executable, "-B", "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for i, (rp, re, rs) in enumerate(refs):
+        got = np.load(tmp_path / f"out{i}.npz")
+        assert (re == 1).sum() >= 2
+        for k in "zf":
+            np.testing.assert_array_equal(got[k + "e"], re, err_msg=str((cases[i], k)))
+            np.testing.assert_array_equal(got[k + "p"], rp, err_msg=str((cases[i], k)))
+            np.testing.assert_array_equal(got[k + "s"], rs, err_msg=str((cases[i], k)))
+
+
 def test_roipool3d_cpu_twins(ops, oracle):
     xyz, boxes, feat = _roi_scene(1, 3000, 20, 6, 9)
     flags = ops.roi.pts_in_boxes3d_cpu(torch.from_numpy(xyz[0]), torch.from_numpy(boxes[0]))

@@ -74,7 +74,8 @@ __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y,
 // BG boxes of one scene per workgroup: every point loaded by the scan is tested against BG box
 // frames, so the scene is streamed from L2 once per BG boxes instead of once per box (at config 5
 // the per-box rescans were 3x the output bytes).
-template <int BG>
+// CR > 0: the copy phase stages CR rows at a time through LDS (see there).
+template <int BG, int CR>
 __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_num, int feat_len,
                                                         int S, const float *__restrict__ xyz,
                                                         const float *__restrict__ boxes3d,
@@ -198,7 +199,43 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
             const int src = sel[sr];
             return j < 3 ? xyz[(size_t)src * 3 + j] : pts_feature[(size_t)src * feat_len + (j - 3)];
         };
-        if (vec_rows) {
+        if (CR > 0) {
+            // Through LDS: a pooled row is 3 + C floats = 524 bytes at C = 128, so a feature row lands 12 bytes off a
+            // 16-byte boundary, and 16-byte stores that straddle 16-byte slots run at HALF the write bandwidth of aligned
+            // ones on this chip (scripts/ubench/row_copy.hip: 2.5 vs 5.1 TB/s, stores only).  The S x (3+C) block of a box is
+            // one contiguous, 16-byte-aligned stream: CR rows are gathered with aligned 16-byte loads (32 lanes per row)
+            // into a tight copy in LDS, and the CR * (3+C) / 4 units of that stretch are stored aligned; two buffers, one
+            // barrier per stretch.  (host: C % 4 == 0, C <= 128, S * (3+C) % 4 == 0, 16-byte-aligned pointers)
+            float *stage = reinterpret_cast<float *>(smem) + (((BG * 4 + 1) * S + 3) & ~3);
+            const int half = tid >> 5, l32 = tid & 31;
+            const int f4 = feat_len >> 2;
+            constexpr int RPH = CR > 0 ? CR / 8 : 1;
+            for (int c0 = 0, it = 0; c0 < S; c0 += CR, ++it) {
+                float *st = stage + (it & 1) * CR * row;
+                const int nr = min(CR, S - c0);
+                float4v v[RPH];
+                float p3[RPH];
+#pragma unroll
+                for (int u = 0; u < RPH; ++u) {
+                    const int src = sel[min(c0 + half * RPH + u, S - 1)];
+                    if (l32 < f4) v[u] = reinterpret_cast<const float4v *>(pts_feature + (size_t)src * feat_len)[l32];
+                    if (l32 < 3) p3[u] = xyz[(size_t)src * 3 + l32];
+                }
+#pragma unroll
+                for (int u = 0; u < RPH; ++u) {
+                    const int r = half * RPH + u;
+                    if (r < nr) {
+                        if (l32 < f4) *reinterpret_cast<float4u *>(st + r * row + 3 + 4 * l32) = v[u];
+                        if (l32 < 3) st[r * row + l32] = p3[u];
+                    }
+                }
+                __syncthreads();
+                float4v *o4 = reinterpret_cast<float4v *>(out + (size_t)c0 * row);
+                const int units = (nr * row) >> 2;
+                for (int q = tid; q < units; q += 256)
+                    __builtin_nontemporal_store(*reinterpret_cast<const float4v *>(st + 4 * q), o4 + q);
+            }
+        } else if (vec_rows) {
             // feature rows are 16-byte aligned in the source: 32 lanes move one row with aligned
             // 16-byte loads and (4-byte aligned) 16-byte stores, lanes 0-2 carry x, y, z; 4 rows
             // per half-wave and trip keep 8 loads in flight per lane
@@ -256,6 +293,190 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
     ROI_PROF(2)
 }
 
+// ---- the large-scene variant: scan and copy overlapped inside the workgroup -------------------------------------------------
+// In roipool3d_kernel every workgroup of the launch scans (VALU-bound), then copies (HBM-bound), all of them in lock-step, so
+// the two phases add (c5: 0.28 + 0.22 ms).  Here the 4 boxes of a workgroup are handled in 4 / SG passes of SG boxes, and the
+// scan loop of pass p carries the copy of pass p-1: each trip of the scan (256 points per wave, ~170 * SG VALU instructions)
+// issues the gathers of one stretch of CR pooled rows before its tests and stores that stretch (through LDS, aligned: see the
+// copy phase of roipool3d_kernel) after them.  The lists hold 16-bit offsets into the wave's quarter of the scene, so a pass needs
+// SG * 4 * S * 2 bytes of lists + SG * S * 4 of selected indices + 2 * CR * (3 + C) * 4 of staging.
+// Measured at c5 (scripts/ablate_roi.sh): 0.56 ms (direct copy) -> 0.52 (staged copy) -> 0.47 (this kernel, SG = 2, CR = 16);
+// scan alone 0.26, copy alone 0.25.  What was tried on top and did not help: one box per pass (0.53: the per-pass overhead
+// of the scan), 32-row stretches (140 VGPRs, 3 waves per SIMD: 0.57), stretches owned by single waves without the workgroup
+// barrier (137 VGPRs: 0.57), starting every CU's third and fourth workgroup 16-130 us late to break the lock-step (slower by
+// a quarter of the delay).
+template <int SG, int CR>
+__global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int boxes_num, int feat_len, int S, const float *__restrict__ xyz,
+                                                             const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
+                                                             float *__restrict__ pooled, int32_t *__restrict__ empty_flag,
+                                                             int32_t *__restrict__ pts_idx, int fill) {
+    constexpr int BG = 4, RPH = CR / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int row = 3 + feat_len;
+    float *stage = reinterpret_cast<float *>(smem);                                     // 2 * CR * row
+    int *sel = reinterpret_cast<int *>(stage + 2 * CR * row);                           // SG * S: the subgroup being copied
+    uint16_t *lists = reinterpret_cast<uint16_t *>(sel + SG * S);                       // SG * 4 * S: the subgroup being scanned
+    __shared__ int wcnt_s[SG * 4];
+    __shared__ int cnt_s[SG];
+
+    const int box0 = blockIdx.x * BG, b = blockIdx.y;
+    const int nb = min(BG, boxes_num - box0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int half = tid >> 5, l32 = tid & 31, f4 = feat_len >> 2;
+    xyz += (size_t)b * pts_num * 3;
+    pts_feature += (size_t)b * pts_num * feat_len;
+    const int Q = (((pts_num + 3) / 4 + 63) / 64) * 64;
+    const int start = min(w * Q, pts_num), end = min(start + Q, pts_num);
+    const int trips = (Q + 255) / 256;
+    const int cpb = (S + CR - 1) / CR;                                                  // stretches per box
+
+    // ---- the copy of one stretch of CR pooled rows, in two halves around the tests of a scan trip: gathers (aligned 16-byte
+    // loads, 32 lanes per row), then -- through LDS, two buffers, one barrier -- CR * (3+C) / 4 aligned 16-byte stores
+    float4v cv[RPH];
+    float cp3[RPH];
+    auto issue = [&](int c) {
+        const int g = c / cpb, c0 = (c - g * cpb) * CR;
+        if (cnt_s[g] == 0) return;
+#pragma unroll
+        for (int u = 0; u < RPH; ++u) {
+            const int src = sel[g * S + min(c0 + half * RPH + u, S - 1)];
+            if (l32 < f4) cv[u] = reinterpret_cast<const float4v *>(pts_feature + (size_t)src * feat_len)[l32];
+            if (l32 < 3) cp3[u] = xyz[(size_t)src * 3 + l32];
+        }
+    };
+    auto finish = [&](int c, int sub0, int parity) {
+        const int g = c / cpb, c0 = (c - g * cpb) * CR;
+        if (cnt_s[g] == 0) return;                                                      // workgroup-uniform
+        float *st = stage + parity * CR * row;
+        const int nr = min(CR, S - c0);
+#pragma unroll
+        for (int u = 0; u < RPH; ++u) {
+            const int r = half * RPH + u;
+            if (r < nr) {
+                if (l32 < f4) *reinterpret_cast<float4u *>(st + r * row + 3 + 4 * l32) = cv[u];
+                if (l32 < 3) st[r * row + l32] = cp3[u];
+            }
+        }
+        __syncthreads();
+        const size_t bm = (size_t)b * boxes_num + box0 + sub0 + g;
+        float4v *o4 = reinterpret_cast<float4v *>(pooled + (bm * S + c0) * (size_t)row);
+        const int units = (nr * row) >> 2;
+        for (int q = tid; q < units; q += 256) __builtin_nontemporal_store(*reinterpret_cast<const float4v *>(st + 4 * q), o4 + q);
+    };
+
+    int parity = 0;
+    for (int sub0 = 0; sub0 < BG + SG; sub0 += SG) {             // pass: scan boxes sub0.., copy boxes sub0 - SG..
+        const bool scanning = sub0 < nb;
+#ifdef WS3D_ROI_NO_COPY
+        const int nchunks = 0;
+#else
+        const int nchunks = sub0 > 0 ? min(SG, nb - (sub0 - SG)) * cpb : 0;             // (sub0 - SG < nb always holds here)
+#endif
+        if (!scanning && nchunks == 0) break;
+        BoxFrame f[SG];
+        int wcnt[SG];
+#pragma unroll
+        for (int g = 0; g < SG; ++g) {
+            f[g] = make_frame(boxes3d + ((size_t)b * boxes_num + box0 + min(sub0 + g, nb - 1)) * 7);
+            wcnt[g] = (scanning && sub0 + g < nb) ? 0 : S;
+        }
+        float nx[4], ny[4], nz[4];
+        auto load_trip = [&](int k0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + u * 64 + lane;
+                const float *pp = xyz + (size_t)min(k, pts_num - 1) * 3;
+                nx[u] = k < end ? pp[0] : __builtin_nanf(""); ny[u] = pp[1]; nz[u] = pp[2];
+            }
+        };
+        bool done = !scanning || start >= end;
+#ifdef WS3D_ROI_NO_SCAN   // ablation: pretend every wave found 40 points
+        for (int g = 0; g < SG; ++g) { if (lane < 40) lists[(g * 4 + w) * S + lane] = (uint16_t)(lane * 7); if (sub0 + g < nb) wcnt[g] = 40; }
+        done = true;
+#endif
+        if (!done) load_trip(start);
+        int next_chunk = 0;
+        const int ntrips = scanning ? trips : 0;
+        for (int t = 0; t < ntrips; ++t) {
+            const int k0 = start + t * 256;
+            const int upto = (int)(((long)(t + 1) * nchunks) / ntrips);
+            const bool has = next_chunk < upto;
+            if (has) issue(next_chunk);
+            if (!done && k0 < end) {
+                float x[4], y[4], z[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { x[u] = nx[u]; y[u] = ny[u]; z[u] = nz[u]; }
+                load_trip(k0 + 256);
+                uint64_t mask[4][SG];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame(f[g], x[u], y[u], z[u]));
+                bool all_full = true;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = t * 256 + u * 64 + lane;                              // offset into the wave's quarter
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) {
+                        const uint64_t mk = mask[u][g];
+                        if (mk) {
+                            const int wc = __builtin_amdgcn_readfirstlane(wcnt[g]);
+                            const int pos = wc + mbcnt(mk);
+                            if (((mk >> lane) & 1ull) && pos < S) lists[(g * 4 + w) * S + pos] = (uint16_t)k;
+                            wcnt[g] = min(wc + (int)__builtin_popcountll(mk), S);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < SG; ++g) all_full = all_full && wcnt[g] >= S;
+                done = all_full;
+            }
+            if (has) { finish(next_chunk, sub0 - SG, parity); parity ^= 1; ++next_chunk; }
+            while (next_chunk < upto) { issue(next_chunk); finish(next_chunk, sub0 - SG, parity); parity ^= 1; ++next_chunk; }
+        }
+        while (next_chunk < nchunks) { issue(next_chunk); finish(next_chunk, sub0 - SG, parity); parity ^= 1; ++next_chunk; }
+        if (!scanning) break;
+        if (lane == 0) {
+#pragma unroll
+            for (int g = 0; g < SG; ++g) wcnt_s[g * 4 + w] = min(wcnt[g], S);
+        }
+        __syncthreads();                                            // lists complete; every stretch of the previous subgroup stored
+        // ---- selected indices of this subgroup: concatenate, truncate, wrap-pad (roipool3d_kernel.cu:139-157)
+        for (int g = 0; g < SG && sub0 + g < nb; ++g) {
+            const size_t bm = (size_t)b * boxes_num + box0 + sub0 + g;
+            const uint16_t *lg = lists + g * 4 * S;
+            const int c0 = wcnt_s[g * 4 + 0], c1 = wcnt_s[g * 4 + 1], c2 = wcnt_s[g * 4 + 2], c3 = wcnt_s[g * 4 + 3];
+            const int cnt = min(c0 + c1 + c2 + c3, S);
+            if (tid == 0) cnt_s[g] = cnt;
+            if (cnt == 0) {      // roipool3d_kernel.cu:147-149,181-183: flag the box, leave its rows untouched
+                if (tid == 0) empty_flag[bm] = 1;
+                if (pts_idx)
+                    for (int q = tid; q < S; q += 256) pts_idx[bm * S + q] = 0;
+                if (fill) {
+                    float4v *o = reinterpret_cast<float4v *>(pooled + bm * (size_t)S * row);
+                    const float4v zero = {0.f, 0.f, 0.f, 0.f};
+                    for (int q = tid; q < (S * row) >> 2; q += 256) o[q] = zero;
+                }
+                continue;
+            }
+            if (fill && tid == 0) empty_flag[bm] = 0;
+            for (int q = tid; q < S; q += 256) {
+                int t = q < cnt ? q : q % cnt;
+                int v;
+                if (t < c0) v = lg[t];
+                else if ((t -= c0) < c1) v = Q + lg[S + t];
+                else if ((t -= c1) < c2) v = 2 * Q + lg[2 * S + t];
+                else v = 3 * Q + lg[3 * S + (t - c2)];
+                sel[g * S + q] = v;
+                if (pts_idx) pts_idx[bm * S + q] = v;
+            }
+        }
+        for (int g = min(SG, nb - sub0); g < SG; ++g)
+            if (tid == 0) cnt_s[g] = 0;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int pts_num,
                                                              const float *__restrict__ pts,
                                                              const float *__restrict__ boxes3d,
@@ -285,23 +506,53 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
     // boxes per workgroup: sharing the scene scan among 4 boxes pays when that still leaves >= 2
     // workgroups per CU (WS3D_ROI_BG overrides for A/B runs)
     static const int bg_env = getenv("WS3D_ROI_BG") ? atoi(getenv("WS3D_ROI_BG")) : 0;
+    static const int cr_env = getenv("WS3D_ROI_STAGE") ? atoi(getenv("WS3D_ROI_STAGE")) : -1;   // 0 / 16 / 32: A/B runs
     int bg = ((long)batch_size * ((boxes_num + 3) / 4) >= 512 && sampled_pts_num <= 1024) ? 4 : 1;
     if (bg_env == 1 || bg_env == 2 || bg_env == 4) bg = bg_env;
-    const size_t smem = sizeof(int) * (size_t)(bg * 4 + 1) * (size_t)sampled_pts_num;
+    const int row = 3 + feature_in_len;
+    // rows staged through LDS by the copy phase (the aligned-store path): what its layout needs, else the direct copy
+    int cr = (feature_in_len >= 4 && (feature_in_len & 3) == 0 && feature_in_len <= 128 && ((long)sampled_pts_num * row) % 4 == 0 &&
+              ((reinterpret_cast<uintptr_t>(pts_feature) | reinterpret_cast<uintptr_t>(pooled_features)) & 15) == 0) ? 32 : 0;
+    if (cr && (cr_env == 0 || cr_env == 16 || cr_env == 32)) cr = cr_env;
+    const size_t lists_ints = ((size_t)(bg * 4 + 1) * (size_t)sampled_pts_num + 3) & ~(size_t)3;
+    const size_t smem = sizeof(int) * lists_ints + sizeof(float) * 2 * (size_t)cr * row;
     if (smem > 150 * 1024 || batch_size > 65535) {
         set_error("ws3d_roipool3d: sampled_pts_num=%d / batch=%d unsupported", sampled_pts_num, batch_size);
         return WS3D_E_UNSUPPORTED;
     }
-#define WS3D_ROI_LAUNCH(BGV)                                                                                       \
+    // large scenes, 4 boxes per workgroup: the variant that overlaps scan and copy inside the workgroup
+    static const int pipe_env = getenv("WS3D_ROI_PIPE") ? atoi(getenv("WS3D_ROI_PIPE")) : -1;   // 0: off; 1 / 2: boxes per pass
+    const int quarter = (((pts_num + 3) / 4 + 63) / 64) * 64;
+    if (bg == 4 && cr > 0 && pipe_env != 0 && quarter <= 65536 && (sampled_pts_num & 3) == 0 && pts_num >= 16 * 1024) {
+        const int sg = pipe_env == 1 ? 1 : 2;
+        if (cr_env != 16 && cr_env != 32) cr = 16;
+        const size_t pm = sizeof(float) * 2 * (size_t)cr * row + sizeof(int) * (size_t)sg * sampled_pts_num +
+                          sizeof(uint16_t) * (size_t)sg * 4 * sampled_pts_num;
+#define WS3D_ROI_PIPE_LAUNCH(SGV, CRV)                                                                                            \
+        {                                                                                                                         \
+            if (pm > 64 * 1024)                                                                                                   \
+                (void)hipFuncSetAttribute((const void *)roipool3d_pipe_kernel<SGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pm); \
+            hipLaunchKernelGGL((roipool3d_pipe_kernel<SGV, CRV>), dim3((boxes_num + 3) / 4, batch_size), dim3(256), pm, as_stream(stream), \
+                               pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,   \
+                               pooled_empty_flag, pts_idx, fill);                                                                 \
+        }
+        if (sg == 1) { if (cr == 16) WS3D_ROI_PIPE_LAUNCH(1, 16) else WS3D_ROI_PIPE_LAUNCH(1, 32) }
+        else { if (cr == 16) WS3D_ROI_PIPE_LAUNCH(2, 16) else WS3D_ROI_PIPE_LAUNCH(2, 32) }
+#undef WS3D_ROI_PIPE_LAUNCH
+        return check_launch("ws3d_roipool3d");
+    }
+#define WS3D_ROI_LAUNCH(BGV, CRV)                                                                                  \
     {                                                                                                              \
         if (smem > 64 * 1024)                                                                                      \
-            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<BGV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<BGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)smem);                                                                  \
-        hipLaunchKernelGGL(roipool3d_kernel<BGV>, dim3((boxes_num + BGV - 1) / BGV, batch_size), dim3(256), smem, \
+        hipLaunchKernelGGL((roipool3d_kernel<BGV, CRV>), dim3((boxes_num + BGV - 1) / BGV, batch_size), dim3(256), smem, \
                            as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,   \
                            pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill);                        \
     }
-    if (bg == 4) WS3D_ROI_LAUNCH(4) else if (bg == 2) WS3D_ROI_LAUNCH(2) else WS3D_ROI_LAUNCH(1)
+#define WS3D_ROI_LAUNCH_BG(CRV) { if (bg == 4) WS3D_ROI_LAUNCH(4, CRV) else if (bg == 2) WS3D_ROI_LAUNCH(2, CRV) else WS3D_ROI_LAUNCH(1, CRV) }
+    if (cr == 32) WS3D_ROI_LAUNCH_BG(32) else if (cr == 16) WS3D_ROI_LAUNCH_BG(16) else WS3D_ROI_LAUNCH_BG(0)
+#undef WS3D_ROI_LAUNCH_BG
 #undef WS3D_ROI_LAUNCH
     return check_launch("ws3d_roipool3d");
 }
