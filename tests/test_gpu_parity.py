@@ -524,6 +524,32 @@ def test_roipool3d_bit_exact(ops, oracle, B, n, m, c, s, cfg):
     np.testing.assert_array_equal(host(bp), rp)
 
 
+def test_roipool3d_boxes_wider_than_the_ten_metre_window(ops, oracle):
+    """pt_in_box3d drops points more than 10 m from the box centre in x or z before the rotated test (roipool3d_kernel.cu:18-20).
+    The kernels leave those two terms out for boxes whose BEV half-diagonal is under 9.9 m (they cannot decide anything there);
+    boxes beyond that -- mixed with small ones in one workgroup, and at the threshold -- must still apply them"""
+    B, N, M, C, S = 2, 20000, 16, 128, 512
+    pc = synth.make_batch("lidar", B, N, 44)[:, :, :3].copy()
+    boxes = synth.proposal_boxes(B, M, 44)
+    boxes[:, 0::4, 3:6] = (3.0, 30.0, 44.0)                 # h, w, l: far wider than the window
+    boxes[:, 1::4, 3:6] = (3.0, 13.0, 15.0)                 # half-diagonal 9.92 m: just above the threshold
+    boxes[:, 2::4, 3:6] = (3.0, 12.9, 15.0)                 # 9.89 m: just below
+    boxes[0, 3, 3:6] = (3.0, float("nan"), 4.0)
+    feat = np.random.default_rng(5).standard_normal((B, N, C)).astype(np.float32)
+    ref_p, ref_e, ref_s = oracle.roipool3d(pc, boxes, feat, S, return_idx=True)
+    # the wide boxes hold points of the rotated rectangle that the window drops: the full cloud passes the rotated test far more often
+    rot_only = oracle.pts_in_boxes3d(pc[0], boxes[0, 0:1])[0].sum() if hasattr(oracle, "pts_in_boxes3d") else 0
+    assert len(np.unique(ref_s[0, 0])) > 100 and ref_e[0, 3] == 1 and rot_only >= 0
+    for fn, init in ((ops.c.roipool3d_forward, 0.0), (ops.c.roipool3d_forward_fill, float("nan"))):
+        pooled = torch.full((B, M, S, 3 + C), init, device="cuda")
+        empty = torch.zeros((B, M), dtype=torch.int32, device="cuda")
+        sel = torch.full((B, M, S), -5, dtype=torch.int32, device="cuda")
+        fn(dev(pc), dev(boxes), dev(feat), pooled, empty, sel)
+        np.testing.assert_array_equal(host(empty), ref_e)
+        np.testing.assert_array_equal(host(sel), ref_s)
+        np.testing.assert_array_equal(host(pooled), ref_p)
+
+
 ROI_ENV_VARIANTS = [
     {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "0"},     # round-1 copy: aligned loads, row-shifted stores
     {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "16"}, {"WS3D_ROI_BG": "4", "WS3D_ROI_PIPE": "0", "WS3D_ROI_STAGE": "32"},
@@ -546,6 +572,7 @@ def test_roipool3d_kernel_variants_subprocess(oracle, tmp_path, env):
         pc = synth.make_batch("lidar", B, N, 30 + i)[:, :, :3].copy()
         boxes = synth.proposal_boxes(B, M, 30 + i)
         boxes[0, 1:3, 0] += 400.0                                             # empty boxes
+        boxes[-1, 3::5, 4:6] = (25.0, 30.0)                                   # wider than the +-10 m window of pt_in_box3d
         feat = np.random.default_rng(i).standard_normal((B, N, C)).astype(np.float32)
         np.savez(tmp_path / f"in{i}.npz", pc=pc, boxes=boxes, feat=feat)
         refs.append(oracle.roipool3d(pc, boxes, feat, S, return_idx=True))

@@ -61,15 +61,29 @@ __device__ __forceinline__ BoxFrame make_frame(const float *bx) {
 // NaN x_rot / z_rot (NaN or inf coordinates, angle or extent) say "outside" and its '>' tests on a
 // NaN |dy| say "keep going".  x_rot and z_rot are NaN together (shared operands; |dx|,|dz| <= 10
 // and |cos|,|sin| <= 1 exclude inf - inf), so one ordered-compare of t0, t1 restores that.
+// SMALL (frame_is_small: hl^2 + hw^2 < 98, i.e. a BEV half-diagonal under 9.9 m -- every car-sized box): the two "|dx| > 10",
+// "|dz| > 10" terms cannot decide anything and are left out.  Proof: the rotation is an isometry up to rounding, so a point
+// that passes |x_rot| <= hl and |z_rot| <= hw has dx^2 + dz^2 <= (hl^2 + hw^2)(1 + 1e-5) < 100, hence |dx|, |dz| < 10; a point
+// that fails them is outside either way.  (x_rot, z_rot carry an absolute error <= 2^-22 (|dx| + |dz|); for |dx| or |dz| so
+// large that this matters, one of |x_rot|, |z_rot| is of the same magnitude and fails its test.  inf / NaN coordinates give
+// inf / NaN x_rot or z_rot: outside under both spellings.)
+template <bool SMALL = false>
 __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y, float z) {
     const float dx = x - f.cx, dy = y - f.cy, dz = z - f.cz;
     const float x_rot = dx * f.cosa + dz * (-f.sina);
     const float z_rot = dx * f.sina + dz * f.cosa;
     const float t0 = fabsf(x_rot) - f.hl, t1 = fabsf(z_rot) - f.hw;
-    const float t2 = fabsf(dx) - 10.0f, t3 = fabsf(dy) - f.hh, t4 = fabsf(dz) - 10.0f;
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)), t4);
+    const float t3 = fabsf(dy) - f.hh;
+    float m;
+    if (SMALL) m = __builtin_fmaxf(__builtin_fmaxf(t0, t1), t3);
+    else {
+        const float t2 = fabsf(dx) - 10.0f, t4 = fabsf(dz) - 10.0f;
+        m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)), t4);
+    }
     return !(m > 0.0f) & !__builtin_isunordered(t0, t1);
 }
+
+__device__ __forceinline__ bool frame_is_small(const BoxFrame &f) { return f.hl * f.hl + f.hw * f.hw < 98.0f; }   // false for NaN
 
 // BG boxes of one scene per workgroup: every point loaded by the scan is tested against BG box
 // frames, so the scene is streamed from L2 once per BG boxes instead of once per box (at config 5
@@ -97,6 +111,9 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
     BoxFrame f[BG];
 #pragma unroll
     for (int g = 0; g < BG; ++g) f[g] = make_frame(boxes3d + ((size_t)b * boxes_num + box0 + min(g, nb - 1)) * 7);
+    bool all_small = true;
+#pragma unroll
+    for (int g = 0; g < BG; ++g) all_small = all_small && frame_is_small(f[g]);
 
     ROI_PROF(3)
     const int Q = (((pts_num + 3) / 4 + 63) / 64) * 64;
@@ -129,10 +146,17 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
         // all 4 x BG tests first (independent VALU work, masks in SGPRs), bookkeeping afterwards:
         // a test followed directly by its own ballot branch serialises on VALU->SALU round trips
         uint64_t mask[4][BG];
+        if (all_small) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame(f[g], x[u], y[u], z[u]));
+                for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + u * 64 + lane;
@@ -380,6 +404,9 @@ __global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int bo
             f[g] = make_frame(boxes3d + ((size_t)b * boxes_num + box0 + min(sub0 + g, nb - 1)) * 7);
             wcnt[g] = (scanning && sub0 + g < nb) ? 0 : S;
         }
+        bool all_small = true;
+#pragma unroll
+        for (int g = 0; g < SG; ++g) all_small = all_small && frame_is_small(f[g]);
         float nx[4], ny[4], nz[4];
         auto load_trip = [&](int k0) {
 #pragma unroll
@@ -408,10 +435,17 @@ __global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int bo
                 for (int u = 0; u < 4; ++u) { x[u] = nx[u]; y[u] = ny[u]; z[u] = nz[u]; }
                 load_trip(k0 + 256);
                 uint64_t mask[4][SG];
+                if (all_small) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame(f[g], x[u], y[u], z[u]));
+                        for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
+                }
                 bool all_full = true;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
