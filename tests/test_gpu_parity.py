@@ -75,8 +75,8 @@ def test_fps_ties(ops, oracle, case):
 
 
 def test_fps_bucket_kernel_subprocess(oracle, tmp_path):
-    """the experimental pruned (bucket) FPS kernel is selected by an env var read once per
-    process: run it in a child and compare with the oracle, incl. heavy duplication (tie rounds)"""
+    """the pruned (bucket) FPS kernel forced for every cloud of 4097..16384 points (env var read once per
+    process): run it in a child and compare with the oracle, incl. heavy duplication (tie rounds)"""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cases = [(2, 16384, 1024, "lidar", 0.02), (1, 5000, 300, "uniform", 0.0), (1, 12345, 777, "lidar", 0.3)]
@@ -151,6 +151,8 @@ FPS_ENV_VARIANTS = [
     {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "0"}, {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "2"},
     {"WS3D_FPS_PAIR": "1", "WS3D_FPS_DUO": "1"},          # two scenes per workgroup, half a step out of phase (even batches)
     {"WS3D_FPS_STREAM": "1"},                            # the round-1 streaming kernel above 16384 points
+    {"WS3D_FPS_BUCKET": "0"},                            # dense sweep also where the pruned kernel is the default
+    {"WS3D_FPS_BUCKET": "1"},                            # pruned kernel for every cloud of 4097..16384 points
 ]
 
 

@@ -711,10 +711,12 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     while ((1 << log2bs) < bs) ++log2bs;
     const int S = (n + bs - 1) / bs;
     const long R = (long)bs * S;  // number of tie-order positions
-    // pruned (bucket) kernel for the large layers; WS3D_FPS_BUCKET=0 keeps the dense kernel (A/B runs)
-    // (experimental, OFF by default: exact, but its per-step chain is not shorter than the dense one)
-    static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : 0;
-    if (use_bucket && n > 4096 && n <= 16384 && m > 1)
+    // pruned (bucket) kernel, fps_bucket.hip: one scene per CU, 0.77 us per step at 16384 points against 1.02 of the dense sweep
+    // -- the choice when the scenes do not outnumber the CUs (two dense scenes per CU sample 512 scenes in 6.1 ms, the pruned
+    // kernel needs 6.4) and the cloud is large (8192 points: 0.78 vs 0.74).  WS3D_FPS_BUCKET=0 / 1 forces the choice (A/B runs).
+    static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : -1;
+    const bool bucket = use_bucket >= 0 ? use_bucket != 0 : (R > 8192 && !fps_pair_mode(b));
+    if (bucket && n > 4096 && n <= 16384 && m > 1)
         return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
     // round-2 kernels (fps_v3.hip: hand-scheduled sweep, winner-only lookup); WS3D_FPS_IMPL=2 keeps the round-1 ones
     static const int impl = getenv("WS3D_FPS_IMPL") ? atoi(getenv("WS3D_FPS_IMPL")) : 3;
