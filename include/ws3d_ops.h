@@ -74,6 +74,15 @@ WS3D_API int ws3d_furthest_point_sampling(int b, int n, int m, const float *xyz,
 WS3D_API int ws3d_furthest_point_sampling_gather(int b, int n, int m, const float *xyz, float *temp,
                                         int32_t *idx, float *new_xyz, ws3d_stream_t stream);
 
+/* FPS + gather of a cloud that is ALREADY in sampling order -- level l+1 of a set-abstraction stack samples the centres
+ * level l selected, in the order it selected them (pointnet2_msg.py:56-70) -- where greedy selection returns idx = 0..m-1
+ * unless two points tie for a maximum.  Same results as ws3d_furthest_point_sampling_gather for ANY input: the nesting is
+ * verified in parallel (every point's running minimum against the picked point's, strictly), and a scene that fails the
+ * check is sampled by a literal restatement of sampling_gpu.cu:93-209.  n <= 4096 (else WS3D_E_UNSUPPORTED), m <= n;
+ * idx (b,m) and new_xyz (b,m,3) are both required (they double as scratch).  No reference counterpart.               */
+WS3D_API int ws3d_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, int32_t *idx, float *new_xyz,
+                                        ws3d_stream_t stream);
+
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)   sampling.cpp:11-20 ->
  * sampling_gpu.cu:8-37.  points (b,c,n), idx (b,npoints) -> out (b,c,npoints).     */
 WS3D_API int ws3d_gather_points(int b, int c, int n, int npoints, const float *points, const int32_t *idx,

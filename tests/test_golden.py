@@ -180,9 +180,15 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     pts = dev(synth.make_batch("lidar", 1, 16384, case["config_id"]))
     fps_log, bq_log = [], []
     orig_fps, orig_qg = pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group
+    orig_nested = pn2_ops.furthest_point_sample_gather_nested
 
     def fps_tap(xyz, npoint):
         r = orig_fps(xyz, npoint)
+        fps_log.append(r[0].cpu().numpy())
+        return r
+
+    def nested_tap(xyz, npoint):          # levels 2-4 of the channels-last path: the verified-prefix kernel
+        r = orig_nested(xyz, npoint)
         fps_log.append(r[0].cpu().numpy())
         return r
 
@@ -207,6 +213,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         return r
 
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
+    pn2_ops.furthest_point_sample_gather_nested = nested_tap
     compat.query_and_group_nlc = nlc_tap
     if channels_last:
         compat.ball_query_wrapper = bq_tap
@@ -217,6 +224,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
             out = model.rpn_forward({'pts_input': pts})
     finally:
         pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = orig_fps, orig_qg
+        pn2_ops.furthest_point_sample_gather_nested = orig_nested
         compat.query_and_group_nlc = orig_nlc
         compat.ball_query_wrapper = orig_bq
         stage1.CHANNELS_LAST_FASTPATH = prev

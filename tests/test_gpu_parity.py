@@ -1550,3 +1550,42 @@ def test_interp_gemm_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
     scale = want.abs().max().item()
     assert err <= 4e-6 * max(scale, 1.0) * np.sqrt((C2 + C1) / 96), (err, scale)
     assert ops.c.interp_gemm(kf, uf, idx, weight, wt[:, :O - 8].contiguous(), bias[:O - 8], True) is None              # O % 64
+
+
+def test_fps_nested_equals_plain_fps(ops, oracle):
+    """ws3d_furthest_point_sampling_nested against the oracle's FPS on the same cloud: clouds in sampling order (the verified
+    path: idx = arange), clouds in arbitrary order and sampling-ordered clouds with exact duplicates (ties: the per-scene
+    fallback), mixed in one batch; ragged sizes, m = n, m = 1"""
+    def sampled(kind, B, N, M, seed, dup=0.0):
+        pc = synth.make_batch(kind, B, N, seed, dup_frac=dup)[:, :, :3].copy()
+        ref = oracle.furthest_point_sample(pc, M)
+        return np.stack([pc[b][ref[b]] for b in range(B)])
+    clouds = [
+        ("sampling order", sampled("lidar", 3, 16384, 4096, 71), 1024, True),
+        ("sampling order, level 3", sampled("lidar", 2, 16384, 4096, 72)[:, :1024].copy(), 256, True),
+        ("sampling order, uniform", sampled("uniform", 2, 5000, 1000, 73), 333, True),
+        ("all of a cloud with duplicates, re-sampled completely", sampled("lidar", 2, 700, 700, 74, dup=0.3), 700, False),
+        ("arbitrary order", synth.make_batch("lidar", 2, 4096, 75)[:, :, :3].copy(), 512, False),
+        ("arbitrary order, ragged", synth.make_batch("uniform", 3, 3001, 76)[:, :, :3].copy(), 777, False),
+        ("tiny", synth.make_batch("uniform", 2, 37, 77)[:, :, :3].copy(), 37, False),
+        ("one point asked", synth.make_batch("uniform", 2, 50, 78)[:, :, :3].copy(), 1, True),
+        ("single point", synth.make_batch("uniform", 1, 1, 79)[:, :, :3].copy(), 1, True),
+    ]
+    mixed = np.stack([sampled("lidar", 1, 8192, 2048, 80)[0], synth.make_batch("lidar", 1, 2048, 81)[0, :, :3]])
+    clouds.append(("mixed batch: scene 0 in sampling order, scene 1 not", mixed, 600, None))
+    for name, pc, M, expect_prefix in clouds:
+        B, N = pc.shape[0], pc.shape[1]
+        ref = oracle.furthest_point_sample(pc, M)
+        idx = torch.full((B, M), -7, dtype=torch.int32, device="cuda")
+        nx = torch.full((B, M, 3), float("nan"), device="cuda")
+        ops.c.furthest_point_sampling_nested(B, N, M, dev(pc), idx, nx)
+        np.testing.assert_array_equal(host(idx), ref, err_msg=name)
+        np.testing.assert_array_equal(host(nx), np.stack([pc[b][ref[b]] for b in range(B)]), err_msg=name)
+        if expect_prefix:
+            assert (ref == np.arange(M)[None]).all(), name          # the nesting property itself, on the oracle's output
+        i2, x2 = ops.pn.furthest_point_sample_gather_nested(dev(pc), M)
+        assert torch.equal(i2, idx) and torch.equal(x2, nx)
+    assert (oracle.furthest_point_sample(mixed, 600)[0] == np.arange(600)).all()
+    with pytest.raises(Exception):
+        ops.c.furthest_point_sampling_nested(1, 5000, 10, torch.zeros((1, 5000, 3), device="cuda"),
+                                             torch.zeros((1, 10), dtype=torch.int32, device="cuda"), torch.zeros((1, 10, 3), device="cuda"))

@@ -28,6 +28,7 @@ SIGNATURES = {
     "ws3d_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),
     "ws3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_furthest_point_sampling_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_furthest_point_sampling_nested": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -32,7 +32,7 @@ DIST_MODES = (0, 1, 2)   # squared-distance conventions (csrc/common.h); 0 is th
 def lib_path(dist_mode: int = 0) -> str:
     return LIB if dist_mode == 0 else os.path.join(HERE, "libws3d_hip_dm%d.so" % dist_mode)
 ARCH = "gfx950"
-SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "proposals.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
+SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "fps_nested.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "proposals.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 

@@ -82,6 +82,16 @@ def furthest_point_sampling_gather(b, n, m, xyz, temp, idx, new_xyz):
     return 1
 
 
+def furthest_point_sampling_nested(b, n, m, xyz, idx, new_xyz):
+    """FPS + gather of a cloud that is already in sampling order (the centres of the previous set-abstraction level):
+    same results as furthest_point_sampling_gather, found by a parallel check instead of m dependent steps.  ws3d extension."""
+    dev = _dev(xyz, idx, new_xyz)
+    _f32(xyz, "xyz"); _i32(idx, "idx"); _f32(new_xyz, "new_xyz")
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_furthest_point_sampling_nested(b, n, m, _p(xyz), _p(idx), _p(new_xyz), _stream()), "fps_nested")
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tensor):
     """sampling.cpp:11-20"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)

@@ -1,0 +1,151 @@
+// fps_nested.hip -- furthest point sampling of a cloud that is ALREADY in sampling order (gfx950).
+//
+// The set-abstraction levels of PointNet++ sample each other's output: level l+1 runs furthest_point_sample on the
+// centres level l selected, in the order level l selected them (pointnet2_modules.py:30-36, pointnet2_msg.py:56-70).  Greedy
+// furthest-point selection has a nesting property: the point the sweep over ALL n points picked at step k maximises the
+// running minimum distance over every subset that contains it, so the sweep over the selected subset picks the same point
+// again -- sampling a cloud that is the output of a sampling pass returns idx = 0, 1, 2, ..., m-1, unless a step has TWO
+// points holding the maximum (then the reference's tie order, which differs between the two launches, decides).  The
+// reference fixture shows it: tests/golden/stage1_forward.npz has fps_idx_1..3 = arange.
+//
+// ws3d_furthest_point_sampling_nested therefore does not trust, it VERIFIES, in parallel instead of m dependent steps:
+//   A  W[k] = min(1e10, d(x_k, x_0), ..., d(x_k, x_{k-1}))            k < m   (the running minimum of point k when it is picked)
+//   B  every point p walks k = 1 .. m-1 with its own running minimum t_p(k) (the reference's arithmetic: the same sqdist3,
+//      fminf, 1e10) and checks t_p(k) < W[k] for p != k -- STRICTLY.  If that holds for all p and k, point k is the unique
+//      maximum of step k, and the reference selects it whatever its tie order: idx = arange, new_xyz = xyz[:m], exactly.
+//   C  a scene that fails the check (ties, or a cloud that was not in sampling order to begin with) is sampled by a literal
+//      restatement of the reference kernel (strided ownership, strict '>', shared-memory tree that keeps the lower slot:
+//      sampling_gpu.cu:86-209) -- slow and rare.
+// Cost at 4096 -> 1024 points x 8 scenes: three short launches, ~25 us, against 600 us of dependent steps.
+// Scratch: W lives in idx (as float bits), the per-scene verdict in new_xyz[0] (as int bits); both are overwritten by C.
+#include <cmath>
+
+#include "common.h"
+
+namespace ws3d {
+
+static int nested_opt_n_threads(int work_size) {      // cuda_utils.h:10-14 (the launcher's own libm expression)
+    const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
+    int v = 1 << pow_2;
+    if (v > 1024) v = 1024;
+    if (v < 1) v = 1;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void fps_nested_w_kernel(int n, int m, const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                           float *__restrict__ new_xyz) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    xyz += (size_t)b * n * 3;
+    if (k == 0) reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3)[0] = 0;       // the verdict: 0 = in sampling order
+    const int kc = min(k, m - 1);
+    const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
+    float w = 1e10f;
+    const int kmax = min(blockIdx.x * 256 + 255, m - 1);       // workgroup-uniform trip count, scalar loads of the samples
+    for (int i = 0; i < kmax; ++i) {
+        const float d = sqdist3(x - xyz[i * 3 + 0], y - xyz[i * 3 + 1], z - xyz[i * 3 + 2]);
+        const float w2 = min_f32(d, w);
+        w = i < k ? w2 : w;
+    }
+    if (k < m) idx[(size_t)b * m + k] = __builtin_bit_cast(int32_t, w);
+}
+
+__global__ __launch_bounds__(256) void fps_nested_check_kernel(int n, int m, const float *__restrict__ xyz, const int32_t *__restrict__ idx,
+                                                               float *__restrict__ new_xyz) {
+    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    xyz += (size_t)b * n * 3;
+    const float *wk = reinterpret_cast<const float *>(idx + (size_t)b * m);
+    const int pc = min(p, n - 1);
+    const float x = xyz[pc * 3 + 0], y = xyz[pc * 3 + 1], z = xyz[pc * 3 + 2];
+    float t = 1e10f;
+    bool bad = false;
+    for (int k = 1; k < m; ++k) {
+        const float d = sqdist3(x - xyz[(k - 1) * 3 + 0], y - xyz[(k - 1) * 3 + 1], z - xyz[(k - 1) * 3 + 2]);
+        t = min_f32(d, t);                                     // the running minimum of point p before step k
+        bad = bad || (p != k && !(t < wk[k]));                 // not strictly below the picked point's: a tie (or out of order)
+    }
+    if (__ballot(bad && p < n) != 0 && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3), 1);
+}
+
+// C: verified scenes get idx = arange and new_xyz = xyz[:m]; the others the reference kernel, restated literally.
+__global__ __launch_bounds__(1024) void fps_nested_finish_kernel(int n, int m, int bs, const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                                 float *__restrict__ new_xyz) {
+    __shared__ float dists[1024];
+    __shared__ int dists_i[1024];
+    __shared__ int verdict;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    new_xyz += (size_t)b * m * 3;
+    if (tid == 0) verdict = reinterpret_cast<const int32_t *>(new_xyz)[0];
+    __syncthreads();
+    if (verdict == 0) {
+        for (int k = tid; k < m; k += 1024) idx[k] = k;
+        for (int e = tid; e < m * 3; e += 1024) new_xyz[e] = xyz[e];
+        return;
+    }
+    // sampling_gpu.cu:93-209 with temp = 1e10 held in registers: thread tid owns k = tid, tid + bs, ... (at most 4: n <= 4096)
+    float px[4], py[4], pz[4], tmp[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int k = tid + s * bs;
+        const bool own = tid < bs && k < n;
+        px[s] = own ? xyz[k * 3 + 0] : 0.f; py[s] = own ? xyz[k * 3 + 1] : 0.f; pz[s] = own ? xyz[k * 3 + 2] : 0.f;
+        tmp[s] = 1e10f;
+    }
+    int old = 0;
+    if (tid == 0) { idx[0] = 0; new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
+    for (int j = 1; j < m; ++j) {
+        const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+        float best = -1.f;
+        int besti = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k = tid + s * bs;
+            if (tid < bs && k < n) {
+                const float d = sqdist3(px[s] - x1, py[s] - y1, pz[s] - z1);
+                const float d2 = min_f32(d, tmp[s]);
+                tmp[s] = d2;
+                besti = d2 > best ? k : besti;
+                best = d2 > best ? d2 : best;
+            }
+        }
+        if (tid < bs) { dists[tid] = best; dists_i[tid] = besti; }
+        __syncthreads();
+        for (int s = bs / 2; s >= 1; s >>= 1) {
+            if (tid < s) {
+                const float v1 = dists[tid], v2 = dists[tid + s];
+                const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                dists[tid] = max_f32(v1, v2);
+                dists_i[tid] = v2 > v1 ? i2 : i1;
+            }
+            __syncthreads();
+        }
+        old = dists_i[0];
+        __syncthreads();                                       // dists_i[0] is rewritten by the next step
+        if (tid == 0) {
+            idx[j] = old;
+            new_xyz[j * 3 + 0] = xyz[old * 3 + 0]; new_xyz[j * 3 + 1] = xyz[old * 3 + 1]; new_xyz[j * 3 + 2] = xyz[old * 3 + 2];
+        }
+    }
+}
+
+}  // namespace ws3d
+
+extern "C" int ws3d_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, int32_t *idx, float *new_xyz,
+                                                   ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || m < 0 || m > n || !xyz || ((!idx || !new_xyz) && m > 0)) {
+        set_error("ws3d_furthest_point_sampling_nested: invalid argument (b=%d n=%d m=%d)", b, n, m);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || m == 0) return WS3D_OK;
+    if (n > 4096 || b > 65535) {
+        set_error("ws3d_furthest_point_sampling_nested: n=%d > 4096 (or b=%d > 65535) is not covered, use ws3d_furthest_point_sampling_gather", n, b);
+        return WS3D_E_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(fps_nested_w_kernel, dim3((m + 255) / 256, b), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
+    hipLaunchKernelGGL(fps_nested_check_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
+    hipLaunchKernelGGL(fps_nested_finish_kernel, dim3(b), dim3(1024), 0, st, n, m, nested_opt_n_threads(n), xyz, idx, new_xyz);
+    return check_launch("furthest_point_sampling_nested");
+}

@@ -31,6 +31,7 @@ from . import nn_blocks, pn2_ops
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
 FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
+NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 
@@ -153,7 +154,8 @@ class _Geometry:
         s_fps.wait_event(start)
         with torch.cuda.stream(s_fps):
             for sa in sas[1:]:
-                _, nx = pn2_ops.furthest_point_sample_gather(self.xyz[-1], sa.npoint)
+                # every level after the first samples the previous level's centres, in the order they were picked
+                _, nx = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS else pn2_ops.furthest_point_sample_gather)(self.xyz[-1], sa.npoint)
                 self.xyz.append(nx)
                 ev = torch.cuda.Event()
                 ev.record(s_fps)
@@ -198,7 +200,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         else:
             sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat)
     else:
-        _, new_xyz = pn2_ops.furthest_point_sample_gather(xyz, sa.npoint)
+        _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
         sorted_xyz = pn2_ops.sort_points_x(xyz)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]

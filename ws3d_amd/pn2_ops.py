@@ -67,6 +67,22 @@ def furthest_point_sample_gather(xyz: torch.Tensor, npoint: int) -> Tuple[torch.
     return idx, new_xyz
 
 
+def furthest_point_sample_gather_nested(xyz: torch.Tensor, npoint: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """furthest_point_sample_gather for a cloud that is the new_xyz of a previous sampling pass (the input of every
+    set-abstraction level after the first): same (idx, new_xyz), bit for bit, without the npoint dependent steps -- the
+    kernel verifies that greedy selection returns the leading npoint points and falls back to the plain kernel per scene
+    where it does not (ties).  Clouds above 4096 points take the plain path."""
+    assert xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    if N > 4096 or npoint > N:
+        return furthest_point_sample_gather(xyz, npoint)
+    idx = _new((B, npoint), torch.int32, xyz)
+    new_xyz = _new((B, npoint, 3), torch.float32, xyz)
+    with torch.no_grad():
+        _C.furthest_point_sampling_nested(B, N, npoint, xyz, idx, new_xyz)
+    return idx, new_xyz
+
+
 def sampling_plan(xyz: torch.Tensor, npoints) -> list:
     """The backbone's chain of furthest-point samplings, ``[new_xyz_1 (B,npoints[0],3), new_xyz_2, ...]``
     with level k sampled from level k-1.  It depends on the coordinates only -- not on any weight --
