@@ -32,18 +32,34 @@ static int nested_opt_n_threads(int work_size) {      // cuda_utils.h:10-14 (the
     return v;
 }
 
+// The samples are staged in LDS once per workgroup (coalesced loads) and read back as broadcast 16-byte records, 8 per trip:
+// a loop that fetches sample k through scalar loads waits a full cache round trip per step (measured: 0.5 us per step).
 __global__ __launch_bounds__(256) void fps_nested_w_kernel(int n, int m, const float *__restrict__ xyz, int32_t *__restrict__ idx,
                                                            float *__restrict__ new_xyz) {
-    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float4 smp[];                         // samples 0 .. kmax-1
+    const int b = blockIdx.y, tid = threadIdx.x, k = blockIdx.x * 256 + tid;
     xyz += (size_t)b * n * 3;
     if (k == 0) reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3)[0] = 0;       // the verdict: 0 = in sampling order
+    const int kmax = min(blockIdx.x * 256 + 255, m - 1);                                 // workgroup-uniform trip count
+    for (int i = tid; i < kmax; i += 256) smp[i] = make_float4(xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], 0.f);
     const int kc = min(k, m - 1);
     const float x = xyz[kc * 3 + 0], y = xyz[kc * 3 + 1], z = xyz[kc * 3 + 2];
+    __syncthreads();
     float w = 1e10f;
-    const int kmax = min(blockIdx.x * 256 + 255, m - 1);       // workgroup-uniform trip count, scalar loads of the samples
-    for (int i = 0; i < kmax; ++i) {
-        const float d = sqdist3(x - xyz[i * 3 + 0], y - xyz[i * 3 + 1], z - xyz[i * 3 + 2]);
-        const float w2 = min_f32(d, w);
+    int i = 0;
+    for (; i + 8 <= kmax; i += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = smp[i + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float w2 = min_f32(sqdist3(x - q[u].x, y - q[u].y, z - q[u].z), w);
+            w = i + u < k ? w2 : w;
+        }
+    }
+    for (; i < kmax; ++i) {
+        const float4 q = smp[i];
+        const float w2 = min_f32(sqdist3(x - q.x, y - q.y, z - q.z), w);
         w = i < k ? w2 : w;
     }
     if (k < m) idx[(size_t)b * m + k] = __builtin_bit_cast(int32_t, w);
@@ -51,19 +67,33 @@ __global__ __launch_bounds__(256) void fps_nested_w_kernel(int n, int m, const f
 
 __global__ __launch_bounds__(256) void fps_nested_check_kernel(int n, int m, const float *__restrict__ xyz, const int32_t *__restrict__ idx,
                                                                float *__restrict__ new_xyz) {
-    const int b = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float4 smp[];                         // record k: {sample k-1, W[k]}, k = 1 .. m-1
+    const int b = blockIdx.y, tid = threadIdx.x, p = blockIdx.x * 256 + tid;
     xyz += (size_t)b * n * 3;
     const float *wk = reinterpret_cast<const float *>(idx + (size_t)b * m);
+    for (int k = 1 + tid; k < m; k += 256) smp[k] = make_float4(xyz[(k - 1) * 3 + 0], xyz[(k - 1) * 3 + 1], xyz[(k - 1) * 3 + 2], wk[k]);
     const int pc = min(p, n - 1);
     const float x = xyz[pc * 3 + 0], y = xyz[pc * 3 + 1], z = xyz[pc * 3 + 2];
+    __syncthreads();
     float t = 1e10f;
     bool bad = false;
-    for (int k = 1; k < m; ++k) {
-        const float d = sqdist3(x - xyz[(k - 1) * 3 + 0], y - xyz[(k - 1) * 3 + 1], z - xyz[(k - 1) * 3 + 2]);
-        t = min_f32(d, t);                                     // the running minimum of point p before step k
-        bad = bad || (p != k && !(t < wk[k]));                 // not strictly below the picked point's: a tie (or out of order)
+    int k = 1;
+    for (; k + 8 <= m; k += 8) {
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = smp[k + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            t = min_f32(sqdist3(x - q[u].x, y - q[u].y, z - q[u].z), t);     // the running minimum of point p before step k + u
+            bad = bad || (p != k + u && !(t < q[u].w));                       // not strictly below the picked point's: a tie
+        }
     }
-    if (__ballot(bad && p < n) != 0 && (threadIdx.x & 63) == 0) atomicOr(reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3), 1);
+    for (; k < m; ++k) {
+        const float4 q = smp[k];
+        t = min_f32(sqdist3(x - q.x, y - q.y, z - q.z), t);
+        bad = bad || (p != k && !(t < q.w));
+    }
+    if (__ballot(bad && p < n) != 0 && (tid & 63) == 0) atomicOr(reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3), 1);
 }
 
 // C: verified scenes get idx = arange and new_xyz = xyz[:m]; the others the reference kernel, restated literally.
@@ -144,8 +174,9 @@ extern "C" int ws3d_furthest_point_sampling_nested(int b, int n, int m, const fl
         return WS3D_E_UNSUPPORTED;
     }
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(fps_nested_w_kernel, dim3((m + 255) / 256, b), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
-    hipLaunchKernelGGL(fps_nested_check_kernel, dim3((n + 255) / 256, b), dim3(256), 0, st, n, m, xyz, idx, new_xyz);
+    const size_t lds = sizeof(float) * 4 * (size_t)m;                                    // <= 64 KB (m <= n <= 4096)
+    hipLaunchKernelGGL(fps_nested_w_kernel, dim3((m + 255) / 256, b), dim3(256), lds, st, n, m, xyz, idx, new_xyz);
+    hipLaunchKernelGGL(fps_nested_check_kernel, dim3((n + 255) / 256, b), dim3(256), lds, st, n, m, xyz, idx, new_xyz);
     hipLaunchKernelGGL(fps_nested_finish_kernel, dim3(b), dim3(1024), 0, st, n, m, nested_opt_n_threads(n), xyz, idx, new_xyz);
     return check_launch("furthest_point_sampling_nested");
 }
