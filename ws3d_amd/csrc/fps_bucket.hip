@@ -45,7 +45,8 @@ constexpr int FB_CELLS = 1024;  // 32 x 32 Z-order cells
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 
-struct FbRec { float v; int pos; float x, y, z; int tie; int pad0, pad1; };  // 32 bytes
+// a wave's published candidate is {value, x, y, z} (16 bytes, one LDS read); "my maximum is attained twice" goes into a
+// bit mask beside the records, the position into an array only thread 0 reads
 
 __device__ __forceinline__ int zcell(float x, float z, float xmin, float zmin, float ix, float iz) {
     const float fx = (x - xmin) * ix, fz = (z - zmin) * iz;
@@ -132,8 +133,10 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
     uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
     int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
     float *bbox = reinterpret_cast<float *>(hist + FB_CELLS);        // FB_NW * FB_SL * 6
-    FbRec *rec = reinterpret_cast<FbRec *>(bbox + FB_NW * FB_SL * 6);  // 2 * FB_NW
-    unsigned *tiekey = reinterpret_cast<unsigned *>(rec + 2 * FB_NW);  // FB_NW
+    float4 *rec = reinterpret_cast<float4 *>(bbox + FB_NW * FB_SL * 6);  // 2 * FB_NW
+    unsigned *tiem = reinterpret_cast<unsigned *>(rec + 2 * FB_NW);    // 4 (3 used): per-step masks of waves reporting a tie
+    int *posr = reinterpret_cast<int *>(tiem + 4);                     // 2 * FB_NW: the candidates' sorted positions (read by thread 0 only)
+    unsigned *tiekey = reinterpret_cast<unsigned *>(posr + 2 * FB_NW);  // FB_NW
     float4 *tiept = reinterpret_cast<float4 *>(tiekey + FB_NW);      // 1 (16-byte aligned by construction)
     float *red = reinterpret_cast<float *>(tiept + 1);               // 4 * FB_NW
     int *wsum = reinterpret_cast<int *>(red + 4 * FB_NW);            // FB_NW
@@ -223,6 +226,9 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
     FbT32 tt;
     { tt.v0 = t[0 % FB_SL]; tt.v1 = t[1 % FB_SL]; tt.v2 = t[2 % FB_SL]; tt.v3 = t[3 % FB_SL]; tt.v4 = t[4 % FB_SL]; tt.v5 = t[5 % FB_SL]; tt.v6 = t[6 % FB_SL]; tt.v7 = t[7 % FB_SL]; tt.v8 = t[8 % FB_SL]; tt.v9 = t[9 % FB_SL]; tt.v10 = t[10 % FB_SL]; tt.v11 = t[11 % FB_SL]; tt.v12 = t[12 % FB_SL]; tt.v13 = t[13 % FB_SL]; tt.v14 = t[14 % FB_SL]; tt.v15 = t[15 % FB_SL]; tt.v16 = t[16 % FB_SL]; tt.v17 = t[17 % FB_SL]; tt.v18 = t[18 % FB_SL]; tt.v19 = t[19 % FB_SL]; tt.v20 = t[20 % FB_SL]; tt.v21 = t[21 % FB_SL]; tt.v22 = t[22 % FB_SL]; tt.v23 = t[23 % FB_SL]; tt.v24 = t[24 % FB_SL]; tt.v25 = t[25 % FB_SL]; tt.v26 = t[26 % FB_SL]; tt.v27 = t[27 % FB_SL]; tt.v28 = t[28 % FB_SL]; tt.v29 = t[29 % FB_SL]; tt.v30 = t[30 % FB_SL]; tt.v31 = t[31 % FB_SL]; }
     float qx = xyz[0], qy = xyz[1], qz = xyz[2];
+    int j3 = 1;                         // j % 3 of the step about to run
+    if (tid < 4) tiem[tid] = 0u;
+    __syncthreads();
     if (tid == 0) {
         idx[0] = 0;
         if (new_xyz) { new_xyz[0] = qx; new_xyz[1] = qy; new_xyz[2] = qz; }
@@ -307,18 +313,23 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
         }
         const int buf = j & 1;
         if (lane == 0) {
-            FbRec r;
-            r.v = wv; r.pos = wpos; r.x = wx; r.y = wy; r.z = wz; r.tie = wtie; r.pad0 = 0; r.pad1 = 0;
-            rec[buf * FB_NW + w] = r;
+            rec[buf * FB_NW + w] = make_float4(wv, wx, wy, wz);
+            posr[buf * FB_NW + w] = wpos;
+            if (wtie) atomicOr(&tiem[j3], 1u << w);
         }
         FBP(6)
         lds_barrier();
         FBP(7)
-        const FbRec r = rec[buf * FB_NW + (lane & (FB_NW - 1))];
+        const float4 r = rec[buf * FB_NW + (lane & (FB_NW - 1))];
+        const unsigned tm = tiem[j3];
+        // the mask of step j + 2: its last readers (step j - 1) are past this barrier, its next writers behind the next one
+        const int j3n = j3 == 2 ? 0 : j3 + 1, j3nn = j3n == 2 ? 0 : j3n + 1;
+        if (tid == 0) tiem[j3nn] = 0u;
+        j3 = j3n;
         float vm;
         {   // max over the 8 records (lanes hold record lane&7): quad xor1, quad xor2, half mirror
             float a, c;
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(r.v));
+            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(r.x));
             asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(a));
             asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(vm) : "v"(c));
 #if FB_NW == 16
@@ -326,14 +337,17 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
             vm = a;
 #endif
         }
-        const unsigned eq2 = (unsigned)__ballot(r.v == vm) & FB_WMASK;
+        const unsigned eq2 = (unsigned)__ballot(r.x == vm) & FB_WMASK;
         const int sel = (int)__builtin_ctz(eq2);
-        const bool ambiguous = __builtin_popcount(eq2) > 1 || __builtin_amdgcn_readlane(r.tie, sel) != 0;
-        int ipos;
+        const bool ambiguous = __builtin_popcount(eq2) > 1 || ((tm >> sel) & 1u) != 0;
         if (!ambiguous) {
-            qx = readlane_f(r.x, sel); qy = readlane_f(r.y, sel); qz = readlane_f(r.z, sel);
-            ipos = __builtin_amdgcn_readlane(r.pos, sel);
+            qx = readlane_f(r.y, sel); qy = readlane_f(r.z, sel); qz = readlane_f(r.w, sel);
+            if (tid == 0) {                      // (wave 0 is rarely the one the others wait for)
+                idx[j] = posr[buf * FB_NW + sel];  // sorted position; translated after the loop
+                if (new_xyz) { new_xyz[j * 3 + 0] = qx; new_xyz[j * 3 + 1] = qy; new_xyz[j * 3 + 2] = qz; }
+            }
         } else {
+            int ipos;
             // ---- resolution round: smallest reference rank among ALL points holding vm
             const float gmax = readlane_f(vm, 0);
             unsigned key = 0xFFFFFFFFu;
@@ -367,12 +381,12 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
             lds_barrier();
             const float4 c = *tiept;
             qx = c.x; qy = c.y; qz = c.z;
+            if (tid == 0) {
+                idx[j] = ipos;
+                if (new_xyz) { new_xyz[j * 3 + 0] = qx; new_xyz[j * 3 + 1] = qy; new_xyz[j * 3 + 2] = qz; }
+            }
         }
         FBP(3)
-        if (tid == 0) {
-            idx[j] = ipos;  // sorted position; translated after the loop
-            if (new_xyz) { new_xyz[j * 3 + 0] = qx; new_xyz[j * 3 + 1] = qy; new_xyz[j * 3 + 2] = qz; }
-        }
     }
 
     // sorted positions -> point indices
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 
 size_t fps_bucket_smem() {
     return sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * FB_NW * FB_SL * 6 +
-           sizeof(FbRec) * 2 * FB_NW + sizeof(unsigned) * FB_NW + sizeof(float4) + sizeof(float) * 4 * FB_NW +
+           sizeof(float4) * 2 * FB_NW + sizeof(unsigned) * (3 * FB_NW + 4) + sizeof(float4) + sizeof(float) * 4 * FB_NW +
            sizeof(int) * FB_NW + 64;
 }
 
