@@ -70,7 +70,7 @@ class C3:
     def _install_hooks(self):
         """HIP-event timers around every C-ABI launch family (only while a timed step runs)."""
         from ws3d_amd import compat
-        fam = {"furthest_point_sampling_gather": "fps", "query_and_group": "ball_query+group",
+        fam = {"furthest_point_sampling_gather": "fps", "furthest_point_sampling_nested": "fps", "ball_query_wrapper": "ball_query+group", "query_and_group": "ball_query+group",
                "query_and_group_nlc": "ball_query+group", "three_interpolate_nlc": "three_interpolate",
                "three_nn_wrapper": "three_nn", "three_nn_with_weights": "three_nn", "three_interpolate_wrapper": "three_interpolate",
                "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
@@ -216,7 +216,11 @@ class C3:
                    "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None, "bound": "hbm"}
             if key == "fps":
                 row.update({"bound": "valu", "lane_instr_per_step": self._fps_lane_instr() * B,
-                            "comment": "4 levels 16384->4096->1024->256->64, one workgroup per scene (8 of 256 CUs)"})
+                            "comment": "4 levels 16384->4096->1024->256->64, one workgroup per scene (8 of 256 CUs).  lane_instr_per_step "
+                                       "is the DENSE sweep's count (8 per point and step): level 1 runs the pruned kernel (fps_bucket.hip, "
+                                       "~6 of 256 buckets updated per step), levels 2-4 the verified-prefix kernel (fps_nested.hip), so "
+                                       "valu_frac here is a dense-equivalent rate, not issue-slot occupancy; the physical VALU roofline "
+                                       "of the dense kernel is the c2 block's"})
             elif key in ("three_nn", "nms(mask+sweep)"):
                 row["comment"] = "ALU-bound search / pair test; the HBM figure is for orientation only"
             rows.append(row)

@@ -48,4 +48,11 @@ for wl in c5:8; do
   python scripts/pmc_traffic.py "$(find /tmp/pmc_${w}_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_${w}_WRITE_SIZE -name '*.db' | head -1)" \
     $OUT/traffic_$w.json "$w batch $nb, bytes per launch, rocprofv3 --pmc in separate passes" $nb > /dev/null 2>>$OUT/pmc_${w}_WRITE_SIZE.log
 done
+# round-2 extras: FPS kernels side by side, the eager step's kernel timeline (side streams), roipool3d ablation, ubenches
+{ python scripts/ab_fps.py default; WS3D_FPS_BUCKET=0 python scripts/ab_fps.py dense 8x16384x4096 256x16384x4096 8x12345x3000; WS3D_FPS_BUCKET=1 python scripts/ab_fps.py pruned 512x16384x4096 256x8192x2048; } > $OUT/fps_ab.txt 2>/dev/null
+rm -rf /tmp/tl; (cd /tmp && $T rocprofv3 --kernel-trace -d /tmp/tl -o t -- python $OLDPWD/scripts/host_issue_time.py > $OLDPWD/$OUT/host_issue_time.txt 2>&1)
+python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_bucket_kernel $OUT/c3_eager_timeline.txt > /dev/null 2>>$OUT/host_issue_time.txt
+$T bash scripts/ablate_roi.sh > $OUT/roipool3d_ablation.txt 2>&1
+$T bash scripts/ubench/fps_bucket_prof.sh > $OUT/fps_bucket_segments.txt 2>&1
+(cd scripts/ubench && hipcc -O3 --offload-arch=gfx950 row_copy.hip -o /tmp/row_copy 2>/dev/null && timeout 120 /tmp/row_copy) > $OUT/ubench_row_copy.txt 2>&1
 ls -la $OUT

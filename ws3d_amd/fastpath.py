@@ -124,7 +124,10 @@ def _side_streams(main: torch.cuda.Stream):
     """the two side streams of a device: the sampling chain and the searches.  ONE pair per device, shared by every caller
     stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has
     descriptors gets time-sliced (measured: a pair per Stage1Pipeline slot, 60 streams, ran every kernel of the process
-    ~1.6x slower -- FPS of the c2 block 0.30 instead of 0.54 of the VALU peak)."""
+    ~1.6x slower -- FPS of the c2 block 0.30 instead of 0.54 of the VALU peak; the limit sits at 24 queues: 20 pipeline
+    slots + the null stream + this pair = 23 is fine, a third side stream -- tried for the second scale of the multi-scale
+    levels and one of the two heads, worth 0.1 ms of latency with a 16-deep pipeline -- made the eager step 7.5 instead of
+    5.4 ms)."""
     key = main.device.index
     pair = _SIDE_STREAMS.get(key)
     if pair is None:

@@ -62,6 +62,11 @@ class Stage1Pipeline:
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
                                    "done": torch.cuda.Event(), "primed": False})
+        if self.depth > 20:
+            import warnings
+            warnings.warn("Stage1Pipeline: depth %d -- beyond 23 hardware queues in one process (the slots, the null stream and "
+                          "the eager path's two side streams) this runtime time-slices the queues and every kernel slows down "
+                          "(measured: 24 queues ran the eager step in 7.5 instead of 5.4 ms)." % self.depth, RuntimeWarning, stacklevel=2)
         if tune_gemms is None:      # WS3D_TUNE_GEMMS=0: keep the library's heuristic GEMM solutions (identical in every process)
             tune_gemms = os.environ.get("WS3D_TUNE_GEMMS", "1") != "0"
         self.use_graph, self.tune_gemms = use_graph, tune_gemms
