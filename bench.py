@@ -172,6 +172,9 @@ class C2:
         self.ev = []
 
     def step(self, timed=False):
+        # (the grid binning needs the coordinates only, but issuing it on a side stream beside the sampling kernel does not pay
+        # at this batch: two sampling workgroups fill a CU's LDS and wave slots, the binning workgroups queue behind them --
+        # measured 7.27 vs 7.23 ms per step, and 6.96 vs 6.28 ms of sampling when the binning gets in first)
         c, B = self.c, self.B
         if timed:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -190,15 +193,22 @@ class C2:
     def kernel_table(self):
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
+        pair = self.B > 256
+        fps_row = {"name": ("fps_v3_kernel<32,512,ZLDS> (dense sweep, two scenes per CU)" if pair else "fps_bucket_kernel (pruned, one scene per CU)") +
+                           " (furthest_point_sample + gather)", "ms_per_step": fps,
+                   "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
+                   "alg_bytes_per_step": a_model_fps() * self.B,
+                   "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_v3_pair_kernel" if pair else "fps_bucket_kernel",
+                   "comment": "VALU-issue-bound: (M-1) dependent argmax steps over a scene that stays on chip (x, y, min-dist in VGPRs, z in LDS "
+                              "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
+                              "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "
+                              "(traffic_bytes_per_launch)" % FPS_VALU_PER_POINT}
+        if not pair:
+            fps_row["comment"] = ("the exact PRUNED kernel (fps_bucket.hip): a step updates ~6 of 256 buckets, so lane_instr_per_step -- the dense "
+                                  "sweep's count -- overstates what is issued and valu_frac is a dense-equivalent rate, not occupancy; the step is "
+                                  "bound by its cross-lane chain (0.76 us).  The physical VALU roofline is that of the dense kernel (batch > 256)")
         return [
-            {"name": ("fps_v3_kernel<32,512,ZLDS> (two scenes per CU)" if self.B > 256 else "fps_v3_kernel<16,1024>") + " (furthest_point_sample + gather)", "ms_per_step": fps,
-             "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
-             "alg_bytes_per_step": a_model_fps() * self.B,
-             "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_v3_pair_kernel" if self.B > 256 else "fps_v3_kernel",
-             "comment": "VALU-issue-bound: (M-1) dependent argmax steps over a scene that stays on chip (x, y, min-dist in VGPRs, z in LDS "
-                        "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
-                        "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "
-                        "(traffic_bytes_per_launch)" % FPS_VALU_PER_POINT},
+            fps_row,
             {"name": "bin_points_grid + ball_query_grid_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
              "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_grid_kernel",
              "comment": "A_model == A_min for this kernel (every input read once, every output written once)"},
