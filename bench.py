@@ -568,7 +568,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-prefetch", action="store_true", help="t1: sample inside the step instead of one step ahead")
-    ap.add_argument("--pipeline-depth", type=int, default=20, help="c3: batches in flight (one HIP stream + graph each)")
+    ap.add_argument("--pipeline-depth", type=int, default=None,
+                    help="c3: batches in flight (one HIP stream + graph each); default 20 on one GPU, 16 with --gpus > 1 (headroom for the "
+                         "collective library's own hardware queues: beyond 23 queues per process the runtime time-slices, DESIGN.md 5.6)")
     args = ap.parse_args()
 
     from ws3d_amd import _lib
@@ -577,6 +579,8 @@ def main():
 
     if args.workload == "c3":
         from bench_c3 import C3
+        if args.pipeline_depth is None:
+            args.pipeline_depth = 20 if world == 1 else 16
         wl = C3(args.batch or 8, rank, world, args.kind, depth=args.pipeline_depth)
     elif args.workload == "c5":
         wl = C5(args.batch or 8, rank, args.kind)
