@@ -76,12 +76,19 @@ __device__ __forceinline__ float max_f32(float a, float b) {
 // max over each 16-lane DPP row, result replicated in all 16 lanes of the row.
 // One v_max_f32_dpp per stage (s_nop 1 = the VALU-write -> DPP-read wait states).
 __device__ __forceinline__ float row16_max(float v) {
+    // ONE asm statement: the compiler pads every dependent pair of single-instruction DPP statements with an s_nop of its own
+    // (it must assume a hazard inside unknown asm), on top of the wait states spelled here
     float r;
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
-    return v;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    return r;
 }
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -93,14 +100,26 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 #define WS3D_WAVE_MAX_BCAST 1
 #endif
 __device__ __forceinline__ float wave_max(float v) {
-    v = row16_max(v);
 #if WS3D_WAVE_MAX_BCAST
-    // fold the four row maxima in the VALU: row_bcast:15 (rows 1,3 <- lane 15 of rows 0,2), then
-    // row_bcast:31 (rows 2,3 <- lane 31); lane 63 ends with the wave maximum -> ONE v_readlane
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-    return readlane_f(v, 63);
+    // four row stages, then the four row maxima folded in the VALU: row_bcast:15 (rows 1,3 <- lane 15 of rows 0,2), row_bcast:31
+    // (rows 2,3 <- lane 31); lane 63 ends with the wave maximum -> ONE v_readlane.  One statement (see row16_max).
+    float r;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+        : "=&v"(r) : "v"(v));
+    return readlane_f(r, 63);
 #else
+    v = row16_max(v);
     const float a = readlane_f(v, 0), b = readlane_f(v, 16), c = readlane_f(v, 32), d = readlane_f(v, 48);
     return max_f32(max_f32(a, b), max_f32(c, d));
 #endif

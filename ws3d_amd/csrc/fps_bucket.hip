@@ -286,7 +286,11 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
         FBP(1)
         if (repick) {
             // the wave's candidate: the bucket holding the largest cached maximum, then the lane inside it
+#if FB_SL <= 16
+            const float wmax = readlane_f(row16_max(bmax), 0);       // the cached maxima live in lanes 0 .. FB_SL-1: one DPP row
+#else
             const float wmax = wave_max(bmax);
+#endif
             const unsigned eqb = (unsigned)__ballot(bmax == wmax) & FB_SLMASK;
             wslot = (int)__builtin_ctz(eqb);
             uint64_t eql = 0;
@@ -327,16 +331,18 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
         if (tid == 0) tiem[j3nn] = 0u;
         j3 = j3n;
         float vm;
-        {   // max over the 8 records (lanes hold record lane&7): quad xor1, quad xor2, half mirror
-            float a, c;
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(r.x));
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(c) : "v"(a));
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(vm) : "v"(c));
+        // max over the FB_NW records (lanes hold record lane & (FB_NW - 1)): one statement, see row16_max
 #if FB_NW == 16
-            asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(a) : "v"(vm));
-            vm = a;
+        vm = row16_max(r.x);
+#else
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+            : "=&v"(vm) : "v"(r.x));
 #endif
-        }
         const unsigned eq2 = (unsigned)__ballot(r.x == vm) & FB_WMASK;
         const int sel = (int)__builtin_ctz(eq2);
         const bool ambiguous = __builtin_popcount(eq2) > 1 || ((tm >> sel) & 1u) != 0;
