@@ -178,6 +178,15 @@ WS3D_API int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, int 
                      const float *new_xyz, const int32_t *nbr, const float *wt, const float *bias, int relu, float *out,
                      ws3d_stream_t stream);
 
+/* The first TWO SharedMLP layers of a set-abstraction scale in one kernel (no reference counterpart): layer 1 as
+ * ws3d_gather_gemm, its activation tile kept on chip, layer 2 (o1 -> o2) multiplied out of it:
+ * out (b*m*nsample, o2) = relu2?(relu1?([f[nbr] | xyz[nbr] - centre] @ w1t + b1) @ w2t + b2).  w1t (c_feat+3, o1) with the
+ * three coordinate rows LAST, w2t (o1, o2), both row-major.  o1 in {64, 128, 256}, o2 % 4 == 0, c_feat % 4 == 0,
+ * rows % 64 == 0, else WS3D_E_UNSUPPORTED.                                                                             */
+WS3D_API int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, int o1, int o2, const float *feats, const float *xyz,
+                      const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1, const float *w2t,
+                      const float *b2, int relu2, float *out, ws3d_stream_t stream);
+
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
  * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +

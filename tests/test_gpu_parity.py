@@ -1589,3 +1589,38 @@ def test_fps_nested_equals_plain_fps(ops, oracle):
     with pytest.raises(Exception):
         ops.c.furthest_point_sampling_nested(1, 5000, 10, torch.zeros((1, 5000, 3), device="cuda"),
                                              torch.zeros((1, 10), dtype=torch.int32, device="cuda"), torch.zeros((1, 10, 3), device="cuda"))
+
+
+@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,r", [(2, 4096, 1024, 16, 96, 64, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 1.0), (1, 1024, 256, 16, 256, 128, 196, 1.0),
+                                              (2, 256, 64, 32, 512, 256, 384, 4.0), (2, 256, 64, 16, 512, 256, 256, 2.0)])
+def test_gather_gemm2_equals_two_layers(ops, B, N, M, ns, C, O1, O2, r):
+    """ws3d_gather_gemm2 (layers 1 + 2 of a set-abstraction SharedMLP, the first activation on chip) against the float64
+    product relu(relu([gf | gx] @ W1 + b1) @ W2 + b2), and against ws3d_gather_gemm followed by a GEMM"""
+    rng = np.random.default_rng(14)
+    pc = synth.make_batch("lidar", B, 16384, 63)[:, :N, :3].copy()
+    xyz = dev(pc)
+    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
+    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32))
+    b1 = dev(rng.standard_normal(O1).astype(np.float32))
+    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32))
+    b2 = dev(rng.standard_normal(O2).astype(np.float32))
+    got = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True)
+    assert got is not None and tuple(got.shape) == (B * M * ns, O2)
+    li = nbr.long()
+    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
+    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
+    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
+    h = torch.relu(x @ w1.double() + b1.double())
+    want = torch.relu(h @ w2.double() + b2.double())
+    err = (got.double() - want).abs().max().item()
+    scale = max(want.abs().max().item(), 1.0)
+    assert err <= 1e-5 * scale * np.sqrt(C / 96), (err, scale)
+    two = torch.relu(ops.c.gather_gemm(feats, xyz, new_xyz, nbr, w1, b1, True) @ w2 + b2)
+    assert (got - two).abs().max().item() <= 2e-5 * scale
+    no_act = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, None, False, w2, None, False)
+    assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2e-5 * scale * np.sqrt(C / 96)
+    assert ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1[:, :O1 - 16].contiguous(), None, True, w2[:O1 - 16].contiguous(), b2, True) is None   # O1

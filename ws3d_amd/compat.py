@@ -357,6 +357,26 @@ def gather_gemm(feats, xyz, new_xyz, nbr, wt_feat_then_xyz, bias, relu):
     return out
 
 
+def gather_gemm2(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2t, b2, relu2):
+    """the first TWO SharedMLP layers with the grouping fused in (the first activation stays on chip): w1t (C+3, O1) with the
+    xyz rows LAST, w2t (O1, O2) -> (B*M*ns, O2), or None when the shape is not covered (C % 4, O1 in {64,128,256}, O2 % 4,
+    rows % 64).  ws3d extension."""
+    dev = _dev(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, w2t)
+    _f32(feats, "feats"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(nbr, "nbr"); _f32(w1t_feat_then_xyz, "w1t"); _f32(w2t, "w2t")
+    B, N, C = feats.shape
+    M, ns = nbr.size(1), nbr.size(2)
+    O1, O2 = w1t_feat_then_xyz.size(1), w2t.size(1)
+    rows = B * M * ns
+    if (C % 4 or O1 not in (64, 128, 256) or O2 % 4 or rows % 64 or w1t_feat_then_xyz.size(0) != C + 3 or w2t.size(0) != O1 or
+            not feats.is_contiguous() or not w2t.is_contiguous() or not w1t_feat_then_xyz.is_contiguous()):
+        return None
+    out = torch.empty((rows, O2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gather_gemm2(B, N, M, ns, C, O1, O2, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(w1t_feat_then_xyz), _p(b1),
+                                            int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), _stream()), "gather_gemm2")
+    return out
+
+
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     """first FP-module layer with the interpolation + skip concat fused in: known_feats (B,M,C2), unknown_feats (B,N,C1) or
     None, idx / weight (B,N,3), wt (C2+C1, O) -> (B*N, O), or None when the shape is not covered.  ws3d extension."""

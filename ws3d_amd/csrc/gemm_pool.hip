@@ -163,6 +163,134 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(int c_feat, int o_dim,
     }
 }
 
+// ---- the first TWO layers of a set-abstraction SharedMLP in one kernel: layer 1 as in gather_gemm_kernel (grouping fused into
+// the A operand), its 64 x O1 activation tile kept in LDS -- [channel][row], the layout the 32 x 32 accumulators write without
+// bank conflicts and layer 2's A operand reads -- and layer 2 (O1 -> O2) multiplied straight out of it, 64 output columns at a
+// time.  Neither the grouped tensor nor the first activation (rows x O1) reaches HBM, and the rows of a tile are gathered once
+// instead of once per 64 output columns.  NB1 = O1 / 64 accumulators per wave in phase 1.
+template <int NB1>
+__global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, int n, int m, int ns, const float *__restrict__ feats,
+                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const int32_t *__restrict__ nbr, const float *__restrict__ w1t,
+                                                           const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                           const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+    constexpr int O1 = NB1 * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    // phase 1: xs[2][GP_KT][GP_XS] | w1s[2][GP_KT][O1];   phase 2 (aliases phase 1): act[O1][GP_XS] | w2s[2][GP_KT][64]
+    float *xs = smem2, *w1s = smem2 + 2 * GP_KT * GP_XS;
+    float *act = smem2, *w2s = smem2 + O1 * GP_XS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const long row0 = (long)blockIdx.x * 64;
+    const int k_dim = c_feat + 3;
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const long r = row0 + xr;
+    const long cm = r / ns;                                   // scene * m + centre
+    const long b = cm / m;
+    const int src = nbr[r];
+    const float *frow = feats + ((size_t)b * n + (size_t)src) * c_feat;
+    const float *prow = xyz + ((size_t)b * n + (size_t)src) * 3;
+    const float *crow = new_xyz + (size_t)cm * 3;
+    auto load_x = [&](int k0) {
+        const int k = k0 + xk;
+        if (k < c_feat) return *reinterpret_cast<const float4 *>(frow + k);
+        if (k == c_feat) return make_float4(prow[0] - crow[0], prow[1] - crow[1], prow[2] - crow[2], 0.f);   // grouped_xyz -= new_xyz
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    float4 wv[NB1];
+    auto load_w1 = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) {
+            const int i = tid + 256 * j, k = k0 + i / (O1 / 4), c4 = i % (O1 / 4);
+            wv[j] = k < k_dim ? *reinterpret_cast<const float4 *>(w1t + (long)k * O1 + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage1 = [&](int buf, const float4 xv) {
+        float *x = xs + buf * GP_KT * GP_XS;
+        x[(xk + 0) * GP_XS + xr] = xv.x; x[(xk + 1) * GP_XS + xr] = xv.y; x[(xk + 2) * GP_XS + xr] = xv.z; x[(xk + 3) * GP_XS + xr] = xv.w;
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) {
+            const int i = tid + 256 * j;
+            *reinterpret_cast<float4 *>(w1s + buf * GP_KT * O1 + (i / (O1 / 4)) * O1 + (i % (O1 / 4)) * 4) = wv[j];
+        }
+    };
+    floatx16 acc1[NB1];
+#pragma unroll
+    for (int j = 0; j < NB1; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc1[j][i] = 0.f;
+    float4 xv = load_x(0);
+    load_w1(0);
+    stage1(0, xv);
+    __syncthreads();
+    const int nt1 = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < nt1; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt1) { xv = load_x((t + 1) * GP_KT); load_w1((t + 1) * GP_KT); }
+        const float *x = xs + cur * GP_KT * GP_XS, *wl = w1s + cur * GP_KT * O1;
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2) {
+            const float a = x[(k + kh) * GP_XS + ar];
+#pragma unroll
+            for (int j = 0; j < NB1; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[(k + kh) * O1 + j * 64 + bc], acc1[j], 0, 0, 0);
+        }
+        if (t + 1 < nt1) stage1(cur ^ 1, xv);
+        __syncthreads();
+    }
+    // layer-1 epilogue into the activation tile (accumulator layout: register v of lane l = row 8*(v/4) + 4*(l/32) + v%4, column l%32)
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+        const int col = j * 64 + bc;
+        const float bv = b1 ? b1[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float y = acc1[j][v] + bv;
+            if (relu1) y = y < 0.f ? 0.f : y;
+            act[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4)] = y;
+        }
+    }
+    // layer 2, 64 output columns per pass; W2 tiles (16 x 64) double-buffered
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const int nchunk = (o2 + 63) / 64;
+    constexpr int nt2 = O1 / GP_KT;
+    for (int c = 0; c < nchunk; ++c) {
+        const int col0 = c * 64;
+        auto load_w2 = [&](int t) {
+            const int col = col0 + wc;      // o2 % 4 == 0: a float4 is inside or outside as a whole
+            return col < o2 ? *reinterpret_cast<const float4 *>(w2t + (long)(t * GP_KT + wk) * o2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        floatx16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+        float4 w2v = load_w2(0);
+        __syncthreads();                    // the activation tile is complete / the previous pass has left w2s
+        *reinterpret_cast<float4 *>(w2s + wk * 64 + wc) = w2v;
+        __syncthreads();
+        for (int t = 0; t < nt2; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt2) w2v = load_w2(t + 1);
+            const float *wl = w2s + cur * GP_KT * 64;
+#pragma unroll
+            for (int k = 0; k < GP_KT; k += 2)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act[(t * GP_KT + k + kh) * GP_XS + ar], wl[(k + kh) * 64 + bc], acc2, 0, 0, 0);
+            if (t + 1 < nt2) *reinterpret_cast<float4 *>(w2s + (cur ^ 1) * GP_KT * 64 + wk * 64 + wc) = w2v;
+            __syncthreads();
+        }
+        const int col = col0 + bc;
+        if (col < o2) {
+            const float bv = b2 ? b2[col] : 0.f;
+            float *o = out + (row0 + wm * 32 + 4 * (lane >> 5)) * (long)o2 + col;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float y = acc2[v] + bv;
+                if (relu2) y = y < 0.f ? 0.f : y;
+                o[(long)(8 * (v / 4) + (v % 4)) * o2] = y;
+            }
+        }
+    }
+}
+
 // ---- first layer of a feature-propagation module with the interpolation and the concatenation fused into its A operand:
 //   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, unknown point p),
 //   X[r, 0:c2]      = w0 f[i0, :] + w1 f[i1, :] + w2 f[i2, :]   (three_interpolate, interpolate_gpu.cu:77-97, the same fmaf
@@ -297,4 +425,31 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
     hipLaunchKernelGGL(interp_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
                        known_feats, unknown_feats, idx, weight, wt, bias, relu, out);
     return check_launch("ws3d_interp_gemm");
+}
+
+extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, int o1, int o2, const float *feats, const float *xyz,
+                                 const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1,
+                                 const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(w1t) | reinterpret_cast<uintptr_t>(w2t);
+    if (b < 0 || n <= 0 || m <= 0 || nsample <= 0 || c_feat <= 0 || (c_feat & 3) || (o1 != 64 && o1 != 128 && o1 != 256) || o2 <= 0 || (o2 & 3) ||
+        (rows & 63) || !feats || !xyz || !new_xyz || !nbr || !w1t || !w2t || !out || (al & 15)) {
+        set_error("ws3d_gather_gemm2: unsupported shape (b=%d n=%d m=%d ns=%d c=%d o1=%d o2=%d; rows %% 64, c %% 4, o1 in {64,128,256}, o2 %% 4)",
+                  b, n, m, nsample, c_feat, o1, o2);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const size_t p1 = (size_t)2 * GP_KT * GP_XS + (size_t)2 * GP_KT * o1, p2 = (size_t)o1 * GP_XS + (size_t)2 * GP_KT * 64;
+    const size_t lds = sizeof(float) * (p1 > p2 ? p1 : p2);
+#define WS3D_GG2(NB)                                                                                                                   \
+    {                                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                                           \
+            (void)hipFuncSetAttribute((const void *)gather_gemm2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL((gather_gemm2_kernel<NB>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), c_feat, o2, n, m, nsample, \
+                           feats, xyz, new_xyz, nbr, w1t, b1, relu1, w2t, b2, relu2, out);                                             \
+    }
+    if (o1 == 64) WS3D_GG2(1) else if (o1 == 128) WS3D_GG2(2) else WS3D_GG2(4)
+#undef WS3D_GG2
+    return check_launch("ws3d_gather_gemm2");
 }

@@ -33,6 +33,7 @@ FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + p
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 
 
@@ -214,10 +215,22 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         if nbr is not None:
             # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
             wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
-            y = _C.gather_gemm(feats, xyz, new_xyz, nbr, wt1, b1, r1)
+            y = None
+            rest = blocks[1:-1]
+            if FUSED_GATHER_GEMM2 and len(blocks) >= 3 and blocks[0].conv.out_channels <= 128:
+                # layers 1 and 2 in one kernel: the first activation never leaves the chip.  (Measured per scale at batch 8,
+                # fused vs gather-GEMM + library GEMM: SA2 44 vs 59 and 101 vs 115 us, SA3 60 vs 63 and 107 vs 112 us; SA4, 256
+                # channels wide with only 128 / 256 row tiles: 98 vs 52 and 120 vs 93 us -- one workgroup per CU, long serial K
+                # loops -- so the widest level keeps the two-kernel form)
+                wt2, b2, r2 = _row_weights(blocks[1])
+                y = _C.gather_gemm2(feats, xyz, new_xyz, nbr, wt1, b1, r1, wt2, b2, r2)
+                if y is not None:
+                    rest = blocks[2:-1]
+            if y is None:
+                y = _C.gather_gemm(feats, xyz, new_xyz, nbr, wt1, b1, r1)
             if y is None:
                 raise RuntimeError("ws3d_gather_gemm declined a shape _gather_gemm_ok accepted")
-            for blk in blocks[1:-1]:
+            for blk in rest:
                 y = _layer(y, blk)
             wt, bias, relu = _row_weights(blocks[-1])
             if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
