@@ -102,15 +102,12 @@ class PointnetFPModule(nn.Module):
         if known is not None:
             # x-binned copy of the known set (None below 256 points): exact pruned 3-NN search
             dist, idx = pointnet2_utils.three_nn(unknown, known, pointnet2_utils.sort_points_xz(known))
-            dist_recip = 1.0 / (dist + 1e-8)
-            norm = torch.sum(dist_recip, dim=2, keepdim=True)
-            weight = dist_recip / norm
-            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
-        else:
-            interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
-        if unknow_feats is not None:
-            new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)  # (B, C2 + C1, n)
-        else:
-            new_features = interpolated_feats
-        new_features = self.mlp(new_features.unsqueeze(-1))
-        return new_features.squeeze(-1)
+            # inverse-distance weights of the three neighbours, normalised (same expression order as pointnet2_modules.py:140-142:
+            # the quotient and the sum round identically)
+            inv_d = 1.0 / (dist + 1e-8)
+            w3 = inv_d / torch.sum(inv_d, dim=2, keepdim=True)
+            upsampled = pointnet2_utils.three_interpolate(known_feats, idx, w3)
+        else:           # no coordinates for the known set: one global feature vector, repeated for every point
+            upsampled = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        stacked = upsampled if unknow_feats is None else torch.cat([upsampled, unknow_feats], dim=1)    # (B, C2 [+ C1], n)
+        return self.mlp(stacked.unsqueeze(-1)).squeeze(-1)

@@ -35,7 +35,7 @@ class FurthestPointSampling(Function):
     @staticmethod
     def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         """xyz (B,N,3), N > npoint -> (B,npoint) int32 indices (pointnet2_utils.py:12-31)."""
-        assert xyz.is_contiguous()
+        _dense(xyz=xyz)
         B, N, _ = xyz.size()
         output = _new((B, npoint), torch.int32, xyz)
         temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
@@ -51,11 +51,18 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+def _dense(**tensors):
+    """the C ABI takes plain row-major device pointers: refuse strided views by name"""
+    for name, t in tensors.items():
+        if t is not None and not t.is_contiguous():
+            raise AssertionError(f"{name} must be contiguous (got strides {tuple(t.stride())} for shape {tuple(t.shape)})")
+
+
 def furthest_point_sample_gather(xyz: torch.Tensor, npoint: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fused FPS + gather: (idx (B,npoint) int32, new_xyz (B,npoint,3)).  new_xyz equals
     gather_operation(xyz^T, idx)^T bit for bit (pure copies).  No temp buffer is needed for
     N <= 16384 (the running min-distance lives in registers)."""
-    assert xyz.is_contiguous()
+    _dense(xyz=xyz)
     B, N, _ = xyz.size()
     idx = _new((B, npoint), torch.int32, xyz)
     new_xyz = _new((B, npoint, 3), torch.float32, xyz)
@@ -72,7 +79,7 @@ def furthest_point_sample_gather_nested(xyz: torch.Tensor, npoint: int) -> Tuple
     set-abstraction level after the first): same (idx, new_xyz), bit for bit, without the npoint dependent steps -- the
     kernel verifies that greedy selection returns the leading npoint points and falls back to the plain kernel per scene
     where it does not (ties).  Clouds above 4096 points take the plain path."""
-    assert xyz.is_contiguous()
+    _dense(xyz=xyz)
     B, N, _ = xyz.size()
     if N > 4096 or npoint > N:
         return furthest_point_sample_gather(xyz, npoint)
@@ -100,18 +107,18 @@ class GatherOperation(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint) -> (B,C,npoint) (pointnet2_utils.py:41-60)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
+        _dense(features=features)
+        _dense(idx=idx)
         B, npoint = idx.size()
         _, C, N = features.size()
         output = _new((B, C, npoint), torch.float32, features)
         _C.gather_points_wrapper(B, C, N, npoint, features, idx, output)
-        ctx.for_backwards = (idx, C, N)
+        ctx.gather_shape = (idx, C, N)
         return output
 
     @staticmethod
     def backward(ctx, grad_out):
-        idx, C, N = ctx.for_backwards
+        idx, C, N = ctx.gather_shape
         B, npoint = idx.size()
         if DETERMINISTIC_BACKWARD:
             grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
@@ -131,8 +138,8 @@ class ThreeNN(Function):
         """unknown (B,N,3), known (B,M,3) -> dist (B,N,3) L2 distance, idx (B,N,3)
         (pointnet2_utils.py:79-99; the kernel returns squared distances, sqrt is taken here).
         sorted_known: optional ``sort_points_x(known)`` -- identical result, pruned search."""
-        assert unknown.is_contiguous()
-        assert known.is_contiguous()
+        _dense(unknown=unknown)
+        _dense(known=known)
         B, N, _ = unknown.size()
         m = known.size(1)
         dist2 = _new((B, N, 3), torch.float32, unknown)
@@ -153,19 +160,19 @@ class ThreeInterpolate(Function):
     @staticmethod
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         """features (B,C,M), idx/weight (B,n,3) -> (B,C,n) (pointnet2_utils.py:110-131)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
-        assert weight.is_contiguous()
+        _dense(features=features)
+        _dense(idx=idx)
+        _dense(weight=weight)
         B, c, m = features.size()
         n = idx.size(1)
-        ctx.three_interpolate_for_backward = (idx, weight, m)
+        ctx.interp_args = (idx, weight, m)
         output = _new((B, c, n), torch.float32, features)
         _C.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
         return output
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
-        idx, weight, m = ctx.three_interpolate_for_backward
+        idx, weight, m = ctx.interp_args
         B, c, n = grad_out.size()
         if DETERMINISTIC_BACKWARD:
             grad_features = torch.empty((B, c, m), dtype=torch.float32, device=grad_out.device)
@@ -184,18 +191,18 @@ class GroupingOperation(Function):
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         """features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)
         (pointnet2_utils.py:158-177)."""
-        assert features.is_contiguous()
-        assert idx.is_contiguous()
+        _dense(features=features)
+        _dense(idx=idx)
         B, nfeatures, nsample = idx.size()
         _, C, N = features.size()
         output = _new((B, C, nfeatures, nsample), torch.float32, features)
         _C.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
-        ctx.for_backwards = (idx, N)
+        ctx.group_shape = (idx, N)
         return output
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
-        idx, N = ctx.for_backwards
+        idx, N = ctx.group_shape
         B, C, npoint, nsample = grad_out.size()
         if DETERMINISTIC_BACKWARD:
             grad_features = torch.empty((B, C, N), dtype=torch.float32, device=grad_out.device)
@@ -214,8 +221,8 @@ class BallQuery(Function):
     def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
         """xyz (B,N,3), new_xyz (B,npoint,3) -> idx (B,npoint,nsample) int32
         (pointnet2_utils.py:202-222)."""
-        assert new_xyz.is_contiguous()
-        assert xyz.is_contiguous()
+        _dense(new_xyz=new_xyz)
+        _dense(xyz=xyz)
         B, N, _ = xyz.size()
         npoint = new_xyz.size(1)
         idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
@@ -305,8 +312,7 @@ def query_and_group(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: tor
                     sorted_xyz: torch.Tensor = None):
     """One kernel for ball_query + grouping(xyz) - centre + grouping(features) + cat:
     (B, 3+C, npoint, nsample) with channel order [dx,dy,dz, features...]."""
-    assert xyz.is_contiguous() and new_xyz.is_contiguous()
-    assert features is None or features.is_contiguous()
+    _dense(xyz=xyz, new_xyz=new_xyz, features=features)
     assert use_xyz or features is not None, "Cannot have not features and not use xyz as a feature!"
     out, idx = _QueryAndGroupFused.apply(radius, nsample, use_xyz, xyz, new_xyz, features, sorted_xyz)
     return (out, idx) if return_idx else out
@@ -335,13 +341,8 @@ class GroupAll(nn.Module):
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
         """-> (B, C+3, 1, N) (pointnet2_utils.py:272-290): pure views/cat, no kernel."""
-        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
-        if features is not None:
-            grouped_features = features.unsqueeze(2)
-            if self.use_xyz:
-                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
-            else:
-                new_features = grouped_features
-        else:
-            new_features = grouped_xyz
-        return new_features
+        coords = xyz.transpose(1, 2).unsqueeze(2)                 # (B, 3, 1, N): the whole cloud is the one group
+        if features is None:
+            return coords
+        feats = features.unsqueeze(2)
+        return torch.cat([coords, feats], dim=1) if self.use_xyz else feats
