@@ -1624,3 +1624,46 @@ def test_gather_gemm2_equals_two_layers(ops, B, N, M, ns, C, O1, O2, r):
     no_act = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, None, False, w2, None, False)
     assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2e-5 * scale * np.sqrt(C / 96)
     assert ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1[:, :O1 - 16].contiguous(), None, True, w2[:O1 - 16].contiguous(), b2, True) is None   # O1
+
+
+def test_eager_side_streams_back_to_back_equal_the_single_stream_forward(ops):
+    """the coordinate-only work of a forward pass runs on two side streams (fastpath._Geometry) and its tensors are allocated
+    there: 24 different batches issued back to back WITHOUT host synchronisation -- plain calls on one stream, and through an
+    eager 3-deep Stage1Pipeline whose slots share the side streams -- must reproduce the single-stream forward exactly
+    (same kernels, same order per batch: any difference would be a cross-stream reuse of live memory)"""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.pipeline import Stage1Pipeline
+    from ws3d_amd.seeded import seeded_state_dict
+    cfg = stage1.RPNConfig(num_points=4096, npoints=(1024, 256, 64, 16), rpn_pre_nms_top_n=1000, rpn_post_nms_top_n=20)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg)
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 5))
+    model = model.cuda().eval()
+    batches = [dev(np.stack([synth.velodyne_scan(4096, seed=100 + 2 * i + j) for j in range(2)])) for i in range(24)]
+    keys = ("rpn_cls", "rpn_reg")
+    prev = fastpath.GEOMETRY_AHEAD
+    try:
+        fastpath.GEOMETRY_AHEAD = False
+        with torch.no_grad():
+            want = []
+            for b in batches:
+                out = model.rpn_forward({"pts_input": b})
+                boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
+                want.append([out[k].clone() for k in keys] + [boxes.clone(), count.clone()])
+        torch.cuda.synchronize()
+        fastpath.GEOMETRY_AHEAD = True
+        with torch.no_grad():
+            got = []
+            for b in batches:                      # no synchronisation between the passes
+                out = model.rpn_forward({"pts_input": b})
+                boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
+                got.append([out[k].clone() for k in keys] + [boxes.clone(), count.clone()])
+        torch.cuda.synchronize()
+        for i, (g, w) in enumerate(zip(got, want)):
+            for a, c in zip(g, w):
+                assert torch.equal(a, c), i
+        pipe = Stage1Pipeline(model, cfg, batch=2, n_points=4096, depth=3, use_graph=False)
+        for i, (f0, nv, o) in enumerate(pipe.map(batches)):
+            assert torch.equal(o["rpn"]["rpn_cls"], want[i][0]) and torch.equal(o["rpn"]["rpn_reg"], want[i][1]), i
+            assert torch.equal(o["boxes"], want[i][2]) and torch.equal(o["count"], want[i][3]), i
+    finally:
+        fastpath.GEOMETRY_AHEAD = prev
