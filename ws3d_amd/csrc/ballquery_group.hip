@@ -682,6 +682,10 @@ __global__ __launch_bounds__(256) void ball_query_sorted_kernel(int n, int m, in
 // and resident waves are what keeps loads in flight.  1-D grid, XCD-aware: workgroup g runs on XCD g % 8 (observed dispatch
 // order), so scene = (g / 8 / tiles) * 8 + g % 8 puts all tiles of a scene on ONE XCD -- its points and features are pulled
 // into one L2 instead of eight.
+// Anatomy at the c2 shape (scripts/ablate_bq.sh, 512 scenes): search alone 0.16 ms, emit alone 0.61 ms (4.4 TB/s of stores), together
+// 0.78 ms.  A variant in which a workgroup takes 4 tiles and wave 0 searches tile t + 1 while waves 1-3 emit tile t was built and
+// measured: 0.90 ms -- the emit is bound by the issue capacity of its waves, not by load latency, so three emitting waves
+// instead of four cost more (emit alone 0.87 ms) than the hidden search saves; not kept.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
                                                               const float *__restrict__ xyz, const char *__restrict__ ws,
@@ -731,7 +735,12 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
             row[pos] = (uint16_t)id;
             ++cnt;
         };
+#ifdef WS3D_BQG_NO_SEARCH   // ablation (scripts/ablate_bq.sh): every centre "finds" 40 neighbours
+        if (active) { for (int q = 0; q < 40 && q < nsample; ++q) row[q] = (uint16_t)((mi * 7 + q * 13) % n); cnt = min(40, nsample); }
+        if (false) {
+#else
         if (active && cx == cx) {
+#endif
             // see ball_query_sorted_kernel for the bounds argument (hits lie within r (1 + 2^-23) of the centre on each axis)
             const int gx = -hdr.pad, gz = params[2];
             const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
@@ -772,7 +781,11 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
         cnt_s[lane] = active ? cnt : 0;
     }
     __syncthreads();
+#ifdef WS3D_BQG_NO_EMIT      // ablation: one word per workgroup keeps the search alive
+    if (tid == 0 && idx_out) idx_out[((size_t)b * m + m0) * nsample] = (int)rows[0] + cnt_s[0];
+#else
     bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
+#endif
 }
 
 static size_t bq_smem(int nsample, size_t idx_bytes) {
