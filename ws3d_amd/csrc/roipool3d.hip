@@ -21,7 +21,7 @@
 
 #ifdef WS3D_ROI_PROF   // scripts/ubench/roi_prof.hip: per-workgroup wall-clock timeline (100 MHz)
 __device__ long long g_roi_prof[8192 * 4];
-#define ROI_PROF(slot) if (threadIdx.x == 0) g_roi_prof[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + slot] = wall_clock64();
+#define ROI_PROF(slot) if (threadIdx.x == 0) g_roi_prof[blockIdx.x * 4 + slot] = wall_clock64();
 #else
 #define ROI_PROF(slot)
 #endif
@@ -30,6 +30,8 @@ namespace ws3d {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float4v float4u __attribute__((aligned(4)));  // 16-byte access, 4-byte aligned
+typedef float f3v __attribute__((ext_vector_type(3)));
+typedef f3v f3u __attribute__((aligned(4)));           // 12-byte access, 4-byte aligned
 
 struct BoxFrame {
     float cx, cy, cz, hh, hw, hl, cosa, sina;
@@ -85,6 +87,22 @@ __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y,
 
 __device__ __forceinline__ bool frame_is_small(const BoxFrame &f) { return f.hl * f.hl + f.hw * f.hw < 98.0f; }   // false for NaN
 
+// XCD-aware workgroup -> (scene, box group) mapping for a 1-D grid of batch * groups workgroups: workgroup g runs on XCD
+// g % 8 (observed dispatch order), so with a batch that is a multiple of 8 scene = (g / 8 / groups) * 8 + g % 8 keeps all
+// workgroups of a scene on ONE XCD -- every one of them streams the whole scene (786 KB at 65536 points), which then stays in
+// that XCD's 4 MB L2 instead of being pulled through all eight (8 scenes = 6.3 MB do not fit one L2).
+__device__ __forceinline__ void roi_scene_group(int batch, int groups, int &b, int &grp) {
+    const int g = blockIdx.x;
+    if ((batch & 7) == 0) {
+        const int j = g >> 3;
+        b = (j / groups) * 8 + (g & 7);
+        grp = j - (j / groups) * groups;
+    } else {
+        b = g / groups;
+        grp = g - b * groups;
+    }
+}
+
 // BG boxes of one scene per workgroup: every point loaded by the scan is tested against BG box
 // frames, so the scene is streamed from L2 once per BG boxes instead of once per box (at config 5
 // the per-box rescans were 3x the output bytes).
@@ -96,14 +114,16 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
                                                         const float *__restrict__ pts_feature,
                                                         float *__restrict__ pooled,
                                                         int32_t *__restrict__ empty_flag,
-                                                        int32_t *__restrict__ pts_idx, int fill) {
+                                                        int32_t *__restrict__ pts_idx, int fill, int batch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lists = reinterpret_cast<int *>(smem);  // BG * 4 * S
     int *sel = lists + BG * 4 * S;               // S
     __shared__ int wcnt_s[BG * 4];
 
     ROI_PROF(0)
-    const int box0 = blockIdx.x * BG, b = blockIdx.y;
+    int b, grp;
+    roi_scene_group(batch, (boxes_num + BG - 1) / BG, b, grp);
+    const int box0 = grp * BG;
     const int nb = min(BG, boxes_num - box0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     xyz += (size_t)b * pts_num * 3;
@@ -128,8 +148,10 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = k0 + u * 64 + lane;   // loads are clamped, never branched; a lane past the
-            const float *p = xyz + (size_t)min(k, pts_num - 1) * 3;  // wave's range gets x = NaN = "outside"
-            nx[u] = k < end ? p[0] : __builtin_nanf(""); ny[u] = p[1]; nz[u] = p[2];
+            // wave's range gets x = NaN = "outside".  ONE 12-byte load per point: three dword loads per point made the scan
+            // address-bound (12 wave loads per trip, each spanning six cache lines)
+            const f3v p = *reinterpret_cast<const f3u *>(xyz + (size_t)min(k, pts_num - 1) * 3);
+            nx[u] = k < end ? p.x : __builtin_nanf(""); ny[u] = p.y; nz[u] = p.z;
         }
     };
 #if defined(WS3D_ROI_NO_SCAN)   // ablation: pretend every wave found 40 points
@@ -330,10 +352,10 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
 // barrier (137 VGPRs: 0.57), starting every CU's third and fourth workgroup 16-130 us late to break the lock-step (slower by
 // a quarter of the delay).
 template <int SG, int CR>
-__global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int boxes_num, int feat_len, int S, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void roipool3d_pipe_kernel(int pts_num, int boxes_num, int feat_len, int S, const float *__restrict__ xyz,
                                                              const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
                                                              float *__restrict__ pooled, int32_t *__restrict__ empty_flag,
-                                                             int32_t *__restrict__ pts_idx, int fill) {
+                                                             int32_t *__restrict__ pts_idx, int fill, int batch) {
     constexpr int BG = 4, RPH = CR / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int row = 3 + feat_len;
@@ -343,7 +365,9 @@ __global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int bo
     __shared__ int wcnt_s[SG * 4];
     __shared__ int cnt_s[SG];
 
-    const int box0 = blockIdx.x * BG, b = blockIdx.y;
+    int b, grp;
+    roi_scene_group(batch, (boxes_num + BG - 1) / BG, b, grp);
+    const int box0 = grp * BG;
     const int nb = min(BG, boxes_num - box0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int half = tid >> 5, l32 = tid & 31, f4 = feat_len >> 2;
@@ -412,8 +436,8 @@ __global__ __launch_bounds__(256) void roipool3d_pipe_kernel(int pts_num, int bo
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int k = k0 + u * 64 + lane;
-                const float *pp = xyz + (size_t)min(k, pts_num - 1) * 3;
-                nx[u] = k < end ? pp[0] : __builtin_nanf(""); ny[u] = pp[1]; nz[u] = pp[2];
+                const f3v pp = *reinterpret_cast<const f3u *>(xyz + (size_t)min(k, pts_num - 1) * 3);      // one 12-byte load per point
+                nx[u] = k < end ? pp.x : __builtin_nanf(""); ny[u] = pp.y; nz[u] = pp.z;
             }
         };
         bool done = !scanning || start >= end;
@@ -566,9 +590,9 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
         {                                                                                                                         \
             if (pm > 64 * 1024)                                                                                                   \
                 (void)hipFuncSetAttribute((const void *)roipool3d_pipe_kernel<SGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pm); \
-            hipLaunchKernelGGL((roipool3d_pipe_kernel<SGV, CRV>), dim3((boxes_num + 3) / 4, batch_size), dim3(256), pm, as_stream(stream), \
+            hipLaunchKernelGGL((roipool3d_pipe_kernel<SGV, CRV>), dim3((unsigned)(((boxes_num + 3) / 4) * batch_size)), dim3(256), pm, as_stream(stream), \
                                pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,   \
-                               pooled_empty_flag, pts_idx, fill);                                                                 \
+                               pooled_empty_flag, pts_idx, fill, batch_size);                                                                 \
         }
         if (sg == 1) { if (cr == 16) WS3D_ROI_PIPE_LAUNCH(1, 16) else WS3D_ROI_PIPE_LAUNCH(1, 32) }
         else { if (cr == 16) WS3D_ROI_PIPE_LAUNCH(2, 16) else WS3D_ROI_PIPE_LAUNCH(2, 32) }
@@ -580,9 +604,9 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
         if (smem > 64 * 1024)                                                                                      \
             (void)hipFuncSetAttribute((const void *)roipool3d_kernel<BGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)smem);                                                                  \
-        hipLaunchKernelGGL((roipool3d_kernel<BGV, CRV>), dim3((boxes_num + BGV - 1) / BGV, batch_size), dim3(256), smem, \
+        hipLaunchKernelGGL((roipool3d_kernel<BGV, CRV>), dim3((unsigned)(((boxes_num + BGV - 1) / BGV) * batch_size)), dim3(256), smem, \
                            as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,   \
-                           pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill);                        \
+                           pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill, batch_size);                        \
     }
 #define WS3D_ROI_LAUNCH_BG(CRV) { if (bg == 4) WS3D_ROI_LAUNCH(4, CRV) else if (bg == 2) WS3D_ROI_LAUNCH(2, CRV) else WS3D_ROI_LAUNCH(1, CRV) }
     if (cr == 32) WS3D_ROI_LAUNCH_BG(32) else if (cr == 16) WS3D_ROI_LAUNCH_BG(16) else WS3D_ROI_LAUNCH_BG(0)
