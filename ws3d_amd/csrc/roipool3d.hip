@@ -446,11 +446,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         done = true;
 #endif
         if (!done) load_trip(start);
-        int next_chunk = 0;
+        int next_chunk = 0, acc = 0, upto = 0;
         const int ntrips = scanning ? trips : 0;
         for (int t = 0; t < ntrips; ++t) {
             const int k0 = start + t * 256;
-            const int upto = (int)(((long)(t + 1) * nchunks) / ntrips);
+            acc += nchunks;                                         // upto = floor((t + 1) * nchunks / ntrips), without the division
+            while (acc >= ntrips) { acc -= ntrips; ++upto; }
             const bool has = next_chunk < upto;
             if (has) issue(next_chunk);
             if (!done && k0 < end) {
