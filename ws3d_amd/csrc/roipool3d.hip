@@ -82,7 +82,7 @@ __device__ __forceinline__ bool pt_in_frame(const BoxFrame &f, float x, float y,
         const float t2 = fabsf(dx) - 10.0f, t4 = fabsf(dz) - 10.0f;
         m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)), t4);
     }
-    return !(m > 0.0f) & !__builtin_isunordered(t0, t1);
+    return !(m > 0.0f) && !__builtin_isunordered(t0, t1);      // (&&: two lane masks and one s_and; '&' materialises both bools in VGPRs)
 }
 
 __device__ __forceinline__ bool frame_is_small(const BoxFrame &f) { return f.hl * f.hl + f.hw * f.hw < 98.0f; }   // false for NaN
@@ -172,12 +172,12 @@ __global__ __launch_bounds__(256) void roipool3d_kernel(int pts_num, int boxes_n
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
+                for (int g = 0; g < BG; ++g) mask[u][g] = __builtin_amdgcn_ballot_w64(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
-                for (int g = 0; g < BG; ++g) mask[u][g] = __ballot(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
+                for (int g = 0; g < BG; ++g) mask[u][g] = __builtin_amdgcn_ballot_w64(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -464,12 +464,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
+                        for (int g = 0; g < SG; ++g) mask[u][g] = __builtin_amdgcn_ballot_w64(pt_in_frame<true>(f[g], x[u], y[u], z[u]));
                 } else {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
 #pragma unroll
-                        for (int g = 0; g < SG; ++g) mask[u][g] = __ballot(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
+                        for (int g = 0; g < SG; ++g) mask[u][g] = __builtin_amdgcn_ballot_w64(pt_in_frame<false>(f[g], x[u], y[u], z[u]));
                 }
                 bool all_full = true;
 #pragma unroll
