@@ -6,6 +6,8 @@
 // accumulated on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate -- same precision
 // class as the library GEMM, different summation order) and reduced over its row groups in registers;
 // only the pooled rows reach HBM.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ws3d {
@@ -91,6 +93,25 @@ __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, co
     }
 }
 
+// XCD-aware tile order for the gather-GEMMs (1-D grid of col_tiles * row_tiles workgroups): workgroup g runs on XCD g % 8
+// (observed dispatch order).  With tps row tiles per scene and a batch that is a multiple of 8,
+//   scene = (g / 8 / (col_tiles * tps)) * 8 + g % 8,   row tile = (g / 8 / col_tiles) % tps,   col tile = (g / 8) % col_tiles
+// keeps (i) all tiles of a scene on ONE XCD -- the rows they gather (4 MB of features per scene at FP1) stay in that L2 instead
+// of being pulled through all eight -- and (ii) the col tiles of a row tile, which gather the SAME rows, next to each other on
+// that XCD (with the 2-D grid they ran on col_tiles different XCDs and each fetched the rows again).  tps = 0: plain order.
+__device__ __forceinline__ void gg_tile(int col_tiles, int tps, long &row_tile, int &col_tile) {
+    const long g = blockIdx.x;
+    if (tps > 0) {
+        const long j = g >> 3;
+        col_tile = (int)(j % col_tiles);
+        const long jj = j / col_tiles;
+        row_tile = ((jj / tps) * 8 + (g & 7)) * tps + jj % tps;
+    } else {
+        col_tile = (int)(g % col_tiles);
+        row_tile = g / col_tiles;
+    }
+}
+
 // ---- first SharedMLP layer of a set-abstraction scale with the GROUPING fused into its A operand:
 //   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, centre m, sample s),
 //   X[r, 0:C] = feats[b, nbr[b, m, s], :]   X[r, C:C+3] = xyz[b, nbr[b, m, s]] - new_xyz[b, m]
@@ -102,13 +123,16 @@ __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, co
 __global__ __launch_bounds__(256) void gather_gemm_kernel(int c_feat, int o_dim, int n, int m, int ns, const float *__restrict__ feats,
                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                           const int32_t *__restrict__ nbr, const float *__restrict__ wt,
-                                                          const float *__restrict__ bias, int relu, float *__restrict__ out) {
+                                                          const float *__restrict__ bias, int relu, float *__restrict__ out, int tps) {
     __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
     __shared__ float ws[2][GP_KT][64];        // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
-    const long row0 = (long)blockIdx.y * 64;
-    const int col0 = blockIdx.x * 64;
+    long row_tile;
+    int col_tile;
+    gg_tile(o_dim / 64, tps, row_tile, col_tile);
+    const long row0 = row_tile * 64;
+    const int col0 = col_tile * 64;
     const int k_dim = c_feat + 3;
     const int xr = tid >> 2, xk = (tid & 3) * 4;
     const int wk = tid >> 4, wc = (tid & 15) * 4;
@@ -300,13 +324,16 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, i
 __global__ __launch_bounds__(256) void interp_gemm_kernel(int c2, int c1, int o_dim, int n, int m, const float *__restrict__ known_feats,
                                                           const float *__restrict__ unknown_feats, const int32_t *__restrict__ idx3,
                                                           const float *__restrict__ w3, const float *__restrict__ wt,
-                                                          const float *__restrict__ bias, int relu, float *__restrict__ out) {
+                                                          const float *__restrict__ bias, int relu, float *__restrict__ out, int tps) {
     __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
     __shared__ float ws[2][GP_KT][64];        // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
-    const long row0 = (long)blockIdx.y * 64;
-    const int col0 = blockIdx.x * 64;
+    long row_tile;
+    int col_tile;
+    gg_tile(o_dim / 64, tps, row_tile, col_tile);
+    const long row0 = row_tile * 64;
+    const int col0 = col_tile * 64;
     const int k_dim = c2 + c1;
     const int xr = tid >> 2, xk = (tid & 3) * 4;
     const int wk = tid >> 4, wc = (tid & 15) * 4;
@@ -402,9 +429,11 @@ extern "C" int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, in
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    if (rows / 64 > 65535) { set_error("ws3d_gather_gemm: too many rows"); return WS3D_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(gather_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c_feat, o_dim, n, m,
-                       nsample, feats, xyz, new_xyz, nbr, wt, bias, relu, out);
+    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    const long per_scene = (long)m * nsample;
+    const int tps = (xcd_env && (b & 7) == 0 && per_scene % 64 == 0) ? (int)(per_scene / 64) : 0;
+    hipLaunchKernelGGL(gather_gemm_kernel, dim3((unsigned)((o_dim / 64) * (rows / 64))), dim3(256), 0, as_stream(stream), c_feat, o_dim, n, m,
+                       nsample, feats, xyz, new_xyz, nbr, wt, bias, relu, out, tps);
     return check_launch("ws3d_gather_gemm");
 }
 
@@ -421,9 +450,10 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    if (rows / 64 > 65535) { set_error("ws3d_interp_gemm: too many rows"); return WS3D_E_UNSUPPORTED; }
-    hipLaunchKernelGGL(interp_gemm_kernel, dim3(o_dim / 64, (unsigned)(rows / 64)), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
-                       known_feats, unknown_feats, idx, weight, wt, bias, relu, out);
+    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    const int tps = (xcd_env && (b & 7) == 0 && n % 64 == 0) ? n / 64 : 0;
+    hipLaunchKernelGGL(interp_gemm_kernel, dim3((unsigned)((o_dim / 64) * (rows / 64))), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
+                       known_feats, unknown_feats, idx, weight, wt, bias, relu, out, tps);
     return check_launch("ws3d_interp_gemm");
 }
 
