@@ -477,7 +477,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const int k = t * 256 + u * 64 + lane;                              // offset into the wave's quarter
 #pragma unroll
                     for (int g = 0; g < SG; ++g) {
+#if defined(WS3D_ROI_SCAN_ABL) && WS3D_ROI_SCAN_ABL == 1      // ablation: tests without the list appends (one hit keeps them alive)
+                        const uint64_t mk = mask[u][g] & (k0 == start ? 1ull : 0ull);
+#elif defined(WS3D_ROI_SCAN_ABL) && WS3D_ROI_SCAN_ABL == 2    // ablation: loads and loop only
+                        const uint64_t mk = (k0 == start && x[u] == 12345.f) ? 1ull : 0ull;
+#else
                         const uint64_t mk = mask[u][g];
+#endif
                         if (mk) {
                             const int wc = __builtin_amdgcn_readfirstlane(wcnt[g]);
                             const int pos = wc + mbcnt(mk);
