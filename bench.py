@@ -610,10 +610,10 @@ def main():
     if hasattr(wl, "latency_mode"):
         # the same step with ONE batch in flight (submit, exchange, wait): what a caller that needs the
         # proposals of this batch before it submits the next one sees
-        lat, lat_detail = wl.latency_mode(n=10)
+        lat, lat_detail = wl.latency_mode(n=20)
         lat_ms = max_over_ranks(lat, world)
         latency = {"batches_in_flight": 1, "ms_per_batch": lat_ms, "value": wl.scenes() * world / (lat_ms * 1e-3),
-                   "unit": getattr(wl, "unit", "scenes/s"), "batches_timed": 10,
+                   "unit": getattr(wl, "unit", "scenes/s"), "batches_timed": 20, "statistic": "median",
                    "launch": min(lat_detail, key=lat_detail.get)[:-3], "rank0_ms_by_launch": lat_detail}
     if use_graph:
         # per-kernel HIP-event table from a few EAGER steps (events cannot be recorded inside a graph);

@@ -161,7 +161,7 @@ class C3:
         self.last = (out, boxes, scores, count, pooled, empty, gathered)
 
     def latency_mode(self, n=10):
-        """ms per batch with ONE batch in flight (submit -> exchange -> wait), two ways of launching it:
+        """median ms per batch with ONE batch in flight (submit -> exchange -> wait), two ways of launching it:
         hipGraph replay of the whole step on one stream, and eager launches with the coordinate-only work (sampling chain of
         levels 2-4, ball-query lists, 3-NN) on side streams beside the GEMMs (ws3d_amd/fastpath.py _Geometry; a captured graph
         with such branches replays slower on this runtime, so the graph keeps one stream) -> (best ms, detail dict)"""
@@ -172,11 +172,13 @@ class C3:
             for _ in range(2):
                 self.step(eager=eager)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
+            ts = []
+            for _ in range(n):                 # median of the per-batch times: eager launches are host-driven, one slow
+                t0 = time.perf_counter()       # iteration (an allocator or interpreter hiccup) should not set the figure
                 self.step(eager=eager)
                 torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / n * 1e3
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return float(np.median(ts))
         from ws3d_amd import fastpath
         detail = {"eager_side_streams_ms" if fastpath.GEOMETRY_AHEAD else "eager_ms": run(True)}
         if getattr(self, "_graph", None) is not None:
