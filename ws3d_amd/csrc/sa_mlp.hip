@@ -12,6 +12,8 @@
 //
 // Not a reference entry point: ws3d_amd/fastpath.py uses it when the shapes match
 // (C0 = 4, C1, C2 <= 32, C3 <= 64, nsample in {16, 32}); anything else takes the GEMM chain.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ws3d {
@@ -96,6 +98,89 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_kernel(long rows, const floa
     }
 }
 
+// ---- the (32, 32, 64) scale on the fp32 matrix cores, all three layers chained IN REGISTERS ----------------------------------
+// Every layer is computed transposed, out^T = W^T X^T, with v_mfma_f32_32x32x2_f32: the A operand is W^T (lane l holds
+// W^T[o = l % 32][k]), the B operand X^T (lane l holds X[row = l % 32][k]; lanes 0-31 supply the first K element of a step,
+// lanes 32-63 the second), and the accumulator comes out as lane = row, register v (with the lane's half h = l / 32) = channel
+// kp(v, h) = 8 (v / 4) + 4 h + v % 4.  That is exactly the shape of the NEXT layer's B operand if step v of the next layer pairs
+// the K elements (kp(v, 0), kp(v, 1)) -- the order of the K steps is free as long as the A operand follows it -- so
+// bias + ReLU are applied to the accumulator registers and they are fed straight back in: no shuffle, no LDS, no barrier
+// between the layers.  The weights live in registers (2 + 16 + 32 per lane, loaded once per wave), a wave walks over tiles of
+// 32 grouped rows (one centre at nsample 32, two at 16); the last layer is multiplied the other way round (same registers,
+// operands swapped) so that the pool runs over registers.
+// 50 MFMAs per tile = 3,200 matrix-core cycles against ~6,500 VALU cycles of the kernel above.
+typedef float sa_f16 __attribute__((ext_vector_type(16)));
+
+template <int NS>
+__global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, const float *__restrict__ x, const float *__restrict__ w1t,
+                                                                const float *__restrict__ b1, const float *__restrict__ w2t,
+                                                                const float *__restrict__ b2, const float *__restrict__ w3t,
+                                                                const float *__restrict__ b3, int relu3, float *__restrict__ out,
+                                                                int out_stride) {
+    static_assert(NS == 16 || NS == 32, "nsample");
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
+    float a1[2], a2[16], a3[2][16], bb1[16], bb2[16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a1[j] = w1t[(2 * j + h) * 32 + c];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        a2[v] = w2t[kp(v) * 32 + c];
+        a3[0][v] = w3t[kp(v) * 64 + c];
+        a3[1][v] = w3t[kp(v) * 64 + 32 + c];
+        bb1[v] = b1[kp(v)];
+        bb2[v] = b2[kp(v)];
+    }
+    const float b3v[2] = {b3[c], b3[32 + c]};
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long tile = wave; tile < tiles; tile += nwaves) {
+        const float4 xr = reinterpret_cast<const float4 *>(x)[tile * 32 + c];          // row c of the tile (both halves)
+        sa_f16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? xr.y : xr.x, acc, 0, 0, 0);   // k = h
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? xr.w : xr.z, acc, 0, 0, 0);   // k = 2 + h
+        float act[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) act[v] = fmaxf(acc[v] + bb1[v], 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            // the LAST layer the other way round, out = X W (the very same registers, operands swapped): lane = channel,
+            // register v (+ half) = row kp(v, h) -- so the pool over the rows of a centre is a maximum over REGISTERS (15
+            // v_max + one exchange between the halves) instead of five DPP stages for each of 16 registers
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
+            const float bias = b3v[blk];
+            if (NS == 32) {
+                float m = acc[0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v) m = fmaxf(m, acc[v]);
+                m = fmaxf(m, __shfl_xor(m, 32));                     // rows 4h .. of the other half
+                m += bias;
+                if (relu3) m = fmaxf(m, 0.f);
+                if (h == 0) out[tile * (long)out_stride + blk * 32 + c] = m;
+            } else {
+                float m0 = acc[0], m1 = acc[8];                      // rows 0-15 (registers 0-7) / rows 16-31 (registers 8-15)
+#pragma unroll
+                for (int v = 1; v < 8; ++v) { m0 = fmaxf(m0, acc[v]); m1 = fmaxf(m1, acc[8 + v]); }
+                m0 = fmaxf(m0, __shfl_xor(m0, 32));
+                m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                float m = (h ? m1 : m0) + bias;                      // half 0 writes the first centre, half 1 the second
+                if (relu3) m = fmaxf(m, 0.f);
+                out[(tile * 2 + h) * (long)out_stride + blk * 32 + c] = m;
+            }
+        }
+    }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, const float *x_rows4,
@@ -113,6 +198,18 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
     const long blocks = (rows + 255) / 256;
     if (blocks > 0x7fffffffL) { set_error("ws3d_sa_mlp3_pool: too many rows"); return WS3D_E_UNSUPPORTED; }
     hipStream_t st = as_stream(stream);
+    // the wide scale on the matrix cores (WS3D_SA_MFMA=0: the VALU kernel, A/B runs)
+    static const int mfma_env = getenv("WS3D_SA_MFMA") ? atoi(getenv("WS3D_SA_MFMA")) : 1;
+    if (mfma_env && c1 == 32 && c2 == 32 && c3 == 64 && (nsample == 16 || nsample == 32) && rows % 32 == 0 &&
+        ((reinterpret_cast<uintptr_t>(b3) | reinterpret_cast<uintptr_t>(w1t)) & 15) == 0) {
+        const long tiles = rows / 32;
+        const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);          // 3 workgroups per CU, waves walk over tiles
+        if (nsample == 32)
+            hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<32>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride);
+        else
+            hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<16>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride);
+        return check_launch("ws3d_sa_mlp3_pool");
+    }
 #define WS3D_SA_MLP(A, B, C, N)                                                                                          \
     if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                                 \
         hipLaunchKernelGGL((sa_mlp3_pool_kernel<A, B, C, N>), dim3((unsigned)blocks), dim3(256), 0, st, rows, x_rows4,   \
