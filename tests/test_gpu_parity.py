@@ -1094,7 +1094,7 @@ def test_channels_last_fast_path_equals_reference_layout_path(ops):
 
 
 @pytest.mark.parametrize("c1,c2,c3,ns,R", [(16, 16, 32, 16, 777), (32, 32, 64, 32, 300), (16, 16, 32, 32, 64), (32, 32, 64, 16, 1),
-                                          (32, 32, 64, 16, 5002), (32, 32, 64, 32, 40001)])   # (the last two: matrix-core kernel, many tiles per wave)
+                                          (32, 32, 64, 16, 5002), (32, 32, 64, 32, 40001), (16, 16, 32, 16, 30000)])   # (matrix-core kernel, many tiles per wave)
 def test_fused_sa_mlp_pool_matches_gemm_chain(ops, c1, c2, c3, ns, R):
     """ws3d_sa_mlp3_pool == three (row GEMM + bias + ReLU) layers + max over nsample, to fp32
     summation-order rounding (a float64 evaluation sits between the two)"""

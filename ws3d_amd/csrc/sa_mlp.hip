@@ -108,30 +108,37 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_kernel(long rows, const floa
 // between the layers.  The weights live in registers (2 + 16 + 32 per lane, loaded once per wave), a wave walks over tiles of
 // 32 grouped rows (one centre at nsample 32, two at 16); the last layer is multiplied the other way round (same registers,
 // operands swapped) so that the pool runs over registers.
-// 50 MFMAs per tile = 3,200 matrix-core cycles against ~6,500 VALU cycles of the kernel above.
+// 50 MFMAs per tile = 3,200 matrix-core cycles against ~6,500 VALU cycles of the kernel above (wide scale; the narrow one,
+// 16-16-32, uses half of the accumulator rows in layers 1 and 2: 18 MFMAs per tile).
 typedef float sa_f16 __attribute__((ext_vector_type(16)));
 
-template <int NS>
+template <int C1, int C2, int C3, int NS>
 __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, const float *__restrict__ x, const float *__restrict__ w1t,
                                                                 const float *__restrict__ b1, const float *__restrict__ w2t,
                                                                 const float *__restrict__ b2, const float *__restrict__ w3t,
                                                                 const float *__restrict__ b3, int relu3, float *__restrict__ out,
                                                                 int out_stride) {
-    static_assert(NS == 16 || NS == 32, "nsample");
+    static_assert((NS == 16 || NS == 32) && (C1 == 16 || C1 == 32) && (C2 == 16 || C2 == 32) && (C3 == 32 || C3 == 64), "shape");
+    constexpr int V1 = C1 / 2, V2 = C2 / 2, NB3 = C3 / 32;      // K steps of layers 2 / 3 (channel pairs), 32-channel blocks of layer 3
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
-    float a1[2], a2[16], a3[2][16], bb1[16], bb2[16];
+    // a 16-channel layer fills half of the 32 accumulator rows: its weights beyond the width are zero, its K steps half as many
+    float a1[2], a2[V1], a3[NB3][V2], bb1[V1], bb2[V2], b3v[NB3];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) a1[j] = w1t[(2 * j + h) * 32 + c];
+    for (int j = 0; j < 2; ++j) a1[j] = c < C1 ? w1t[(2 * j + h) * C1 + c] : 0.f;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        a2[v] = w2t[kp(v) * 32 + c];
-        a3[0][v] = w3t[kp(v) * 64 + c];
-        a3[1][v] = w3t[kp(v) * 64 + 32 + c];
+    for (int v = 0; v < V1; ++v) {
+        a2[v] = c < C2 ? w2t[kp(v) * C2 + c] : 0.f;
         bb1[v] = b1[kp(v)];
+    }
+#pragma unroll
+    for (int v = 0; v < V2; ++v) {
+#pragma unroll
+        for (int blk = 0; blk < NB3; ++blk) a3[blk][v] = w3t[kp(v) * C3 + blk * 32 + c];
         bb2[v] = b2[kp(v)];
     }
-    const float b3v[2] = {b3[c], b3[32 + c]};
+#pragma unroll
+    for (int blk = 0; blk < NB3; ++blk) b3v[blk] = b3[blk * 32 + c];
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
     for (long tile = wave; tile < tiles; tile += nwaves) {
         const float4 xr = reinterpret_cast<const float4 *>(x)[tile * 32 + c];          // row c of the tile (both halves)
@@ -142,22 +149,22 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, cons
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? xr.w : xr.z, acc, 0, 0, 0);   // k = 2 + h
         float act[16];
 #pragma unroll
-        for (int v = 0; v < 16; ++v) act[v] = fmaxf(acc[v] + bb1[v], 0.f);
+        for (int v = 0; v < V1; ++v) act[v] = fmaxf(acc[v] + bb1[v], 0.f);
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
+        for (int v = 0; v < V1; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
+        for (int v = 0; v < V2; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
+        for (int blk = 0; blk < NB3; ++blk) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
             // the LAST layer the other way round, out = X W (the very same registers, operands swapped): lane = channel,
             // register v (+ half) = row kp(v, h) -- so the pool over the rows of a centre is a maximum over REGISTERS (15
             // v_max + one exchange between the halves) instead of five DPP stages for each of 16 registers
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
+            for (int v = 0; v < V2; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
             const float bias = b3v[blk];
             if (NS == 32) {
                 float m = acc[0];
@@ -200,15 +207,20 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
     hipStream_t st = as_stream(stream);
     // the wide scale on the matrix cores (WS3D_SA_MFMA=0: the VALU kernel, A/B runs)
     static const int mfma_env = getenv("WS3D_SA_MFMA") ? atoi(getenv("WS3D_SA_MFMA")) : 1;
-    if (mfma_env && c1 == 32 && c2 == 32 && c3 == 64 && (nsample == 16 || nsample == 32) && rows % 32 == 0 &&
-        ((reinterpret_cast<uintptr_t>(b3) | reinterpret_cast<uintptr_t>(w1t)) & 15) == 0) {
+    if (mfma_env && rows % 32 == 0) {
         const long tiles = rows / 32;
         const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);          // 3 workgroups per CU, waves walk over tiles
-        if (nsample == 32)
-            hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<32>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride);
-        else
-            hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<16>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride);
-        return check_launch("ws3d_sa_mlp3_pool");
+#define WS3D_SA_MFMA_CASE(A, B, C, N)                                                                                     \
+        if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                              \
+            hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<A, B, C, N>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, \
+                               w3t, b3, relu3, out, out_stride);                                                          \
+            return check_launch("ws3d_sa_mlp3_pool");                                                                     \
+        }
+        WS3D_SA_MFMA_CASE(32, 32, 64, 32)
+        WS3D_SA_MFMA_CASE(32, 32, 64, 16)
+        WS3D_SA_MFMA_CASE(16, 16, 32, 16)
+        WS3D_SA_MFMA_CASE(16, 16, 32, 32)
+#undef WS3D_SA_MFMA_CASE
     }
 #define WS3D_SA_MLP(A, B, C, N)                                                                                          \
     if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                                 \
