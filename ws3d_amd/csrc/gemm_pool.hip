@@ -23,13 +23,30 @@ __device__ __forceinline__ float gp_nanmax(float a, float b) { return (a > b || 
 template <int NS>
 __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, const float *__restrict__ x,
                                                         const float *__restrict__ wt, const float *__restrict__ bias,
-                                                        int relu, float *__restrict__ out, int out_stride) {
+                                                        int relu, float *__restrict__ out, int out_stride, int xcd) {
     __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
     __shared__ float ws[2][GP_KT][64];        // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
-    const long row0 = (long)blockIdx.y * 64;
-    const int col0 = blockIdx.x * 64;
+    // 1-D grid; the col tiles of a row tile read the SAME activation rows: next to each other on ONE XCD (workgroup g runs on
+    // XCD g % 8) the second .. eighth read hits that L2 (with col tiles on blockIdx.x they ran on different XCDs and the
+    // activation -- 100 MB at SA2 -- came out of HBM once per col tile)
+    const int col_tiles = o_dim / 64;
+    long row_tile;
+    int col_tile;
+    {
+        const long g = blockIdx.x;
+        if (xcd) {
+            const long j = g >> 3;
+            col_tile = (int)(j % col_tiles);
+            row_tile = (j / col_tiles) * 8 + (g & 7);
+        } else {
+            col_tile = (int)(g % col_tiles);
+            row_tile = g / col_tiles;
+        }
+    }
+    const long row0 = row_tile * 64;
+    const int col0 = col_tile * 64;
     // global -> register staging: X tile 64 rows x 16 k (one float4 per thread), W tile 16 k x 64 cols
     const int xr = tid >> 2, xk = (tid & 3) * 4;
     const int wk = tid >> 4, wc = (tid & 15) * 4;
@@ -408,12 +425,14 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    if (rows / 64 > 65535) { set_error("ws3d_gemm_pool: too many rows"); return WS3D_E_UNSUPPORTED; }
-    const dim3 grid(o_dim / 64, (unsigned)(rows / 64)), block(256);
+    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    const long row_tiles = rows / 64;
+    const int xcd = (xcd_env && row_tiles % 8 == 0) ? 1 : 0;
+    const dim3 grid((unsigned)((o_dim / 64) * row_tiles)), block(256);
     if (nsample == 16)
-        hipLaunchKernelGGL(gemm_pool_kernel<16>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride);
+        hipLaunchKernelGGL(gemm_pool_kernel<16>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd);
     else
-        hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride);
+        hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd);
     return check_launch("ws3d_gemm_pool");
 }
 
