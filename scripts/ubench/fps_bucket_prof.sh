@@ -16,6 +16,9 @@ temp = torch.full((B, N), 1e10, device="cuda")
 compat.furthest_point_sampling_gather(B, N, M, xyz, temp, idx, nx)
 torch.cuda.synchronize()
 t = temp[0, :64].cpu().numpy().reshape(8, 8)
+win = temp[0, 128:256].cpu().numpy().reshape(16, 8).sum(0)
+edges = [1, 32, 64, 128, 256, 512, 1024, 2048, M]
+print("buckets updated per step, all 16 waves together, by step window: " + ", ".join("[%d,%d): %.1f" % (edges[i], edges[i + 1], win[i] / max(edges[i + 1] - edges[i], 1)) for i in range(8)))
 names = ["bbox test", "updates", "pick", "read+reduce", "active buckets (sum)", "steps with any", "publish", "barrier wait"]
 for w in range(8):  # (the first 8 waves)
     print("wave %d: " % w + "  ".join("%s %.0f" % (names[k], t[w, k] / (M - 1)) for k in (0, 1, 2, 6, 7, 3)) + "  | active/step %.2f, steps with any %.2f" % (t[w, 4] / (M - 1), t[w, 5] / (M - 1)))

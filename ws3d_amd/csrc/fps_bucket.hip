@@ -239,6 +239,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
     bool have = false;
 #ifdef FB_PROF
     long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long pt = clock64();
 #define FBP(k) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
 #else
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
         FBP(0)
 #ifdef FB_PROF
         pc[4] += __builtin_popcount(need); pc[5] += need != 0u;
+        { const int wdw = min(max(27 - __builtin_clz((unsigned)j), 0), 7); pw[wdw] += __builtin_popcount(need); }   // windows [1,32) [32,64) ... [1024,2048) [2048,..)
 #endif
         // ---- update the surviving buckets and their cached maxima: wave-uniform branches, every slot statically indexed, one
         // group test per 8 slots (typically one bucket of the wave survives).  (A loop over the set bits with a switch inside
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 #ifdef FB_PROF
     __syncthreads();
     if (temp && lane == 0)
-        for (int k = 0; k < 8; ++k) temp[w * 8 + k] = (float)pc[k];
+        for (int k = 0; k < 8; ++k) { temp[w * 8 + k] = (float)pc[k]; temp[128 + w * 8 + k] = (float)pw[k]; }
 #endif
 }
 
