@@ -1668,3 +1668,33 @@ def test_eager_side_streams_back_to_back_equal_the_single_stream_forward(ops):
             assert torch.equal(o["boxes"], want[i][2]) and torch.equal(o["count"], want[i][3]), i
     finally:
         fastpath.GEOMETRY_AHEAD = prev
+
+
+@pytest.mark.parametrize("rows,o2,relu2,bias", [(32, 1, False, True), (4096, 40, False, True), (16384 + 32, 1, False, True),
+                                                 (2048, 64, True, True), (1024, 33, True, False), (131072, 40, False, True)])
+def test_mlp2_rows_matches_two_layers(rows, o2, relu2, bias):
+    """ws3d_mlp2_rows (both layers of a head in one kernel, activation in registers) against the same two layers in float64"""
+    import torch
+    from ws3d_amd import compat as C
+    g = torch.Generator().manual_seed(rows + o2)
+    x = torch.randn(rows, 128, generator=g).cuda()
+    w1t = (torch.randn(128, 128, generator=g) / 11).cuda()
+    w2t = (torch.randn(128, o2, generator=g) / 11).cuda()
+    b1 = torch.randn(128, generator=g).cuda() if bias else None
+    b2 = torch.randn(o2, generator=g).cuda() if bias else None
+    y = C.mlp2_rows(x, w1t, b1, True, w2t, b2, relu2)
+    assert y is not None and y.shape == (rows, o2)
+    h = x.double() @ w1t.double()
+    if bias:
+        h = h + b1.double()
+    h = h.clamp_min(0)
+    ref = h @ w2t.double()
+    if bias:
+        ref = ref + b2.double()
+    if relu2:
+        ref = ref.clamp_min(0)
+    err = (y.double() - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    # shapes outside the kernel's cover: None, the caller runs two GEMMs
+    assert C.mlp2_rows(x[:, :64].contiguous(), w1t[:64].contiguous(), b1, True, w2t, b2, relu2) is None
+    assert C.mlp2_rows(x[:31], w1t, b1, True, w2t, b2, relu2) is None

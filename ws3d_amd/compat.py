@@ -397,6 +397,23 @@ def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     return out
 
 
+def mlp2_rows(x2d, w1t, b1, relu1, w2t, b2, relu2):
+    """two pointwise layers on rows in one kernel: x2d (R,128) @ w1t (128,128) -> @ w2t (128,O2 <= 64) -> (R,O2), or None when
+    the shape is not covered (the caller runs two GEMMs).  ws3d extension."""
+    dev = _dev(x2d, w1t, w2t)
+    _f32(x2d, "x2d"); _f32(w1t, "w1t"); _f32(w2t, "w2t")
+    R, K = x2d.shape
+    O1, O2 = w1t.size(1), w2t.size(1)
+    if (K != 128 or O1 != 128 or w1t.size(0) != 128 or w2t.size(0) != 128 or O2 > 64 or R % 32 or not x2d.is_contiguous() or
+            not w1t.is_contiguous() or not w2t.is_contiguous()):
+        return None
+    out = torch.empty((R, O2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_mlp2_rows(R, K, O1, O2, _p(x2d), _p(w1t), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)),
+                                         _p(out), _stream()), "mlp2_rows")
+    return out
+
+
 def pool_nsample(x):
     """x (..., nsample) contiguous fp32 -> (max over the last axis (...), position of the maximum u8);
     F.max_pool2d(kernel=[1, nsample]) scan rule (first maximum, NaN propagates).  ws3d extension."""

@@ -188,6 +188,93 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, cons
     }
 }
 
+// ---- two pointwise layers on rows, 128 -> 128 -> o2 (o2 <= 64): the two heads of the RPN --------------------------------------
+// Same register chaining as above.  Layer 1 transposed (A = W1^T from LDS, B = the rows: lane (row, half h) holds the 64
+// channels 64 h .. 64 h + 63 of its row, step s pairs channels s and 64 + s), four accumulators = all 128 output channels of
+// the 32 rows; bias + ReLU in place; layer 2 the other way round (A = those registers, B = W2 from LDS, lane = output channel),
+// so the result comes out row-major.  The (rows, 128) activation between the layers (67 MB per head at 131072 rows, written
+// by one library GEMM and read back by the next, which is HBM-bound at o2 = 1 / 40) never exists.
+template <int O2B>    // 32-column blocks of layer 2
+__global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, const float *__restrict__ x, const float *__restrict__ w1t,
+                                                        const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                        const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem_m2[];
+    // LDS banks: the two halves of a wave read rows 64 apart (layer 1) / 4 apart (layer 2); rows k >= 64 of W1 are stored with
+    // their columns XOR 32, and W2's row stride is 40 / 72 floats (4 rows = 32 banks), so the halves hit disjoint banks
+    constexpr int W2S = O2B == 1 ? 40 : 72;
+    float *w1s = smem_m2;                       // [128][128]  W1^T as given: w1t[k][o]
+    float *w2s = w1s + 128 * 128;               // [128][W2S], zero beyond o2
+    float *b1s = w2s + 128 * W2S;               // [128]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    for (int i = tid; i < 128 * 128 / 4; i += 512) {
+        const int k = i >> 5, o4 = i & 31;
+        reinterpret_cast<float4 *>(w1s)[k * 32 + (k >= 64 ? o4 ^ 8 : o4)] = reinterpret_cast<const float4 *>(w1t)[i];
+    }
+    for (int i = tid; i < 128 * O2B * 32; i += 512) {
+        const int k = i / (O2B * 32), o = i - k * (O2B * 32);
+        w2s[k * W2S + o] = o < o2 ? w2t[(long)k * o2 + o] : 0.f;
+    }
+    if (tid < 128) b1s[tid] = b1 ? b1[tid] : 0.f;
+    __syncthreads();
+    auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
+    const long wave = (long)blockIdx.x * 8 + (tid >> 6), nwaves = (long)gridDim.x * 8;
+    const float *wbase = w1s + 64 * h * 128 + c + 32 * h;       // column block blk of this half's rows sits at (blk ^ h) * 32
+    // (prefetching the next tile's rows into 64 more registers was measured: 60 vs 54 us at 131072 rows x (128 -> 128 -> 1))
+    for (long tile = wave; tile < tiles; tile += nwaves) {
+        float xv[64];
+        const float4 *xp = reinterpret_cast<const float4 *>(x + (tile * 32 + c) * 128 + 64 * h);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 t = xp[q];
+            xv[4 * q] = t.x; xv[4 * q + 1] = t.y; xv[4 * q + 2] = t.z; xv[4 * q + 3] = t.w;
+        }
+        sa_f16 acc[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[blk][i] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 64; ++s2) {
+            const float *wrow = wbase + s2 * 128;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(blk >> 1) * 64 + ((blk & 1) ? 32 - 64 * h : 0)], xv[s2], acc[blk], 0, 0, 0);
+            if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keeps the LDS reads of later steps from piling up in registers
+        }
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float y = acc[blk][v] + b1s[blk * 32 + kp(v)];
+                acc[blk][v] = relu1 ? fmaxf(y, 0.f) : y;
+            }
+#pragma unroll
+        for (int blk2 = 0; blk2 < O2B; ++blk2) {
+            sa_f16 acc2;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                {
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[blk][v], w2s[(blk * 32 + kp(v)) * W2S + blk2 * 32 + c], acc2, 0, 0, 0);
+                    if ((v & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            const int col = blk2 * 32 + c;
+            if (col < o2) {
+                const float bv = b2 ? b2[col] : 0.f;
+                float *o = out + (tile * 32 + 4 * h) * (long)o2 + col;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float y = acc2[v] + bv;
+                    if (relu2) y = fmaxf(y, 0.f);
+                    o[(long)(8 * (v / 4) + (v % 4)) * o2] = y;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, const float *x_rows4,
@@ -235,4 +322,25 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
 #undef WS3D_SA_MLP
     set_error("ws3d_sa_mlp3_pool: no kernel for widths (%d, %d, %d) x nsample %d", c1, c2, c3, nsample);
     return WS3D_E_UNSUPPORTED;
+}
+
+extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x_rows, const float *w1t, const float *b1, int relu1,
+                              const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(w1t);
+    if (rows < 0 || k_dim != 128 || o1 != 128 || o2 <= 0 || o2 > 64 || (rows & 31) || !x_rows || !w1t || !w2t || !out || (al & 15)) {
+        set_error("ws3d_mlp2_rows: unsupported shape (rows=%ld k=%d o1=%d o2=%d; 128 -> 128 -> <= 64, rows %% 32)", rows, k_dim, o1, o2);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const long tiles = rows / 32;
+    const unsigned grid = (unsigned)(tiles / 8 < 256 ? (tiles + 7) / 8 : 256);        // one 8-wave workgroup per CU, waves walk over tiles
+    const int o2b = o2 <= 32 ? 1 : 2;
+    const size_t lds = sizeof(float) * (128 * 128 + 128 * (size_t)(o2b == 1 ? 40 : 72) + 128);
+    auto go = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), tiles, o2, x_rows, w1t, b1, relu1, w2t, b2, relu2, out);
+    };
+    if (o2b == 1) go(mlp2_rows_kernel<1>); else go(mlp2_rows_kernel<2>);
+    return check_launch("ws3d_mlp2_rows");
 }

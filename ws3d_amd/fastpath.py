@@ -33,6 +33,7 @@ FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + p
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 
@@ -77,7 +78,14 @@ def _blocks(seq):
 
 
 def mlp_rows(x2d: torch.Tensor, seq) -> torch.Tensor:
-    for blk in _blocks(seq):
+    blocks = _blocks(seq)
+    if FUSED_MLP2_ROWS and len(blocks) == 2 and x2d.size(1) == 128 and x2d.is_contiguous():
+        # the heads (128 -> 128 -> 1 / 40): both layers in one kernel, the activation between them stays in registers
+        (w1, b1, r1), (w2, b2, r2) = _row_weights(blocks[0]), _row_weights(blocks[1])
+        y = _C.mlp2_rows(x2d, w1, b1, r1, w2, b2, r2)
+        if y is not None:
+            return y
+    for blk in blocks:
         x2d = _layer(x2d, blk)
     return x2d
 
