@@ -288,9 +288,11 @@ WS3D_API int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, c
 /* Two pointwise layers on rows in one kernel, 128 -> 128 -> o2 (o2 <= 64; the RPN's classification and regression heads):
  * out (rows, o2) = relu2?(relu1?(x @ w1t + b1) @ w2t + b2), w1t (128, 128) and w2t (128, o2) row-major, biases may be NULL.
  * The (rows, 128) activation between the layers stays in registers (fp32 matrix cores).  rows % 32 == 0; other shapes
- * return WS3D_E_UNSUPPORTED (the caller runs two GEMMs).  ws3d extension, used by ws3d_amd/fastpath.py.               */
+ * return WS3D_E_UNSUPPORTED (the caller runs two GEMMs).  ticket: one device int, ZERO on entry (consumed: it counts the
+ * 32-row tiles handed out), or NULL for a static split of the rows over the workgroups -- slower when other streams hold
+ * compute units.  ws3d extension, used by ws3d_amd/fastpath.py.                                                        */
 WS3D_API int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x_rows, const float *w1t, const float *b1, int relu1,
-                   const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream);
+                   const float *w2t, const float *b2, int relu2, float *out, int *ticket, ws3d_stream_t stream);
 
 /* -------------------------------------------------------------------- iou3d_cuda */
 

@@ -1698,3 +1698,32 @@ def test_mlp2_rows_matches_two_layers(rows, o2, relu2, bias):
     # shapes outside the kernel's cover: None, the caller runs two GEMMs
     assert C.mlp2_rows(x[:, :64].contiguous(), w1t[:64].contiguous(), b1, True, w2t, b2, relu2) is None
     assert C.mlp2_rows(x[:31], w1t, b1, True, w2t, b2, relu2) is None
+
+
+@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
+def test_gemm_pool_tile_variants_subprocess(tile):
+    """every selectable output tile of ws3d_gemm_pool (WS3D_GP_TILE = row blocks, column blocks of 64 per workgroup) against the
+    float64 product + group max; shapes on and off the tile multiples (those fall back to the 64 x 64 kernel)"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import compat as c
+        for rows, ns, k, o, relu in [(128, 16, 4, 128, True), (256, 32, 100, 256, False), (2048, 16, 196, 256, True), (4096, 32, 384, 512, True),
+                                     (192, 32, 64, 64, True), (65536, 32, 96, 128, True)]:
+            g = torch.Generator().manual_seed(rows + k)
+            x = torch.randn((rows, k), generator=g).cuda(); wt = (torch.randn((k, o), generator=g) * 0.2).cuda(); b = torch.randn((o,), generator=g).cuda()
+            y = x.double() @ wt.double() + b.double()
+            if relu: y = torch.relu(y)
+            ref = y.view(rows // ns, ns, o).amax(dim=1)
+            out = torch.full((rows // ns, o + 64), 7.0, device="cuda")
+            assert c.gemm_pool(x, wt, b, relu, ns, out, 64)
+            assert bool((out[:, :64] == 7.0).all())
+            err = float((out[:, 64:].double() - ref).abs().max())
+            assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (rows, ns, k, o, err)
+        print("ok")
+    """)
+    env = dict(os.environ, WS3D_GP_TILE=tile)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

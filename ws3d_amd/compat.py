@@ -397,9 +397,10 @@ def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     return out
 
 
-def mlp2_rows(x2d, w1t, b1, relu1, w2t, b2, relu2):
+def mlp2_rows(x2d, w1t, b1, relu1, w2t, b2, relu2, ticket=None):
     """two pointwise layers on rows in one kernel: x2d (R,128) @ w1t (128,128) -> @ w2t (128,O2 <= 64) -> (R,O2), or None when
-    the shape is not covered (the caller runs two GEMMs).  ws3d extension."""
+    the shape is not covered (the caller runs two GEMMs).  ticket: a zeroed int32 element (consumed) for the dynamic hand-out
+    of row tiles; None = a fresh one.  ws3d extension."""
     dev = _dev(x2d, w1t, w2t)
     _f32(x2d, "x2d"); _f32(w1t, "w1t"); _f32(w2t, "w2t")
     R, K = x2d.shape
@@ -408,9 +409,11 @@ def mlp2_rows(x2d, w1t, b1, relu1, w2t, b2, relu2):
             not w1t.is_contiguous() or not w2t.is_contiguous()):
         return None
     out = torch.empty((R, O2), dtype=torch.float32, device=dev)
+    if ticket is None:
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_mlp2_rows(R, K, O1, O2, _p(x2d), _p(w1t), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)),
-                                         _p(out), _stream()), "mlp2_rows")
+                                         _p(out), _p(ticket), _stream()), "mlp2_rows")
     return out
 
 

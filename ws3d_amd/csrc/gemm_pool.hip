@@ -110,6 +110,159 @@ __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, co
     }
 }
 
+// The same product with a (64 MB) x (64 NB) output tile per workgroup: each of the 2 x 2 waves holds MB x NB accumulators of
+// 32 x 32, one k-step costs MB + NB LDS reads for MB NB matrix instructions, and the L2 -> LDS traffic per flop falls with the
+// tile (64 x 64: 16 flop per byte, 128 x 128: 32).  Measured on the six last-layer shapes (scripts/ubench/gemm_pool_tiles.sh,
+// profiles/r02_gemm_pool_tiles.txt): L2 requests and LDS cycles halve at 128 x 128, the kernel time does not move (0.288 vs
+// 0.293 ms in total): SQ_VALU_MFMA_BUSY_CYCLES = 64 clk x the instruction count at every tile, i.e. the matrix pipe is busy
+// 77 % of the kernel at the 2.0 GHz the chip sustains under this kernel (s_memtime / s_memrealtime, gemm_pool_prof.sh; a
+// register-only loop of the same instruction holds 2.35 GHz and 154 TFLOP/s, scripts/ubench/mfma_f32_peak.hip).
+#ifdef GP_PROF       // scripts/ubench/gemm_pool_prof.sh: per-wave time stamps of the tile loop (s_memtime)
+__device__ long long gp_prof[8 * 65536];
+#define GP_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GP_STAMP(var) do { } while (0)
+#endif
+template <int NS, int MB, int NB>
+__global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim, const float *__restrict__ x,
+                                                            const float *__restrict__ wt, const float *__restrict__ bias,
+                                                            int relu, float *__restrict__ out, int out_stride, int xcd) {
+    constexpr int TM = 64 * MB, TN = 64 * NB, XS = TM + 1;
+    __shared__ float xs[2][GP_KT][XS];        // [k][row]
+    __shared__ float ws[2][GP_KT][TN];        // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int col_tiles = o_dim / TN;
+    long row_tile;
+    int col_tile;
+    {
+        const long g = blockIdx.x;
+        if (xcd) {
+            const long j = g >> 3;
+            col_tile = (int)(j % col_tiles);
+            row_tile = (j / col_tiles) * 8 + (g & 7);
+        } else {
+            col_tile = (int)(g % col_tiles);
+            row_tile = g / col_tiles;
+        }
+    }
+    const long row0 = row_tile * TM;
+    const int col0 = col_tile * TN;
+    float4 xv[MB], wv[NB];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 2, k = k0 + (idx & 3) * 4;
+            xv[i] = k < k_dim ? *reinterpret_cast<const float4 *>(x + (row0 + r) * (long)k_dim + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j, k = k0 + idx / (16 * NB), c = (idx % (16 * NB)) * 4;
+            wv[j] = k < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)k * o_dim + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 2, k = (idx & 3) * 4;
+            xs[buf][k + 0][r] = xv[i].x; xs[buf][k + 1][r] = xv[i].y; xs[buf][k + 2][r] = xv[i].z; xs[buf][k + 3][r] = xv[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<float4 *>(&ws[buf][idx / (16 * NB)][(idx % (16 * NB)) * 4]) = wv[j];
+        }
+    };
+    floatx16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    long long ts0 = 0, ts1 = 0, ta = 0, tb = 0, tc = 0, s_mma = 0, s_stage = 0, s_bar = 0;
+    (void)ts0; (void)ts1; (void)ta; (void)tb; (void)tc; (void)s_mma; (void)s_stage; (void)s_bar;
+#ifdef GP_PROF
+    const long long rt0 = __builtin_amdgcn_s_memrealtime();       // constant 100 MHz
+#endif
+    GP_STAMP(ts0);
+    load(0);
+    stage(0);
+    __syncthreads();
+    GP_STAMP(ts1);
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 * MB + (lane & 31), bc = wn * 32 * NB + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        GP_STAMP(ta);
+        if (t + 1 < ntiles) load((t + 1) * GP_KT);
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2) {
+            float a[MB], bq[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) a[i] = xs[cur][k + kh][ar + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bq[j] = ws[cur][k + kh][bc + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        GP_STAMP(tb);
+        if (t + 1 < ntiles) stage(cur ^ 1);
+        GP_STAMP(tc);
+        __syncthreads();
+#ifdef GP_PROF
+        { long long td; GP_STAMP(td); s_mma += tb - ta; s_stage += tc - tb; s_bar += td - tc; }
+#endif
+    }
+#ifdef GP_PROF
+    {
+        long long te; GP_STAMP(te);
+        const long wv = (long)blockIdx.x * 4 + w;
+        if (lane == 0 && wv < 65536) {
+            long long *q = gp_prof + wv * 8;
+            q[0] = ts0; q[1] = ts1; q[2] = s_mma; q[3] = s_stage; q[4] = s_bar; q[5] = te;
+            q[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_ID
+            q[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = col0 + bc + 32 * j;
+            const float bv = bias ? bias[col] : 0.f;
+            const long rbase = row0 + wm * 32 * MB + 32 * i;
+            if (NS == 16) {
+                float m0 = acc[i][j][0], m1 = acc[i][j][8];
+#pragma unroll
+                for (int v = 1; v < 8; ++v) { m0 = gp_nanmax(m0, acc[i][j][v]); m1 = gp_nanmax(m1, acc[i][j][8 + v]); }
+                m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+                m1 = gp_nanmax(m1, __shfl_xor(m1, 32));
+                if (lane < 32) {
+                    const long g = rbase / 16;
+                    float r0 = m0 + bv, r1 = m1 + bv;
+                    if (relu) { r0 = r0 < 0.f ? 0.f : r0; r1 = r1 < 0.f ? 0.f : r1; }
+                    out[g * out_stride + col] = r0;
+                    out[(g + 1) * out_stride + col] = r1;
+                }
+            } else {
+                float m0 = acc[i][j][0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v) m0 = gp_nanmax(m0, acc[i][j][v]);
+                m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+                if (lane < 32) {
+                    const long g = rbase / 32;
+                    float r0 = m0 + bv;
+                    if (relu) r0 = r0 < 0.f ? 0.f : r0;
+                    out[g * out_stride + col] = r0;
+                }
+            }
+        }
+}
+
 // XCD-aware tile order for the gather-GEMMs (1-D grid of col_tiles * row_tiles workgroups): workgroup g runs on XCD g % 8
 // (observed dispatch order).  With tps row tiles per scene and a batch that is a multiple of 8,
 //   scene = (g / 8 / (col_tiles * tps)) * 8 + g % 8,   row tile = (g / 8 / col_tiles) % tps,   col tile = (g / 8) % col_tiles
@@ -426,6 +579,29 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
     }
     if (rows == 0) return WS3D_OK;
     static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    // tile: 128 x 128 when that still gives two workgroups per CU (same kernel time as 64 x 64 -- the matrix pipe is the bound at
+    // either size -- at half the L2 and LDS traffic: +1.3 % in the 20-deep pipeline), else 64 x 64.  WS3D_GP_TILE = MB NB: A/B runs
+    static const int tile_forced = getenv("WS3D_GP_TILE") ? atoi(getenv("WS3D_GP_TILE")) : 0;
+    const int tile_env = tile_forced ? tile_forced : ((rows % 128 == 0 && o_dim % 128 == 0 && (rows / 128) * (o_dim / 128) >= 512) ? 22 : 11);
+    {
+        const int mb = tile_env / 10, nb = tile_env % 10;
+        static const bool force_big = getenv("WS3D_GP_FORCE_BIG") != nullptr;
+        if ((tile_env != 11 || force_big) && rows % (64 * mb) == 0 && o_dim % (64 * nb) == 0) {
+            const long rt = rows / (64 * mb);
+            const int xc = (xcd_env && rt % 8 == 0) ? 1 : 0;
+            const dim3 grid((unsigned)((o_dim / (64 * nb)) * rt)), block(256);
+#define GP_BIG(M_, N_)                                                                                                              \
+    if (mb == M_ && nb == N_) {                                                                                                     \
+        if (nsample == 16)                                                                                                          \
+            hipLaunchKernelGGL((gemm_pool_big_kernel<16, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc); \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gemm_pool_big_kernel<32, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc); \
+        return check_launch("ws3d_gemm_pool");                                                                                      \
+    }
+            GP_BIG(1, 1) GP_BIG(2, 1) GP_BIG(1, 2) GP_BIG(2, 2)
+#undef GP_BIG
+        }
+    }
     const long row_tiles = rows / 64;
     const int xcd = (xcd_env && row_tiles % 8 == 0) ? 1 : 0;
     const dim3 grid((unsigned)((o_dim / 64) * row_tiles)), block(256);
@@ -502,3 +678,9 @@ extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, i
 #undef WS3D_GG2
     return check_launch("ws3d_gather_gemm2");
 }
+
+#ifdef GP_PROF
+extern "C" __attribute__((visibility("default"))) int ws3d_gp_prof_read(long long *host, long n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws3d::gp_prof), sizeof(long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, cons
 template <int O2B>    // 32-column blocks of layer 2
 __global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, const float *__restrict__ x, const float *__restrict__ w1t,
                                                         const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                        const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+                                                        const float *__restrict__ b2, int relu2, float *__restrict__ out,
+                                                        int *__restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) float smem_m2[];
     // LDS banks: the two halves of a wave read rows 64 apart (layer 1) / 4 apart (layer 2); rows k >= 64 of W1 are stored with
     // their columns XOR 32, and W2's row stride is 40 / 72 floats (4 rows = 32 banks), so the halves hit disjoint banks
@@ -205,7 +206,9 @@ __global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, cons
     float *w1s = smem_m2;                       // [128][128]  W1^T as given: w1t[k][o]
     float *w2s = w1s + 128 * 128;               // [128][W2S], zero beyond o2
     float *b1s = w2s + 128 * W2S;               // [128]
+    __shared__ int first_chunk[2];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
+    if (ticket && tid == 0) first_chunk[0] = atomicAdd(ticket, 1);
     for (int i = tid; i < 128 * 128 / 4; i += 512) {
         const int k = i >> 5, o4 = i & 31;
         reinterpret_cast<float4 *>(w1s)[k * 32 + (k >= 64 ? o4 ^ 8 : o4)] = reinterpret_cast<const float4 *>(w1t)[i];
@@ -217,10 +220,18 @@ __global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, cons
     if (tid < 128) b1s[tid] = b1 ? b1[tid] : 0.f;
     __syncthreads();
     auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
-    const long wave = (long)blockIdx.x * 8 + (tid >> 6), nwaves = (long)gridDim.x * 8;
     const float *wbase = w1s + 64 * h * 128 + c + 32 * h;       // column block blk of this half's rows sits at (blk ^ h) * 32
     // (prefetching the next tile's rows into 64 more registers was measured: 60 vs 54 us at 131072 rows x (128 -> 128 -> 1))
-    for (long tile = wave; tile < tiles; tile += nwaves) {
+    // chunks of 8 tiles (one per wave) are handed out by a ticket counter when the caller provides one (zero on entry): with a
+    // static split a workgroup that has to wait for a CU (one per CU fits; a sampling kernel of another stream may hold eight of
+    // them for 3 ms) would run its share after everybody else has finished -- measured 115 vs 68 us with 20 batches in flight.
+    // One atomic per workgroup and chunk, issued a chunk ahead (per wave and tile they serialise on the one address: +40 us).
+    long chunk = ticket ? first_chunk[0] : blockIdx.x;
+    for (int par = 0; chunk * 8 < tiles; par ^= 1) {
+        int ahead = 0;
+        if (ticket && tid == 0) ahead = atomicAdd(ticket, 1);        // consumed after this chunk's work
+        const long tile = chunk * 8 + (tid >> 6);
+        if (tile < tiles) {
         float xv[64];
         const float4 *xp = reinterpret_cast<const float4 *>(x + (tile * 32 + c) * 128 + 64 * h);
 #pragma unroll
@@ -271,6 +282,14 @@ __global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, cons
                     o[(long)(8 * (v / 4) + (v % 4)) * o2] = y;
                 }
             }
+        }
+        }
+        if (ticket) {
+            if (tid == 0) first_chunk[par ^ 1] = ahead;
+            __syncthreads();
+            chunk = first_chunk[par ^ 1];
+        } else {
+            chunk += gridDim.x;
         }
     }
 }
@@ -325,7 +344,7 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
 }
 
 extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x_rows, const float *w1t, const float *b1, int relu1,
-                              const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+                              const float *w2t, const float *b2, int relu2, float *out, int *ticket, ws3d_stream_t stream) {
     using namespace ws3d;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(w1t);
     if (rows < 0 || k_dim != 128 || o1 != 128 || o2 <= 0 || o2 > 64 || (rows & 31) || !x_rows || !w1t || !w2t || !out || (al & 15)) {
@@ -339,7 +358,7 @@ extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float 
     const size_t lds = sizeof(float) * (128 * 128 + 128 * (size_t)(o2b == 1 ? 40 : 72) + 128);
     auto go = [&](auto kern) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), tiles, o2, x_rows, w1t, b1, relu1, w2t, b2, relu2, out);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), tiles, o2, x_rows, w1t, b1, relu1, w2t, b2, relu2, out, ticket);
     };
     if (o2b == 1) go(mlp2_rows_kernel<1>); else go(mlp2_rows_kernel<2>);
     return check_launch("ws3d_mlp2_rows");

@@ -77,12 +77,12 @@ def _blocks(seq):
     return [m for m in seq if isinstance(m, nn_blocks._ConvBlock)]
 
 
-def mlp_rows(x2d: torch.Tensor, seq) -> torch.Tensor:
+def mlp_rows(x2d: torch.Tensor, seq, ticket=None) -> torch.Tensor:
     blocks = _blocks(seq)
     if FUSED_MLP2_ROWS and len(blocks) == 2 and x2d.size(1) == 128 and x2d.is_contiguous():
         # the heads (128 -> 128 -> 1 / 40): both layers in one kernel, the activation between them stays in registers
         (w1, b1, r1), (w2, b2, r2) = _row_weights(blocks[0]), _row_weights(blocks[1])
-        y = _C.mlp2_rows(x2d, w1, b1, r1, w2, b2, r2)
+        y = _C.mlp2_rows(x2d, w1, b1, r1, w2, b2, r2, ticket)
         if y is not None:
             return y
     for blk in blocks:
@@ -318,8 +318,9 @@ def rpn_forward(model, pts_input: torch.Tensor) -> dict:
     xyz, feats = backbone_forward(rpn.backbone_net, pts_input)            # (B,N,3), (B,N,128)
     B, N, C = feats.shape
     rows = feats.view(B * N, C)
-    rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer).view(B, N, -1)
-    rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer).view(B, N, -1)
+    tickets = torch.zeros(2, dtype=torch.int32, device=rows.device) if FUSED_MLP2_ROWS else (None, None)   # one fill for both heads
+    rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
+    rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
     return {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz,
             "backbone_features": feats.transpose(1, 2),                   # (B,C,N) view of the (B,N,C) tensor
             "backbone_features_nlc": feats}
