@@ -1727,3 +1727,36 @@ def test_gemm_pool_tile_variants_subprocess(tile):
     env = dict(os.environ, WS3D_GP_TILE=tile)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
+def test_interp_gemm_tile_variants_subprocess(tile):
+    """every selectable output tile of ws3d_interp_gemm (WS3D_IG_TILE) against three_interpolate + concat + float64 product,
+    including the c1 = 1 ragged skip block of FP1 and shapes off the tile multiples (which run the 64 x 64 kernel)"""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path.insert(0, {root!r})
+        from ws3d_amd import compat as c, synth
+        rng = np.random.default_rng(9)
+        for B, N, M, C2, C1, O in [(8, 1024, 256, 64, 1, 128), (2, 512, 128, 96, 32, 256), (8, 256, 64, 128, 0, 128), (1, 192, 48, 32, 5, 64),
+                                   (16, 2048, 512, 256, 1, 128)]:
+            pc = synth.make_batch("lidar", B, 16384, 62)[:, :N, :3].copy()
+            unknown = torch.from_numpy(pc).cuda(); known = unknown[:, ::N // M].contiguous()
+            kf = torch.from_numpy(rng.standard_normal((B, M, C2)).astype(np.float32)).cuda()
+            uf = torch.from_numpy(rng.standard_normal((B, N, C1)).astype(np.float32)).cuda() if C1 else None
+            idx, weight = c.three_nn_with_weights(unknown, known, None)
+            wt = torch.from_numpy((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32)).cuda()
+            bias = torch.from_numpy(rng.standard_normal(O).astype(np.float32)).cuda()
+            got = c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
+            interp = torch.empty((B, N, C2), device="cuda"); c.three_interpolate_nlc(kf, idx, weight, interp)
+            x = interp if uf is None else torch.cat((interp, uf), dim=2)
+            want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
+            err = (got.double() - want).abs().max().item()
+            assert err <= 4e-6 * max(want.abs().max().item(), 1.0) * np.sqrt((C2 + C1) / 96), (B, N, M, C2, C1, O, err)
+        print("ok")
+    """)
+    env = dict(os.environ, WS3D_IG_TILE=tile)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

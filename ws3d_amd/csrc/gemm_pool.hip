@@ -565,6 +565,125 @@ __global__ __launch_bounds__(256) void interp_gemm_kernel(int c2, int c1, int o_
     }
 }
 
+// interp_gemm_kernel with a (64 MB) x (64 NB) output tile (see gemm_pool_big_kernel): besides the lighter L2 / LDS traffic the
+// interpolated A tile -- three gathered rows and three fmaf per element -- is built once per 64 NB output columns instead of
+// once per 64 (at FP1, 128 output channels: exactly once).
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, int o_dim, int n, int m, const float *__restrict__ known_feats,
+                                                              const float *__restrict__ unknown_feats, const int32_t *__restrict__ idx3,
+                                                              const float *__restrict__ w3, const float *__restrict__ wt,
+                                                              const float *__restrict__ bias, int relu, float *__restrict__ out, int tps) {
+    constexpr int TM = 64 * MB, TN = 64 * NB, XS = TM + 1;
+    __shared__ float xs[2][GP_KT][XS];        // [k][row]
+    __shared__ float ws[2][GP_KT][TN];        // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    long row_tile;
+    int col_tile;
+    gg_tile(o_dim / TN, tps, row_tile, col_tile);
+    const long row0 = row_tile * TM;
+    const int col0 = col_tile * TN;
+    const int k_dim = c2 + c1;
+    const int xk = (tid & 3) * 4;
+    const float *f0[MB], *f1[MB], *f2[MB], *urow[MB];
+    float w0[MB], w1[MB], w2[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const long r = row0 + (tid >> 2) + 64 * i;
+        const long b = r / n;
+        const float *base = known_feats + (size_t)b * m * c2;
+        f0[i] = base + (size_t)idx3[r * 3 + 0] * c2; f1[i] = base + (size_t)idx3[r * 3 + 1] * c2; f2[i] = base + (size_t)idx3[r * 3 + 2] * c2;
+        w0[i] = w3[r * 3 + 0]; w1[i] = w3[r * 3 + 1]; w2[i] = w3[r * 3 + 2];
+        urow[i] = unknown_feats ? unknown_feats + (size_t)r * c1 : nullptr;
+    }
+    float4 xv[MB], wv[NB];
+    auto load = [&](int k0) {
+        const int k = k0 + xk;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            if (k < c2) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(f0[i] + k), p1 = *reinterpret_cast<const float4 *>(f1[i] + k),
+                             p2 = *reinterpret_cast<const float4 *>(f2[i] + k);
+                xv[i] = make_float4(__builtin_fmaf(w2[i], p2.x, __builtin_fmaf(w0[i], p0.x, w1[i] * p1.x)),
+                                    __builtin_fmaf(w2[i], p2.y, __builtin_fmaf(w0[i], p0.y, w1[i] * p1.y)),
+                                    __builtin_fmaf(w2[i], p2.z, __builtin_fmaf(w0[i], p0.z, w1[i] * p1.z)),
+                                    __builtin_fmaf(w2[i], p2.w, __builtin_fmaf(w0[i], p0.w, w1[i] * p1.w)));
+            } else {
+                const int ku = k - c2;
+                if (ku + 3 < c1) {
+                    xv[i] = *reinterpret_cast<const float4 *>(urow[i] + ku);            // c1 % 4 == 0: aligned
+                } else {
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};                                  // the ragged tail (c1 = 1 at FP1)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (ku + q < c1) v[q] = urow[i][ku + q];
+                    xv[i] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j, kk = k0 + idx / (16 * NB), c = (idx % (16 * NB)) * 4;
+            wv[j] = kk < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)kk * o_dim + col0 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int r = (tid >> 2) + 64 * i;
+            xs[buf][xk + 0][r] = xv[i].x; xs[buf][xk + 1][r] = xv[i].y; xs[buf][xk + 2][r] = xv[i].z; xs[buf][xk + 3][r] = xv[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = tid + 256 * j;
+            *reinterpret_cast<float4 *>(&ws[buf][idx / (16 * NB)][(idx % (16 * NB)) * 4]) = wv[j];
+        }
+    };
+    floatx16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    load(0);
+    stage(0);
+    __syncthreads();
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 * MB + (lane & 31), bc = wn * 32 * NB + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) load((t + 1) * GP_KT);
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2) {
+            float a[MB], bq[NB];
+#pragma unroll
+            for (int i = 0; i < MB; ++i) a[i] = xs[cur][k + kh][ar + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) bq[j] = ws[cur][k + kh][bc + 32 * j];
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) stage(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int col = col0 + bc + 32 * j;
+            const float bv = bias ? bias[col] : 0.f;
+            float *o = out + (row0 + wm * 32 * MB + 32 * i + 4 * (lane >> 5)) * (long)o_dim + col;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float y = acc[i][j][v] + bv;
+                if (relu) y = y < 0.f ? 0.f : y;
+                o[(long)(8 * (v / 4) + (v % 4)) * o_dim] = y;
+            }
+        }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
@@ -646,6 +765,24 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
     }
     if (rows == 0) return WS3D_OK;
     static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    // 64 x 128 output tiles where they leave two workgroups per CU (FP1..FP3 of the c3 network): the interpolated A tile is built
+    // half as often; measured 120 / 119 / 81 us against 128 / 131 / 82 at 64 x 64 and 119 / 123 / 90 at 128 x 128
+    // (profiles/r02_interp_gemm_tiles.txt).  WS3D_IG_TILE = MB NB: A/B runs
+    static const int tile_forced = getenv("WS3D_IG_TILE") ? atoi(getenv("WS3D_IG_TILE")) : 0;
+    const int tile = tile_forced ? tile_forced : ((o_dim % 128 == 0 && (rows / 64) * (o_dim / 128) >= 512) ? 12 : 11);
+    const int mb = tile / 10, nb = tile % 10;
+    if (tile != 11 && rows % (64 * mb) == 0 && o_dim % (64 * nb) == 0) {
+        const int tpsb = (xcd_env && (b & 7) == 0 && n % (64 * mb) == 0) ? n / (64 * mb) : 0;
+        const dim3 grid((unsigned)((o_dim / (64 * nb)) * (rows / (64 * mb))));
+#define IG_BIG(M_, N_)                                                                                                                  \
+    if (mb == M_ && nb == N_) {                                                                                                         \
+        hipLaunchKernelGGL((interp_gemm_big_kernel<M_, N_>), grid, dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m, known_feats,   \
+                           unknown_feats, idx, weight, wt, bias, relu, out, tpsb);                                                      \
+        return check_launch("ws3d_interp_gemm");                                                                                        \
+    }
+        IG_BIG(2, 1) IG_BIG(1, 2) IG_BIG(2, 2)
+#undef IG_BIG
+    }
     const int tps = (xcd_env && (b & 7) == 0 && n % 64 == 0) ? n / 64 : 0;
     hipLaunchKernelGGL(interp_gemm_kernel, dim3((unsigned)((o_dim / 64) * (rows / 64))), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
                        known_feats, unknown_feats, idx, weight, wt, bias, relu, out, tps);
