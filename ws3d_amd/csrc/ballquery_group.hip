@@ -422,7 +422,7 @@ __global__ __launch_bounds__(1024) void bin_points_x_kernel(int n, const float *
 __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const float *__restrict__ xyz, char *__restrict__ ws) {
     // 64 KB + one pad word per 16: thread t scans words 16 t .. 16 t + 15, stored at 17 t + i -- conflict-free (unpadded, the
     // 64 lanes of a wave hit two banks: 16-way conflicts on every access of the scan)
-    __shared__ unsigned hist[GRID16_CELLS / 2 + GRID16_CELLS / 32];
+    __shared__ __attribute__((aligned(16))) unsigned hist[GRID16_CELLS / 2 + GRID16_CELLS / 32];
 #define HW(wi) ((wi) + ((wi) >> 4))
     __shared__ int wsum[16];
     __shared__ float red[4][16];
@@ -516,16 +516,38 @@ __global__ __launch_bounds__(1024) void bin_points_grid_kernel(int n, const floa
     }
     if (tid == 1023 && ncell == GRID16_CELLS) start[GRID16_CELLS] = (uint16_t)n;   // the sentinel behind a full table
     __syncthreads();
+    // every point's slot first (registers), then the sorted records go out through LDS in stretches of 4096 slots -- the
+    // counters' memory, free once the slots are known -- as whole 64 KB runs.  Scattered straight from the registers the 16-byte
+    // records reach HBM as partial lines that are evicted and re-merged: 402 MB written per 512 scenes for 134 MB of records
+    // (rocprofv3 WRITE_SIZE), and the kernel ran at that traffic's speed
+    unsigned slot2[SORT_MAX_N / 2048];                            // two 16-bit slots per register (0xffff: no point)
 #pragma unroll
     for (int s = 0; s < SORT_MAX_N / 1024; ++s) {
-        const int i = tid + 1024 * s;
-        if (i >= n) continue;
-        const int c = cell_of(pt[s]);
-        const unsigned old = atomicAdd(&hist[HW(c >> 1)], 1u << (16 * (c & 1)));
-        const int pos = (int)((old >> (16 * (c & 1))) & 0xffffu);
-        sorted[pos] = make_float4(pt[s].x, pt[s].y, pt[s].z, __int_as_float(i));
+        unsigned sl = 0xffffu;
+        if (tid + 1024 * s < n) {
+            const int c = cell_of(pt[s]);
+            const unsigned old = atomicAdd(&hist[HW(c >> 1)], 1u << (16 * (c & 1)));
+            sl = (old >> (16 * (c & 1))) & 0xffffu;
+        }
+        slot2[s >> 1] = (s & 1) ? (slot2[s >> 1] | (sl << 16)) : sl;
     }
 #undef HW
+    __syncthreads();
+    float4 *stage = reinterpret_cast<float4 *>(hist);             // 4352 records fit, 4096 used
+    for (int q0 = 0; q0 < n; q0 += 4096) {
+#pragma unroll
+        for (int s = 0; s < SORT_MAX_N / 1024; ++s) {
+            const unsigned rel = ((slot2[s >> 1] >> (16 * (s & 1))) & 0xffffu) - (unsigned)q0;
+            if (rel < 4096u) stage[rel] = make_float4(pt[s].x, pt[s].y, pt[s].z, __int_as_float(tid + 1024 * s));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = q0 + tid + 1024 * j;
+            if (i < n) sorted[i] = stage[tid + 1024 * j];
+        }
+        __syncthreads();
+    }
 }
 
 // One workgroup = 64 centres (one per lane) x 4 waves; wave j scans the j-th quarter of every
