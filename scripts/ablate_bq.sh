@@ -4,11 +4,11 @@ set -e
 cd "$(dirname "$0")/.."
 OBJ=ws3d_amd/csrc/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden"
-for v in NO_SEARCH NO_EMIT; do
+for v in NO_SEARCH NO_EMIT PACKED_ABL; do
   hipcc $FLAGS -DWS3D_BQS_$v -DWS3D_BQG_$v -c ws3d_amd/csrc/ballquery_group.hip -o /tmp/bq_$v.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libws3d_$v.so $(ls $OBJ/*.o | grep -v ballquery_group) /tmp/bq_$v.o
 done
-for v in FULL NO_SEARCH NO_EMIT; do
+for v in FULL NO_SEARCH NO_EMIT PACKED_ABL; do
   WS3D_ALT_LIB=$([ $v = FULL ] && echo "" || echo /tmp/libws3d_$v.so) python - <<PY
 import os, sys
 sys.path.insert(0, ".")

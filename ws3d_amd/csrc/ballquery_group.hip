@@ -182,8 +182,14 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int id = ok[h] ? (int)r[u] : 0;
+#ifdef WS3D_BQG_PACKED_ABL    // ablation (scripts/ablate_bq.sh): what ONE aligned 16-byte gather per sample would cost (values are wrong)
+                        const float4 v = reinterpret_cast<const float4 *>(xyz)[id * 3 / 4];
+                        p[h][u] = f3v{v.x, v.y, v.z};
+                        f[h][u] = v.w;
+#else
                         p[h][u] = *reinterpret_cast<const f3u *>(xyz + (size_t)id * 3);
                         f[h][u] = fb[id];
+#endif
                     }
                 }
 #pragma unroll
