@@ -362,17 +362,25 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(int c_feat, int o_dim,
 // bank conflicts and layer 2's A operand reads -- and layer 2 (O1 -> O2) multiplied straight out of it, 64 output columns at a
 // time.  Neither the grouped tensor nor the first activation (rows x O1) reaches HBM, and the rows of a tile are gathered once
 // instead of once per 64 output columns.  NB1 = O1 / 64 accumulators per wave in phase 1.
-template <int NB1>
+// POOL = 16 | 32 (= ns): the THIRD layer and the pool over nsample follow in the same kernel -- layer 2's 64 x O2 tile goes to LDS
+// next to layer 1's instead of to HBM, layer 3 (O2 -> O3) is multiplied out of it 64 columns at a time and reduced over its row
+// groups in registers as in gemm_pool_kernel: of a whole SharedMLP only the pooled rows (rows / ns, O3) reach HBM.
+template <int NB1, int POOL = 0>
 __global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, int n, int m, int ns, const float *__restrict__ feats,
                                                            const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                            const int32_t *__restrict__ nbr, const float *__restrict__ w1t,
                                                            const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                           const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+                                                           const float *__restrict__ b2, int relu2, float *__restrict__ out,
+                                                           int o3 = 0, const float *__restrict__ w3t = nullptr,
+                                                           const float *__restrict__ b3 = nullptr, int relu3 = 0, int out_stride = 0) {
     constexpr int O1 = NB1 * 64;
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     // phase 1: xs[2][GP_KT][GP_XS] | w1s[2][GP_KT][O1];   phase 2 (aliases phase 1): act[O1][GP_XS] | w2s[2][GP_KT][64]
+    // with POOL: act[O1][GP_XS] | act2[O2P][GP_XS] | w2s[2][GP_KT][64],  O2P = o2 rounded up to the k-tile; layer 3's W tiles
+    // ([2][GP_KT][128]) reuse act
+    const int o2p = POOL ? (o2 + GP_KT - 1) / GP_KT * GP_KT : 0;
     float *xs = smem2, *w1s = smem2 + 2 * GP_KT * GP_XS;
-    float *act = smem2, *w2s = smem2 + O1 * GP_XS;
+    float *act = smem2, *act2 = smem2 + O1 * GP_XS, *w2s = smem2 + (O1 + o2p) * GP_XS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
     const long row0 = (long)blockIdx.x * 64;
@@ -472,7 +480,17 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, i
             __syncthreads();
         }
         const int col = col0 + bc;
-        if (col < o2) {
+        if (POOL) {
+            if (col < o2p) {          // columns o2 .. o2p - 1: the zero padding of layer 3's k dimension
+                const float bv = (col < o2 && b2) ? b2[col] : 0.f;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    float y = acc2[v] + bv;
+                    if (relu2) y = y < 0.f ? 0.f : y;
+                    act2[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * (lane >> 5) + (v % 4)] = col < o2 ? y : 0.f;
+                }
+            }
+        } else if (col < o2) {
             const float bv = b2 ? b2[col] : 0.f;
             float *o = out + (row0 + wm * 32 + 4 * (lane >> 5)) * (long)o2 + col;
 #pragma unroll
@@ -480,6 +498,80 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, i
                 float y = acc2[v] + bv;
                 if (relu2) y = y < 0.f ? 0.f : y;
                 o[(long)(8 * (v / 4) + (v % 4)) * o2] = y;
+            }
+        }
+    }
+    if (POOL) {
+        // layer 3 out of act2, 128 output columns per pass (o3 % 128 == 0; two accumulators per wave: half the barriers and
+        // half the reads of the activation of a 64-column pass), then the max over each group of POOL rows
+        const int nt3 = o2p / GP_KT;
+        const int wk3 = tid >> 5, wc3 = (tid & 31) * 4;          // W3 tile 16 x 128: two float4 per thread (rows wk3, wk3 + 8)
+        float *w3s = smem2;                                      // [2][GP_KT][128] in layer 1's activation tile, which is dead by now (O1 * GP_XS >= 4096)
+        for (int c = 0; c < o3 / 128; ++c) {
+            const int col0 = c * 128;
+            float4 w3v[2];
+            auto load_w3 = [&](int t) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k = t * GP_KT + wk3 + 8 * q;
+                    w3v[q] = k < o2 ? *reinterpret_cast<const float4 *>(w3t + (long)k * o3 + col0 + wc3) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            auto stage_w3 = [&](int buf) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(w3s + buf * GP_KT * 128 + (wk3 + 8 * q) * 128 + wc3) = w3v[q];
+            };
+            floatx16 acc3[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc3[q][i] = 0.f;
+            load_w3(0);
+            __syncthreads();                // act2 is complete, act is dead / the previous pass has left w3s
+            stage_w3(0);
+            __syncthreads();
+            for (int t = 0; t < nt3; ++t) {
+                const int cur = t & 1;
+                if (t + 1 < nt3) load_w3(t + 1);
+                const float *wl = w3s + cur * GP_KT * 128;
+#pragma unroll
+                for (int k = 0; k < GP_KT; k += 2) {
+                    const float a = act2[(t * GP_KT + k + kh) * GP_XS + ar];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) acc3[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[(k + kh) * 128 + q * 64 + bc], acc3[q], 0, 0, 0);
+                }
+                if (t + 1 < nt3) stage_w3(cur ^ 1);
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int col = col0 + q * 64 + bc;
+                const float bv = b3 ? b3[col] : 0.f;
+                if (POOL == 16) {
+                    float m0 = acc3[q][0], m1 = acc3[q][8];
+#pragma unroll
+                    for (int v = 1; v < 8; ++v) { m0 = gp_nanmax(m0, acc3[q][v]); m1 = gp_nanmax(m1, acc3[q][8 + v]); }
+                    m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+                    m1 = gp_nanmax(m1, __shfl_xor(m1, 32));
+                    if (lane < 32) {
+                        const long g = (row0 + wm * 32) / 16;
+                        float r0 = m0 + bv, r1 = m1 + bv;
+                        if (relu3) { r0 = r0 < 0.f ? 0.f : r0; r1 = r1 < 0.f ? 0.f : r1; }
+                        out[g * out_stride + col] = r0;
+                        out[(g + 1) * out_stride + col] = r1;
+                    }
+                } else {
+                    float m0 = acc3[q][0];
+#pragma unroll
+                    for (int v = 1; v < 16; ++v) m0 = gp_nanmax(m0, acc3[q][v]);
+                    m0 = gp_nanmax(m0, __shfl_xor(m0, 32));
+                    if (lane < 32) {
+                        const long g = (row0 + wm * 32) / 32;
+                        float r0 = m0 + bv;
+                        if (relu3) r0 = r0 < 0.f ? 0.f : r0;
+                        out[g * out_stride + col] = r0;
+                    }
+                }
             }
         }
     }
@@ -814,6 +906,38 @@ extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, i
     if (o1 == 64) WS3D_GG2(1) else if (o1 == 128) WS3D_GG2(2) else WS3D_GG2(4)
 #undef WS3D_GG2
     return check_launch("ws3d_gather_gemm2");
+}
+
+extern "C" int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_feat, int o1, int o2, int o3, const float *feats, const float *xyz,
+                                      const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1,
+                                      const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3, int relu3,
+                                      float *out, int out_stride, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(w1t) | reinterpret_cast<uintptr_t>(w2t) |
+                         reinterpret_cast<uintptr_t>(w3t);
+    const size_t o2p = (size_t)(o2 + GP_KT - 1) / GP_KT * GP_KT;
+    const size_t p1 = (size_t)2 * GP_KT * GP_XS + (size_t)2 * GP_KT * o1, p2 = ((size_t)o1 + o2p) * GP_XS + (size_t)2 * GP_KT * 64;
+    const size_t lds = sizeof(float) * (p1 > p2 ? p1 : p2);
+    if (b < 0 || n <= 0 || m <= 0 || (nsample != 16 && nsample != 32) || c_feat <= 0 || (c_feat & 3) || (o1 != 64 && o1 != 128) || o2 <= 0 ||
+        (o2 & 3) || o3 <= 0 || (o3 & 127) || (rows & 63) || !feats || !xyz || !new_xyz || !nbr || !w1t || !w2t || !w3t || !out ||
+        out_stride < o3 || (al & 15) || lds > 150 * 1024) {
+        set_error("ws3d_gather_gemm3_pool: unsupported shape (b=%d n=%d m=%d ns=%d c=%d o1=%d o2=%d o3=%d; ns 16|32, c, o2 %% 4, o1 in {64,128}, "
+                  "o3 %% 128, rows %% 64, tile <= 150 KB of LDS)", b, n, m, nsample, c_feat, o1, o2, o3);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+#define WS3D_GG3(NB, NS)                                                                                                               \
+    {                                                                                                                                  \
+        if (lds > 64 * 1024)                                                                                                           \
+            (void)hipFuncSetAttribute((const void *)gather_gemm2_kernel<NB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gather_gemm2_kernel<NB, NS>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), c_feat, o2, n, m, nsample, \
+                           feats, xyz, new_xyz, nbr, w1t, b1, relu1, w2t, b2, relu2, out, o3, w3t, b3, relu3, out_stride);              \
+    }
+    if (o1 == 64) { if (nsample == 16) WS3D_GG3(1, 16) else WS3D_GG3(1, 32) }
+    else          { if (nsample == 16) WS3D_GG3(2, 16) else WS3D_GG3(2, 32) }
+#undef WS3D_GG3
+    return check_launch("ws3d_gather_gemm3_pool");
 }
 
 #ifdef GP_PROF

@@ -33,6 +33,11 @@ FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + p
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+# ws3d_gather_gemm3_pool: grouping + 3 layers + pool in one kernel.  OFF by default: at SA2 it is faster alone (62 vs 72 and 146 vs
+# 156 us per batch of 8) and 10-30 us off the latency, but the 20-deep pipeline loses 1.5 % with it (5,029 / 4,961 vs 5,076 / 5,092
+# scenes/s, ABAB on one box: 50 KB of LDS per workgroup leave less room beside the other streams' kernels); SA3 is slower either way
+FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
+FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
@@ -223,6 +228,10 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         if nbr is not None:
             # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
             wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
+            if (FUSED_GATHER_GEMM3 and len(blocks) == 3 and blocks[0].conv.out_channels <= FUSED_GATHER_GEMM3_MAX_O1 and
+                    _C.gather_gemm3_pool(feats, xyz, new_xyz, nbr, wt1, b1, r1, *_row_weights(blocks[1]), *_row_weights(blocks[2]), out, col)):
+                col += width       # the whole SharedMLP + pool in one kernel: only the pooled rows reach HBM
+                continue
             y = None
             rest = blocks[1:-1]
             if FUSED_GATHER_GEMM2 and len(blocks) >= 3 and blocks[0].conv.out_channels <= 128:
