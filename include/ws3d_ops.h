@@ -197,6 +197,19 @@ WS3D_API int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_feat
                            const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3, int relu3,
                            float *out, int out_stride, ws3d_stream_t stream);
 
+/* Layer 1 of a set-abstraction SharedMLP without its per-pair product: W [f_j ; x_j - c] = W_f f_j + W_x (x_j - c), and
+ * P = feats @ W_f (b * n rows, o1 columns at row stride p_stride: ONE GEMM over the points of a scene, by the caller) replaces the
+ * product over the b * m * nsample (centre, sample) pairs.  Per pair: gather P's row of the neighbour, add the three-term xyz
+ * product (w1x (3, o1): the x, y, z rows of W^T; centred coordinates, as pointnet2_utils.py:255-258) + b1, ReLU.
+ *   ws3d_pgather_gemm2: ... then layer 2 (w2t (o1, o2)) as in ws3d_gather_gemm2 -> out (rows, o2); o1 in {64, 128}, m * nsample % 64
+ *   ws3d_pgather_rows:  layer 1 alone -> out (rows, o1); o1 % 4, P / w1x / b1 / out 16-byte aligned
+ * Same function as ws3d_gather_gemm(2) up to fp32 summation order.  ws3d extension, used by ws3d_amd/fastpath.py.          */
+WS3D_API int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
+                       const float *new_xyz, const int32_t *nbr, const float *w1x, const float *b1, int relu1,
+                       const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream);
+WS3D_API int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const float *pmat, int p_stride, const float *xyz, const float *new_xyz,
+                      const int32_t *nbr, const float *w1x, const float *b1, int relu1, float *out, ws3d_stream_t stream);
+
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
  * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +

@@ -1818,7 +1818,7 @@ def test_fast_path_switches_agree(ops):
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM")
+    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -1828,16 +1828,56 @@ def test_fast_path_switches_agree(ops):
             out = model.rpn_forward({"pts_input": pts})
         return out["rpn_cls"].clone(), out["rpn_reg"].clone()
     try:
-        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False)
+        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 64}, {"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 128},
-                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True},
+                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True},
                    {"FUSED_GATHER_GEMM3": True, "FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
-            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False}, **kw))
+            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False}, **kw))
             for g, b, s in zip(got, base, scale):
                 assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
     finally:
         for n, v in saved.items():
             setattr(fastpath, n, v)
+
+
+@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,r", [(2, 4096, 1024, 16, 96, 64, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 1.0), (1, 1024, 256, 16, 256, 128, 196, 1.0),
+                                              (2, 256, 64, 32, 512, 256, 384, 4.0), (1, 512, 128, 16, 8, 64, 20, 1.0)])
+def test_per_point_layer1_equals_the_grouped_product(ops, B, N, M, ns, C, O1, O2, r):
+    """ws3d_pgather_gemm2 / ws3d_pgather_rows (layer 1 as feats @ W_f over the POINTS, gathered per pair, + the centred xyz term)
+    against the float64 product over the grouped rows and against ws3d_gather_gemm(2); P carries a second scale's columns, so
+    the column offset and the row stride are exercised"""
+    rng = np.random.default_rng(16)
+    pc = synth.make_batch("lidar", B, 16384, 65)[:, :N, :3].copy()
+    xyz = dev(pc)
+    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
+    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
+    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
+    other = dev(rng.standard_normal((C, 64)).astype(np.float32))                  # another scale's columns in front
+    pmat = feats.view(B * N, C) @ torch.cat((other, w1[:C]), dim=1)
+    w1x = w1[C:].contiguous()
+    li = nbr.long()
+    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
+    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
+    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
+    h = torch.relu(x @ w1.double() + b1.double())
+    tol = 1e-5 * np.sqrt(max(C, 96) / 96)
+    rows = ops.c.pgather_rows(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True)
+    assert rows is not None and tuple(rows.shape) == (B * M * ns, O1)
+    assert (rows.double() - h).abs().max().item() <= tol * max(h.abs().max().item(), 1.0)
+    assert (rows - ops.c.gather_gemm(feats, xyz, new_xyz, nbr, w1, b1, True)).abs().max().item() <= 2 * tol * max(h.abs().max().item(), 1.0)
+    if O1 <= 128:
+        want = torch.relu(h @ w2.double() + b2.double())
+        got = ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True)
+        assert got is not None and tuple(got.shape) == (B * M * ns, O2)
+        assert (got.double() - want).abs().max().item() <= tol * max(want.abs().max().item(), 1.0)
+        no_act = ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, None, False, w2, None, False)
+        assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2 * tol * max(want.abs().max().item(), 1.0)
+    else:
+        assert ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True) is None

@@ -402,6 +402,41 @@ def gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2
     return True
 
 
+def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2):
+    """layer 1 from the per-point product P = feats @ W_f (pmat (B*N, W) row-major, this scale's columns col0 .. col0 + o1) +
+    the xyz term (w1x (3, o1)) + bias + ReLU, then layer 2 (w2t (o1, O2)): -> (B*M*ns, O2), or None when the shape is not
+    covered (o1 in {64, 128}, O2 % 4, M*ns % 64).  ws3d extension."""
+    dev = _dev(pmat, xyz, new_xyz, nbr, w1x, w2t)
+    _f32(pmat, "pmat"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(nbr, "nbr"); _f32(w1x, "w1x"); _f32(w2t, "w2t")
+    B, N = xyz.size(0), xyz.size(1)
+    M, ns = nbr.size(1), nbr.size(2)
+    O2 = w2t.size(1)
+    if (o1 not in (64, 128) or O2 % 4 or (M * ns) % 64 or pmat.dim() != 2 or pmat.size(0) != B * N or pmat.stride(1) != 1 or
+            col0 < 0 or col0 + o1 > pmat.size(1) or tuple(w1x.shape) != (3, o1) or w2t.size(0) != o1 or not w1x.is_contiguous() or not w2t.is_contiguous()):
+        return None
+    out = torch.empty((B * M * ns, O2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pgather_gemm2(B, N, M, ns, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(nbr), _p(w1x), _p(b1),
+                                             int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), _stream()), "pgather_gemm2")
+    return out
+
+
+def pgather_rows(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1):
+    """layer 1 alone from the per-point product: -> (B*M*ns, o1), or None when the shape is not covered (o1, col0, row stride % 4)."""
+    dev = _dev(pmat, xyz, new_xyz, nbr, w1x)
+    _f32(pmat, "pmat"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(nbr, "nbr"); _f32(w1x, "w1x")
+    B, N = xyz.size(0), xyz.size(1)
+    M, ns = nbr.size(1), nbr.size(2)
+    if (o1 % 4 or col0 % 4 or pmat.dim() != 2 or pmat.size(0) != B * N or pmat.stride(1) != 1 or pmat.stride(0) % 4 or col0 < 0 or
+            col0 + o1 > pmat.size(1) or tuple(w1x.shape) != (3, o1) or not w1x.is_contiguous() or pmat.data_ptr() % 16):
+        return None
+    out = torch.empty((B * M * ns, o1), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pgather_rows(B, N, M, ns, o1, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(nbr), _p(w1x), _p(b1),
+                                            int(bool(relu1)), _p(out), _stream()), "pgather_rows")
+    return out
+
+
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     """first FP-module layer with the interpolation + skip concat fused in: known_feats (B,M,C2), unknown_feats (B,N,C1) or
     None, idx / weight (B,N,3), wt (C2+C1, O) -> (B*N, O), or None when the shape is not covered.  ws3d extension."""

@@ -577,6 +577,133 @@ __global__ __launch_bounds__(256) void gather_gemm2_kernel(int c_feat, int o2, i
     }
 }
 
+// ---- layer 1 of a set-abstraction SharedMLP WITHOUT its per-pair product.  The layer is linear in the grouped row,
+//   W [f_j ; x_j - c] = W_f f_j + W_x (x_j - c),
+// and W_f f_j depends on the SOURCE point j only: P = feats @ W_f is one small GEMM over the n points of a scene instead of a
+// product over its m * ns (centre, sample) pairs -- 12 x fewer rows at SA2..SA4 (ns = 16 + 32 pairs per centre, n = 4 m), i.e.
+// 15 % of all the fp32 matrix work of the network.  What is left per pair is a gather of P's row (O1 floats instead of the C
+// feature channels: half the bytes), the three-term xyz product -- kept in the centred form, so nothing cancels -- bias and ReLU.
+// pgather_gemm2_kernel: that, feeding layer 2 as in gather_gemm2_kernel (the accumulators of layer 1 START at the gathered P
+// values and take two matrix steps for [dx dy dz 0]); pgather_rows_kernel: layer 1 alone (rows x O1), for the widest level.
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm2_kernel(int o2, int n, int m, int ns, const float *__restrict__ pmat, int p_stride,
+                                                            const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                            const int32_t *__restrict__ nbr, const float *__restrict__ w1x,
+                                                            const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                            const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+    constexpr int O1 = NB1 * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float *act = smem2, *w2s = smem2 + O1 * GP_XS;           // act[O1][GP_XS] | w2s[2][GP_KT][64]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const long row0 = (long)blockIdx.x * 64;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    const long scene = row0 / ((long)m * ns);               // a 64-row tile lies inside one scene (m * ns % 64 == 0)
+    // this lane's row of the A operand: the centred coordinates, k = 0..3 -> (dx, dy | dz, 0) over the two halves of the wave
+    float a0, a1;
+    {
+        const long r = row0 + ar;
+        const long cm = r / ns;
+        const int src = nbr[r];
+        const float *pr = xyz + ((size_t)scene * n + (size_t)src) * 3, *cr = new_xyz + (size_t)cm * 3;
+        const float dx = pr[0] - cr[0], dy = pr[1] - cr[1], dz = pr[2] - cr[2];
+        a0 = kh ? dy : dx;
+        a1 = kh ? 0.f : dz;
+    }
+    // accumulators start at P[source point of the row][column]: register v of lane l = row 8 (v / 4) + 4 (l / 32) + v % 4
+    floatx16 acc1[NB1];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int src = nbr[row0 + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4)];
+        const float *prow = pmat + ((size_t)scene * n + (size_t)src) * p_stride + bc;
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) acc1[j][v] = prow[j * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+        const int col = j * 64 + bc;
+        const float wb0 = w1x[kh * O1 + col];                         // k = 0 | 1: the x | y row of W_x
+        const float wb1 = kh ? 0.f : w1x[2 * O1 + col];               // k = 2 | 3: the z row | the zero pad
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb0, acc1[j], 0, 0, 0);
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb1, acc1[j], 0, 0, 0);
+        const float bv = b1 ? b1[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float y = acc1[j][v] + bv;
+            if (relu1) y = y < 0.f ? 0.f : y;
+            act[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4)] = y;
+        }
+    }
+    // layer 2, 64 output columns per pass; W2 tiles (16 x 64) double-buffered (as in gather_gemm2_kernel)
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const int nchunk = (o2 + 63) / 64;
+    constexpr int nt2 = O1 / GP_KT;
+    for (int c = 0; c < nchunk; ++c) {
+        const int col0 = c * 64;
+        auto load_w2 = [&](int t) {
+            const int col = col0 + wc;      // o2 % 4 == 0: a float4 is inside or outside as a whole
+            return col < o2 ? *reinterpret_cast<const float4 *>(w2t + (long)(t * GP_KT + wk) * o2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        floatx16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+        float4 w2v = load_w2(0);
+        __syncthreads();                    // the activation tile is complete / the previous pass has left w2s
+        *reinterpret_cast<float4 *>(w2s + wk * 64 + wc) = w2v;
+        __syncthreads();
+        for (int t = 0; t < nt2; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt2) w2v = load_w2(t + 1);
+            const float *wl = w2s + cur * GP_KT * 64;
+#pragma unroll
+            for (int k = 0; k < GP_KT; k += 2)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act[(t * GP_KT + k + kh) * GP_XS + ar], wl[(k + kh) * 64 + bc], acc2, 0, 0, 0);
+            if (t + 1 < nt2) *reinterpret_cast<float4 *>(w2s + (cur ^ 1) * GP_KT * 64 + wk * 64 + wc) = w2v;
+            __syncthreads();
+        }
+        const int col = col0 + bc;
+        if (col < o2) {
+            const float bv = b2 ? b2[col] : 0.f;
+            float *o = out + (row0 + wm * 32 + 4 * kh) * (long)o2 + col;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float y = acc2[v] + bv;
+                if (relu2) y = y < 0.f ? 0.f : y;
+                o[(long)(8 * (v / 4) + (v % 4)) * o2] = y;
+            }
+        }
+    }
+}
+
+// layer 1 alone: out[r, :] = relu?( P[source of r, :] + W_x (x - c) + b1 ); 64 threads x float4 per 256 columns, rows walked
+__global__ __launch_bounds__(256) void pgather_rows_kernel(long rows, int o1, int n, int m, int ns, const float *__restrict__ pmat, int p_stride,
+                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const int32_t *__restrict__ nbr, const float *__restrict__ w1x,
+                                                           const float *__restrict__ b1, int relu1, float *__restrict__ out) {
+    const int q4 = o1 >> 2;                                   // float4 per row
+    const long total = rows * q4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / q4;
+        const int c4 = (int)(e - r * q4) * 4;
+        const long cm = r / ns, scene = cm / m;
+        const int src = nbr[r];
+        const float *pr = xyz + ((size_t)scene * n + (size_t)src) * 3, *cr = new_xyz + (size_t)cm * 3;
+        const float dx = pr[0] - cr[0], dy = pr[1] - cr[1], dz = pr[2] - cr[2];
+        const float4 pv = *reinterpret_cast<const float4 *>(pmat + ((size_t)scene * n + (size_t)src) * p_stride + c4);
+        const float4 wx = *reinterpret_cast<const float4 *>(w1x + c4), wy = *reinterpret_cast<const float4 *>(w1x + o1 + c4),
+                     wz = *reinterpret_cast<const float4 *>(w1x + 2 * o1 + c4);
+        const float4 bv = b1 ? *reinterpret_cast<const float4 *>(b1 + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 y;
+        // the order of the matrix path: P, + dx wx, + dy wy, + dz wz, + bias
+        y.x = __builtin_fmaf(dz, wz.x, __builtin_fmaf(dy, wy.x, __builtin_fmaf(dx, wx.x, pv.x))) + bv.x;
+        y.y = __builtin_fmaf(dz, wz.y, __builtin_fmaf(dy, wy.y, __builtin_fmaf(dx, wx.y, pv.y))) + bv.y;
+        y.z = __builtin_fmaf(dz, wz.z, __builtin_fmaf(dy, wy.z, __builtin_fmaf(dx, wx.z, pv.z))) + bv.z;
+        y.w = __builtin_fmaf(dz, wz.w, __builtin_fmaf(dy, wy.w, __builtin_fmaf(dx, wx.w, pv.w))) + bv.w;
+        if (relu1) { y.x = y.x < 0.f ? 0.f : y.x; y.y = y.y < 0.f ? 0.f : y.y; y.z = y.z < 0.f ? 0.f : y.z; y.w = y.w < 0.f ? 0.f : y.w; }
+        *reinterpret_cast<float4 *>(out + r * (long)o1 + c4) = y;
+    }
+}
+
 // ---- first layer of a feature-propagation module with the interpolation and the concatenation fused into its A operand:
 //   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, unknown point p),
 //   X[r, 0:c2]      = w0 f[i0, :] + w1 f[i1, :] + w2 f[i2, :]   (three_interpolate, interpolate_gpu.cu:77-97, the same fmaf
@@ -938,6 +1065,45 @@ extern "C" int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_fe
     else          { if (nsample == 16) WS3D_GG3(2, 16) else WS3D_GG3(2, 32) }
 #undef WS3D_GG3
     return check_launch("ws3d_gather_gemm3_pool");
+}
+
+extern "C" int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
+                                  const float *new_xyz, const int32_t *nbr, const float *w1x, const float *b1, int relu1,
+                                  const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    if (b < 0 || n <= 0 || m <= 0 || nsample <= 0 || (o1 != 64 && o1 != 128) || o2 <= 0 || (o2 & 3) || ((long)m * nsample) % 64 || p_stride < o1 ||
+        !pmat || !xyz || !new_xyz || !nbr || !w1x || !w2t || !out || (reinterpret_cast<uintptr_t>(w2t) & 15)) {
+        set_error("ws3d_pgather_gemm2: unsupported shape (b=%d n=%d m=%d ns=%d o1=%d o2=%d; m * ns %% 64, o1 in {64,128}, o2 %% 4)", b, n, m, nsample, o1, o2);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const size_t lds = sizeof(float) * ((size_t)o1 * GP_XS + (size_t)2 * GP_KT * 64);
+    if (o1 == 64)
+        hipLaunchKernelGGL((pgather_gemm2_kernel<1>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), o2, n, m, nsample, pmat, p_stride,
+                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out);
+    else
+        hipLaunchKernelGGL((pgather_gemm2_kernel<2>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), o2, n, m, nsample, pmat, p_stride,
+                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out);
+    return check_launch("ws3d_pgather_gemm2");
+}
+
+extern "C" int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const float *pmat, int p_stride, const float *xyz, const float *new_xyz,
+                                 const int32_t *nbr, const float *w1x, const float *b1, int relu1, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(pmat) | reinterpret_cast<uintptr_t>(w1x) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(out);
+    if (b < 0 || n <= 0 || m <= 0 || nsample <= 0 || o1 <= 0 || (o1 & 3) || p_stride < o1 || (p_stride & 3) || !pmat || !xyz || !new_xyz || !nbr ||
+        !w1x || !out || (al & 15)) {
+        set_error("ws3d_pgather_rows: unsupported shape (b=%d n=%d m=%d ns=%d o1=%d stride=%d; o1, stride %% 4, 16-byte aligned)", b, n, m, nsample, o1, p_stride);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const long units = rows * (o1 >> 2);
+    const unsigned grid = (unsigned)((units + 255) / 256 < 8192 ? (units + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pgather_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, o1, n, m, nsample, pmat, p_stride, xyz, new_xyz, nbr, w1x, b1,
+                       relu1, out);
+    return check_launch("ws3d_pgather_rows");
 }
 
 #ifdef GP_PROF

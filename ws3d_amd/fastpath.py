@@ -38,6 +38,7 @@ GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling c
 # scenes/s, ABAB on one box: 50 KB of LDS per workgroup leave less room beside the other streams' kernels); SA3 is slower either way
 FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
 FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
+PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
@@ -115,6 +116,25 @@ def supported(model) -> bool:
 def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
     return (FUSED_GATHER_GEMM and c_feat >= 16 and c_feat % 4 == 0 and grouper.use_xyz and len(blocks) >= 2 and
             blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
+
+
+def _per_point_l1(sa, feats: torch.Tensor, nbrs):
+    """(P, column offsets, [W_x per scale]): P = feats (B*N, C) @ [W_f of every scale whose first layer gathers its own rows]"""
+    B, N, C = feats.shape
+    wts = [(_row_weights_xyz_last(_blocks(mlp)[0])[0] if nbr is not None else None) for mlp, nbr in zip(sa.mlps, nbrs)]
+    cache = sa.__dict__.get("_pp_cache")
+    if cache is None or len(cache[0]) != len(wts) or any(a is not b for a, b in zip(cache[0], wts)):
+        used = [w for w in wts if w is not None]
+        wcat = torch.cat([w[:C] for w in used], dim=1).contiguous()                      # (C, sum O1)
+        offs, w1xs, o = [], [], 0
+        for w in wts:
+            offs.append(o if w is not None else -1)
+            w1xs.append(w[C:C + 3].contiguous() if w is not None else None)
+            o += w.size(1) if w is not None else 0
+        cache = (wts, wcat, offs, w1xs)
+        if not torch.cuda.is_current_stream_capturing():
+            sa.__dict__["_pp_cache"] = cache
+    return torch.mm(feats.view(B * N, C), cache[1]), cache[2], cache[3]
 
 
 def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
@@ -225,11 +245,35 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
     out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     col = 0
-    for grouper, mlp, width, nbr in zip(sa.groupers, sa.mlps, widths, nbrs):
+    pp = None
+    for si, (grouper, mlp, width, nbr) in enumerate(zip(sa.groupers, sa.mlps, widths, nbrs)):
         blocks = _blocks(mlp)
         if nbr is not None:
             # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
             wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
+            if PER_POINT_L1 and len(blocks) >= 3:
+                # layer 1 is linear in the grouped row: its feature part is ONE product over the level's points (both scales in
+                # one GEMM), the pairs only gather that row and add the xyz term
+                if pp is None:
+                    pp = _per_point_l1(sa, feats, nbrs)
+                pmat, offs, w1xs = pp
+                o1 = blocks[0].conv.out_channels
+                y = None
+                if o1 <= 128:
+                    wt2, b2, r2 = _row_weights(blocks[1])
+                    y = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2)
+                    rest_pp = blocks[2:-1]
+                if y is None:
+                    y = _C.pgather_rows(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1)
+                    rest_pp = blocks[1:-1]
+                if y is not None:
+                    for blk in rest_pp:
+                        y = _layer(y, blk)
+                    wt, bias, relu = _row_weights(blocks[-1])
+                    if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
+                        _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
+                    col += width
+                    continue
             if (FUSED_GATHER_GEMM3 and len(blocks) == 3 and blocks[0].conv.out_channels <= FUSED_GATHER_GEMM3_MAX_O1 and
                     _C.gather_gemm3_pool(feats, xyz, new_xyz, nbr, wt1, b1, r1, *_row_weights(blocks[1]), *_row_weights(blocks[2]), out, col)):
                 col += width       # the whole SharedMLP + pool in one kernel: only the pooled rows reach HBM
