@@ -210,6 +210,15 @@ WS3D_API int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2
 WS3D_API int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const float *pmat, int p_stride, const float *xyz, const float *new_xyz,
                       const int32_t *nbr, const float *w1x, const float *b1, int relu1, float *out, ws3d_stream_t stream);
 
+/* First layer of a feature-propagation module without its product over the interpolated channels: interpolation is linear,
+ * so Q = known_feats @ W_a (b * m rows, o columns, by the caller: a product over the KNOWN points) is interpolated instead of the
+ * features:  out[r, :] = relu?( w0 Q[i0] + w1 Q[i1] + w2 Q[i2] + lin[r, :] )  with lin = skip @ W_b + bias (rows, o) from the
+ * caller, or, lin == NULL and c1 <= 4 skip channels, skip (rows, c1) @ wb (c1, o) + bias evaluated inside.  idx / weight
+ * (b, n, 3) as three_interpolate's (interpolate.cpp:37-56).  o % 4 == 0, float pointers 16-byte aligned.  Same function as
+ * ws3d_interp_gemm up to fp32 summation order.  ws3d extension, used by ws3d_amd/fastpath.py.                              */
+WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const int32_t *idx, const float *weight, const float *lin,
+                      const float *skip, int c1, const float *wb, const float *bias, int relu, float *out, ws3d_stream_t stream);
+
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
  * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +

@@ -1818,7 +1818,7 @@ def test_fast_path_switches_agree(ops):
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1")
+    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -1828,14 +1828,14 @@ def test_fast_path_switches_agree(ops):
             out = model.rpn_forward({"pts_input": pts})
         return out["rpn_cls"].clone(), out["rpn_reg"].clone()
     try:
-        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False)
+        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False, PER_POINT_FP=False)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 64}, {"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 128},
-                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True},
+                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True},
                    {"FUSED_GATHER_GEMM3": True, "FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
-            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False}, **kw))
+            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False}, **kw))
             for g, b, s in zip(got, base, scale):
                 assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
     finally:
@@ -1881,3 +1881,41 @@ def test_per_point_layer1_equals_the_grouped_product(ops, B, N, M, ns, C, O1, O2
         assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2 * tol * max(want.abs().max().item(), 1.0)
     else:
         assert ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True) is None
+
+
+@pytest.mark.parametrize("B,N,M,C2,C1,O", [(2, 4096, 1024, 256, 96, 256), (1, 16384, 4096, 128, 1, 128), (2, 1024, 256, 512, 256, 512),
+                                           (2, 256, 64, 512, 512, 512), (2, 1024, 256, 128, 0, 64), (1, 300, 70, 64, 3, 20)])
+def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
+    """ws3d_qinterp_rows (first FP layer as the interpolation of Q = known_feats @ W_a + the skip channels' product) against
+    three_interpolate + concat + float64 product, and against ws3d_interp_gemm where that applies; both skip forms (lin from
+    a GEMM, <= 4 channels evaluated inside), no skip, no bias"""
+    rng = np.random.default_rng(17)
+    pc = synth.make_batch("lidar", B, 16384, 66)[:, :N, :3].copy()
+    unknown = dev(pc)
+    known = unknown[:, ::max(N // M, 1)][:, :M].contiguous()
+    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
+    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
+    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
+    wt = dev((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32))
+    bias = dev(rng.standard_normal(O).astype(np.float32))
+    interp = torch.empty((B, N, C2), device="cuda")
+    ops.c.three_interpolate_nlc(kf, idx, weight, interp)
+    x = interp if uf is None else torch.cat((interp, uf), dim=2)
+    want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
+    q = (kf.view(B * M, C2) @ wt[:C2]).view(B, M, O)
+    tol = 6e-6 * max(want.abs().max().item(), 1.0) * np.sqrt((C2 + C1) / 96)
+    if C1 > 4:
+        lin = torch.addmm(bias, uf.view(B * N, C1), wt[C2:].contiguous())
+        got = ops.c.qinterp_rows(q, idx, weight, lin=lin, relu=True)
+    else:
+        got = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=bias, relu=True)
+    assert got is not None and tuple(got.shape) == (B * N, O)
+    assert (got.double() - want).abs().max().item() <= tol
+    if O % 64 == 0 and (B * N) % 64 == 0:
+        fused = ops.c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
+        if fused is not None:
+            assert (got - fused).abs().max().item() <= 2 * tol
+    if C1 <= 4:
+        nb = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=None, relu=False)
+        assert (nb.double() - x.view(-1, C2 + C1).double() @ wt.double()).abs().max().item() <= tol
+        assert ops.c.qinterp_rows(q[:, :, :O - 1].contiguous(), idx, weight, relu=True) is None if (O - 1) % 4 else True

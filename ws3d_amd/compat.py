@@ -437,6 +437,25 @@ def pgather_rows(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1):
     return out
 
 
+def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=True):
+    """first FP layer from the per-KNOWN-point product Q = known_feats @ W_a (B, M, O): interpolate Q's rows (idx / weight (B, N, 3)),
+    add lin (B*N, O) = skip @ W_b + bias -- or, lin None and <= 4 skip channels, skip (B, N, C1) @ wb (C1, O) + bias -- and ReLU:
+    -> (B*N, O), or None when the shape is not covered.  ws3d extension."""
+    dev = _dev(q, idx, weight)
+    _f32(q, "q"); _i32(idx, "idx"); _f32(weight, "weight")
+    B, M, O = q.shape
+    N = idx.size(1)
+    c1 = 0 if skip is None else skip.size(2)
+    if (O % 4 or not q.is_contiguous() or (lin is None and c1 > 4) or (lin is not None and (tuple(lin.shape) != (B * N, O) or not lin.is_contiguous())) or
+            (lin is None and c1 > 0 and (wb is None or tuple(wb.shape) != (c1, O) or not wb.is_contiguous() or not skip.is_contiguous()))):
+        return None
+    out = torch.empty((B * N, O), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_qinterp_rows(B, N, M, O, _p(q), _p(idx), _p(weight), _p(lin), _p(skip), c1, _p(wb), _p(bias), int(bool(relu)), _p(out),
+                                            _stream()), "qinterp_rows")
+    return out
+
+
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     """first FP-module layer with the interpolation + skip concat fused in: known_feats (B,M,C2), unknown_feats (B,N,C1) or
     None, idx / weight (B,N,3), wt (C2+C1, O) -> (B*N, O), or None when the shape is not covered.  ws3d extension."""

@@ -704,6 +704,49 @@ __global__ __launch_bounds__(256) void pgather_rows_kernel(long rows, int o1, in
     }
 }
 
+// ---- first layer of a feature-propagation module WITHOUT its per-point product over the interpolated channels.  Interpolation
+// is linear, so  W_a (w0 f[i0] + w1 f[i1] + w2 f[i2]) = w0 (W_a f)[i0] + w1 (W_a f)[i1] + w2 (W_a f)[i2]:  Q = known_feats @ W_a
+// is one product over the m KNOWN points (a quarter of the unknown ones), and the layer is
+//   out[r, :] = relu?( w0 Q[i0, :] + w1 Q[i1, :] + w2 Q[i2, :] + lin[r, :] ),   lin = skip @ W_b + bias
+// where lin comes from a GEMM over the skip channels only (lin != NULL), or -- c1 <= 4 skip channels (FP1: one) -- is
+// evaluated here as fmaf chains over skip[r, 0:c1] and wb (c1, o).  The interpolation uses three_interpolate's expression
+// (interpolate_gpu.cu:77-97) on Q's rows.  One float4 of a row per thread.
+__global__ __launch_bounds__(256) void qinterp_rows_kernel(long rows, int o, int n, int m, const float *__restrict__ q, const int32_t *__restrict__ idx3,
+                                                           const float *__restrict__ w3, const float *__restrict__ lin,
+                                                           const float *__restrict__ skip, int c1, const float *__restrict__ wb,
+                                                           const float *__restrict__ bias, int relu, float *__restrict__ out) {
+    const int q4 = o >> 2;
+    const long total = rows * q4;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long r = e / q4;
+        const int c4 = (int)(e - r * q4) * 4;
+        const long scene = r / n;
+        const int i0 = idx3[r * 3 + 0], i1 = idx3[r * 3 + 1], i2 = idx3[r * 3 + 2];
+        const float w0 = w3[r * 3 + 0], w1 = w3[r * 3 + 1], w2 = w3[r * 3 + 2];
+        const float *qb = q + (size_t)scene * m * o + c4;
+        const float4 p0 = *reinterpret_cast<const float4 *>(qb + (size_t)i0 * o), p1 = *reinterpret_cast<const float4 *>(qb + (size_t)i1 * o),
+                     p2 = *reinterpret_cast<const float4 *>(qb + (size_t)i2 * o);
+        float4 y = make_float4(__builtin_fmaf(w2, p2.x, __builtin_fmaf(w0, p0.x, w1 * p1.x)), __builtin_fmaf(w2, p2.y, __builtin_fmaf(w0, p0.y, w1 * p1.y)),
+                               __builtin_fmaf(w2, p2.z, __builtin_fmaf(w0, p0.z, w1 * p1.z)), __builtin_fmaf(w2, p2.w, __builtin_fmaf(w0, p0.w, w1 * p1.w)));
+        if (lin) {
+            const float4 l4 = *reinterpret_cast<const float4 *>(lin + r * (long)o + c4);
+            y.x += l4.x; y.y += l4.y; y.z += l4.z; y.w += l4.w;
+        } else {
+            for (int k = 0; k < c1; ++k) {
+                const float sv = skip[r * (long)c1 + k];
+                const float4 wv = *reinterpret_cast<const float4 *>(wb + (long)k * o + c4);
+                y.x = __builtin_fmaf(sv, wv.x, y.x); y.y = __builtin_fmaf(sv, wv.y, y.y); y.z = __builtin_fmaf(sv, wv.z, y.z); y.w = __builtin_fmaf(sv, wv.w, y.w);
+            }
+            if (bias) {
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + c4);
+                y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+            }
+        }
+        if (relu) { y.x = y.x < 0.f ? 0.f : y.x; y.y = y.y < 0.f ? 0.f : y.y; y.z = y.z < 0.f ? 0.f : y.z; y.w = y.w < 0.f ? 0.f : y.w; }
+        *reinterpret_cast<float4 *>(out + r * (long)o + c4) = y;
+    }
+}
+
 // ---- first layer of a feature-propagation module with the interpolation and the concatenation fused into its A operand:
 //   out[r, o] = relu?( sum_k X[r, k] Wt[k, o] + bias[o] ),   r = (scene b, unknown point p),
 //   X[r, 0:c2]      = w0 f[i0, :] + w1 f[i1, :] + w2 f[i2, :]   (three_interpolate, interpolate_gpu.cu:77-97, the same fmaf
@@ -1104,6 +1147,25 @@ extern "C" int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const
     hipLaunchKernelGGL(pgather_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, o1, n, m, nsample, pmat, p_stride, xyz, new_xyz, nbr, w1x, b1,
                        relu1, out);
     return check_launch("ws3d_pgather_rows");
+}
+
+extern "C" int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const int32_t *idx, const float *weight, const float *lin,
+                                 const float *skip, int c1, const float *wb, const float *bias, int relu, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * n;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(wb) |
+                         reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(out);
+    if (b < 0 || n <= 0 || m <= 0 || o <= 0 || (o & 3) || !q || !idx || !weight || !out || (al & 15) || c1 < 0 ||
+        (!lin && c1 > 0 && (!skip || !wb)) || (!lin && c1 > 4)) {
+        set_error("ws3d_qinterp_rows: unsupported shape (b=%d n=%d m=%d o=%d c1=%d; o %% 4, 16-byte aligned, c1 <= 4 without lin)", b, n, m, o, c1);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const long units = rows * (o >> 2);
+    const unsigned grid = (unsigned)((units + 255) / 256 < 16384 ? (units + 255) / 256 : 16384);
+    hipLaunchKernelGGL(qinterp_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, o, n, m, q, idx, weight, lin, skip, lin ? 0 : c1, wb, bias,
+                       relu, out);
+    return check_launch("ws3d_qinterp_rows");
 }
 
 #ifdef GP_PROF

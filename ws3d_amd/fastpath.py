@@ -39,6 +39,7 @@ GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling c
 FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
 FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
+PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
@@ -66,6 +67,16 @@ def _row_weights_xyz_last(block):
         if not torch.cuda.is_current_stream_capturing():
             block.__dict__["_row_cache_xyz_last"] = cache
     return cache[1], bias, relu
+
+
+def _split_rows(block, wt: torch.Tensor, c2: int):
+    """(wt[:c2], wt[c2:]) as contiguous matrices, cached on the block (the interpolated / the skip channels of an FP module's first layer)"""
+    cache = block.__dict__.get("_split_cache")
+    if cache is None or cache[0] is not wt or cache[1] != c2:
+        cache = (wt, c2, wt[:c2].contiguous(), wt[c2:].contiguous())
+        if not torch.cuda.is_current_stream_capturing():
+            block.__dict__["_split_cache"] = cache
+    return cache[2], cache[3]
 
 
 def _layer(x2d: torch.Tensor, block) -> torch.Tensor:
@@ -327,6 +338,22 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
     blocks = _blocks(fp.mlp)
     # (the fused kernel has no split-K: the deepest module -- 2048 rows x K = 1536 at batch 8, 256 workgroups of 96 k-tiles -- is
     # faster as interpolate + library GEMM, 55 vs 84 us)
+    if PER_POINT_FP and blocks and blocks[0].conv.out_channels % 4 == 0:
+        # interpolation is linear: the first layer's product over the interpolated channels is taken over the KNOWN points
+        # (a quarter of the rows), the skip channels over the unknown ones, and one row kernel interpolates + adds + ReLU
+        wt1, b1, r1 = _row_weights(blocks[0])
+        wa, wb = _split_rows(blocks[0], wt1, c2)
+        m = known_feats.size(1)
+        q = torch.mm(known_feats.reshape(B * m, c2), wa).view(B, m, -1)
+        if c1 > 4:
+            lin = torch.mm(unknown_feats.reshape(B * n, c1), wb) if b1 is None else torch.addmm(b1, unknown_feats.reshape(B * n, c1), wb)
+            y = _C.qinterp_rows(q, idx, weight, lin=lin, relu=r1)
+        else:
+            y = _C.qinterp_rows(q, idx, weight, skip=None if c1 == 0 else unknown_feats.contiguous(), wb=wb if c1 else None, bias=b1, relu=r1)
+        if y is not None:
+            for blk in blocks[1:]:
+                y = _layer(y, blk)
+            return y.view(B, n, -1)
     if FUSED_INTERP_GEMM and blocks and blocks[0].conv.out_channels % 64 == 0 and B * n >= 8192:
         wt1, b1, r1 = _row_weights(blocks[0])
         y = _C.interp_gemm(known_feats.contiguous(), None if unknown_feats is None else unknown_feats.contiguous(), idx, weight, wt1, b1, r1)
