@@ -219,6 +219,26 @@ WS3D_API int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const f
 WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const int32_t *idx, const float *weight, const float *lin,
                       const float *skip, int c1, const float *wb, const float *bias, int relu, float *out, ws3d_stream_t stream);
 
+/* Compact (centre, sample) pairs.  A ball-query list holds its hits in ascending order, padded with the first one
+ * (ball_query_gpu.cu:29-44); a padded row repeats row 0 of its centre in every SharedMLP layer and cannot change the maximum over
+ * nsample, so the layers may run over the DISTINCT pairs only -- bit-identical results.
+ *   ws3d_compact_pairs_count: cnt[c] = number of distinct neighbours of centre c (centres = b * m rows of nbr (centres, nsample))
+ *   ws3d_compact_pairs_rows:  with incl = the INCLUSIVE prefix sum of cnt (by the caller): rowc[t] / rowsrc[t] = centre / source
+ *                             point of compact row t, *total = incl[centres - 1]; rowc, rowsrc hold centres * nsample ints
+ *   ws3d_pgather_gemm2_compact: ws3d_pgather_gemm2 over the compact rows (o1 in {64, 128, 256}) -> out (total rows, o2); launched for max_rows rows,
+ *                             workgroups beyond *total return at once
+ *   ws3d_gemm_pool_compact:   last layer + ReLU + max over each centre's rows by integer atomic max into out[centre, 0:o_dim]
+ *                             (row stride out_stride), which the caller ZEROES first; the layer must end in a ReLU
+ * ws3d extensions, used by ws3d_amd/fastpath.py.                                                                          */
+WS3D_API int ws3d_compact_pairs_count(long centres, int nsample, const int32_t *nbr, int32_t *cnt, ws3d_stream_t stream);
+WS3D_API int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t *nbr, const int32_t *cnt, const int32_t *incl, int32_t *rowc,
+                            int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);
+WS3D_API int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
+                               const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
+                               const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream);
+WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
+                           const float *wt, const float *bias, float *out, int out_stride, ws3d_stream_t stream);
+
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
  * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +

@@ -1818,7 +1818,7 @@ def test_fast_path_switches_agree(ops):
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP")
+    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -1828,14 +1828,14 @@ def test_fast_path_switches_agree(ops):
             out = model.rpn_forward({"pts_input": pts})
         return out["rpn_cls"].clone(), out["rpn_reg"].clone()
     try:
-        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False, PER_POINT_FP=False)
+        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False, PER_POINT_FP=False, COMPACT_PAIRS=False)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 64}, {"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 128},
-                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True},
+                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
                    {"FUSED_GATHER_GEMM3": True, "FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
-            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False}, **kw))
+            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False}, **kw))
             for g, b, s in zip(got, base, scale):
                 assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
     finally:
@@ -1919,3 +1919,56 @@ def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
         nb = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=None, relu=False)
         assert (nb.double() - x.view(-1, C2 + C1).double() @ wt.double()).abs().max().item() <= tol
         assert ops.c.qinterp_rows(q[:, :, :O - 1].contiguous(), idx, weight, relu=True) is None if (O - 1) % 4 else True
+
+
+@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),
+                                                  (1, 1024, 256, 32, 256, 128, 196, 256, 2.0), (2, 4096, 1024, 32, 96, 64, 96, 128, 6.0),
+                                                  (2, 256, 64, 32, 512, 256, 384, 512, 4.0), (1, 512, 37, 16, 8, 64, 20, 64, 0.01)])
+def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, C, O1, O2, O3, r):
+    """the SharedMLP over the DISTINCT (centre, sample) pairs (ws3d_compact_pairs_* / ws3d_pgather_gemm2_compact /
+    ws3d_gemm_pool_compact) gives exactly the pooled rows of the dense kernels: padded rows repeat row 0 of their centre.  Radii
+    from "every list is one point" (0.01) over the network's to "every list is full" (6.0); the pair table itself is checked
+    against the lists"""
+    rng = np.random.default_rng(18)
+    pc = synth.make_batch("lidar", B, 16384, 67)[:, :N, :3].copy()
+    xyz = dev(pc)
+    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
+    rowc, rowsrc, total = ops.c.compact_pairs(nbr)
+    T = int(total.item())
+    want_pairs = []
+    nb = host(nbr).reshape(B * M, ns)
+    for c_ in range(B * M):
+        row = nb[c_]
+        k = 1 + int((row[1:] > row[:-1]).sum())
+        assert len(set(row[:k].tolist())) == k and set(row.tolist()) == set(row[:k].tolist())
+        want_pairs += [(c_, int(v)) for v in row[:k]]
+    assert T == len(want_pairs)
+    assert list(zip(host(rowc)[:T].tolist(), host(rowsrc)[:T].tolist())) == want_pairs
+    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
+    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
+    w3 = dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)); b3 = dev(rng.standard_normal(O3).astype(np.float32))
+    pmat = feats.view(B * N, C) @ w1[:C]
+    w1x = w1[C:].contiguous()
+    dense = torch.empty((B * M, O3), device="cuda")
+    y = ops.c.pgather_gemm2(pmat, 0, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True) if (M * ns) % 64 == 0 else None
+    if y is not None and ops.c.gemm_pool(y, w3, b3, True, ns, dense, 0):
+        pass
+    else:   # shapes the dense kernels decline: the float64 chain decides (round-off instead of bit-equality)
+        dense = None
+    out = torch.zeros((B * M, O3 + 64), device="cuda")
+    yc = ops.c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True)
+    assert yc is not None and ops.c.gemm_pool_compact(yc, (rowc, rowsrc, total), w3, b3, out, 64)
+    assert bool((out[:, :64] == 0).all())
+    if dense is not None:
+        assert torch.equal(out[:, 64:], dense)
+    li = nbr.long()
+    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
+    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
+    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
+    h = torch.relu(torch.relu(x @ w1.double() + b1.double()) @ w2.double() + b2.double())
+    want = torch.relu(h @ w3.double() + b3.double()).view(B * M, ns, O3).amax(dim=1)
+    assert (out[:, 64:].double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0) * np.sqrt(max(C, 96) / 96)

@@ -456,6 +456,65 @@ def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=T
     return out
 
 
+def compact_pairs(nbr):
+    """(B, M, ns) ball-query lists -> (rowc, rowsrc, total): the DISTINCT (centre, source point) pairs as compact rows (int32
+    tensors of B*M*ns entries, the first `total` -- a 1-element device tensor -- valid); a list's padding repeats its first hit
+    and cannot change any layer's maximum over nsample.  ws3d extension."""
+    dev = _dev(nbr)
+    _i32(nbr, "nbr")
+    B, M, ns = nbr.shape
+    centres = B * M
+    cnt = torch.empty(centres, dtype=torch.int32, device=dev)
+    rowc = torch.empty(centres * ns, dtype=torch.int32, device=dev)
+    rowsrc = torch.empty(centres * ns, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        lib = _lib.load()
+        check(lib.ws3d_compact_pairs_count(centres, ns, _p(nbr), _p(cnt), _stream()), "compact_pairs_count")
+        incl = torch.cumsum(cnt, dim=0, dtype=torch.int32)
+        check(lib.ws3d_compact_pairs_rows(centres, ns, _p(nbr), _p(cnt), _p(incl), _p(rowc), _p(rowsrc), _p(total), _stream()), "compact_pairs_rows")
+    return rowc, rowsrc, total
+
+
+def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w2t, b2, relu2):
+    """pgather_gemm2 over the compact rows of compact_pairs: -> (B*M*ns, O2) of which the first `total` rows are written, or None
+    when the shape is not covered (o1 in {64, 128, 256}, O2 % 4).  ws3d extension."""
+    rowc, rowsrc, total = pairs
+    dev = _dev(pmat, xyz, new_xyz, rowc, w1x, w2t)
+    _f32(pmat, "pmat"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(w1x, "w1x"); _f32(w2t, "w2t")
+    B, N = xyz.size(0), xyz.size(1)
+    M = new_xyz.size(1)
+    O2 = w2t.size(1)
+    rows = rowc.numel()
+    if (o1 not in (64, 128, 256) or O2 % 4 or pmat.dim() != 2 or pmat.size(0) != B * N or pmat.stride(1) != 1 or col0 < 0 or col0 + o1 > pmat.size(1) or
+            tuple(w1x.shape) != (3, o1) or w2t.size(0) != o1 or not w1x.is_contiguous() or not w2t.is_contiguous()):
+        return None
+    out = torch.empty((rows, O2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_pgather_gemm2_compact(B, N, M, rows, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc),
+                                                     _p(rowsrc), _p(total), _p(w1x), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out),
+                                                     _stream()), "pgather_gemm2_compact")
+    return out
+
+
+def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset):
+    """last SharedMLP layer (+ bias + ReLU) over the compact rows + max over each centre's rows, by atomic max into
+    out2d[:, col_offset : col_offset + O] -- which must be ZERO on entry.  True, or False when the shape is not covered
+    (K % 4, O % 64).  ws3d extension."""
+    rowc, rowsrc, total = pairs
+    dev = _dev(x_rows, rowc, wt, out2d)
+    _f32(x_rows, "x_rows"); _f32(wt, "wt"); _f32(out2d, "out2d")
+    rows, k = x_rows.shape
+    o = wt.size(1)
+    if (k % 4 or o % 64 or wt.size(0) != k or rows != rowc.numel() or not x_rows.is_contiguous() or not wt.is_contiguous() or out2d.dim() != 2 or
+            out2d.stride(1) != 1 or col_offset < 0 or col_offset + o > out2d.size(1)):
+        return False
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_gemm_pool_compact(rows, k, o, _p(x_rows), _p(rowc), _p(total), _p(wt), _p(bias), out2d.data_ptr() + 4 * col_offset,
+                                                 out2d.stride(0), _stream()), "gemm_pool_compact")
+    return True
+
+
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
     """first FP-module layer with the interpolation + skip concat fused in: known_feats (B,M,C2), unknown_feats (B,N,C1) or
     None, idx / weight (B,N,3), wt (C2+C1, O) -> (B*N, O), or None when the shape is not covered.  ws3d extension."""

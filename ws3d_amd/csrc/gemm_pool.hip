@@ -704,6 +704,200 @@ __global__ __launch_bounds__(256) void pgather_rows_kernel(long rows, int o1, in
     }
 }
 
+// ---- compact (centre, sample) pairs.  A ball-query list holds its hits in ascending order and is padded with the first one
+// (ball_query_gpu.cu:29-44): every padded row of the grouped tensor repeats row 0 of its centre, gives the same activations in
+// every layer and cannot change the maximum over nsample.  On FPS-sampled lidar most of a list is padding (synthetic KITTI-shaped
+// clouds: 1.0-2.1 distinct neighbours of 16 / 32; centres are spread evenly over space, points are not), so the SharedMLP is run
+// over the DISTINCT pairs only: cnt[c] = 1 + #{s >= 1: nbr[c][s] > nbr[c][s-1]}, an exclusive prefix sum gives each centre its
+// first compact row, pair_rows_kernel writes (centre, source point) per compact row, the layer kernels walk those rows --
+// launched for the worst case, tiles beyond the total (a device-side number) return at once -- and the last layer reduces
+// with an atomic max into the centre's row (bias and ReLU first: values >= 0 order as integers; the output starts at 0).
+// Bit-identical to the dense path: a row's activations do not depend on which rows share its tile.
+__global__ __launch_bounds__(256) void pair_count_kernel(long centres, int ns, const int32_t *__restrict__ nbr, int32_t *__restrict__ cnt) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= centres) return;
+    const int32_t *row = nbr + c * ns;
+    int k = 1, prev = row[0];
+    for (int s2 = 1; s2 < ns; ++s2) { const int v = row[s2]; k += v > prev; prev = v; }
+    cnt[c] = k;
+}
+
+__global__ __launch_bounds__(256) void pair_rows_kernel(long centres, int ns, const int32_t *__restrict__ nbr, const int32_t *__restrict__ cnt,
+                                                        const int32_t *__restrict__ incl, int32_t *__restrict__ rowc, int32_t *__restrict__ rowsrc,
+                                                        int32_t *__restrict__ total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= centres * ns) return;
+    const long c = e / ns;
+    const int s2 = (int)(e - c * ns);
+    const int k = cnt[c], first = incl[c] - k;              // incl: inclusive prefix sum of cnt
+    if (s2 < k) { rowc[first + s2] = (int32_t)c; rowsrc[first + s2] = nbr[e]; }
+    if (e == 0) *total = incl[centres - 1];
+}
+
+// pgather_gemm2_kernel over compact rows: (centre, source) per row from rowc / rowsrc, *total rows in all
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int n, int m, const float *__restrict__ pmat, int p_stride,
+                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                                    const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+    constexpr int O1 = NB1 * 64;
+    const long T = *total;
+    const long row0 = (long)blockIdx.x * 64;
+    if (row0 >= T) return;                                   // workgroup-uniform
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    float *act = smem2, *w2s = smem2 + O1 * GP_XS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    float a0, a1;
+    {
+        const long t = min(row0 + ar, T - 1);                // rows behind the end repeat the last one (never stored)
+        const long cm = rowc[t];
+        const long scene = cm / m;
+        const int src = rowsrc[t];
+        const float *pr = xyz + ((size_t)scene * n + (size_t)src) * 3, *cr = new_xyz + (size_t)cm * 3;
+        const float dx = pr[0] - cr[0], dy = pr[1] - cr[1], dz = pr[2] - cr[2];
+        a0 = kh ? dy : dx;
+        a1 = kh ? 0.f : dz;
+    }
+    floatx16 acc1[NB1];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long t = min(row0 + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4), T - 1);
+        const long scene = rowc[t] / m;
+        const float *prow = pmat + ((size_t)scene * n + (size_t)rowsrc[t]) * p_stride + bc;
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) acc1[j][v] = prow[j * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+        const int col = j * 64 + bc;
+        const float wb0 = w1x[kh * O1 + col];
+        const float wb1 = kh ? 0.f : w1x[2 * O1 + col];
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb0, acc1[j], 0, 0, 0);
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb1, acc1[j], 0, 0, 0);
+        const float bv = b1 ? b1[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float y = acc1[j][v] + bv;
+            if (relu1) y = y < 0.f ? 0.f : y;
+            act[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4)] = y;
+        }
+    }
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const int nchunk = (o2 + 63) / 64;
+    constexpr int nt2 = O1 / GP_KT;
+    for (int c = 0; c < nchunk; ++c) {
+        const int col0 = c * 64;
+        auto load_w2 = [&](int t) {
+            const int col = col0 + wc;
+            return col < o2 ? *reinterpret_cast<const float4 *>(w2t + (long)(t * GP_KT + wk) * o2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        floatx16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+        float4 w2v = load_w2(0);
+        __syncthreads();
+        *reinterpret_cast<float4 *>(w2s + wk * 64 + wc) = w2v;
+        __syncthreads();
+        for (int t = 0; t < nt2; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt2) w2v = load_w2(t + 1);
+            const float *wl = w2s + cur * GP_KT * 64;
+#pragma unroll
+            for (int k = 0; k < GP_KT; k += 2)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act[(t * GP_KT + k + kh) * GP_XS + ar], wl[(k + kh) * 64 + bc], acc2, 0, 0, 0);
+            if (t + 1 < nt2) *reinterpret_cast<float4 *>(w2s + (cur ^ 1) * GP_KT * 64 + wk * 64 + wc) = w2v;
+            __syncthreads();
+        }
+        const int col = col0 + bc;
+        if (col < o2) {
+            const float bv = b2 ? b2[col] : 0.f;
+            const long rb = row0 + wm * 32 + 4 * kh;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long t = rb + 8 * (v / 4) + (v % 4);
+                float y = acc2[v] + bv;
+                if (relu2) y = y < 0.f ? 0.f : y;
+                if (t < T) out[t * (long)o2 + col] = y;
+            }
+        }
+    }
+}
+
+// last layer over compact rows + max over each centre's rows: out[centre, col] = max(out, relu(x W + b)) by integer atomic max
+// (out starts at 0, every candidate is >= 0 after the ReLU: the float order is the integer order)
+__global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o_dim, const float *__restrict__ x, const int32_t *__restrict__ rowc,
+                                                                const int32_t *__restrict__ total, const float *__restrict__ wt,
+                                                                const float *__restrict__ bias, float *__restrict__ out, int out_stride) {
+    const long T = *total;
+    const int col_tiles = o_dim / 64;
+    const long row_tile = blockIdx.x / col_tiles;
+    const int col_tile = (int)(blockIdx.x - row_tile * col_tiles);
+    const long row0 = row_tile * 64;
+    if (row0 >= T) return;
+    __shared__ float xs[2][GP_KT][GP_XS];
+    __shared__ float ws[2][GP_KT][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int col0 = col_tile * 64;
+    const int xr = tid >> 2, xk = (tid & 3) * 4;
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const float *xp = x + min(row0 + xr, T - 1) * (long)k_dim;
+    auto load_x = [&](int k0) {
+        const int k = k0 + xk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(xp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto load_w = [&](int k0) {
+        const int k = k0 + wk;
+        return k < k_dim ? *reinterpret_cast<const float4 *>(wt + (long)k * o_dim + col0 + wc) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto stage = [&](int buf, const float4 xv, const float4 wv) {
+        xs[buf][xk + 0][xr] = xv.x; xs[buf][xk + 1][xr] = xv.y; xs[buf][xk + 2][xr] = xv.z; xs[buf][xk + 3][xr] = xv.w;
+        *reinterpret_cast<float4 *>(&ws[buf][wk][wc]) = wv;
+    };
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float4 xv = load_x(0), wv = load_w(0);
+    stage(0, xv, wv);
+    __syncthreads();
+    const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) { xv = load_x((t + 1) * GP_KT); wv = load_w((t + 1) * GP_KT); }
+#pragma unroll
+        for (int k = 0; k < GP_KT; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[cur][k + kh][ar], ws[cur][k + kh][bc], acc, 0, 0, 0);
+        if (t + 1 < ntiles) stage(cur ^ 1, xv, wv);
+        __syncthreads();
+    }
+    const int col = col0 + bc;
+    const float bv = bias ? bias[col] : 0.f;
+    const long rb = row0 + wm * 32 + 4 * kh;
+    // consecutive rows mostly belong to one centre: combine runs inside the lane's 16 rows before touching memory
+    long prev_c = -1;
+    float run = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long t = rb + 8 * (v / 4) + (v % 4);
+        if (t >= T) continue;
+        const long c = rowc[t];
+        float y = acc[v] + bv;
+        y = y < 0.f ? 0.f : y;
+        if (c != prev_c) {
+            if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + prev_c * out_stride + col), __float_as_int(run));
+            prev_c = c; run = y;
+        } else {
+            run = y > run ? y : run;
+        }
+    }
+    if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + prev_c * out_stride + col), __float_as_int(run));
+}
+
 // ---- first layer of a feature-propagation module WITHOUT its per-point product over the interpolated channels.  Interpolation
 // is linear, so  W_a (w0 f[i0] + w1 f[i1] + w2 f[i2]) = w0 (W_a f)[i0] + w1 (W_a f)[i1] + w2 (W_a f)[i2]:  Q = known_feats @ W_a
 // is one product over the m KNOWN points (a quarter of the unknown ones), and the layer is
@@ -1166,6 +1360,66 @@ extern "C" int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, con
     hipLaunchKernelGGL(qinterp_rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), rows, o, n, m, q, idx, weight, lin, skip, lin ? 0 : c1, wb, bias,
                        relu, out);
     return check_launch("ws3d_qinterp_rows");
+}
+
+extern "C" int ws3d_compact_pairs_count(long centres, int nsample, const int32_t *nbr, int32_t *cnt, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (centres < 0 || nsample <= 0 || !nbr || !cnt) { set_error("ws3d_compact_pairs_count: invalid argument"); return WS3D_E_INVALID; }
+    if (centres == 0) return WS3D_OK;
+    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)((centres + 255) / 256)), dim3(256), 0, as_stream(stream), centres, nsample, nbr, cnt);
+    return check_launch("ws3d_compact_pairs_count");
+}
+
+extern "C" int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t *nbr, const int32_t *cnt, const int32_t *incl, int32_t *rowc,
+                                       int32_t *rowsrc, int32_t *total, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (centres <= 0 || nsample <= 0 || !nbr || !cnt || !incl || !rowc || !rowsrc || !total) {
+        set_error("ws3d_compact_pairs_rows: invalid argument");
+        return WS3D_E_INVALID;
+    }
+    hipLaunchKernelGGL(pair_rows_kernel, dim3((unsigned)((centres * nsample + 255) / 256)), dim3(256), 0, as_stream(stream), centres, nsample, nbr, cnt,
+                       incl, rowc, rowsrc, total);
+    return check_launch("ws3d_compact_pairs_rows");
+}
+
+extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
+                                          const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
+                                          const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b <= 0 || n <= 0 || m <= 0 || max_rows <= 0 || (o1 != 64 && o1 != 128 && o1 != 256) || o2 <= 0 || (o2 & 3) || p_stride < o1 || !pmat || !xyz || !new_xyz ||
+        !rowc || !rowsrc || !total || !w1x || !w2t || !out || (reinterpret_cast<uintptr_t>(w2t) & 15)) {
+        set_error("ws3d_pgather_gemm2_compact: unsupported shape (b=%d n=%d m=%d rows<=%ld o1=%d o2=%d; o1 in {64,128,256}, o2 %% 4)", b, n, m, max_rows, o1, o2);
+        return WS3D_E_UNSUPPORTED;
+    }
+    const size_t lds = sizeof(float) * ((size_t)o1 * GP_XS + (size_t)2 * GP_KT * 64);
+    const unsigned grid = (unsigned)((max_rows + 63) / 64);
+    if (o1 == 64)
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<1>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+    else if (o1 == 128)
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<2>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+    else {
+        static bool attr = false;          // 74 KB of LDS: above the default limit
+        if (!attr) { (void)hipFuncSetAttribute((const void *)pgather_gemm2_compact_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<4>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+    }
+    return check_launch("ws3d_pgather_gemm2_compact");
+}
+
+extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
+                                      const float *wt, const float *bias, float *out, int out_stride, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(wt);
+    if (max_rows <= 0 || k_dim <= 0 || (k_dim & 3) || o_dim <= 0 || (o_dim & 63) || !x_rows || !rowc || !total || !wt || !out || out_stride < o_dim ||
+        (al & 15)) {
+        set_error("ws3d_gemm_pool_compact: unsupported shape (rows<=%ld k=%d o=%d; o %% 64, k %% 4)", max_rows, k_dim, o_dim);
+        return WS3D_E_UNSUPPORTED;
+    }
+    const unsigned grid = (unsigned)(((max_rows + 63) / 64) * (o_dim / 64));
+    hipLaunchKernelGGL(gemm_pool_compact_kernel, dim3(grid), dim3(256), 0, as_stream(stream), k_dim, o_dim, x_rows, rowc, total, wt, bias, out, out_stride);
+    return check_launch("ws3d_gemm_pool_compact");
 }
 
 #ifdef GP_PROF

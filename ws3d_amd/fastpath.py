@@ -39,6 +39,7 @@ GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling c
 FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
 FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
+COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # SA2 / SA3: the SharedMLP over the distinct (centre, sample) pairs only
 PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
@@ -129,6 +130,14 @@ def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
             blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
 
 
+class _PairList:
+    """a (B, M, ns) neighbour list together with its compact distinct pairs (rowc, rowsrc, total)"""
+    __slots__ = ("nbr", "pairs")
+
+    def __init__(self, nbr, pairs):
+        self.nbr, self.pairs = nbr, pairs
+
+
 def _per_point_l1(sa, feats: torch.Tensor, nbrs):
     """(P, column offsets, [W_x per scale]): P = feats (B*N, C) @ [W_f of every scale whose first layer gathers its own rows]"""
     B, N, C = feats.shape
@@ -158,6 +167,9 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
             continue
         nbr = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
         _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
+        if COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256 and len(_blocks(mlp)) == 3:
+            # the distinct pairs of the lists (coordinate-only work: with the lists on the search stream)
+            nbr = _PairList(nbr, _C.compact_pairs(nbr))
         lists.append(nbr)
     return lists
 
@@ -254,11 +266,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         sorted_xyz = pn2_ops.sort_points_x(xyz)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
-    out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
+    out = (torch.zeros if any(isinstance(x, _PairList) for x in nbrs) else torch.empty)((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     col = 0
     pp = None
     for si, (grouper, mlp, width, nbr) in enumerate(zip(sa.groupers, sa.mlps, widths, nbrs)):
         blocks = _blocks(mlp)
+        pairs = None
+        if isinstance(nbr, _PairList):
+            nbr, pairs = nbr.nbr, nbr.pairs
         if nbr is not None:
             # neighbour lists only, then layer 1 gathers its own rows: the (rows, 3 + C) grouped tensor never exists
             wt1, b1, r1 = _row_weights_xyz_last(blocks[0])
@@ -270,6 +285,15 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 pmat, offs, w1xs = pp
                 o1 = blocks[0].conv.out_channels
                 y = None
+                wt3, b3, r3 = _row_weights(blocks[-1])
+                if pairs is not None and o1 <= 256 and len(blocks) == 3 and r3:
+                    # the whole SharedMLP over the DISTINCT (centre, sample) pairs: padded rows repeat row 0 and cannot change the
+                    # maximum; `out` is zero-initialised for the atomic max of the last layer
+                    wt2, b2, r2 = _row_weights(blocks[1])
+                    yc = _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2)
+                    if yc is not None and _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col):
+                        col += width
+                        continue
                 if o1 <= 128:
                     wt2, b2, r2 = _row_weights(blocks[1])
                     y = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2)
