@@ -239,6 +239,15 @@ WS3D_API int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int 
 WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
                            const float *wt, const float *bias, float *out, int out_stride, ws3d_stream_t stream);
 
+/* ws3d_sa_mlp3_pool over compact pairs (see ws3d_compact_pairs_*): the first level's three-layer SharedMLP (16-16-32 or 32-32-64,
+ * every layer with bias + ReLU) on rows [x_j - c, f_j] built here from xyz (b, n, 3), new_xyz (b, m, 3) and the ONE feature
+ * channel feat (b, n); max over each centre's rows by integer atomic max into out[centre, 0:c3] (row stride out_stride), which
+ * the caller ZEROES.  Other widths return WS3D_E_UNSUPPORTED.  ws3d extension, used by ws3d_amd/fastpath.py.               */
+WS3D_API int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                              const float *feat, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1t,
+                              const float *b1, const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                              int out_stride, ws3d_stream_t stream);
+
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,
  * pointnet2_modules.py:138-155, on channels-last tensors): out (b*n, o) = relu?([w0 f[i0] + w1 f[i1] + w2 f[i2] | u] @ wt +

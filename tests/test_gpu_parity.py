@@ -1972,3 +1972,30 @@ def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, 
     h = torch.relu(torch.relu(x @ w1.double() + b1.double()) @ w2.double() + b2.double())
     want = torch.relu(h @ w3.double() + b3.double()).view(B * M, ns, O3).amax(dim=1)
     assert (out[:, 64:].double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0) * np.sqrt(max(C, 96) / 96)
+
+
+@pytest.mark.parametrize("ns,widths,r", [(16, (16, 16, 32), 0.1), (32, (32, 32, 64), 0.5), (32, (32, 32, 64), 3.0), (16, (16, 16, 32), 0.001)])
+def test_sa1_compact_chain_is_bit_identical_to_the_grouped_one(ops, ns, widths, r):
+    """ws3d_sa_mlp3_pool_compact (first level over the distinct pairs, rows built from xyz / new_xyz / the feature channel) gives
+    exactly ws3d_sa_mlp3_pool on the grouped tensor of ws3d_query_and_group_nlc"""
+    rng = np.random.default_rng(19)
+    B, N, M = 2, 16384, 4096
+    pc = synth.make_batch("lidar", B, N, 68)
+    xyz = dev(pc[:, :, :3].copy()); feat = dev(pc[:, :, 3:4].copy())
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    srt = ops.c.sort_points_x(xyz)
+    layers = []
+    cin = 4
+    for wdt in widths:
+        layers.append((dev((rng.standard_normal((cin, wdt)) / np.sqrt(cin)).astype(np.float32)), dev(rng.standard_normal(wdt).astype(np.float32) * 0.1), True))
+        cin = wdt
+    g = ops.c.query_and_group_nlc(r, ns, xyz, new_xyz, feat, True, srt)
+    dense = torch.empty((B * M, widths[2]), device="cuda")
+    assert ops.c.sa_mlp3_pool(g.view(-1, 4), ns, layers, dense, 0)
+    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, srt)
+    out = torch.zeros((B * M, widths[2] + 32), device="cuda")
+    assert ops.c.sa_mlp3_pool_compact(xyz, new_xyz, feat, ops.c.compact_pairs(nbr), layers, out, 32)
+    assert bool((out[:, :32] == 0).all())
+    assert torch.equal(out[:, 32:], dense)

@@ -601,6 +601,26 @@ def sa_mlp3_pool(x_rows4, nsample, layers, out, col0=0):
     return True
 
 
+def sa_mlp3_pool_compact(xyz, new_xyz, feat1, pairs, layers, out, col0=0):
+    """sa_mlp3_pool over the compact pairs of compact_pairs: rows [x_j - c, f_j] built from xyz (B,N,3), new_xyz (B,M,3) and the one
+    feature channel feat1 (B,N,1) or (B,N); atomic max into out[:, col0:col0+c3], which must be ZERO on entry.  False when there
+    is no kernel for these widths / flags."""
+    (w1, b1, r1), (w2, b2, r2), (w3, b3, r3) = layers
+    widths = (w1.size(1), w2.size(1), w3.size(1))
+    if (widths not in ((16, 16, 32), (32, 32, 64)) or w1.size(0) != 4 or not (r1 and r2 and r3) or b1 is None or b2 is None or b3 is None or
+            feat1.numel() != xyz.size(0) * xyz.size(1) or not feat1.is_contiguous()):
+        return False
+    rowc, rowsrc, total = pairs
+    dev = _dev(xyz, new_xyz, feat1, rowc, out)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(feat1, "feat1"); _f32(out, "out")
+    view = out[:, col0:col0 + widths[2]]
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_sa_mlp3_pool_compact(xyz.size(0), xyz.size(1), new_xyz.size(1), rowc.numel(), widths[0], widths[1], widths[2], _p(xyz),
+                                                    _p(new_xyz), _p(feat1), _p(rowc), _p(rowsrc), _p(total), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
+                                                    _p(b3), view.data_ptr(), out.size(1), _stream()), "sa_mlp3_pool_compact")
+    return True
+
+
 def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_tensor, sorted_known=None):
     """interpolate.cpp:14-23 (+ optional x-binned copy of `known` from sort_points_x: same result)"""
     dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)

@@ -188,6 +188,99 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, cons
     }
 }
 
+// ---- the same chain over COMPACT (centre, sample) pairs (gemm_pool.hip: a ball-query list is mostly padding, a padded row
+// repeats row 0 of its centre and cannot change the maximum).  Row t = (centre rowc[t], source point rowsrc[t]); the 4-channel
+// input row [dx dy dz f] is built here from xyz / new_xyz / the one feature channel -- no grouped tensor -- and the pool is an
+// integer atomic max of the ReLU'd values (>= 0) into the centre's row, which the caller zeroes.  *total rows; the grid is
+// sized for the worst case and waves walk the tiles that exist.
+template <int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                   const float *__restrict__ feat, const int32_t *__restrict__ rowc,
+                                                                   const int32_t *__restrict__ rowsrc, const int32_t *__restrict__ total,
+                                                                   const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                                   const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                                   const float *__restrict__ w3t, const float *__restrict__ b3,
+                                                                   float *__restrict__ out, int out_stride) {
+    static_assert((C1 == 16 || C1 == 32) && (C2 == 16 || C2 == 32) && (C3 == 32 || C3 == 64), "shape");
+    constexpr int V1 = C1 / 2, V2 = C2 / 2, NB3 = C3 / 32;
+    const long T = *total;
+    const long tiles = (T + 31) / 32;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    if (wave >= tiles) return;
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
+    float a1[2], a2[V1], a3[NB3][V2], bb1[V1], bb2[V2], b3v[NB3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a1[j] = c < C1 ? w1t[(2 * j + h) * C1 + c] : 0.f;
+#pragma unroll
+    for (int v = 0; v < V1; ++v) {
+        a2[v] = c < C2 ? w2t[kp(v) * C2 + c] : 0.f;
+        bb1[v] = b1[kp(v)];
+    }
+#pragma unroll
+    for (int v = 0; v < V2; ++v) {
+#pragma unroll
+        for (int blk = 0; blk < NB3; ++blk) a3[blk][v] = w3t[kp(v) * C3 + blk * 32 + c];
+        bb2[v] = b2[kp(v)];
+    }
+#pragma unroll
+    for (int blk = 0; blk < NB3; ++blk) b3v[blk] = b3[blk * 32 + c];
+    for (long tile = wave; tile < tiles; tile += nwaves) {
+        float4 xr;
+        {
+            const long t = min(tile * 32 + c, T - 1);
+            const long cm = rowc[t];
+            const int src = rowsrc[t];
+            const size_t p = (size_t)(cm / m) * n + (size_t)src;
+            const float *pr = xyz + p * 3, *cr = new_xyz + (size_t)cm * 3;
+            xr = make_float4(pr[0] - cr[0], pr[1] - cr[1], pr[2] - cr[2], feat[p]);
+        }
+        sa_f16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? xr.y : xr.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? xr.w : xr.z, acc, 0, 0, 0);
+        float act[16];
+#pragma unroll
+        for (int v = 0; v < V1; ++v) act[v] = fmaxf(acc[v] + bb1[v], 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int v = 0; v < V1; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < V2; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
+        // the centres of this lane's 16 rows (rows kp(v)), once for all channel blocks
+        int cen[16];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const long t = tile * 32 + kp(v);
+            cen[v] = t < T ? rowc[t] : -1;
+        }
+#pragma unroll
+        for (int blk = 0; blk < NB3; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int v = 0; v < V2; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
+            const float bias = b3v[blk];
+            int prev = -1;
+            float run = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                if (cen[v] < 0) continue;
+                const float y = fmaxf(acc[v] + bias, 0.f);
+                if (cen[v] != prev) {
+                    if (prev >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev * out_stride + blk * 32 + c), __float_as_int(run));
+                    prev = cen[v]; run = y;
+                } else {
+                    run = fmaxf(run, y);
+                }
+            }
+            if (prev >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev * out_stride + blk * 32 + c), __float_as_int(run));
+        }
+    }
+}
+
 // ---- two pointwise layers on rows, 128 -> 128 -> o2 (o2 <= 64): the two heads of the RPN --------------------------------------
 // Same register chaining as above.  Layer 1 transposed (A = W1^T from LDS, B = the rows: lane (row, half h) holds the 64
 // channels 64 h .. 64 h + 63 of its row, step s pairs channels s and 64 + s), four accumulators = all 128 output channels of
@@ -362,4 +455,29 @@ extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float 
     };
     if (o2b == 1) go(mlp2_rows_kernel<1>); else go(mlp2_rows_kernel<2>);
     return check_launch("ws3d_mlp2_rows");
+}
+
+extern "C" int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                                         const float *feat, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1t,
+                                         const float *b1, const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
+                                         int out_stride, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b <= 0 || n <= 0 || m <= 0 || max_rows <= 0 || !xyz || !new_xyz || !feat || !rowc || !rowsrc || !total || !w1t || !b1 || !w2t || !b2 || !w3t ||
+        !b3 || !out || out_stride < c3) {
+        set_error("ws3d_sa_mlp3_pool_compact: invalid argument (b=%d n=%d m=%d rows<=%ld)", b, n, m, max_rows);
+        return WS3D_E_INVALID;
+    }
+    const long tiles = (max_rows + 31) / 32;
+    const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);
+#define WS3D_SA_COMPACT(A, B, C)                                                                                                        \
+    if (c1 == A && c2 == B && c3 == C) {                                                                                                \
+        hipLaunchKernelGGL((sa_mlp3_compact_mfma_kernel<A, B, C>), dim3(grid), dim3(256), 0, as_stream(stream), n, m, xyz, new_xyz, feat, rowc, \
+                           rowsrc, total, w1t, b1, w2t, b2, w3t, b3, out, out_stride);                                                  \
+        return check_launch("ws3d_sa_mlp3_pool_compact");                                                                               \
+    }
+    WS3D_SA_COMPACT(32, 32, 64)
+    WS3D_SA_COMPACT(16, 16, 32)
+#undef WS3D_SA_COMPACT
+    set_error("ws3d_sa_mlp3_pool_compact: no kernel for widths (%d, %d, %d)", c1, c2, c3);
+    return WS3D_E_UNSUPPORTED;
 }

@@ -266,7 +266,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         sorted_xyz = pn2_ops.sort_points_x(xyz)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
-    out = (torch.zeros if any(isinstance(x, _PairList) for x in nbrs) else torch.empty)((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
+    out = (torch.zeros if COMPACT_PAIRS else torch.empty)((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)   # zeros: the atomic max
     col = 0
     pp = None
     for si, (grouper, mlp, width, nbr) in enumerate(zip(sa.groupers, sa.mlps, widths, nbrs)):
@@ -335,6 +335,13 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
             col += width
             continue
+        if COMPACT_PAIRS and FUSED_SA_MLP and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
+            # first level: lists only (no grouped tensor), their distinct pairs, the three layers chained in registers over those
+            nbr1 = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
+            _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr1, sorted_xyz)
+            if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, _C.compact_pairs(nbr1), [_row_weights(b) for b in blocks], out, col):
+                col += width
+                continue
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
         # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
