@@ -230,6 +230,9 @@ WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const
  *   ws3d_gemm_pool_compact:   last layer + ReLU + max over each centre's rows by integer atomic max into out[centre, 0:o_dim]
  *                             (row stride out_stride), which the caller ZEROES first; the layer must end in a ReLU
  * ws3d extensions, used by ws3d_amd/fastpath.py.                                                                          */
+ /* ws3d_compact_pairs: count + placement in ONE launch (*total must be ZERO on entry; the order of the compact rows is then arrival
+ *  order of the 256-centre workgroups -- undefined, and irrelevant to every consumer above) */
+WS3D_API int ws3d_compact_pairs(long centres, int nsample, const int32_t *nbr, int32_t *rowc, int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);
 WS3D_API int ws3d_compact_pairs_count(long centres, int nsample, const int32_t *nbr, int32_t *cnt, ws3d_stream_t stream);
 WS3D_API int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t *nbr, const int32_t *cnt, const int32_t *incl, int32_t *rowc,
                             int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);

@@ -1937,7 +1937,7 @@ def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, 
     ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
     nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
     ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    rowc, rowsrc, total = ops.c.compact_pairs(nbr)
+    rowc, rowsrc, total = ops.c.compact_pairs(nbr, ordered=True)
     T = int(total.item())
     want_pairs = []
     nb = host(nbr).reshape(B * M, ns)
@@ -1948,6 +1948,15 @@ def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, 
         want_pairs += [(c_, int(v)) for v in row[:k]]
     assert T == len(want_pairs)
     assert list(zip(host(rowc)[:T].tolist(), host(rowsrc)[:T].tolist())) == want_pairs
+    rc1, rs1, t1 = ops.c.compact_pairs(nbr)                          # one launch: same pairs, centres in arrival order
+    assert int(t1.item()) == T
+    got1 = list(zip(host(rc1)[:T].tolist(), host(rs1)[:T].tolist()))
+    assert sorted(got1) == sorted(want_pairs)
+    firsts = {}
+    for i_, (c_, _) in enumerate(got1):
+        firsts.setdefault(c_, []).append(i_)
+    assert all(v == list(range(v[0], v[0] + len(v))) for v in firsts.values())       # a centre's rows are contiguous
+    rowc, rowsrc, total = rc1, rs1, t1                                # the network uses this form
     w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
     w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
     w3 = dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)); b3 = dev(rng.standard_normal(O3).astype(np.float32))

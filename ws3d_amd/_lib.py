@@ -77,6 +77,7 @@ SIGNATURES = {
     "ws3d_pgather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ws3d_pgather_rows": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_qinterp_rows": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "ws3d_compact_pairs": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_compact_pairs_count": (_i, [C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_compact_pairs_rows": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_pgather_gemm2_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

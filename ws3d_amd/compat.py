@@ -456,10 +456,22 @@ def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=T
     return out
 
 
-def compact_pairs(nbr):
+def compact_pairs(nbr, ordered=False):
     """(B, M, ns) ball-query lists -> (rowc, rowsrc, total): the DISTINCT (centre, source point) pairs as compact rows (int32
     tensors of B*M*ns entries, the first `total` -- a 1-element device tensor -- valid); a list's padding repeats its first hit
-    and cannot change any layer's maximum over nsample.  ws3d extension."""
+    and cannot change any layer's maximum over nsample.  ordered=False: one launch, rows of a centre contiguous, centres in
+    arrival order of their workgroups; ordered=True: centres ascending (count kernel + prefix sum + placement kernel).
+    ws3d extension."""
+    if not ordered:
+        dev = _dev(nbr)
+        _i32(nbr, "nbr")
+        B, M, ns = nbr.shape
+        rowc = torch.empty(B * M * ns, dtype=torch.int32, device=dev)
+        rowsrc = torch.empty(B * M * ns, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            check(_lib.load().ws3d_compact_pairs(B * M, ns, _p(nbr), _p(rowc), _p(rowsrc), _p(total), _stream()), "compact_pairs")
+        return rowc, rowsrc, total
     dev = _dev(nbr)
     _i32(nbr, "nbr")
     B, M, ns = nbr.shape

@@ -734,6 +734,36 @@ __global__ __launch_bounds__(256) void pair_rows_kernel(long centres, int ns, co
     if (e == 0) *total = incl[centres - 1];
 }
 
+// count + placement in one launch: a workgroup takes 256 centres, scans their counts in LDS and reserves its stretch of compact rows
+// with ONE atomic add on *total (zero on entry).  The stretches of different workgroups land in arrival order -- the ORDER of the
+// compact rows is not defined, and nothing depends on it: a row's activations are its own and the maximum is order-free.
+__global__ __launch_bounds__(256) void pair_compact_kernel(long centres, int ns, const int32_t *__restrict__ nbr, int32_t *__restrict__ rowc,
+                                                           int32_t *__restrict__ rowsrc, int32_t *__restrict__ total) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long c = (long)blockIdx.x * 256 + tid;
+    int k = 0;
+    if (c < centres) {
+        const int32_t *row = nbr + c * ns;
+        int prev = row[0];
+        k = 1;
+        for (int s2 = 1; s2 < ns; ++s2) { const int v = row[s2]; k += v > prev; prev = v; }
+    }
+    int v = k;
+    for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
+    if (lane == 63) wsum[w] = v;
+    __syncthreads();
+    if (tid == 0) base_s = atomicAdd(total, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    __syncthreads();
+    int first = base_s + v - k;
+    for (int i = 0; i < w; ++i) first += wsum[i];
+    if (c < centres) {
+        const int32_t *row = nbr + c * ns;
+        for (int s2 = 0; s2 < k; ++s2) { rowc[first + s2] = (int32_t)c; rowsrc[first + s2] = row[s2]; }
+    }
+}
+
 // pgather_gemm2_kernel over compact rows: (centre, source) per row from rowc / rowsrc, *total rows in all
 template <int NB1>
 __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int n, int m, const float *__restrict__ pmat, int p_stride,
@@ -789,8 +819,8 @@ __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int 
     const int wk = tid >> 4, wc = (tid & 15) * 4;
     const int nchunk = (o2 + 63) / 64;
     constexpr int nt2 = O1 / GP_KT;
-    for (int c = 0; c < nchunk; ++c) {
-        const int col0 = c * 64;
+    for (int c = blockIdx.y; c < nchunk; c += gridDim.y) {       // the 64-column passes of layer 2 are spread over gridDim.y workgroups (each
+        const int col0 = c * 64;                                   // rebuilds layer 1's tile: a gather and two matrix steps): compact launches are small
         auto load_w2 = [&](int t) {
             const int col = col0 + wc;
             return col < o2 ? *reinterpret_cast<const float4 *>(w2t + (long)(t * GP_KT + wk) * o2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1382,6 +1412,15 @@ extern "C" int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t 
     return check_launch("ws3d_compact_pairs_rows");
 }
 
+extern "C" int ws3d_compact_pairs(long centres, int nsample, const int32_t *nbr, int32_t *rowc, int32_t *rowsrc, int32_t *total,
+                                  ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (centres < 0 || nsample <= 0 || !nbr || !rowc || !rowsrc || !total) { set_error("ws3d_compact_pairs: invalid argument"); return WS3D_E_INVALID; }
+    if (centres == 0) return WS3D_OK;
+    hipLaunchKernelGGL(pair_compact_kernel, dim3((unsigned)((centres + 255) / 256)), dim3(256), 0, as_stream(stream), centres, nsample, nbr, rowc, rowsrc, total);
+    return check_launch("ws3d_compact_pairs");
+}
+
 extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                           const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
                                           const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
@@ -1392,17 +1431,17 @@ extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, in
         return WS3D_E_UNSUPPORTED;
     }
     const size_t lds = sizeof(float) * ((size_t)o1 * GP_XS + (size_t)2 * GP_KT * 64);
-    const unsigned grid = (unsigned)((max_rows + 63) / 64);
+    const dim3 grid((unsigned)((max_rows + 63) / 64), (unsigned)((o2 + 63) / 64));
     if (o1 == 64)
-        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<1>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<1>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
     else if (o1 == 128)
-        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<2>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<2>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
     else {
         static bool attr = false;          // 74 KB of LDS: above the default limit
         if (!attr) { (void)hipFuncSetAttribute((const void *)pgather_gemm2_compact_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<4>), dim3(grid), dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+        hipLaunchKernelGGL((pgather_gemm2_compact_kernel<4>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
     }
     return check_launch("ws3d_pgather_gemm2_compact");
