@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from ws3d_amd import dist as wdist
-from ws3d_amd import roipool3d_ops, synth
+from ws3d_amd import fastpath, roipool3d_ops, synth
 from ws3d_amd.seeded import seeded_state_dict
 from ws3d_amd.stage1 import DEFAULT_CFG, Stage1Net, proposals_from_rpn
 
@@ -97,7 +97,11 @@ class C3:
                 "launch": ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth)
                 if getattr(self, "_graph", None) is not None
                 else "eager (graph capture failed: %s)" % getattr(self, "_graph_err", "not attempted"),
-                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}
+                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                # data-dependent work: the SharedMLPs run over the DISTINCT (centre, sample) pairs of the ball-query lists (bit-identical
+                # to all m * nsample rows; these synthetic clouds: 1.0-2.1 distinct of 16 / 32, profiles/r02_neighbour_list_fill.txt)
+                "sharedmlp_rows": ("distinct pairs of the ball-query lists (WS3D_COMPACT_PAIRS=0: all m*nsample rows)"
+                                   if fastpath.COMPACT_PAIRS and fastpath.PER_POINT_L1 else "all m*nsample rows")}
 
     @torch.no_grad()
     def _body(self, pts=None):
