@@ -226,19 +226,23 @@ class _Geometry:
         self.nn, self.nn_ready = [], []
         c_feat = [c0] + [sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) for sa in sas]
         with torch.cuda.stream(s_search):
-            for i in range(len(sas)):
+            # first what the SA levels wait for (their lists, in the order they run), then the 3-NN of the FP modules, deepest
+            # first as they run: with the SharedMLPs over the compact pairs the caller's stream reaches level 2 some 0.1 ms
+            # after level 1's sampling, and the 3-NN of FP1 (131072 queries) in front of level 2's lists was on its path
+            for i in range(1, len(sas)):
                 s_search.wait_event(fps_done[i])                                     # level i + 1 exists
-                if i >= 1:                                                           # (level 0: fused query+group on the caller's stream)
-                    srt = pn2_ops.sort_points_x(self.xyz[i])
-                    self.sorted.append(srt)
-                    self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i]))
-                    ev = torch.cuda.Event()
-                    ev.record(s_search)
-                    self.sa_ready.append(ev)
-                self.nn.append(_C.three_nn_with_weights(self.xyz[i], self.xyz[i + 1], pn2_ops.sort_points_xz(self.xyz[i + 1])))
+                srt = pn2_ops.sort_points_x(self.xyz[i])
+                self.sorted.append(srt)
+                self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i]))
                 ev = torch.cuda.Event()
                 ev.record(s_search)
-                self.nn_ready.append(ev)
+                self.sa_ready.append(ev)
+            self.nn, self.nn_ready = [None] * len(sas), [None] * len(sas)
+            for i in range(len(sas) - 1, -1, -1):
+                self.nn[i] = _C.three_nn_with_weights(self.xyz[i], self.xyz[i + 1], pn2_ops.sort_points_xz(self.xyz[i + 1]))
+                ev = torch.cuda.Event()
+                ev.record(s_search)
+                self.nn_ready[i] = ev
         self.main, self.side = main, (s_fps, s_search)
 
     def release(self):
