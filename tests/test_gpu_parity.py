@@ -2008,3 +2008,33 @@ def test_sa1_compact_chain_is_bit_identical_to_the_grouped_one(ops, ns, widths, 
     assert ops.c.sa_mlp3_pool_compact(xyz, new_xyz, feat, ops.c.compact_pairs(nbr), layers, out, 32)
     assert bool((out[:, :32] == 0).all())
     assert torch.equal(out[:, 32:], dense)
+
+
+def test_compact_and_dense_sharedmlps_give_the_same_network_outputs(ops):
+    """the SharedMLPs over the distinct pairs compute what the dense kernels compute: the fill threshold that chooses between them
+    (fastpath.COMPACT_MAX_FILL, calibrated once per scale) is a speed decision only"""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.seeded import seeded_state_dict
+    cfg = stage1.RPNConfig(num_points=16384, rpn_pre_nms_top_n=1000, rpn_post_nms_top_n=20)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg)
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    model = model.cuda().eval()
+    pts = dev(np.stack([synth.velodyne_scan(16384, seed=400 + j) for j in range(4)]))
+    saved = (fastpath.COMPACT_MAX_FILL, fastpath.COMPACT_PAIRS, fastpath.PER_POINT_L1)
+    try:
+        fastpath.COMPACT_PAIRS, fastpath.PER_POINT_L1 = True, True
+        outs = []
+        for thr in (0.55, -1.0, 2.0):                    # calibrated choice / always dense / always compact
+            fastpath.COMPACT_MAX_FILL = thr
+            with torch.no_grad():
+                o = model.rpn_forward({"pts_input": pts})
+            outs.append((o["rpn_cls"].clone(), o["rpn_reg"].clone()))
+        assert fastpath._PAIR_FILL and all(0.0 < v <= 1.0 for v in fastpath._PAIR_FILL.values())
+        # SA1-SA3: the same kernels' arithmetic row by row (bit-identical pooled features, see the kernel-level tests); SA4's dense
+        # form runs its middle layer on the library GEMM, whose summation order differs: fp32 round-off there
+        for a in outs[1:]:
+            for x_, y_ in zip(a, outs[0]):
+                assert float((x_ - y_).abs().max()) <= 2e-5 * max(float(y_.abs().max()), 1.0)
+        assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1], outs[0][1])       # calibrated == always compact here
+    finally:
+        fastpath.COMPACT_MAX_FILL, fastpath.COMPACT_PAIRS, fastpath.PER_POINT_L1 = saved

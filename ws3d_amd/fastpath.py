@@ -39,6 +39,7 @@ GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling c
 FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
 FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
+COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # a scale whose lists are fuller than this keeps the dense kernels
 COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # SA2 / SA3: the SharedMLP over the distinct (centre, sample) pairs only
 PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
@@ -130,6 +131,22 @@ def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
             blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
 
 
+_PAIR_FILL = {}      # (n, npoint, radius, nsample) -> fraction of distinct rows seen at the first eager pass over such a scale
+
+
+def _pairs_pay(key, pairs, rows: int) -> bool:
+    """The compact path beats the dense kernels up to ~60 % distinct rows (profiles/r02_compact_vs_dense_fill.txt: 46 vs 133 us at
+    5 %, 111 vs 129 at 48 %, 180 vs 122 at 96 %) -- both are exact, so this is a speed decision only.  The fill of a scale is read
+    ONCE, at its first eager pass (one host synchronisation; Stage1Pipeline's priming runs do it before the capture), and kept."""
+    fill = _PAIR_FILL.get(key)
+    if fill is None:
+        if torch.cuda.is_current_stream_capturing():
+            return True                                  # never seen eagerly: lidar lists are sparse
+        fill = float(pairs[2].item()) / max(rows, 1)
+        _PAIR_FILL[key] = fill
+    return fill <= COMPACT_MAX_FILL
+
+
 class _PairList:
     """a (B, M, ns) neighbour list together with its compact distinct pairs (rowc, rowsrc, total)"""
     __slots__ = ("nbr", "pairs")
@@ -169,7 +186,9 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
         _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
         if COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256 and len(_blocks(mlp)) == 3:
             # the distinct pairs of the lists (coordinate-only work: with the lists on the search stream)
-            nbr = _PairList(nbr, _C.compact_pairs(nbr))
+            pairs = _C.compact_pairs(nbr)
+            if _pairs_pay((xyz.size(1), sa.npoint, float(grouper.radius), grouper.nsample), pairs, nbr.numel()):
+                nbr = _PairList(nbr, pairs)
         lists.append(nbr)
     return lists
 
@@ -341,11 +360,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             continue
         if COMPACT_PAIRS and FUSED_SA_MLP and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
             # first level: lists only (no grouped tensor), their distinct pairs, the three layers chained in registers over those
-            nbr1 = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
-            _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr1, sorted_xyz)
-            if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, _C.compact_pairs(nbr1), [_row_weights(b) for b in blocks], out, col):
-                col += width
-                continue
+            key1 = (xyz.size(1), sa.npoint, float(grouper.radius), grouper.nsample)
+            if _PAIR_FILL.get(key1, 0.0) <= COMPACT_MAX_FILL:
+                nbr1 = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
+                _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr1, sorted_xyz)
+                pairs1 = _C.compact_pairs(nbr1)
+                if _pairs_pay(key1, pairs1, nbr1.numel()) and _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, [_row_weights(b) for b in blocks], out, col):
+                    col += width
+                    continue
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
         # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
