@@ -558,7 +558,7 @@ def c2_block(batch, rank, kind, steps=10, warmup=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps; default 80 for c3 (four rounds over the 20 slots: the fill and the drain of the pipeline are inside the timed region), 40 otherwise")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5", "s2", "t1"],
                     help="c3 (default) = BASELINE.json's headline: Stage-1 RPN forward + NMS + roipool3d, batch 8/GPU, with the c2 block")
@@ -572,6 +572,8 @@ def main():
                     help="c3: batches in flight (one HIP stream + graph each); default 20 on one GPU, 16 with --gpus > 1 (headroom for the "
                          "collective library's own hardware queues: beyond 23 queues per process the runtime time-slices, DESIGN.md 5.6)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 80 if args.workload == "c3" else 40
 
     from ws3d_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 T="timeout 900"
 $T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 $T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-$T python bench.py --steps 80 --no-cpu-baseline --c2-batch 0  2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps80.json
+$T python bench.py --steps 160 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
 $T python bench.py --pipeline-depth 1 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
 GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
 $T python bench.py --workload c2                              2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b512.json
