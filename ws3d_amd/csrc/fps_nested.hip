@@ -16,7 +16,10 @@
 //   C  a scene that fails the check (ties, or a cloud that was not in sampling order to begin with) is sampled by a literal
 //      restatement of the reference kernel (strided ownership, strict '>', shared-memory tree that keeps the lower slot:
 //      sampling_gpu.cu:86-209) -- slow and rare.
-// Cost at 4096 -> 1024 points x 8 scenes: three short launches, ~25 us, against 600 us of dependent steps.
+// Cost at 4096 -> 1024 points x 8 scenes: three short launches (~130 us stand-alone) against 600 us of dependent steps.
+// (Giving every point a 16-lane DPP row in A and B -- row-wide minimum / prefix minimum over the samples 16 j + c -- cut that to
+// 44 us but doubles the instructions: c3 lost 1.5 % throughput for no latency gain -- the caller's stream does not wait here --
+// so the one-thread-per-point form stays.)
 // Scratch: W lives in idx (as float bits), the per-scene verdict in new_xyz[0] (as int bits); both are overwritten by C.
 #include <cmath>
 
