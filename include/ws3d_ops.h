@@ -99,6 +99,10 @@ WS3D_API int ws3d_gather_points_grad(int b, int c, int n, int npoints, const flo
  * untouched.  sorted: NULL, or the output of ws3d_sort_points_x for this xyz.       */
 WS3D_API int ws3d_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                     const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream);
+/* ws3d_ball_query that also writes the rows of centres WITHOUT a hit (as zeros: what the reference's callers see in their
+ * zero-initialised idx tensor, pointnet2_utils.py:201), so that idx need not be cleared first.  ws3d extension.           */
+WS3D_API int ws3d_ball_query_fill(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                         const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream);
 
 /* Optional accelerator for ws3d_ball_query / ws3d_query_and_group (no reference counterpart):
  * a per-scene copy of xyz counting-sorted into uniform x cells (float4 {x,y,z,index} x n, a

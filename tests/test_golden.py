@@ -212,11 +212,19 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         bq_log.append((n, _sha(idx.cpu().numpy().astype(np.int32))))
         return r
 
+    orig_bql = compat.ball_query_lists
+
+    def bql_tap(radius, nsample, xyz, new_xyz, sorted_xyz=None):                  # ... through the entry that needs no cleared idx
+        idx = orig_bql(radius, nsample, xyz, new_xyz, sorted_xyz)
+        bq_log.append((xyz.size(1), _sha(idx.cpu().numpy().astype(np.int32))))
+        return idx
+
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
     pn2_ops.furthest_point_sample_gather_nested = nested_tap
     compat.query_and_group_nlc = nlc_tap
     if channels_last:
         compat.ball_query_wrapper = bq_tap
+        compat.ball_query_lists = bql_tap
     prev = stage1.CHANNELS_LAST_FASTPATH
     stage1.CHANNELS_LAST_FASTPATH = channels_last
     try:
@@ -227,6 +235,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         pn2_ops.furthest_point_sample_gather_nested = orig_nested
         compat.query_and_group_nlc = orig_nlc
         compat.ball_query_wrapper = orig_bq
+        compat.ball_query_lists = orig_bql
         stage1.CHANNELS_LAST_FASTPATH = prev
     assert ("backbone_features_nlc" in out) == channels_last
     assert len(fps_log) == 4 and len(bq_log) == 8

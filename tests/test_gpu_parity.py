@@ -2038,3 +2038,22 @@ def test_compact_and_dense_sharedmlps_give_the_same_network_outputs(ops):
         assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1], outs[0][1])       # calibrated == always compact here
     finally:
         fastpath.COMPACT_MAX_FILL, fastpath.COMPACT_PAIRS, fastpath.PER_POINT_L1 = saved
+
+
+def test_ball_query_fill_equals_ball_query_on_a_cleared_tensor(ops):
+    """ws3d_ball_query_fill into an UNCLEARED tensor == ws3d_ball_query into zeros, for every search kernel (grid, x slabs, brute
+    force) and with centres that have no hit at all (NaN centres, a radius of 0)"""
+    pc = synth.make_batch("lidar", 2, 16384, 69)[:, :, :3].copy()
+    for n, m, r, ns in ((16384, 4096, 0.5, 32), (4096, 1024, 1.0, 16), (700, 100, 2.0, 8), (4096, 512, 0.0, 16)):
+        xyz = dev(pc[:, :n].copy())
+        new_xyz = xyz[:, :m].clone()
+        new_xyz[0, 3] = float("nan")                       # a centre without any hit
+        for srt in (ops.c.sort_points_x(xyz), ops.c.sort_points_x(xyz, grid=False), None):
+            want = torch.zeros((2, m, ns), dtype=torch.int32, device="cuda")
+            ops.c.ball_query_wrapper(2, n, m, r, ns, new_xyz, xyz, want, srt)
+            got = ops.c.ball_query_lists(r, ns, xyz, new_xyz, srt)
+            got2 = torch.full((2, m, ns), 123456, dtype=torch.int32, device="cuda")
+            from ws3d_amd import _lib
+            _lib.check(_lib.load().ws3d_ball_query_fill(2, n, m, float(r), ns, new_xyz.data_ptr(), xyz.data_ptr(), got2.data_ptr(),
+                                                        srt.data_ptr() if srt is not None else None, torch.cuda.current_stream().cuda_stream))
+            assert torch.equal(got, want) and torch.equal(got2, want)

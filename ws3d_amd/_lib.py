@@ -32,6 +32,7 @@ SIGNATURES = {
     "ws3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_ball_query_fill": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_sorted_points_bytes": (_sz, [_i, _i]),
     "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_xz": (_i, [_i, _i, _vp, _vp, _vp]),

@@ -165,6 +165,19 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx
     return 1
 
 
+def ball_query_lists(radius, nsample, xyz, new_xyz, sorted_xyz=None):
+    """(B, M, nsample) int32 ball-query lists into a fresh (uncleared) tensor: rows of centres without a hit come out as zeros, as in
+    a zero-initialised idx of ball_query_wrapper.  ws3d extension."""
+    dev = _dev(xyz, new_xyz, sorted_xyz)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_ball_query_fill(B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx), _p(sorted_xyz), _stream()),
+              "ball_query_fill")
+    return idx
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
     """group_points.cpp:25-36"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)

@@ -64,11 +64,16 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
     if (nbatch < 0) nbatch = (int)gridDim.y;      // scenes of the launch (the 1-D grid kernel passes it)
     const int total_e = NC * nsample;
     if (!FUSED) {
-        // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44)
+        // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44); use_xyz bit 2 (the _fill entry
+        // point): such rows are written as zeros -- what the reference's callers get from their zero-initialised idx tensor
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
+        const bool fill = (use_xyz & 4) != 0;
         for (int e = tid; e < total_e; e += NT) {
             const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m && cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+            if (m0 + c < m) {
+                if (cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+                else if (fill) o[e] = 0;
+            }
         }
         return;
     }
@@ -837,7 +842,8 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     if (b == 0 || m == 0) return WS3D_OK;
     // channel split (fused only): enough workgroups to fill 256 CUs, at least 8 channels each
     int gz = 1;
-    use_xyz = (use_xyz ? 1 : 0) | (nlc ? 2 : 0);   // bit 1 selects the channels-last epilogue (row-wise, no channel split)
+    use_xyz = FUSED ? ((use_xyz ? 1 : 0) | (nlc ? 2 : 0))   // bit 1 selects the channels-last epilogue (row-wise, no channel split)
+                    : (use_xyz & 4);                        // index-only kernels: bit 2 = write zero rows for centres without a hit
     if (FUSED && c >= 16 && !nlc) {
         const long tiles = (long)b * ((m + 63) / 64);
         while (gz < 64 && tiles * gz < 1024 && c / (gz * 2) >= 8) gz *= 2;
@@ -1016,6 +1022,12 @@ extern "C" int ws3d_ball_query(int b, int n, int m, float radius, int nsample, c
                                const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream) {
     return ws3d::bq_launch<false>(b, n, m, 0, radius, nsample, 0, xyz, new_xyz, nullptr, idx, nullptr, sorted,
                                   ws3d::as_stream(stream), "ws3d_ball_query");
+}
+
+extern "C" int ws3d_ball_query_fill(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                    const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream) {
+    return ws3d::bq_launch<false>(b, n, m, 0, radius, nsample, 4, xyz, new_xyz, nullptr, idx, nullptr, sorted,
+                                  ws3d::as_stream(stream), "ws3d_ball_query_fill");
 }
 
 extern "C" int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample,

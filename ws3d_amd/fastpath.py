@@ -182,8 +182,7 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
         if not _gather_gemm_ok(sa, grouper, _blocks(mlp), c_feat, B):
             lists.append(None)
             continue
-        nbr = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
-        _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr, sorted_xyz)
+        nbr = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
         if COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256 and len(_blocks(mlp)) == 3:
             # the distinct pairs of the lists (coordinate-only work: with the lists on the search stream)
             pairs = _C.compact_pairs(nbr)
@@ -362,8 +361,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             # first level: lists only (no grouped tensor), their distinct pairs, the three layers chained in registers over those
             key1 = (xyz.size(1), sa.npoint, float(grouper.radius), grouper.nsample)
             if _PAIR_FILL.get(key1, 0.0) <= COMPACT_MAX_FILL:
-                nbr1 = torch.zeros((B, sa.npoint, grouper.nsample), dtype=torch.int32, device=xyz.device)
-                _C.ball_query_wrapper(B, xyz.size(1), sa.npoint, grouper.radius, grouper.nsample, new_xyz, xyz, nbr1, sorted_xyz)
+                nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
                 pairs1 = _C.compact_pairs(nbr1)
                 if _pairs_pay(key1, pairs1, nbr1.numel()) and _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, [_row_weights(b) for b in blocks], out, col):
                     col += width
