@@ -9,8 +9,10 @@ one batch in flight, both in the same line), and -- outside the timed region -- 
 (configs[1]: FPS 16384->4096 + fused ball_query/group, the "FPS+group HBM GB/s" half of the metric)
 with the `roofline` of the path's dominant kernel.
 
-N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N ...``
-(one rank per GPU, RCCL).  Scenes are independent, so the path shards with NO data-path
+N > 1 runs one rank per GPU over RCCL, either way of starting it: under the driver's ``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`` (RANK / WORLD_SIZE from the environment), or as plain ``python bench.py --gpus N``,
+which starts its own N ranks (`_self_launch`).  A world size that differs from --gpus, or more RCCL ranks than devices, exits
+non-zero; the line carries ``config.ranks_seen`` and the communicator's size.  Scenes are independent, so the path shards with NO data-path
 collective: every rank processes its own ``batch`` scenes ("weak" scaling); the only exchange
 is the fixed-shape all-gather of per-scene proposals in the c3 workload.
 
@@ -42,6 +44,43 @@ import time
 # queue serialise.  The c3 pipeline keeps 20 batches in flight on 20 streams, so the cap is raised
 # BEFORE the runtime starts (measured: 2,106 scenes/s with 4 queues / 3 in flight, 3,850 with 32 / 20).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+
+
+def _self_launch():
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it (no WORLD_SIZE / RANK in the environment): start the
+    N ranks here -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` on 127.0.0.1 and a free port, one rank per
+    GPU -- pass their output through (rank 0 prints the one JSON line) and exit with their status.  Under a launcher
+    (the driver's torch.distributed.run) this does nothing; a world size that differs from --gpus is an error in
+    dist_setup(), never a silent one-GPU measurement.  Runs before torch is imported: the parent never touches HIP."""
+    gpus, argv = 1, sys.argv[1:]
+    for i, a in enumerate(argv):
+        try:
+            if a == "--gpus" and i + 1 < len(argv):
+                gpus = int(argv[i + 1])
+            elif a.startswith("--gpus="):
+                gpus = int(a.split("=", 1)[1])
+        except ValueError:
+            return                                      # argparse reports it
+    if gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, WS3D_BENCH_SELF_LAUNCHED="1")
+    if os.environ.get("WS3D_BENCH_LAUNCH_DRYRUN"):      # tests/test_bench_launch.py: the command, without running it
+        print(json.dumps({"self_launch": cmd}))
+        sys.exit(0)
+    print("[bench] --gpus %d without a launcher: starting %d ranks: %s" % (gpus, gpus, " ".join(cmd[1:8])), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _self_launch()
 
 import numpy as np
 import torch
@@ -110,9 +149,17 @@ def repeat_for(fn, min_seconds=8.0, max_reps=200):
 
 
 def dist_setup(gpus):
+    """-> (world, rank, local device, communicator description).  The world size MUST equal --gpus: a mismatch exits non-zero
+    (``python bench.py --gpus N`` launches its own N ranks, _self_launch; under a launcher WORLD_SIZE says what was started)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    comm = {"backend": None, "size": 1, "ranks_seen": 1, "launcher": "none (single process)"}
+    if world != gpus:
+        if rank == 0:
+            print(f"[bench] error: --gpus {gpus} but the launcher started WORLD_SIZE={world} rank(s); refusing to report a line for "
+                  f"another world size than the one asked for", file=sys.stderr, flush=True)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -120,17 +167,33 @@ def dist_setup(gpus):
         # WS3D_DIST_BACKEND=gloo: control-flow test of the multi-rank path on a box with fewer GPUs
         # than ranks (ranks then share devices); the driver's runs use nccl (= RCCL over xGMI)
         backend = os.environ.get("WS3D_DIST_BACKEND", "nccl")
-        local = local % max(torch.cuda.device_count(), 1)
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and world > ndev:
+            if rank == 0:
+                print(f"[bench] error: --gpus {world} over RCCL needs {world} devices, this box shows {ndev} "
+                      f"(WS3D_DIST_BACKEND=gloo is the control-flow test mode that lets ranks share a device)", file=sys.stderr, flush=True)
+            sys.exit(3)
+        local = local % max(ndev, 1)
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # every rank adds one: what the communicator actually spans, next to what it says about itself
+        seen = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(seen)
+        devs = [None] * world
+        dist.all_gather_object(devs, "%s:%d" % (os.uname().nodename, local))
+        comm = {"backend": "rccl (torch 'nccl')" if backend == "nccl" else backend, "size": dist.get_world_size(), "ranks_seen": int(seen.item()),
+                "devices": devs, "launcher": "bench.py self-launch (torch.distributed.run)" if os.environ.get("WS3D_BENCH_SELF_LAUNCHED")
+                else "external (WORLD_SIZE/RANK from the environment)"}
+        if comm["size"] != gpus or comm["ranks_seen"] != gpus:
+            if rank == 0:
+                print(f"[bench] error: communicator spans {comm['size']} rank(s), {comm['ranks_seen']} answered, --gpus {gpus}", file=sys.stderr, flush=True)
+            sys.exit(4)
     else:
         torch.cuda.set_device(0)
-    if world != gpus and rank == 0:
-        print(f"[bench] warning: --gpus {gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    return world, rank, local
+    return world, rank, local, comm
 
 
 def barrier_sync(world):
@@ -577,7 +640,7 @@ def main():
 
     from ws3d_amd import _lib
     _lib.load()  # fail loudly if the HIP library is missing
-    world, rank, local = dist_setup(args.gpus)
+    world, rank, local, comm = dist_setup(args.gpus)
 
     if args.workload == "c3":
         from bench_c3 import C3
@@ -644,7 +707,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
             "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
-            "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS}, **wl.config()),  # (c5 overrides n_points)
+            "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS, "ranks_seen": comm["ranks_seen"],
+                            "communicator": comm}, **wl.config()),  # (c5 overrides n_points)
         }
         if latency is not None:
             out["throughput_mode"] = {"batches_in_flight": getattr(wl, "depth", 1), "ms_per_batch": ms_per_step, "value": value,

@@ -109,6 +109,33 @@ def test_two_ranks_c2_shards_without_a_collective(tmp_path):
         json.dump(out, f)
 
 
+def test_gpus_2_without_a_launcher_starts_two_ranks(tmp_path):
+    """``python bench.py --gpus 2`` -- the shape of the driver's command, NO torch.distributed.run around it -- starts its own
+    two ranks (gloo here: both share the one GPU of the box) and reports n_gpus == 2 with both ranks seen"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WS3D_DIST_BACKEND="gloo", WS3D_TUNE_GEMMS="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--workload", "c3", "--pipeline-depth", "2", "--c2-batch", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["ranks_seen"] == 2 and out["config"]["communicator"]["size"] == 2
+    assert "self-launch" in out["config"]["communicator"]["launcher"] and "all_gather" in out["config"]["exchange"]
+
+
+def test_more_rccl_ranks_than_devices_is_an_error():
+    """two RCCL ranks on a one-GPU box cannot be measured: rc != 0 and no JSON line (never a silent one-GPU figure)"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WS3D_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--workload", "c2", "--batch", "8"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], (p.stdout + p.stderr)[-2000:]
+    assert "needs 2 devices" in p.stderr
+
+
 def test_rccl_all_gather_runs_in_the_graph_mode_pipeline():
     """world size 1 under the nccl (= RCCL) backend with the collective forced: the exchange as the pipeline issues it
     (on the slot's side stream, after a graph replay) executes through RCCL on this 1-GPU box"""
