@@ -47,6 +47,9 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
+/* bumped whenever an entry point is added or a signature changes (2: launch gates of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists;
+ * 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
+#define WS3D_ABI_VERSION 2
 WS3D_API int ws3d_abi_version(void);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
  * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
@@ -171,7 +174,7 @@ WS3D_API int ws3d_pool_nsample_grad(long rows, int nsample, const float *grad_ou
  * out (rows/nsample, o) with row stride out_stride.  fp32 matrix cores, fp32 accumulate.
  * WS3D_E_UNSUPPORTED for other shapes (the caller keeps the two-launch path).                       */
 WS3D_API int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
-                            const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream);
+                            const float *bias, int relu, float *out, int out_stride, const int32_t *gate, long gate_limit, ws3d_stream_t stream);
 
 /* First SharedMLP layer of a set-abstraction scale with the grouping fused into the GEMM's A operand (no reference
  * counterpart; replaces QueryAndGroup -> Conv2d(1x1)+BN+ReLU, pointnet2_utils.py:241-264 + pytorch_utils.py:20-32, on
@@ -210,7 +213,7 @@ WS3D_API int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_feat
  * Same function as ws3d_gather_gemm(2) up to fp32 summation order.  ws3d extension, used by ws3d_amd/fastpath.py.          */
 WS3D_API int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                        const float *new_xyz, const int32_t *nbr, const float *w1x, const float *b1, int relu1,
-                       const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream);
+                       const float *w2t, const float *b2, int relu2, float *out, const int32_t *gate, long gate_limit, ws3d_stream_t stream);
 WS3D_API int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const float *pmat, int p_stride, const float *xyz, const float *new_xyz,
                       const int32_t *nbr, const float *w1x, const float *b1, int relu1, float *out, ws3d_stream_t stream);
 
@@ -222,6 +225,17 @@ WS3D_API int ws3d_pgather_rows(int b, int n, int m, int nsample, int o1, const f
  * ws3d_interp_gemm up to fp32 summation order.  ws3d extension, used by ws3d_amd/fastpath.py.                              */
 WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const int32_t *idx, const float *weight, const float *lin,
                       const float *skip, int c1, const float *wb, const float *bias, int relu, float *out, ws3d_stream_t stream);
+
+/* Launch gates (device-side dispatch between the compact and the dense form of a SharedMLP; ABI version 2).  Both forms are exact;
+ * which one is faster depends on how full the ball-query lists are (break-even ~55 % distinct rows), a number that only exists
+ * on the device and changes per batch -- a captured hipGraph cannot branch on the host.  So the caller launches BOTH forms and
+ * every kernel of a form reads the pair total in its prologue:
+ *   compact kernels (ws3d_pgather_gemm2_compact, ws3d_gemm_pool_compact, ws3d_sa_mlp3_pool_compact): `limit` -- run iff *total <= limit
+ *                  (limit < 0: always);
+ *   dense kernels   (ws3d_pgather_gemm2, ws3d_gemm_pool, ws3d_sa_mlp3_pool_lists): `gate`, `gate_limit` -- run iff *gate > gate_limit
+ *                  (gate == NULL: always), gate = the `total` word of ws3d_compact_pairs.
+ * The form that does not run costs one launch whose workgroups return at once.  Exactly one of the two writes the result; with
+ * the same limit on both sides the decision is consistent whatever the total.                                                 */
 
 /* Compact (centre, sample) pairs.  A ball-query list holds its hits in ascending order, padded with the first one
  * (ball_query_gpu.cu:29-44); a padded row repeats row 0 of its centre in every SharedMLP layer and cannot change the maximum over
@@ -242,9 +256,9 @@ WS3D_API int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t *n
                             int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);
 WS3D_API int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
-                               const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream);
+                               const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, long limit, ws3d_stream_t stream);
 WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
-                           const float *wt, const float *bias, float *out, int out_stride, ws3d_stream_t stream);
+                           const float *wt, const float *bias, float *out, int out_stride, long limit, ws3d_stream_t stream);
 
 /* ws3d_sa_mlp3_pool over compact pairs (see ws3d_compact_pairs_*): the first level's three-layer SharedMLP (16-16-32 or 32-32-64,
  * every layer with bias + ReLU) on rows [x_j - c, f_j] built here from xyz (b, n, 3), new_xyz (b, m, 3) and the ONE feature
@@ -253,7 +267,15 @@ WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const f
 WS3D_API int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
                               const float *feat, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1t,
                               const float *b1, const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
-                              int out_stride, ws3d_stream_t stream);
+                              int out_stride, long limit, ws3d_stream_t stream);
+
+/* The same three layers + pool over ALL rows of the neighbour lists nbr (b, m, nsample), rows built here like above (no grouped
+ * tensor), the pool over registers and STORED (no atomics, out need not be zeroed): replaces ws3d_query_and_group_nlc +
+ * ws3d_sa_mlp3_pool, bit-identical to it and to the compact form.  nsample 16 | 32, widths 16-16-32 | 32-32-64.              */
+WS3D_API int ws3d_sa_mlp3_pool_lists(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                            const float *feat, const int32_t *nbr, const float *w1t, const float *b1, const float *w2t, const float *b2,
+                            const float *w3t, const float *b3, int relu3, float *out, int out_stride, const int32_t *gate, long gate_limit,
+                            ws3d_stream_t stream);
 
 /* First layer of a feature-propagation module with three_interpolate and the skip concatenation fused into the GEMM's A
  * operand (no reference counterpart; replaces three_interpolate -> torch.cat -> Conv2d(1x1)+BN+ReLU,

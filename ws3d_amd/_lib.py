@@ -15,6 +15,8 @@ DIST_MODE = int(os.environ.get("WS3D_DIST_MODE", "0") or 0)
 LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B builds
     _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
+ABI_VERSION = 2     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
+
 _vp = C.c_void_p
 _i = C.c_int
 _f = C.c_float
@@ -49,7 +51,7 @@ SIGNATURES = {
     "ws3d_bn_relu_train_bwd": (_i, [_i, _i, C.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_conv1x1_wgrad_workspace_bytes": (C.c_size_t, [_i, _i, _i, C.c_long]),
     "ws3d_conv1x1_wgrad": (_i, [_i, _i, _i, C.c_long, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
-    "ws3d_gemm_pool": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ws3d_gemm_pool": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_pool_nsample": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
     "ws3d_pool_nsample_grad": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp]),
     "ws3d_scatter_workspace_bytes": (C.c_size_t, [_i, _i, _i, C.c_long]),
@@ -75,15 +77,16 @@ SIGNATURES = {
     "ws3d_gather_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_gather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ws3d_gather_gemm3_pool": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "ws3d_pgather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "ws3d_pgather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.c_long, _vp]),
     "ws3d_pgather_rows": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_qinterp_rows": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ws3d_compact_pairs": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_compact_pairs_count": (_i, [C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_compact_pairs_rows": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "ws3d_pgather_gemm2_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
-    "ws3d_gemm_pool_compact": (_i, [C.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ws3d_pgather_gemm2_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_long, _vp]),
+    "ws3d_gemm_pool_compact": (_i, [C.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
+    "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
+    "ws3d_sa_mlp3_pool_lists": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_interp_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_gather_boxes_bev": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_select_proposals": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -122,6 +125,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.ws3d_abi_version() != ABI_VERSION:
+        raise Ws3dError(f"{LIB_PATH} exports ABI version {lib.ws3d_abi_version()}, this package binds version {ABI_VERSION}: "
+                        "rebuild it (`python -m ws3d_amd.build`)")
     if not os.environ.get("WS3D_HIP_LIB") and lib.ws3d_dist_mode() != DIST_MODE:
         raise Ws3dError(f"{LIB_PATH} was built with WS3D_DIST_MODE={lib.ws3d_dist_mode()}, expected {DIST_MODE}: rebuild it")
     _lib = lib

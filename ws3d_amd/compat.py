@@ -335,9 +335,18 @@ def conv1x1_wgrad(grad_out, x, shape=None):
     return gw
 
 
-def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0):
+def _gate(gate):
+    """(total tensor, limit) -> (pointer, limit) of a dense kernel's launch gate (run iff *total > limit); None -> always run"""
+    if gate is None:
+        return None, 0
+    total, limit = gate
+    return total.data_ptr(), int(limit)
+
+
+def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0, gate=None):
     """out[:, col0:col0+O] = act(max over each group of nsample rows of x_rows @ wt + bias); False when the
-    shape is not covered by the fused kernel (rows, O multiples of 64, K of 4, nsample 16 / 32).  ws3d extension."""
+    shape is not covered by the fused kernel (rows, O multiples of 64, K of 4, nsample 16 / 32).  gate = (total, limit):
+    device-side dispatch, the kernel runs iff *total > limit (ws3d_ops.h "launch gates").  ws3d extension."""
     dev = _dev(x_rows, wt, bias)
     _f32(x_rows, "x_rows"); _f32(wt, "wt")
     rows, k = x_rows.shape
@@ -347,7 +356,7 @@ def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0):
     view = out[:, col0:col0 + o]
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_gemm_pool(rows, nsample, k, o, _p(x_rows), _p(wt), _p(bias), int(bool(relu)), view.data_ptr(),
-                                         out.size(1), _stream()), "gemm_pool")
+                                         out.size(1), *_gate(gate), _stream()), "gemm_pool")
     return True
 
 
@@ -415,7 +424,7 @@ def gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2
     return True
 
 
-def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2):
+def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out=None, gate=None):
     """layer 1 from the per-point product P = feats @ W_f (pmat (B*N, W) row-major, this scale's columns col0 .. col0 + o1) +
     the xyz term (w1x (3, o1)) + bias + ReLU, then layer 2 (w2t (o1, O2)): -> (B*M*ns, O2), or None when the shape is not
     covered (o1 in {64, 128}, O2 % 4, M*ns % 64).  ws3d extension."""
@@ -427,10 +436,13 @@ def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, re
     if (o1 not in (64, 128) or O2 % 4 or (M * ns) % 64 or pmat.dim() != 2 or pmat.size(0) != B * N or pmat.stride(1) != 1 or
             col0 < 0 or col0 + o1 > pmat.size(1) or tuple(w1x.shape) != (3, o1) or w2t.size(0) != o1 or not w1x.is_contiguous() or not w2t.is_contiguous()):
         return None
-    out = torch.empty((B * M * ns, O2), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B * M * ns, O2), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (B * M * ns, O2) or not out.is_contiguous():
+        raise ValueError("pgather_gemm2: out must be a contiguous (B*M*ns, O2) tensor")
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_pgather_gemm2(B, N, M, ns, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(nbr), _p(w1x), _p(b1),
-                                             int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), _stream()), "pgather_gemm2")
+                                             int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), *_gate(gate), _stream()), "pgather_gemm2")
     return out
 
 
@@ -501,9 +513,10 @@ def compact_pairs(nbr, ordered=False):
     return rowc, rowsrc, total
 
 
-def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w2t, b2, relu2):
+def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w2t, b2, relu2, limit=-1):
     """pgather_gemm2 over the compact rows of compact_pairs: -> (B*M*ns, O2) of which the first `total` rows are written, or None
-    when the shape is not covered (o1 in {64, 128, 256}, O2 % 4).  ws3d extension."""
+    when the shape is not covered (o1 in {64, 128, 256}, O2 % 4).  limit >= 0: runs iff total <= limit (launch gate).
+    ws3d extension."""
     rowc, rowsrc, total = pairs
     dev = _dev(pmat, xyz, new_xyz, rowc, w1x, w2t)
     _f32(pmat, "pmat"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(w1x, "w1x"); _f32(w2t, "w2t")
@@ -518,11 +531,11 @@ def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_pgather_gemm2_compact(B, N, M, rows, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc),
                                                      _p(rowsrc), _p(total), _p(w1x), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out),
-                                                     _stream()), "pgather_gemm2_compact")
+                                                     int(limit), _stream()), "pgather_gemm2_compact")
     return out
 
 
-def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset):
+def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset, limit=-1):
     """last SharedMLP layer (+ bias + ReLU) over the compact rows + max over each centre's rows, by atomic max into
     out2d[:, col_offset : col_offset + O] -- which must be ZERO on entry.  True, or False when the shape is not covered
     (K % 4, O % 64).  ws3d extension."""
@@ -536,7 +549,7 @@ def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset):
         return False
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_gemm_pool_compact(rows, k, o, _p(x_rows), _p(rowc), _p(total), _p(wt), _p(bias), out2d.data_ptr() + 4 * col_offset,
-                                                 out2d.stride(0), _stream()), "gemm_pool_compact")
+                                                 out2d.stride(0), int(limit), _stream()), "gemm_pool_compact")
     return True
 
 
@@ -626,7 +639,7 @@ def sa_mlp3_pool(x_rows4, nsample, layers, out, col0=0):
     return True
 
 
-def sa_mlp3_pool_compact(xyz, new_xyz, feat1, pairs, layers, out, col0=0):
+def sa_mlp3_pool_compact(xyz, new_xyz, feat1, pairs, layers, out, col0=0, limit=-1):
     """sa_mlp3_pool over the compact pairs of compact_pairs: rows [x_j - c, f_j] built from xyz (B,N,3), new_xyz (B,M,3) and the one
     feature channel feat1 (B,N,1) or (B,N); atomic max into out[:, col0:col0+c3], which must be ZERO on entry.  False when there
     is no kernel for these widths / flags."""
@@ -642,7 +655,27 @@ def sa_mlp3_pool_compact(xyz, new_xyz, feat1, pairs, layers, out, col0=0):
     with torch.cuda.device(dev):
         check(_lib.load().ws3d_sa_mlp3_pool_compact(xyz.size(0), xyz.size(1), new_xyz.size(1), rowc.numel(), widths[0], widths[1], widths[2], _p(xyz),
                                                     _p(new_xyz), _p(feat1), _p(rowc), _p(rowsrc), _p(total), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
-                                                    _p(b3), view.data_ptr(), out.size(1), _stream()), "sa_mlp3_pool_compact")
+                                                    _p(b3), view.data_ptr(), out.size(1), int(limit), _stream()), "sa_mlp3_pool_compact")
+    return True
+
+
+def sa_mlp3_pool_lists(xyz, new_xyz, feat1, nbr, layers, out, col0=0, gate=None):
+    """the first level's three layers + pool over ALL rows of the neighbour lists nbr (B, M, ns), rows [x_j - c, f_j] built inside
+    (no grouped tensor), the pooled rows STORED into out[:, col0:col0+c3]: == query_and_group_nlc + sa_mlp3_pool, bit for bit.
+    gate = (total, limit): runs iff *total > limit.  False when there is no kernel for these widths / flags."""
+    (w1, b1, r1), (w2, b2, r2), (w3, b3, r3) = layers
+    widths = (w1.size(1), w2.size(1), w3.size(1))
+    ns = nbr.size(2)
+    if (widths not in ((16, 16, 32), (32, 32, 64)) or w1.size(0) != 4 or ns not in (16, 32) or not (r1 and r2) or b1 is None or b2 is None or b3 is None or
+            feat1.numel() != xyz.size(0) * xyz.size(1) or not feat1.is_contiguous() or nbr.numel() % 32):
+        return False
+    dev = _dev(xyz, new_xyz, feat1, nbr, out)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(feat1, "feat1"); _i32(nbr, "nbr"); _f32(out, "out")
+    view = out[:, col0:col0 + widths[2]]
+    with torch.cuda.device(dev):
+        check(_lib.load().ws3d_sa_mlp3_pool_lists(xyz.size(0), xyz.size(1), new_xyz.size(1), ns, widths[0], widths[1], widths[2], _p(xyz), _p(new_xyz),
+                                                  _p(feat1), _p(nbr), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), int(bool(r3)), view.data_ptr(),
+                                                  out.size(1), *_gate(gate), _stream()), "sa_mlp3_pool_lists")
     return True
 
 

@@ -27,7 +27,7 @@ int check_launch(const char *what) {
 
 }  // namespace ws3d
 
-extern "C" int ws3d_abi_version(void) { return 1; }
+extern "C" int ws3d_abi_version(void) { return WS3D_ABI_VERSION; }
 
 extern "C" int ws3d_dist_mode(void) { return WS3D_DIST_MODE; }
 

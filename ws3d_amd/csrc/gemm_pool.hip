@@ -23,7 +23,9 @@ __device__ __forceinline__ float gp_nanmax(float a, float b) { return (a > b || 
 template <int NS>
 __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, const float *__restrict__ x,
                                                         const float *__restrict__ wt, const float *__restrict__ bias,
-                                                        int relu, float *__restrict__ out, int out_stride, int xcd) {
+                                                        int relu, float *__restrict__ out, int out_stride, int xcd,
+                                                        const int32_t *__restrict__ gate, long gate_limit) {
+    if (gate && (long)*gate <= gate_limit) return;        // device-side dispatch (ws3d_ops.h "launch gates"): the compact kernels run instead
     __shared__ float xs[2][GP_KT][GP_XS];     // [k][row]
     __shared__ float ws[2][GP_KT][64];        // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -126,7 +128,9 @@ __device__ long long gp_prof[8 * 65536];
 template <int NS, int MB, int NB>
 __global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim, const float *__restrict__ x,
                                                             const float *__restrict__ wt, const float *__restrict__ bias,
-                                                            int relu, float *__restrict__ out, int out_stride, int xcd) {
+                                                            int relu, float *__restrict__ out, int out_stride, int xcd,
+                                                            const int32_t *__restrict__ gate, long gate_limit) {
+    if (gate && (long)*gate <= gate_limit) return;
     constexpr int TM = 64 * MB, TN = 64 * NB, XS = TM + 1;
     __shared__ float xs[2][GP_KT][XS];        // [k][row]
     __shared__ float ws[2][GP_KT][TN];        // [k][col]
@@ -590,7 +594,9 @@ __global__ __launch_bounds__(256) void pgather_gemm2_kernel(int o2, int n, int m
                                                             const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                             const int32_t *__restrict__ nbr, const float *__restrict__ w1x,
                                                             const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                            const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+                                                            const float *__restrict__ b2, int relu2, float *__restrict__ out,
+                                                            const int32_t *__restrict__ gate, long gate_limit) {
+    if (gate && (long)*gate <= gate_limit) return;
     constexpr int O1 = NB1 * 64;
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     float *act = smem2, *w2s = smem2 + O1 * GP_XS;           // act[O1][GP_XS] | w2s[2][GP_KT][64]
@@ -771,11 +777,11 @@ __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int 
                                                                     const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
                                                                     const int32_t *__restrict__ total, const float *__restrict__ w1x,
                                                                     const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                                    const float *__restrict__ b2, int relu2, float *__restrict__ out) {
+                                                                    const float *__restrict__ b2, int relu2, float *__restrict__ out, long limit) {
     constexpr int O1 = NB1 * 64;
     const long T = *total;
     const long row0 = (long)blockIdx.x * 64;
-    if (row0 >= T) return;                                   // workgroup-uniform
+    if (row0 >= T || (limit >= 0 && T > limit)) return;      // workgroup-uniform; beyond the limit the dense kernels run instead
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     float *act = smem2, *w2s = smem2 + O1 * GP_XS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -861,13 +867,13 @@ __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int 
 // (out starts at 0, every candidate is >= 0 after the ReLU: the float order is the integer order)
 __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o_dim, const float *__restrict__ x, const int32_t *__restrict__ rowc,
                                                                 const int32_t *__restrict__ total, const float *__restrict__ wt,
-                                                                const float *__restrict__ bias, float *__restrict__ out, int out_stride) {
+                                                                const float *__restrict__ bias, float *__restrict__ out, int out_stride, long limit) {
     const long T = *total;
     const int col_tiles = o_dim / 64;
     const long row_tile = blockIdx.x / col_tiles;
     const int col_tile = (int)(blockIdx.x - row_tile * col_tiles);
     const long row0 = row_tile * 64;
-    if (row0 >= T) return;
+    if (row0 >= T || (limit >= 0 && T > limit)) return;
     __shared__ float xs[2][GP_KT][GP_XS];
     __shared__ float ws[2][GP_KT][64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
 }  // namespace ws3d
 
 extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, const float *x_rows, const float *wt,
-                              const float *bias, int relu, float *out, int out_stride, ws3d_stream_t stream) {
+                              const float *bias, int relu, float *out, int out_stride, const int32_t *gate, long gate_limit, ws3d_stream_t stream) {
     using namespace ws3d;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(wt);
     if (rows < 0 || (nsample != 16 && nsample != 32) || k_dim <= 0 || (k_dim & 3) || o_dim <= 0 || (o_dim & 63) || (rows & 63) ||
@@ -1198,9 +1204,9 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
 #define GP_BIG(M_, N_)                                                                                                              \
     if (mb == M_ && nb == N_) {                                                                                                     \
         if (nsample == 16)                                                                                                          \
-            hipLaunchKernelGGL((gemm_pool_big_kernel<16, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc); \
+            hipLaunchKernelGGL((gemm_pool_big_kernel<16, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc, gate, gate_limit); \
         else                                                                                                                        \
-            hipLaunchKernelGGL((gemm_pool_big_kernel<32, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc); \
+            hipLaunchKernelGGL((gemm_pool_big_kernel<32, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc, gate, gate_limit); \
         return check_launch("ws3d_gemm_pool");                                                                                      \
     }
             GP_BIG(1, 1) GP_BIG(2, 1) GP_BIG(1, 2) GP_BIG(2, 2)
@@ -1211,9 +1217,9 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
     const int xcd = (xcd_env && row_tiles % 8 == 0) ? 1 : 0;
     const dim3 grid((unsigned)((o_dim / 64) * row_tiles)), block(256);
     if (nsample == 16)
-        hipLaunchKernelGGL(gemm_pool_kernel<16>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd);
+        hipLaunchKernelGGL(gemm_pool_kernel<16>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd, gate, gate_limit);
     else
-        hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd);
+        hipLaunchKernelGGL(gemm_pool_kernel<32>, grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xcd, gate, gate_limit);
     return check_launch("ws3d_gemm_pool");
 }
 
@@ -1336,7 +1342,7 @@ extern "C" int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_fe
 
 extern "C" int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                   const float *new_xyz, const int32_t *nbr, const float *w1x, const float *b1, int relu1,
-                                  const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+                                  const float *w2t, const float *b2, int relu2, float *out, const int32_t *gate, long gate_limit, ws3d_stream_t stream) {
     using namespace ws3d;
     const long rows = (long)b * m * nsample;
     if (b < 0 || n <= 0 || m <= 0 || nsample <= 0 || (o1 != 64 && o1 != 128) || o2 <= 0 || (o2 & 3) || ((long)m * nsample) % 64 || p_stride < o1 ||
@@ -1348,10 +1354,10 @@ extern "C" int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int 
     const size_t lds = sizeof(float) * ((size_t)o1 * GP_XS + (size_t)2 * GP_KT * 64);
     if (o1 == 64)
         hipLaunchKernelGGL((pgather_gemm2_kernel<1>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), o2, n, m, nsample, pmat, p_stride,
-                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out);
+                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out, gate, gate_limit);
     else
         hipLaunchKernelGGL((pgather_gemm2_kernel<2>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), o2, n, m, nsample, pmat, p_stride,
-                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out);
+                           xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out, gate, gate_limit);
     return check_launch("ws3d_pgather_gemm2");
 }
 
@@ -1423,7 +1429,7 @@ extern "C" int ws3d_compact_pairs(long centres, int nsample, const int32_t *nbr,
 
 extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                           const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
-                                          const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, ws3d_stream_t stream) {
+                                          const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, long limit, ws3d_stream_t stream) {
     using namespace ws3d;
     if (b <= 0 || n <= 0 || m <= 0 || max_rows <= 0 || (o1 != 64 && o1 != 128 && o1 != 256) || o2 <= 0 || (o2 & 3) || p_stride < o1 || !pmat || !xyz || !new_xyz ||
         !rowc || !rowsrc || !total || !w1x || !w2t || !out || (reinterpret_cast<uintptr_t>(w2t) & 15)) {
@@ -1434,21 +1440,21 @@ extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, in
     const dim3 grid((unsigned)((max_rows + 63) / 64), (unsigned)((o2 + 63) / 64));
     if (o1 == 64)
         hipLaunchKernelGGL((pgather_gemm2_compact_kernel<1>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
-                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     else if (o1 == 128)
         hipLaunchKernelGGL((pgather_gemm2_compact_kernel<2>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
-                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     else {
         static bool attr = false;          // 74 KB of LDS: above the default limit
         if (!attr) { (void)hipFuncSetAttribute((const void *)pgather_gemm2_compact_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
         hipLaunchKernelGGL((pgather_gemm2_compact_kernel<4>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
-                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out);
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     }
     return check_launch("ws3d_pgather_gemm2_compact");
 }
 
 extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
-                                      const float *wt, const float *bias, float *out, int out_stride, ws3d_stream_t stream) {
+                                      const float *wt, const float *bias, float *out, int out_stride, long limit, ws3d_stream_t stream) {
     using namespace ws3d;
     const uintptr_t al = reinterpret_cast<uintptr_t>(x_rows) | reinterpret_cast<uintptr_t>(wt);
     if (max_rows <= 0 || k_dim <= 0 || (k_dim & 3) || o_dim <= 0 || (o_dim & 63) || !x_rows || !rowc || !total || !wt || !out || out_stride < o_dim ||
@@ -1457,7 +1463,7 @@ extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const
         return WS3D_E_UNSUPPORTED;
     }
     const unsigned grid = (unsigned)(((max_rows + 63) / 64) * (o_dim / 64));
-    hipLaunchKernelGGL(gemm_pool_compact_kernel, dim3(grid), dim3(256), 0, as_stream(stream), k_dim, o_dim, x_rows, rowc, total, wt, bias, out, out_stride);
+    hipLaunchKernelGGL(gemm_pool_compact_kernel, dim3(grid), dim3(256), 0, as_stream(stream), k_dim, o_dim, x_rows, rowc, total, wt, bias, out, out_stride, limit);
     return check_launch("ws3d_gemm_pool_compact");
 }
 

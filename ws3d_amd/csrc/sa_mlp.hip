@@ -200,13 +200,13 @@ __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m,
                                                                    const float *__restrict__ w1t, const float *__restrict__ b1,
                                                                    const float *__restrict__ w2t, const float *__restrict__ b2,
                                                                    const float *__restrict__ w3t, const float *__restrict__ b3,
-                                                                   float *__restrict__ out, int out_stride) {
+                                                                   float *__restrict__ out, int out_stride, long limit) {
     static_assert((C1 == 16 || C1 == 32) && (C2 == 16 || C2 == 32) && (C3 == 32 || C3 == 64), "shape");
     constexpr int V1 = C1 / 2, V2 = C2 / 2, NB3 = C3 / 32;
     const long T = *total;
     const long tiles = (T + 31) / 32;
     const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
-    if (wave >= tiles) return;
+    if (wave >= tiles || (limit >= 0 && T > limit)) return;       // beyond the limit sa_mlp3_lists_mfma_kernel runs instead
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
     float a1[2], a2[V1], a3[NB3][V2], bb1[V1], bb2[V2], b3v[NB3];
@@ -277,6 +277,94 @@ __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m,
                 }
             }
             if (prev >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev * out_stride + blk * 32 + c), __float_as_int(run));
+        }
+    }
+}
+
+// ---- the same chain over ALL rows of the neighbour lists, without a grouped tensor: row r = (centre r / NS, source point
+// nbr[r]) is built here like in the compact kernel, the pool runs over registers like in sa_mlp3_pool_mfma_kernel (a tile of 32
+// rows holds one centre at NS = 32, two at 16) and is STORED -- no atomics, no zeroed output.  This is the dense side of the
+// device-side dispatch: launched next to the compact kernel with a gate on the pair total (run iff *gate > gate_limit; a null
+// gate always runs), it replaces ws3d_query_and_group_nlc + ws3d_sa_mlp3_pool (25 MB of grouped rows written and read back per
+// batch of 8 scenes).  Bit-identical to both: a row's activations are its own, the maximum is order-free.
+template <int C1, int C2, int C3, int NS>
+__global__ __launch_bounds__(256) void sa_mlp3_lists_mfma_kernel(long tiles, int n, int m, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                 const float *__restrict__ feat, const int32_t *__restrict__ nbr,
+                                                                 const float *__restrict__ w1t, const float *__restrict__ b1,
+                                                                 const float *__restrict__ w2t, const float *__restrict__ b2,
+                                                                 const float *__restrict__ w3t, const float *__restrict__ b3, int relu3,
+                                                                 float *__restrict__ out, int out_stride, const int32_t *__restrict__ gate,
+                                                                 long gate_limit) {
+    static_assert((NS == 16 || NS == 32) && (C1 == 16 || C1 == 32) && (C2 == 16 || C2 == 32) && (C3 == 32 || C3 == 64), "shape");
+    if (gate && (long)*gate <= gate_limit) return;
+    constexpr int V1 = C1 / 2, V2 = C2 / 2, NB3 = C3 / 32;
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    auto kp = [&](int v) { return 8 * (v / 4) + 4 * h + (v % 4); };
+    float a1[2], a2[V1], a3[NB3][V2], bb1[V1], bb2[V2], b3v[NB3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a1[j] = c < C1 ? w1t[(2 * j + h) * C1 + c] : 0.f;
+#pragma unroll
+    for (int v = 0; v < V1; ++v) {
+        a2[v] = c < C2 ? w2t[kp(v) * C2 + c] : 0.f;
+        bb1[v] = b1[kp(v)];
+    }
+#pragma unroll
+    for (int v = 0; v < V2; ++v) {
+#pragma unroll
+        for (int blk = 0; blk < NB3; ++blk) a3[blk][v] = w3t[kp(v) * C3 + blk * 32 + c];
+        bb2[v] = b2[kp(v)];
+    }
+#pragma unroll
+    for (int blk = 0; blk < NB3; ++blk) b3v[blk] = b3[blk * 32 + c];
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long tile = wave; tile < tiles; tile += nwaves) {
+        float4 xr;
+        {
+            const long r = tile * 32 + c;
+            const long cm = r / NS;
+            const size_t p = (size_t)(cm / m) * n + (size_t)nbr[r];
+            const float *pr = xyz + p * 3, *cr = new_xyz + (size_t)cm * 3;
+            xr = make_float4(pr[0] - cr[0], pr[1] - cr[1], pr[2] - cr[2], feat[p]);
+        }
+        sa_f16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], h ? xr.y : xr.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], h ? xr.w : xr.z, acc, 0, 0, 0);
+        float act[16];
+#pragma unroll
+        for (int v = 0; v < V1; ++v) act[v] = fmaxf(acc[v] + bb1[v], 0.f);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int v = 0; v < V1; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < V2; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
+#pragma unroll
+        for (int blk = 0; blk < NB3; ++blk) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int v = 0; v < V2; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
+            const float bias = b3v[blk];
+            if (NS == 32) {
+                float mx = acc[0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v) mx = fmaxf(mx, acc[v]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx += bias;
+                if (relu3) mx = fmaxf(mx, 0.f);
+                if (h == 0) out[tile * (long)out_stride + blk * 32 + c] = mx;
+            } else {
+                float m0 = acc[0], m1 = acc[8];
+#pragma unroll
+                for (int v = 1; v < 8; ++v) { m0 = fmaxf(m0, acc[v]); m1 = fmaxf(m1, acc[8 + v]); }
+                m0 = fmaxf(m0, __shfl_xor(m0, 32));
+                m1 = fmaxf(m1, __shfl_xor(m1, 32));
+                float mx = (h ? m1 : m0) + bias;
+                if (relu3) mx = fmaxf(mx, 0.f);
+                out[(tile * 2 + h) * (long)out_stride + blk * 32 + c] = mx;
+            }
         }
     }
 }
@@ -460,7 +548,7 @@ extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float 
 extern "C" int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
                                          const float *feat, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1t,
                                          const float *b1, const float *w2t, const float *b2, const float *w3t, const float *b3, float *out,
-                                         int out_stride, ws3d_stream_t stream) {
+                                         int out_stride, long limit, ws3d_stream_t stream) {
     using namespace ws3d;
     if (b <= 0 || n <= 0 || m <= 0 || max_rows <= 0 || !xyz || !new_xyz || !feat || !rowc || !rowsrc || !total || !w1t || !b1 || !w2t || !b2 || !w3t ||
         !b3 || !out || out_stride < c3) {
@@ -472,12 +560,40 @@ extern "C" int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int
 #define WS3D_SA_COMPACT(A, B, C)                                                                                                        \
     if (c1 == A && c2 == B && c3 == C) {                                                                                                \
         hipLaunchKernelGGL((sa_mlp3_compact_mfma_kernel<A, B, C>), dim3(grid), dim3(256), 0, as_stream(stream), n, m, xyz, new_xyz, feat, rowc, \
-                           rowsrc, total, w1t, b1, w2t, b2, w3t, b3, out, out_stride);                                                  \
+                           rowsrc, total, w1t, b1, w2t, b2, w3t, b3, out, out_stride, limit);                                           \
         return check_launch("ws3d_sa_mlp3_pool_compact");                                                                               \
     }
     WS3D_SA_COMPACT(32, 32, 64)
     WS3D_SA_COMPACT(16, 16, 32)
 #undef WS3D_SA_COMPACT
     set_error("ws3d_sa_mlp3_pool_compact: no kernel for widths (%d, %d, %d)", c1, c2, c3);
+    return WS3D_E_UNSUPPORTED;
+}
+
+extern "C" int ws3d_sa_mlp3_pool_lists(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz, const float *new_xyz,
+                                       const float *feat, const int32_t *nbr, const float *w1t, const float *b1, const float *w2t, const float *b2,
+                                       const float *w3t, const float *b3, int relu3, float *out, int out_stride, const int32_t *gate, long gate_limit,
+                                       ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * m * nsample;
+    if (b <= 0 || n <= 0 || m <= 0 || (nsample != 16 && nsample != 32) || (rows & 31) || !xyz || !new_xyz || !feat || !nbr || !w1t || !b1 || !w2t || !b2 ||
+        !w3t || !b3 || !out || out_stride < c3) {
+        set_error("ws3d_sa_mlp3_pool_lists: invalid argument (b=%d n=%d m=%d nsample=%d)", b, n, m, nsample);
+        return WS3D_E_INVALID;
+    }
+    const long tiles = rows / 32;
+    const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);
+#define WS3D_SA_LISTS(A, B, C, N)                                                                                                       \
+    if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                                                \
+        hipLaunchKernelGGL((sa_mlp3_lists_mfma_kernel<A, B, C, N>), dim3(grid), dim3(256), 0, as_stream(stream), tiles, n, m, xyz, new_xyz, feat, nbr, \
+                           w1t, b1, w2t, b2, w3t, b3, relu3, out, out_stride, gate, gate_limit);                                        \
+        return check_launch("ws3d_sa_mlp3_pool_lists");                                                                                 \
+    }
+    WS3D_SA_LISTS(32, 32, 64, 32)
+    WS3D_SA_LISTS(16, 16, 32, 16)
+    WS3D_SA_LISTS(32, 32, 64, 16)
+    WS3D_SA_LISTS(16, 16, 32, 32)
+#undef WS3D_SA_LISTS
+    set_error("ws3d_sa_mlp3_pool_lists: no kernel for widths (%d, %d, %d) x nsample %d", c1, c2, c3, nsample);
     return WS3D_E_UNSUPPORTED;
 }

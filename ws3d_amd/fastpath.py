@@ -29,6 +29,7 @@ from . import nn_blocks, pn2_ops
 
 
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
+SA1_FROM_LISTS = os.environ.get("WS3D_SA1_FROM_LISTS", "1") != "0"  # first level: rows built from the neighbour lists inside the MLP kernel (0: grouped tensor)
 FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
@@ -39,8 +40,15 @@ GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling c
 FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
 FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
-COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # a scale whose lists are fuller than this keeps the dense kernels
-COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # SA2 / SA3: the SharedMLP over the distinct (centre, sample) pairs only
+COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # lists fuller than this (distinct rows / all rows) take the dense kernels
+COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # the SharedMLPs over the distinct (centre, sample) pairs only (0: all m * nsample rows)
+# How a scale chooses between the compact and the dense form of its SharedMLP (both exact):
+#   device  (default) both forms are launched, every kernel reads the pair total of THIS batch in its prologue and the form on the
+#           wrong side of COMPACT_MAX_FILL returns at once (include/ws3d_ops.h "launch gates") -- no host synchronisation, nothing
+#           latched per process, a captured hipGraph adapts per batch;
+#   compact always the compact kernels (A/B runs).
+# WS3D_COMPACT_PAIRS=0 is "always dense".
+PAIR_DISPATCH = os.environ.get("WS3D_PAIR_DISPATCH", "device")
 PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
@@ -131,20 +139,34 @@ def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
             blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
 
 
-_PAIR_FILL = {}      # (n, npoint, radius, nsample) -> fraction of distinct rows seen at the first eager pass over such a scale
+def _pair_limit(rows: int, dense_available: bool) -> int:
+    """the launch gate of a scale with `rows` = B * npoint * nsample list entries: the compact kernels run iff the distinct pairs
+    of this batch number <= limit, the dense ones iff > limit (-1: no gate, always compact).  The compact path beats the dense
+    kernels up to ~55-60 % distinct rows (profiles/r02_compact_vs_dense_fill.txt: 46 vs 133 us at 5 %, 111 vs 129 at 48 %, 180 vs
+    122 at 96 %); both are exact, so this is a speed decision only -- taken on the device, per batch."""
+    if PAIR_DISPATCH != "device" or not dense_available:
+        return -1
+    return max(0, int(COMPACT_MAX_FILL * rows))          # 0: a batch always holds >= 1 pair, i.e. always dense
 
 
-def _pairs_pay(key, pairs, rows: int) -> bool:
-    """The compact path beats the dense kernels up to ~60 % distinct rows (profiles/r02_compact_vs_dense_fill.txt: 46 vs 133 us at
-    5 %, 111 vs 129 at 48 %, 180 vs 122 at 96 %) -- both are exact, so this is a speed decision only.  The fill of a scale is read
-    ONCE, at its first eager pass (one host synchronisation; Stage1Pipeline's priming runs do it before the capture), and kept."""
-    fill = _PAIR_FILL.get(key)
-    if fill is None:
-        if torch.cuda.is_current_stream_capturing():
-            return True                                  # never seen eagerly: lidar lists are sparse
-        fill = float(pairs[2].item()) / max(rows, 1)
-        _PAIR_FILL[key] = fill
-    return fill <= COMPACT_MAX_FILL
+@torch.no_grad()
+def list_fill(net, pointcloud: torch.Tensor):
+    """distinct (centre, sample) pairs / all list entries of every ball-query scale of the backbone on this batch -- the statistic
+    the launch gates act on -- as a list of dicts.  A diagnostic (bench.py's ``list_fill``): runs the sampling chain and the
+    searches on their own and synchronises; the forward pass itself never reads these numbers on the host."""
+    xyz = pointcloud[..., 0:3].contiguous()
+    rows = []
+    for level, sa in enumerate(net.SA_modules):
+        _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
+        srt = pn2_ops.sort_points_x(xyz)
+        for g in sa.groupers:
+            nbr = _C.ball_query_lists(g.radius, g.nsample, xyz, new_xyz, srt)
+            total = _C.compact_pairs(nbr)[2]
+            rows.append({"level": level + 1, "n": xyz.size(1), "npoint": sa.npoint, "radius": float(g.radius), "nsample": g.nsample,
+                         "distinct_per_list": float(total.item()) / max(nbr.numel() // g.nsample, 1),
+                         "fill": float(total.item()) / max(nbr.numel(), 1)})
+        xyz = new_xyz
+    return rows
 
 
 class _PairList:
@@ -185,9 +207,7 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
         nbr = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
         if COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256 and len(_blocks(mlp)) == 3:
             # the distinct pairs of the lists (coordinate-only work: with the lists on the search stream)
-            pairs = _C.compact_pairs(nbr)
-            if _pairs_pay((xyz.size(1), sa.npoint, float(grouper.radius), grouper.nsample), pairs, nbr.numel()):
-                nbr = _PairList(nbr, pairs)
+            nbr = _PairList(nbr, _C.compact_pairs(nbr))
         lists.append(nbr)
     return lists
 
@@ -310,10 +330,21 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 wt3, b3, r3 = _row_weights(blocks[-1])
                 if pairs is not None and o1 <= 256 and len(blocks) == 3 and r3:
                     # the whole SharedMLP over the DISTINCT (centre, sample) pairs: padded rows repeat row 0 and cannot change the
-                    # maximum; `out` is zero-initialised for the atomic max of the last layer
+                    # maximum; `out` is zero-initialised for the atomic max of the last layer.  Device-side dispatch: the dense form
+                    # (all rows, pooled in registers, stored) is launched behind it into the same buffers, and the pair total of
+                    # this batch decides in every kernel's prologue which of the two runs
                     wt2, b2, r2 = _row_weights(blocks[1])
-                    yc = _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2)
-                    if yc is not None and _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col):
+                    rows, ns, o3 = nbr.numel(), grouper.nsample, wt3.size(1)
+                    dense_ok = (o1 in (64, 128) and (sa.npoint * ns) % 64 == 0 and rows // 64 <= 65535 and o3 % 64 == 0 and
+                                wt2.size(1) % 4 == 0 and ns in (16, 32))
+                    limit = _pair_limit(rows, dense_ok)
+                    yc = _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, limit=limit)
+                    if yc is not None and _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col, limit=limit):
+                        if limit >= 0:
+                            gate = (pairs[2], limit)
+                            yd = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2, out=yc, gate=gate)
+                            if yd is None or not _C.gemm_pool(yd, wt3, b3, r3, ns, out, col, gate=gate):
+                                raise RuntimeError("the gated dense kernels declined a shape _pair_limit accepted")
                         col += width
                         continue
                 if o1 <= 128:
@@ -357,13 +388,21 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
             col += width
             continue
-        if COMPACT_PAIRS and FUSED_SA_MLP and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
-            # first level: lists only (no grouped tensor), their distinct pairs, the three layers chained in registers over those
-            key1 = (xyz.size(1), sa.npoint, float(grouper.radius), grouper.nsample)
-            if _PAIR_FILL.get(key1, 0.0) <= COMPACT_MAX_FILL:
-                nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
+        if FUSED_SA_MLP and SA1_FROM_LISTS and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
+            # first level: lists only (no grouped tensor), the three layers chained in registers -- over the distinct pairs of the
+            # lists (atomic max into the zeroed `out`) or over all their rows (pool in registers, stored), decided on the device
+            layers = [_row_weights(b) for b in blocks]
+            nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
+            if not COMPACT_PAIRS:
+                if _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col):
+                    col += width
+                    continue
+            else:
                 pairs1 = _C.compact_pairs(nbr1)
-                if _pairs_pay(key1, pairs1, nbr1.numel()) and _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, [_row_weights(b) for b in blocks], out, col):
+                limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
+                if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
+                    if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
+                        raise RuntimeError("ws3d_sa_mlp3_pool_lists declined a shape ws3d_sa_mlp3_pool_compact accepted")
                     col += width
                     continue
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)

@@ -97,6 +97,121 @@ def lidar_cloud(n: int, seed: int, n_cars: int = 15, dup_frac: float = 0.0,
     return pc
 
 
+# --------------------------------------------------------------------------- hdl64: a ray-cast Velodyne HDL-64E scan
+# KITTI's sensor: 64 beams, +2 deg ... -8.33 deg at 1/3 deg (upper block) and -8.83 ... -24.33 deg at 1/2 deg (lower block),
+# ~0.18 deg of azimuth per firing at 10 Hz, 1.73 m above the road; the camera of the rect frame sits 0.08 m below and 0.27 m
+# in front of it (Tr_velo_to_cam of KITTI_CALIB_TEXT).  What the reference feeds the network is such a scan cropped to the
+# camera image and PC_AREA_SCOPE and then sub-sampled to 16384 points with every point beyond 40 m kept
+# (lib/datasets/kitti_rcnn_dataset.py:399-447, restated in kitti_io.sample_point_choice): near-range ground rings put dozens of
+# points inside the r = 0.5 m ball of an SA1 centre -- the regime the `lidar` generator above (1-2 distinct neighbours per
+# list) never reaches.
+HDL64_ELEVATION_DEG = np.concatenate([2.0 - np.arange(32) / 3.0, -8.83 - 0.5 * np.arange(32)])
+HDL64_AZIMUTH_STEP_DEG = 0.18
+HDL64_SENSOR = (0.0, -0.08, -0.27)     # beam origin in the rect camera frame (x right, y down, z forward); road at y = 1.65
+HDL64_ROAD_Y = 1.65
+KITTI_P2 = (721.5377, 609.5593, 172.854, 1242, 375)   # fx = fy, cx, cy, image width, height
+
+
+def _ray_boxes(o, d, boxes, az_lo=None, az_step=None):
+    """nearest entry distance of the rays o + t d, d (64, A, 3) on a regular azimuth grid (column a covers azimuth
+    az_lo + a az_step up to one step of per-beam offset), into oriented boxes (K,7) [x, y_bottom, z, h, w, l, ry] (the reference's
+    frame: l along the box's x, w along its z, rotation about y) -> (64, A) t, inf where nothing is hit.  Each box is tested
+    against the azimuth columns its bounding circle can cover only."""
+    nb, na = d.shape[0], d.shape[1]
+    best = np.full((nb, na), np.inf)
+    for bx in boxes:
+        c, s = np.cos(bx[6]), np.sin(bx[6])
+        ctr = np.array([bx[0], bx[1] - bx[3] / 2, bx[2]])
+        half = np.array([bx[5] / 2, bx[3] / 2, bx[4] / 2])                         # along the box's x (l), y (h), z (w)
+        rel = o - ctr
+        rho = np.hypot(rel[0], rel[2])                                              # ground distance sensor -> box centre
+        rad = np.hypot(half[0], half[2])
+        a0, a1 = 0, na
+        if rho > rad * 1.05:
+            mid, wid = np.arctan2(-rel[0], -rel[2]), np.arcsin(rad / rho) + 2.5 * az_step
+            a0 = max(0, int(np.floor((mid - wid - az_lo) / az_step)))
+            a1 = min(na, int(np.ceil((mid + wid - az_lo) / az_step)) + 1)
+            if a1 <= a0:
+                continue
+        dd = d[:, a0:a1]
+        ob = np.array([rel[0] * c - rel[2] * s, rel[1], rel[0] * s + rel[2] * c])   # origin in the box frame
+        db = np.stack([dd[..., 0] * c - dd[..., 2] * s, dd[..., 1], dd[..., 0] * s + dd[..., 2] * c], -1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / db
+            t1, t2 = (-half - ob) * inv, (half - ob) * inv
+        tn, tf = np.minimum(t1, t2).max(-1), np.maximum(t1, t2).min(-1)
+        hit = (tn <= tf) & (tn > 0.5)
+        best[:, a0:a1] = np.minimum(best[:, a0:a1], np.where(hit, tn, np.inf))
+    return best
+
+
+def hdl64_scene_boxes(seed: int, n_cars: int = 15) -> np.ndarray:
+    """the objects of one ray-cast scene: `n_cars` cars standing on the road (the proposals' ground truth, same seeding as
+    lidar_cloud), two building fronts along the road and eight poles / trunks -> (n_cars + 10, 7)"""
+    r = _rng(seed * 6151 + 7)
+    cars = random_boxes3d(n_cars, seed * 7919 + 13, jitter=0.1).astype(np.float64)
+    cars[:, 1] = HDL64_ROAD_Y
+    walls = np.array([[side * r.uniform(9.0, 22.0), HDL64_ROAD_Y, r.uniform(25.0, 45.0), r.uniform(4.0, 9.0), r.uniform(50.0, 70.0), 1.0,
+                       r.uniform(-0.06, 0.06)] for side in (-1.0, 1.0)])          # l = 1 m thick (x), w = 50-70 m long (z)
+    poles = np.stack([r.uniform(-20.0, 20.0, 8), np.full(8, HDL64_ROAD_Y), r.uniform(6.0, 60.0, 8), r.uniform(2.5, 6.0, 8),
+                      r.uniform(0.2, 0.5, 8), r.uniform(0.2, 0.5, 8), r.uniform(-np.pi, np.pi, 8)], 1)
+    return np.concatenate([cars, walls, poles], 0)
+
+
+def hdl64_scan(seed: int, n_cars: int = 15, return_boxes: bool = False, sweep: int = 0):
+    """one ray-cast sweep of the forward quadrant, cropped like the reference's ``get_valid_flag`` (inside the 1242 x 375 image,
+    in front of the camera, inside PC_AREA_SCOPE) -> (n, 4) float64 [x, y, z (rect camera frame), intensity in [0, 1)], n ~ 19-23 k.
+    `sweep` > 0: another sweep over the SAME scene (same objects) with its own firing offsets and range noise"""
+    r = _rng(seed + 104729 * sweep)
+    elev = np.deg2rad(HDL64_ELEVATION_DEG)
+    step = np.deg2rad(HDL64_AZIMUTH_STEP_DEG)
+    az0 = np.arange(-43.0, 43.0, HDL64_AZIMUTH_STEP_DEG) * np.pi / 180.0      # the image frustum is +-40.7 deg wide
+    # every laser fires at its own fixed azimuth offset inside a step (the sensor's staggered layout), plus firing jitter
+    az = az0[None, :] + r.uniform(0.0, step, (64, 1)) + r.normal(0.0, 0.02 * step, (64, az0.size))
+    el = elev[:, None] + r.normal(0.0, np.deg2rad(0.01), (64, az0.size))
+    d = np.stack([np.cos(el) * np.sin(az), -np.sin(el), np.cos(el) * np.cos(az)], 2)              # (64, A, 3)
+    o = np.asarray(HDL64_SENSOR, dtype=np.float64)
+    boxes = hdl64_scene_boxes(seed, n_cars)
+    with np.errstate(divide="ignore"):
+        t_road = np.where(d[..., 1] > 1e-6, (HDL64_ROAD_Y - o[1]) / d[..., 1], np.inf)
+    t = np.minimum(t_road, _ray_boxes(o, d, boxes, az0[0], step))
+    ok = np.isfinite(t) & (t < 120.0)
+    t, d = t[ok], d[ok]
+    t = t + r.normal(0.0, 0.015, t.shape)                                       # range noise of the sensor
+    pts = o[None, :] + t[:, None] * d
+    fx, cx, cy, w, h = KITTI_P2
+    z = pts[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u, v = fx * pts[:, 0] / z + cx, fx * pts[:, 1] / z + cy
+    keep = (z >= 0) & (u >= 0) & (u < w) & (v >= 0) & (v < h)
+    (x0, x1), (y0, y1), (z0, z1) = PC_AREA_SCOPE
+    keep &= (pts[:, 0] >= x0) & (pts[:, 0] <= x1) & (pts[:, 1] >= y0) & (pts[:, 1] <= y1) & (z >= z0) & (z <= z1)
+    pts = pts[keep]
+    scan = np.concatenate([pts, r.uniform(0.0, 1.0, (pts.shape[0], 1))], 1)
+    if return_boxes:
+        return scan, boxes[:n_cars].astype(np.float32)
+    return scan
+
+
+def hdl64_cloud(n: int, seed: int, n_cars: int = 15, return_boxes: bool = False):
+    """(n, 4) float32 network input from a ray-cast HDL-64E scan: the reference's sub-sampling to n points -- all points
+    beyond 40 m kept, near ones drawn without replacement, a smaller scan tiled (kitti_rcnn_dataset.py:424-447 via
+    kitti_io.sample_point_choice) on a seeded ``RandomState`` -- and intensity - 0.5.  The scan itself holds ~20 k points; for
+    n above that (c5's 65536) four sweeps with independent noise are merged first (a denser sensor, not a tiled copy)."""
+    from .kitti_io import sample_point_choice
+    scan, boxes = hdl64_scan(seed, n_cars, return_boxes=True)
+    k = 1
+    while scan.shape[0] < n and k < 8:
+        scan = np.concatenate([scan, hdl64_scan(seed, n_cars, sweep=k)], 0)
+        k += 1
+    rs = np.random.RandomState(seed % (2 ** 31))
+    choice = sample_point_choice(scan[:, 2], n, rs)
+    pc = np.concatenate([scan[choice, :3], scan[choice, 3:] - 0.5], 1).astype(np.float32)
+    if return_boxes:
+        return pc, boxes
+    return pc
+
+
 def make_batch(kind: str, batch: int, n: int, config_id: int, dup_frac: float = 0.0) -> np.ndarray:
     """(batch, n, 4) float32; seed = 1000*config_id + scene index."""
     out = np.empty((batch, n, 4), dtype=np.float32)
@@ -106,6 +221,8 @@ def make_batch(kind: str, batch: int, n: int, config_id: int, dup_frac: float = 
             out[s] = uniform_cloud(n, seed)
         elif kind == "lidar":
             out[s] = lidar_cloud(n, seed, dup_frac=dup_frac)
+        elif kind == "hdl64":
+            out[s] = hdl64_cloud(n, seed)
         else:
             raise ValueError(kind)
     return out
