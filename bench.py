@@ -217,14 +217,14 @@ class C2:
 
     name = "c2_fps_ballquery_group"
 
-    def __init__(self, batch, rank, kind="lidar"):
+    def __init__(self, batch, rank, kind="hdl64"):
         from ws3d_amd import compat, synth
         self.c = compat
         self.B = batch
         pc = np.empty((batch, N_PTS, 4), dtype=np.float32)
         for s in range(batch):
             seed = 1000 * 2 + rank * batch + s
-            pc[s] = synth.lidar_cloud(N_PTS, seed) if kind == "lidar" else synth.uniform_cloud(N_PTS, seed)
+            pc[s] = synth.cloud(kind, N_PTS, seed)
         self.pc_host = pc
         self.xyz = torch.from_numpy(pc[:, :, :3].copy()).cuda()
         self.feat = torch.from_numpy(np.ascontiguousarray(pc[:, :, 3:].transpose(0, 2, 1))).cuda()
@@ -286,7 +286,7 @@ class C2:
     def scenes(self):
         return self.B
 
-    def cpu_baseline(self, min_seconds=8.0):
+    def cpu_baseline(self, min_seconds=6.0):
         """CPU oracle port (same arithmetic, OpenMP over scenes/centres) on a bounded sample."""
         import oracle
         threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
@@ -329,7 +329,7 @@ class C5:
     def __init__(self, batch, rank, kind="lidar"):
         from ws3d_amd import compat, kitti_utils, synth
         self.c, self.B = compat, batch
-        pc = np.stack([synth.lidar_cloud(self.N, 1000 * 5 + rank * batch + s) for s in range(batch)])
+        pc = np.stack([synth.cloud(kind, self.N, 1000 * 5 + rank * batch + s) for s in range(batch)])
         boxes = synth.proposal_boxes(batch, self.M, 5)
         for b in range(batch):   # half of the proposals sit exactly on the synthetic cars (non-empty RoIs)
             cars = synth.random_boxes3d(15, (1000 * 5 + rank * batch + b) * 7919 + 13)
@@ -386,7 +386,7 @@ class C5:
         return {"roipool_a_min_bytes_per_scene": b, "a_min": b * scenes_per_s_per_gpu / 1e9,
                 "nms_pairs_per_s": self.M * (self.M - 1) // 2 * scenes_per_s_per_gpu}
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, min_seconds=6.0):
         import oracle
         threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
         oracle.set_threads(threads)
@@ -397,7 +397,7 @@ class C5:
         def one_pass():
             pooled, empty = oracle.roipool3d(self.pc_host[:ns, :, :3], boxes, feat, self.S)
             return pooled, empty, [oracle.nms_sorted(bev[b], self.THR, False) for b in range(ns)]
-        (pooled, empty, keep), dt, reps = repeat_for(one_pass)
+        (pooled, empty, keep), dt, reps = repeat_for(one_pass, min_seconds)
         oracle.set_threads(1)
         ok = bool(np.array_equal(self.empty[:ns].cpu().numpy(), empty) and np.array_equal(self.pooled[:ns].cpu().numpy(), pooled) and
                   all(np.array_equal(self.keep[b, :int(self.num[b])].cpu().numpy(), keep[b]) for b in range(ns)))
@@ -421,6 +421,7 @@ class S2:
     def __init__(self, batch, rank, kind="lidar"):
         from ws3d_amd import compat, pn2_ops, synth
         self.c, self.pn, self.B = compat, pn2_ops, batch
+        self.kind = "roi_clouds"     # synth.roi_clouds: points pooled for one proposal, whatever --kind says
         self.pts_host = synth.roi_clouds(batch, self.N, 6 + rank)
         B, N, C, M1, M2, NS = batch, self.N, self.C, self.M1, self.M2, self.NS
         self.xyz = torch.from_numpy(self.pts_host).cuda()
@@ -489,7 +490,7 @@ class S2:
         return {"group_a_min_bytes_per_roi": b, "a_min": b * rois_per_s_per_gpu / 1e9,
                 "a_min_frac_of_8TBs": b * rois_per_s_per_gpu / HBM_PEAK}
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, min_seconds=6.0):
         import oracle
         threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
         oracle.set_threads(threads)
@@ -507,7 +508,7 @@ class S2:
             q2 = oracle.ball_query(self.R2, self.NS, n1, n2)
             g2 = oracle.grouping_operation(feat2, q2)
             return i1, q1, g1, i2, q2, g2
-        (i1, q1, g1, i2, q2, g2), dt, reps = repeat_for(one_pass)
+        (i1, q1, g1, i2, q2, g2), dt, reps = repeat_for(one_pass, min_seconds)
         oracle.set_threads(1)
         ok = bool(np.array_equal(self.idx1[:ns].cpu().numpy(), i1) and np.array_equal(self.nbr1[:ns].cpu().numpy(), q1) and
                   np.array_equal(self.out1[:ns, 3:].cpu().numpy(), g1) and np.array_equal(self.idx2[:ns].cpu().numpy(), i2) and
@@ -530,7 +531,8 @@ def step_percentiles(wl):
 
 
 def _traffic_file(kernel_key):
-    """'fps_zlds_kernel' -> (profiles/traffic.json, key); 'c5:roipool3d_kernel' -> (profiles/traffic_c5.json, key)"""
+    """'fps_zlds_kernel' -> (profiles/traffic.json, key); 'c5:roipool3d_kernel' -> (profiles/traffic_c5.json, key);
+    'fps_bucket_valu:hdl64' -> (profiles/traffic_fps_bucket_valu.json, 'hdl64')"""
     if kernel_key and ":" in kernel_key:
         tag, key = kernel_key.split(":", 1)
         return os.path.join(ROOT, "profiles", "traffic_%s.json" % tag), key
@@ -618,6 +620,61 @@ def c2_block(batch, rank, kind, steps=10, warmup=2):
     return wl, blk
 
 
+def c3_side_runs(wl, args, value, latency):
+    """c3, one GPU, after the timed region: the same step (a) with the SharedMLPs over ALL m * nsample rows (the distinct-pairs form is
+    exact, but how much it saves is a property of the data: `list_fill`), (b) on the other scene generator.  Every block is a fresh
+    Stage1Pipeline over the same weights (captured graphs, same depth, same number of timed steps) -> dict merged into the line."""
+    from bench_c3 import C3
+    from ws3d_amd import fastpath
+
+    def run(w):
+        for _ in range(args.warmup):
+            w.step()
+        if not w.capture():
+            return None
+        for _ in range(2):
+            w.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            w.step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lat, detail = w.latency_mode(n=10)
+        w.release()
+        return {"value": w.scenes() * args.steps / dt, "unit": "scenes/s", "ms_per_batch": dt / args.steps * 1e3, "latency_ms_per_batch": lat,
+                "latency_launch": min(detail, key=detail.get)[:-3], "sharedmlp_rows": w.rows_mode, "steps": args.steps}
+
+    out = {"list_fill": {"generator": wl.kind, "scales": wl.list_fill(),
+                         "note": "distinct (centre, sample) pairs / all m * nsample list entries per ball-query scale on the timed batch; the "
+                                 "SharedMLP of a scale runs over the distinct pairs iff its fill <= %.2f, decided on the device per batch" % fastpath.COMPACT_MAX_FILL}}
+    wl.release()
+    saved = fastpath.COMPACT_PAIRS
+    try:
+        fastpath.COMPACT_PAIRS = False
+        r = run(C3(wl.B, wl.rank, 1, wl.kind, depth=wl.depth, model=wl.model))
+    finally:
+        fastpath.COMPACT_PAIRS = saved
+    if r is not None:
+        out["all_rows"] = r
+        out["value_all_rows"] = r["value"]
+    other = "lidar" if wl.kind != "lidar" else "hdl64"
+    w2 = C3(wl.B, wl.rank, 1, other, depth=wl.depth, model=wl.model)
+    fill2 = w2.list_fill()
+    r2 = run(w2)
+    if r2 is not None:
+        r2["list_fill"] = fill2
+        try:
+            fastpath.COMPACT_PAIRS = False
+            r3 = run(C3(wl.B, wl.rank, 1, other, depth=wl.depth, model=wl.model))
+        finally:
+            fastpath.COMPACT_PAIRS = saved
+        if r3 is not None:
+            r2["value_all_rows"], r2["all_rows_latency_ms_per_batch"] = r3["value"], r3["latency_ms_per_batch"]
+        out["other_generator"] = dict({"generator": other}, **r2)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -627,8 +684,13 @@ def main():
                     help="c3 (default) = BASELINE.json's headline: Stage-1 RPN forward + NMS + roipool3d, batch 8/GPU, with the c2 block")
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c3/c5 default 8, c2 default 512, s2 default 800)")
     ap.add_argument("--c2-batch", type=int, default=512, help="c3: scenes per launch of the embedded c2 block (0 = skip it)")
-    ap.add_argument("--kind", default="lidar", choices=["lidar", "uniform"])
+    ap.add_argument("--kind", default="hdl64", choices=["hdl64", "lidar", "uniform"],
+                    help="synthetic scene generator: hdl64 (default) = ray-cast HDL-64E scan sub-sampled like the reference's dataset (KITTI's point "
+                         "density); lidar = SURVEY 8d's sparse statistical model (the headline of rounds 1-2); uniform = iid in the scope box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=5.0, help="wall time of each CPU-oracle sample (the default line holds two)")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="c3: skip the blocks measured after the timed region (all_rows = SharedMLPs over all m*nsample rows; the other generator)")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-prefetch", action="store_true", help="t1: sample inside the step instead of one step ahead")
     ap.add_argument("--pipeline-depth", type=int, default=None,
@@ -671,6 +733,9 @@ def main():
     dt = max_over_ranks(time.perf_counter() - t0, world)
 
     # ---- everything below is outside the timed region
+    total_scenes = wl.scenes() * world * args.steps
+    value = total_scenes / dt
+    ms_per_step = dt / args.steps * 1e3
     latency = None
     if hasattr(wl, "latency_mode"):
         # the same step with ONE batch in flight (submit, exchange, wait): what a caller that needs the
@@ -688,17 +753,16 @@ def main():
         torch.cuda.synchronize()
     if os.environ.get("WS3D_BENCH_DUMP") and hasattr(wl, "dump"):
         wl.dump(os.environ["WS3D_BENCH_DUMP"])
+    kernels = finish_kernel_rows(wl.kernel_table(), wl.scenes()) if rank == 0 else None
+    side = {}
+    if args.workload == "c3" and world == 1 and not args.no_side_runs and use_graph:
+        side = c3_side_runs(wl, args, value, latency)
     c2wl = c2blk = None
     if args.workload == "c3" and args.c2_batch > 0:
         c2wl, c2blk = c2_block(args.c2_batch, rank, args.kind)
     barrier_sync(world)
 
-    total_scenes = wl.scenes() * world * args.steps
-    value = total_scenes / dt
-    ms_per_step = dt / args.steps * 1e3
-
     if rank == 0:
-        kernels = finish_kernel_rows(wl.kernel_table(), wl.scenes())
         dom = max((k for k in kernels if k["launches_per_step"] > 0), key=lambda k: k["ms_per_step"])
         per_gpu = value / world
         out = {
@@ -706,7 +770,7 @@ def main():
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic ({args.kind}, seed=1000*config+scene, random-init weights)",
+            "data": f"synthetic ({getattr(wl, 'kind', args.kind)}, seed=1000*config+scene, random-init weights)",
             "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS, "ranks_seen": comm["ranks_seen"],
                             "communicator": comm}, **wl.config()),  # (c5 overrides n_points)
         }
@@ -721,19 +785,26 @@ def main():
             out["roofline"] = roofline_of(c2dom, "c2 block of this run (batch %d per launch)" % c2blk["batch_per_gpu"])
             c3fps = next((k for k in kernels if k.get("bound") == "valu"), None)
             if c3fps is not None:
+                us = c3fps.get("us_per_fps_step")
+                pmc = load_traffic("fps_bucket_valu:" + args.kind)
                 out["roofline"]["same_kernel_family_in_the_timed_c3_step"] = {
-                    "ms_per_step_eager": c3fps["ms_per_step"], "workgroups": wl.scenes(),
-                    "valu_frac_of_chip": c3fps["valu_frac"], "valu_frac_of_occupied_CUs": c3fps["valu_frac"] * 256 / max(wl.scenes(), 1),
-                    "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs; throughput mode overlaps 20 batches"}
+                    "kernel": "fps_bucket_kernel (exact pruned sampling, level 1: 16384 -> 4096)", "ms_per_step_eager": c3fps["ms_per_step"],
+                    "workgroups": wl.scenes(), "us_per_fps_step": us, "clk_per_fps_step_at_2.4GHz": None if us is None else us * 2400.0,
+                    "valu_share_of_occupied_CUs_pmc": pmc,
+                    "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs (throughput mode overlaps 20 batches).  This kernel is "
+                            "chain-bound, not VALU-bound: its figure is the length of one sampling step (box test, bucket update, pick, record "
+                            "exchange), in us and clk; valu_share_of_occupied_CUs_pmc = SQ_INSTS_VALU x 2 clk / (4 SIMDs x busy clk) of the CUs it "
+                            "runs on, from the committed --pmc pass of this generator (profiles/traffic_fps_bucket_valu.json) or null"}
             out["c2"] = c2blk
         else:
             out["roofline"] = roofline_of(dom, "the timed region (HIP events on the launch stream)")
+        out.update(side)
         out.update({"kernels": kernels, "step_ms_percentiles": step_percentiles(wl), "path_gbps_per_gpu": wl.path_gbps(per_gpu)})
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = wl.cpu_baseline()
+                out["cpu_baseline"] = wl.cpu_baseline(min_seconds=args.cpu_baseline_seconds)
                 if c2wl is not None:
-                    out["c2"]["cpu_baseline"] = c2wl.cpu_baseline(min_seconds=6.0)
+                    out["c2"]["cpu_baseline"] = c2wl.cpu_baseline(min_seconds=args.cpu_baseline_seconds)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
                 out.setdefault("cpu_baseline", {"error": repr(e)})
         print(json.dumps(out), flush=True)

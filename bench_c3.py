@@ -45,48 +45,92 @@ def _interp_bytes(cfg):
     return nn_b, interp_b
 
 
+# HIP-event timers around every C-ABI launch family of the step (ws3d_amd.compat is what fastpath / stage1 / roipool3d_ops call; the
+# wrappers are installed once and record only while the ACTIVE workload runs a timed step).  What is left of the forward pass after
+# these families is library work: Tensile GEMMs and at::native glue.
+FAMILIES = {
+    "furthest_point_sampling_gather": "fps level 1 (16384 -> 4096)", "furthest_point_sampling_nested": "fps levels 2-4 (verified prefix)",
+    "sort_points_x": "binning (grid / x slabs / xz grid)", "sort_points_xz": "binning (grid / x slabs / xz grid)",
+    "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
+    "compact_pairs": "pair compaction",
+    "sa_mlp3_pool": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)", "sa_mlp3_pool_compact": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
+    "sa_mlp3_pool_lists": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
+    "pgather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "pgather_gemm2_compact": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
+    "pgather_rows": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "gather_gemm": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
+    "gather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "gather_gemm3_pool": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
+    "gemm_pool": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)", "gemm_pool_compact": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
+    "rowmax_rows": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
+    "three_nn_wrapper": "three_nn (+ weights)", "three_nn_with_weights": "three_nn (+ weights)",
+    "qinterp_rows": "FP first layer (interpolate + add, own kernels)", "interp_gemm": "FP first layer (interpolate + add, own kernels)",
+    "three_interpolate_nlc": "FP first layer (interpolate + add, own kernels)", "three_interpolate_wrapper": "FP first layer (interpolate + add, own kernels)",
+    "mlp2_rows": "heads (2 layers, own MFMA kernel)",
+    "decode_center_boxes": "proposals: decode + top-k + gather + select", "topk_sorted": "proposals: decode + top-k + gather + select",
+    "gather_boxes_bev": "proposals: decode + top-k + gather + select", "select_proposals": "proposals: decode + top-k + gather + select",
+    "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d", "roipool3d_forward_fill": "roipool3d"}
+IN_FORWARD = lambda fam: not fam.startswith(("proposals", "nms", "roipool"))   # families inside rpn_forward (the rest follow it)
+_ACTIVE = None
+_HOOKED = False
+
+
+def _install_hooks():
+    global _HOOKED
+    if _HOOKED:
+        return
+    _HOOKED = True
+    from ws3d_amd import compat
+    for fn_name, key in FAMILIES.items():
+        orig = getattr(compat, fn_name)
+
+        def wrapped(*a, __orig=orig, __key=key, **kw):
+            wl = _ACTIVE
+            if wl is None or not wl._timed:
+                return __orig(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = __orig(*a, **kw)
+            e1.record()
+            wl.op_ev.setdefault(__key, []).append((e0, e1))
+            return r
+        setattr(compat, fn_name, wrapped)
+
+
 class C3:
     name = "c3_stage1_rpn_forward_nms_roipool"
     # = BASELINE.json "metric"; `value` is its scenes/sec half at configs[2] (Stage-1 RPN forward incl. proposal NMS +
     # roipool3d, batch 8/GPU), the "FPS+group HBM GB/s" half is the c2 block of the same line
     metric = "KITTI scenes/sec (16384 pts) Stage-1 RPN fwd, 1/2/4/8 GPU; FPS+group HBM GB/s"
 
-    def __init__(self, batch, rank, world, kind="lidar", depth=2):
+    def __init__(self, batch, rank, world, kind="hdl64", depth=2, model=None):
         self.B, self.rank, self.world, self.cfg = batch, rank, world, DEFAULT_CFG
         self.depth = max(1, depth)
-        self.pc_host = np.stack([synth.lidar_cloud(16384, 1000 * 3 + rank * batch + s) if kind == "lidar"
-                                 else synth.uniform_cloud(16384, 1000 * 3 + rank * batch + s) for s in range(batch)])
+        self.kind = kind
+        self.pc_host = np.stack([synth.cloud(kind, 16384, 1000 * 3 + rank * batch + s) for s in range(batch)])
         self.pts = torch.from_numpy(self.pc_host).cuda()
         self._i = 0
-        model = Stage1Net(mode='TEST').eval()
-        model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
-        self.model = model.cuda()
+        if model is None:
+            model = Stage1Net(mode='TEST').eval()
+            model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+            model = model.cuda()
+        self.model = model
         self.ev = []
         self.last = None
         self.op_ev = {}
         self._timed = False
-        self._install_hooks()
+        self.rows_mode = ("distinct pairs / all rows chosen per batch on the device (launch gates, fill <= %.2f -> distinct pairs)" % fastpath.COMPACT_MAX_FILL
+                          if fastpath.PAIR_DISPATCH == "device" else "distinct pairs of the ball-query lists, always") \
+            if fastpath.COMPACT_PAIRS and fastpath.PER_POINT_L1 else "all m*nsample rows"
+        _install_hooks()
 
-    def _install_hooks(self):
-        """HIP-event timers around every C-ABI launch family (only while a timed step runs)."""
-        from ws3d_amd import compat
-        fam = {"furthest_point_sampling_gather": "fps", "furthest_point_sampling_nested": "fps", "ball_query_wrapper": "ball_query+group", "query_and_group": "ball_query+group",
-               "query_and_group_nlc": "ball_query+group", "three_interpolate_nlc": "three_interpolate",
-               "three_nn_wrapper": "three_nn", "three_nn_with_weights": "three_nn", "three_interpolate_wrapper": "three_interpolate",
-               "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d"}
-        for fn_name, key in fam.items():
-            orig = getattr(compat, fn_name)
+    def release(self):
+        """drop the pipeline (20 slots of intermediates + graphs) before another workload is built"""
+        self.pipe = None
+        self._graph = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
 
-            def wrapped(*a, __orig=orig, __key=key, **kw):
-                if not self._timed:
-                    return __orig(*a, **kw)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = __orig(*a, **kw)
-                e1.record()
-                self.op_ev.setdefault(__key, []).append((e0, e1))
-                return r
-            setattr(compat, fn_name, wrapped)
+    def list_fill(self):
+        """distinct pairs / list entries per ball-query scale on this workload's batch (the statistic the launch gates act on)"""
+        return fastpath.list_fill(self.model.rpn.backbone_net, self.pts)
 
     def config(self):
         c = self.cfg
@@ -94,14 +138,11 @@ class C3:
                 "pre_nms": c.rpn_pre_nms_top_n, "nms_thresh": c.rpn_nms_thresh, "post_nms": c.rpn_post_nms_top_n,
                 "roipool": {"sampled": c.roi_sampled_pts, "channels": 128, "extra_width": c.roi_extra_width},
                 "exchange": "all_gather of (B,100,8) proposals" if self.world > 1 else "none (1 GPU)",
-                "launch": ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth)
-                if getattr(self, "_graph", None) is not None
-                else "eager (graph capture failed: %s)" % getattr(self, "_graph_err", "not attempted"),
+                "launch": getattr(self, "_launch_desc", "eager (graph capture not attempted)"),
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
-                # data-dependent work: the SharedMLPs run over the DISTINCT (centre, sample) pairs of the ball-query lists (bit-identical
-                # to all m * nsample rows; these synthetic clouds: 1.0-2.1 distinct of 16 / 32, profiles/r02_neighbour_list_fill.txt)
-                "sharedmlp_rows": ("distinct pairs of the ball-query lists (WS3D_COMPACT_PAIRS=0: all m*nsample rows)"
-                                   if fastpath.COMPACT_PAIRS and fastpath.PER_POINT_L1 else "all m*nsample rows")}
+                # data-dependent work: the SharedMLPs may run over the DISTINCT (centre, sample) pairs of the ball-query lists (bit-identical
+                # to all m * nsample rows); `list_fill` in the line says how full this data's lists are, `all_rows` what the other form costs
+                "sharedmlp_rows": self.rows_mode}
 
     @torch.no_grad()
     def _body(self, pts=None):
@@ -124,10 +165,14 @@ class C3:
         ok = self.pipe.capture_all()
         self._graph = True if ok else None
         self._graph_err = self.pipe.graph_error
+        self._launch_desc = ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth) if ok \
+            else "eager (graph capture failed: %s)" % self._graph_err
         return ok
 
     @torch.no_grad()
     def step(self, timed=False, eager=False):
+        global _ACTIVE
+        _ACTIVE = self
         if getattr(self, "_graph", None) is not None and not timed and not eager:
             ticket = self.pipe.submit()                    # inputs already resident in the slot's buffer
             slot = self.pipe.slots[ticket % self.depth]
@@ -212,32 +257,41 @@ class C3:
         cfg, B = self.cfg, self.B
         nn_b, interp_b = _interp_bytes(cfg)
         roi_b = cfg.rpn_post_nms_top_n * cfg.roi_sampled_pts * (3 + 128) * 4 + cfg.num_points * (3 + 128) * 4
-        alg = {"fps": _fps_model_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn": nn_b * B,
-               "three_interpolate": interp_b * B, "roipool3d": roi_b * B,
+        n1, m1 = cfg.num_points, cfg.npoints[0]
+        fps1_b = (m1 - 1) * n1 * 12 + m1 * 4
+        alg = {"fps level 1 (16384 -> 4096)": fps1_b * B, "fps levels 2-4 (verified prefix)": (_fps_model_bytes(cfg) - fps1_b) * B,
+               "ball_query": _qg_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn (+ weights)": nn_b * B,
+               "FP first layer (interpolate + add, own kernels)": interp_b * B, "roipool3d": roi_b * B,
                "nms(mask+sweep)": (cfg.rpn_pre_nms_top_n * 20 + cfg.rpn_pre_nms_top_n * 141 * 8) * B}
         rows = []
         for key, evs in self.op_ev.items():
             ms = float(sum(a.elapsed_time(b) for a, b in evs)) / steps
             row = {"name": key, "ms_per_step": ms, "launches_per_step": len(evs) / steps,
                    "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None, "bound": "hbm"}
-            if key == "fps":
-                row.update({"bound": "valu", "lane_instr_per_step": self._fps_lane_instr() * B,
-                            "comment": "4 levels 16384->4096->1024->256->64, one workgroup per scene (8 of 256 CUs).  lane_instr_per_step "
-                                       "is the DENSE sweep's count (8 per point and step): level 1 runs the pruned kernel (fps_bucket.hip, "
-                                       "~6 of 256 buckets updated per step), levels 2-4 the verified-prefix kernel (fps_nested.hip), so "
-                                       "valu_frac here is a dense-equivalent rate, not issue-slot occupancy; the physical VALU roofline "
-                                       "of the dense kernel is the c2 block's"})
-            elif key in ("three_nn", "nms(mask+sweep)"):
+            if key.startswith("fps level 1"):
+                from bench import fps_lane_instr
+                row.update({"bound": "valu", "lane_instr_per_step": fps_lane_instr(n1, m1) * B, "us_per_fps_step": ms * 1e3 / (m1 - 1),
+                            "comment": "one workgroup per scene (8 of 256 CUs): the exact pruned kernel (fps_bucket.hip) on clouds this size.  "
+                                       "lane_instr_per_step is the DENSE sweep's count (8 per point and step) and valu_frac therefore a "
+                                       "dense-equivalent rate, not issue-slot occupancy: a step updates a few of 256 buckets and is bound by "
+                                       "its cross-lane chain -- us_per_fps_step is the figure to watch"})
+            elif key.startswith("fps levels"):
+                row["comment"] = "1024 + 256 + 64 picks verified as the leading prefix of the previous level's order (fps_nested.hip)"
+            elif key.startswith(("three_nn", "nms", "ball_query")):
                 row["comment"] = "ALU-bound search / pair test; the HBM figure is for orientation only"
+            elif key.startswith(("SharedMLP", "heads", "FP first")):
+                row["bound"] = "mfma" if not key.startswith("FP first") else "hbm"
             rows.append(row)
+        rows.sort(key=lambda r: -r["ms_per_step"])
         fwd = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
-        custom_in_fwd = sum(r["ms_per_step"] for r in rows if r["name"] in ("fps", "ball_query+group", "three_nn", "three_interpolate"))
-        rows.append({"name": "torch (SharedMLP GEMMs with fused epilogues, BN-folded, cat, heads) [hipBLASLt/rocBLAS] + pool kernels",
-                     "ms_per_step": max(fwd - custom_in_fwd, 0.0), "launches_per_step": 0, "alg_bytes_per_step": 0,
+        custom_in_fwd = sum(r["ms_per_step"] for r in rows if IN_FORWARD(r["name"]))
+        rows.append({"name": "library residual of rpn_forward: Tensile GEMMs (per-point products P / Q, skip products, second FP layers) + at::native "
+                             "glue (fills, cat, copies)", "ms_per_step": max(fwd - custom_in_fwd, 0.0), "launches_per_step": 0, "alg_bytes_per_step": 0,
                      "traffic_key": None, "bound": "library"})
         self.breakdown = {"rpn_forward_ms": fwd,
                           "proposals_nms_ms": float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev])),
-                          "roipool_ms": float(np.mean([a[2].elapsed_time(a[3]) for a in self.ev]))}
+                          "roipool_ms": float(np.mean([a[2].elapsed_time(a[3]) for a in self.ev])),
+                          "own_launches_per_step": float(sum(r["launches_per_step"] for r in rows))}
         return rows
 
     def path_gbps(self, scenes_per_s_per_gpu):

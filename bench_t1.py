@@ -25,6 +25,7 @@ class T1:
 
     def __init__(self, batch, rank, world, kind="lidar", prefetch=True):
         self.B, self.rank, self.world, self.cfg, self.tcfg = batch, rank, world, stage1.DEFAULT_CFG, TrainConfig()
+        self.kind = "lidar"          # SyntheticCenters (train_rpn.py) draws its scenes from synth.lidar_cloud whatever --kind says
         self.dev = torch.device("cuda", torch.cuda.current_device())
         torch.manual_seed(1234)
         model = stage1.Stage1Net(mode="TRAIN", cfg=self.cfg)

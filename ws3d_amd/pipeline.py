@@ -46,6 +46,20 @@ def _hw_queue_cap() -> int:
         return 4
 
 
+_SLOT_STREAMS = {}      # device index -> the slot streams handed out so far
+
+
+def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
+    """stream of slot j on `device`: ONE pool per device, shared by every Stage1Pipeline of the process.  A HIP stream may claim
+    a hardware queue for as long as it lives, and beyond 23 queues in one process this runtime time-slices them (every kernel
+    1.4-1.6 x slower, measured); a second pipeline (another model, a re-capture, bench.py's side runs) therefore reuses the
+    streams of the first instead of adding `depth` more.  Pipelines that share streams simply serialise on them."""
+    pool = _SLOT_STREAMS.setdefault(device.index if device.index is not None else torch.cuda.current_device(), [])
+    while len(pool) <= j:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[j]
+
+
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
@@ -57,8 +71,8 @@ class Stage1Pipeline:
         self.graph_error = None
         self.slots = []
         with torch.cuda.device(self.device):
-            for _ in range(self.depth):
-                stream = torch.cuda.Stream(device=self.device)
+            for j in range(self.depth):
+                stream = _slot_stream(self.device, j)
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
                                    "done": torch.cuda.Event(), "primed": False})

@@ -212,19 +212,26 @@ def hdl64_cloud(n: int, seed: int, n_cars: int = 15, return_boxes: bool = False)
     return pc
 
 
+GENERATORS = ("hdl64", "lidar", "uniform")
+
+
+def cloud(kind: str, n: int, seed: int, dup_frac: float = 0.0) -> np.ndarray:
+    """(n, 4) float32 scene of one of the seeded generators: 'hdl64' (ray-cast HDL-64E scan, the reference's sub-sampling: KITTI's
+    point density), 'lidar' (SURVEY 8d's sparse statistical model), 'uniform' (iid in the scope box)"""
+    if kind == "uniform":
+        return uniform_cloud(n, seed)
+    if kind == "lidar":
+        return lidar_cloud(n, seed, dup_frac=dup_frac)
+    if kind == "hdl64":
+        return hdl64_cloud(n, seed)
+    raise ValueError(kind)
+
+
 def make_batch(kind: str, batch: int, n: int, config_id: int, dup_frac: float = 0.0) -> np.ndarray:
     """(batch, n, 4) float32; seed = 1000*config_id + scene index."""
     out = np.empty((batch, n, 4), dtype=np.float32)
     for s in range(batch):
-        seed = 1000 * config_id + s
-        if kind == "uniform":
-            out[s] = uniform_cloud(n, seed)
-        elif kind == "lidar":
-            out[s] = lidar_cloud(n, seed, dup_frac=dup_frac)
-        elif kind == "hdl64":
-            out[s] = hdl64_cloud(n, seed)
-        else:
-            raise ValueError(kind)
+        out[s] = cloud(kind, n, 1000 * config_id + s, dup_frac)
     return out
 
 
