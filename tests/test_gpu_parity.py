@@ -1991,482 +1991,6 @@ def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, 
     gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
     gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
     x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
-    want = torch.relu(x @ wt.double() + bias.double())
-    err = (got.double() - want).abs().max().item()
-    scale = want.abs().max().item()
-    assert err <= 4e-6 * max(scale, 1.0) * np.sqrt(C / 96), (err, scale)
-    assert ops.c.gather_gemm(feats[:, :, :C - 2].contiguous(), xyz, new_xyz, nbr, wt[:C + 1].contiguous(), bias, True) is None   # C % 4
-
-
-@pytest.mark.parametrize("B,N,M,C2,C1,O", [(2, 4096, 1024, 256, 96, 128), (1, 16384, 4096, 128, 1, 128), (2, 1024, 256, 512, 256, 256),
-                                           (2, 256, 64, 512, 512, 512), (2, 1024, 256, 128, 0, 64)])
-def test_interp_gemm_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
-    """ws3d_interp_gemm (three_interpolate + skip concat fused into the first FP layer, fp32 matrix cores) against the bit-exact
-    three_interpolate rows, concatenated with the skip features, @ W + b in float64"""
-    rng = np.random.default_rng(9)
-    pc = synth.make_batch("lidar", B, 16384, 62)[:, :N, :3].copy()
-    unknown = dev(pc)
-    known = unknown[:, ::N // M].contiguous()
-    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
-    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
-    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
-    wt = dev((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32))
-    bias = dev(rng.standard_normal(O).astype(np.float32))
-    got = ops.c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
-    assert got is not None and tuple(got.shape) == (B * N, O)
-    interp = torch.empty((B, N, C2), device="cuda")
-    ops.c.three_interpolate_nlc(kf, idx, weight, interp)
-    x = interp if uf is None else torch.cat((interp, uf), dim=2)
-    want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
-    err = (got.double() - want).abs().max().item()
-    scale = want.abs().max().item()
-    assert err <= 4e-6 * max(scale, 1.0) * np.sqrt((C2 + C1) / 96), (err, scale)
-    assert ops.c.interp_gemm(kf, uf, idx, weight, wt[:, :O - 8].contiguous(), bias[:O - 8], True) is None              # O % 64
-
-
-def test_fps_nested_equals_plain_fps(ops, oracle):
-    """ws3d_furthest_point_sampling_nested against the oracle's FPS on the same cloud: clouds in sampling order (the verified
-    path: idx = arange), clouds in arbitrary order and sampling-ordered clouds with exact duplicates (ties: the per-scene
-    fallback), mixed in one batch; ragged sizes, m = n, m = 1"""
-    def sampled(kind, B, N, M, seed, dup=0.0):
-        pc = synth.make_batch(kind, B, N, seed, dup_frac=dup)[:, :, :3].copy()
-        ref = oracle.furthest_point_sample(pc, M)
-        return np.stack([pc[b][ref[b]] for b in range(B)])
-    clouds = [
-        ("sampling order", sampled("lidar", 3, 16384, 4096, 71), 1024, True),
-        ("sampling order, level 3", sampled("lidar", 2, 16384, 4096, 72)[:, :1024].copy(), 256, True),
-        ("sampling order, uniform", sampled("uniform", 2, 5000, 1000, 73), 333, True),
-        ("all of a cloud with duplicates, re-sampled completely", sampled("lidar", 2, 700, 700, 74, dup=0.3), 700, False),
-        ("arbitrary order", synth.make_batch("lidar", 2, 4096, 75)[:, :, :3].copy(), 512, False),
-        ("arbitrary order, ragged", synth.make_batch("uniform", 3, 3001, 76)[:, :, :3].copy(), 777, False),
-        ("tiny", synth.make_batch("uniform", 2, 37, 77)[:, :, :3].copy(), 37, False),
-        ("one point asked", synth.make_batch("uniform", 2, 50, 78)[:, :, :3].copy(), 1, True),
-        ("single point", synth.make_batch("uniform", 1, 1, 79)[:, :, :3].copy(), 1, True),
-    ]
-    mixed = np.stack([sampled("lidar", 1, 8192, 2048, 80)[0], synth.make_batch("lidar", 1, 2048, 81)[0, :, :3]])
-    clouds.append(("mixed batch: scene 0 in sampling order, scene 1 not", mixed, 600, None))
-    for name, pc, M, expect_prefix in clouds:
-        B, N = pc.shape[0], pc.shape[1]
-        ref = oracle.furthest_point_sample(pc, M)
-        idx = torch.full((B, M), -7, dtype=torch.int32, device="cuda")
-        nx = torch.full((B, M, 3), float("nan"), device="cuda")
-        ops.c.furthest_point_sampling_nested(B, N, M, dev(pc), idx, nx)
-        np.testing.assert_array_equal(host(idx), ref, err_msg=name)
-        np.testing.assert_array_equal(host(nx), np.stack([pc[b][ref[b]] for b in range(B)]), err_msg=name)
-        if expect_prefix:
-            assert (ref == np.arange(M)[None]).all(), name          # the nesting property itself, on the oracle's output
-        i2, x2 = ops.pn.furthest_point_sample_gather_nested(dev(pc), M)
-        assert torch.equal(i2, idx) and torch.equal(x2, nx)
-    assert (oracle.furthest_point_sample(mixed, 600)[0] == np.arange(600)).all()
-    with pytest.raises(Exception):
-        ops.c.furthest_point_sampling_nested(1, 5000, 10, torch.zeros((1, 5000, 3), device="cuda"),
-                                             torch.zeros((1, 10), dtype=torch.int32, device="cuda"), torch.zeros((1, 10, 3), device="cuda"))
-
-
-@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,r", [(2, 4096, 1024, 16, 96, 64, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 1.0), (1, 1024, 256, 16, 256, 128, 196, 1.0),
-                                              (2, 256, 64, 32, 512, 256, 384, 4.0), (2, 256, 64, 16, 512, 256, 256, 2.0)])
-def test_gather_gemm2_equals_two_layers(ops, B, N, M, ns, C, O1, O2, r):
-    """ws3d_gather_gemm2 (layers 1 + 2 of a set-abstraction SharedMLP, the first activation on chip) against the float64
-    product relu(relu([gf | gx] @ W1 + b1) @ W2 + b2), and against ws3d_gather_gemm followed by a GEMM"""
-    rng = np.random.default_rng(14)
-    pc = synth.make_batch("lidar", B, 16384, 63)[:, :N, :3].copy()
-    xyz = dev(pc)
-    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
-    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
-    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
-    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
-    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32))
-    b1 = dev(rng.standard_normal(O1).astype(np.float32))
-    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32))
-    b2 = dev(rng.standard_normal(O2).astype(np.float32))
-    got = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True)
-    assert got is not None and tuple(got.shape) == (B * M * ns, O2)
-    li = nbr.long()
-    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
-    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
-    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
-    h = torch.relu(x @ w1.double() + b1.double())
-    want = torch.relu(h @ w2.double() + b2.double())
-    err = (got.double() - want).abs().max().item()
-    scale = max(want.abs().max().item(), 1.0)
-    assert err <= 1e-5 * scale * np.sqrt(C / 96), (err, scale)
-    two = torch.relu(ops.c.gather_gemm(feats, xyz, new_xyz, nbr, w1, b1, True) @ w2 + b2)
-    assert (got - two).abs().max().item() <= 2e-5 * scale
-    no_act = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, None, False, w2, None, False)
-    assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2e-5 * scale * np.sqrt(C / 96)
-    assert ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1[:, :O1 - 16].contiguous(), None, True, w2[:O1 - 16].contiguous(), b2, True) is None   # O1
-
-
-def test_eager_side_streams_back_to_back_equal_the_single_stream_forward(ops):
-    """the coordinate-only work of a forward pass runs on two side streams (fastpath._Geometry) and its tensors are allocated
-    there: 24 different batches issued back to back WITHOUT host synchronisation -- plain calls on one stream, and through an
-    eager 3-deep Stage1Pipeline whose slots share the side streams -- must reproduce the single-stream forward exactly
-    (same kernels, same order per batch: any difference would be a cross-stream reuse of live memory)"""
-    from ws3d_amd import fastpath, stage1
-    from ws3d_amd.pipeline import Stage1Pipeline
-    from ws3d_amd.seeded import seeded_state_dict
-    cfg = stage1.RPNConfig(num_points=4096, npoints=(1024, 256, 64, 16), rpn_pre_nms_top_n=1000, rpn_post_nms_top_n=20)
-    model = stage1.Stage1Net(mode="TEST", cfg=cfg)
-    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 5))
-    model = model.cuda().eval()
-    batches = [dev(np.stack([synth.velodyne_scan(4096, seed=100 + 2 * i + j) for j in range(2)])) for i in range(24)]
-    keys = ("rpn_cls", "rpn_reg")
-    prev = fastpath.GEOMETRY_AHEAD
-    try:
-        fastpath.GEOMETRY_AHEAD = False
-        with torch.no_grad():
-            want = []
-            for b in batches:
-                out = model.rpn_forward({"pts_input": b})
-                boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
-                want.append([out[k].clone() for k in keys] + [boxes.clone(), count.clone()])
-        torch.cuda.synchronize()
-        fastpath.GEOMETRY_AHEAD = True
-        with torch.no_grad():
-            got = []
-            for b in batches:                      # no synchronisation between the passes
-                out = model.rpn_forward({"pts_input": b})
-                boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
-                got.append([out[k].clone() for k in keys] + [boxes.clone(), count.clone()])
-        torch.cuda.synchronize()
-        for i, (g, w) in enumerate(zip(got, want)):
-            for a, c in zip(g, w):
-                assert torch.equal(a, c), i
-        pipe = Stage1Pipeline(model, cfg, batch=2, n_points=4096, depth=3, use_graph=False)
-        for i, (f0, nv, o) in enumerate(pipe.map(batches)):
-            assert torch.equal(o["rpn"]["rpn_cls"], want[i][0]) and torch.equal(o["rpn"]["rpn_reg"], want[i][1]), i
-            assert torch.equal(o["boxes"], want[i][2]) and torch.equal(o["count"], want[i][3]), i
-    finally:
-        fastpath.GEOMETRY_AHEAD = prev
-
-
-@pytest.mark.parametrize("rows,o2,relu2,bias", [(32, 1, False, True), (4096, 40, False, True), (16384 + 32, 1, False, True),
-                                                 (2048, 64, True, True), (1024, 33, True, False), (131072, 40, False, True)])
-def test_mlp2_rows_matches_two_layers(rows, o2, relu2, bias):
-    """ws3d_mlp2_rows (both layers of a head in one kernel, activation in registers) against the same two layers in float64"""
-    import torch
-    from ws3d_amd import compat as C
-    g = torch.Generator().manual_seed(rows + o2)
-    x = torch.randn(rows, 128, generator=g).cuda()
-    w1t = (torch.randn(128, 128, generator=g) / 11).cuda()
-    w2t = (torch.randn(128, o2, generator=g) / 11).cuda()
-    b1 = torch.randn(128, generator=g).cuda() if bias else None
-    b2 = torch.randn(o2, generator=g).cuda() if bias else None
-    y = C.mlp2_rows(x, w1t, b1, True, w2t, b2, relu2)
-    assert y is not None and y.shape == (rows, o2)
-    h = x.double() @ w1t.double()
-    if bias:
-        h = h + b1.double()
-    h = h.clamp_min(0)
-    ref = h @ w2t.double()
-    if bias:
-        ref = ref + b2.double()
-    if relu2:
-        ref = ref.clamp_min(0)
-    err = (y.double() - ref).abs().max().item()
-    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
-    # shapes outside the kernel's cover: None, the caller runs two GEMMs
-    assert C.mlp2_rows(x[:, :64].contiguous(), w1t[:64].contiguous(), b1, True, w2t, b2, relu2) is None
-    assert C.mlp2_rows(x[:31], w1t, b1, True, w2t, b2, relu2) is None
-
-
-@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
-def test_gemm_pool_tile_variants_subprocess(tile):
-    """every selectable output tile of ws3d_gemm_pool (WS3D_GP_TILE = row blocks, column blocks of 64 per workgroup) against the
-    float64 product + group max; shapes on and off the tile multiples (those fall back to the 64 x 64 kernel)"""
-    import subprocess, sys, os, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent(f"""
-        import sys, torch
-        sys.path.insert(0, {root!r})
-        from ws3d_amd import compat as c
-        for rows, ns, k, o, relu in [(128, 16, 4, 128, True), (256, 32, 100, 256, False), (2048, 16, 196, 256, True), (4096, 32, 384, 512, True),
-                                     (192, 32, 64, 64, True), (65536, 32, 96, 128, True)]:
-            g = torch.Generator().manual_seed(rows + k)
-            x = torch.randn((rows, k), generator=g).cuda(); wt = (torch.randn((k, o), generator=g) * 0.2).cuda(); b = torch.randn((o,), generator=g).cuda()
-            y = x.double() @ wt.double() + b.double()
-            if relu: y = torch.relu(y)
-            ref = y.view(rows // ns, ns, o).amax(dim=1)
-            out = torch.full((rows // ns, o + 64), 7.0, device="cuda")
-            assert c.gemm_pool(x, wt, b, relu, ns, out, 64)
-            assert bool((out[:, :64] == 7.0).all())
-            err = float((out[:, 64:].double() - ref).abs().max())
-            assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (rows, ns, k, o, err)
-        print("ok")
-    """)
-    env = dict(os.environ, WS3D_GP_TILE=tile)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-
-
-@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
-def test_interp_gemm_tile_variants_subprocess(tile):
-    """every selectable output tile of ws3d_interp_gemm (WS3D_IG_TILE) against three_interpolate + concat + float64 product,
-    including the c1 = 1 ragged skip block of FP1 and shapes off the tile multiples (which run the 64 x 64 kernel)"""
-    import subprocess, sys, os, textwrap
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = textwrap.dedent(f"""
-        import sys, numpy as np, torch
-        sys.path.insert(0, {root!r})
-        from ws3d_amd import compat as c, synth
-        rng = np.random.default_rng(9)
-        for B, N, M, C2, C1, O in [(8, 1024, 256, 64, 1, 128), (2, 512, 128, 96, 32, 256), (8, 256, 64, 128, 0, 128), (1, 192, 48, 32, 5, 64),
-                                   (16, 2048, 512, 256, 1, 128)]:
-            pc = synth.make_batch("lidar", B, 16384, 62)[:, :N, :3].copy()
-            unknown = torch.from_numpy(pc).cuda(); known = unknown[:, ::N // M].contiguous()
-            kf = torch.from_numpy(rng.standard_normal((B, M, C2)).astype(np.float32)).cuda()
-            uf = torch.from_numpy(rng.standard_normal((B, N, C1)).astype(np.float32)).cuda() if C1 else None
-            idx, weight = c.three_nn_with_weights(unknown, known, None)
-            wt = torch.from_numpy((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32)).cuda()
-            bias = torch.from_numpy(rng.standard_normal(O).astype(np.float32)).cuda()
-            got = c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
-            interp = torch.empty((B, N, C2), device="cuda"); c.three_interpolate_nlc(kf, idx, weight, interp)
-            x = interp if uf is None else torch.cat((interp, uf), dim=2)
-            want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
-            err = (got.double() - want).abs().max().item()
-            assert err <= 4e-6 * max(want.abs().max().item(), 1.0) * np.sqrt((C2 + C1) / 96), (B, N, M, C2, C1, O, err)
-        print("ok")
-    """)
-    env = dict(os.environ, WS3D_IG_TILE=tile)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
-
-
-@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),
-                                                  (1, 1024, 256, 16, 256, 128, 196, 256, 1.0), (1, 1024, 256, 32, 256, 128, 196, 256, 2.0),
-                                                  (1, 512, 64, 16, 8, 64, 20, 128, 1.0)])
-def test_gather_gemm3_pool_equals_three_layers_and_pool(ops, B, N, M, ns, C, O1, O2, O3, r):
-    """ws3d_gather_gemm3_pool (grouping + the three SharedMLP layers + max over nsample in one kernel, both activations in LDS)
-    against the float64 chain, and against ws3d_gather_gemm2 + ws3d_gemm_pool; written into a column slice of a wider matrix;
-    O2 off the k-tile (196, 20: the zero-padded tail of layer 3's k dimension)"""
-    rng = np.random.default_rng(15)
-    pc = synth.make_batch("lidar", B, 16384, 64)[:, :N, :3].copy()
-    xyz = dev(pc)
-    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
-    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
-    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
-    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
-    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
-    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
-    w3 = dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)); b3 = dev(rng.standard_normal(O3).astype(np.float32))
-    out = torch.full((B * M, O3 + 64), 7.0, device="cuda")
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True, w3, b3, True, out, 64)
-    assert bool((out[:, :64] == 7.0).all())
-    li = nbr.long()
-    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
-    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
-    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
-    h = torch.relu(x @ w1.double() + b1.double())
-    h = torch.relu(h @ w2.double() + b2.double())
-    want = torch.relu(h @ w3.double() + b3.double()).view(B * M, ns, O3).amax(dim=1)
-    err = (out[:, 64:].double() - want).abs().max().item()
-    scale = max(want.abs().max().item(), 1.0)
-    assert err <= 1.5e-5 * scale * np.sqrt(max(C, 96) / 96), (err, scale)
-    if O2 % 4 == 0 and O3 % 64 == 0:
-        two = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True)
-        ref = torch.empty((B * M, O3), device="cuda")
-        assert ops.c.gemm_pool(two, w3, b3, True, ns, ref, 0)
-        assert (out[:, 64:] - ref).abs().max().item() <= 2e-5 * scale
-    # no bias, no activation on the last layer
-    out2 = torch.empty((B * M, O3), device="cuda")
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True, w3, None, False, out2, 0)
-    want2 = (h @ w3.double()).view(B * M, ns, O3).amax(dim=1)
-    assert (out2.double() - want2).abs().max().item() <= 1.5e-5 * max(want2.abs().max().item(), 1.0) * np.sqrt(max(C, 96) / 96)
-    # declined shapes
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr[:, :, :ns - 1].contiguous(), w1, b1, True, w2, b2, True, w3, b3, True, out2, 0) is False
-
-
-def test_fast_path_switches_agree(ops):
-    """the optional fusions of the inference fast path (whole-SharedMLP kernel at SA2 / SA3, two-layer heads, two-layer
-    gather-GEMM, fused interpolation) switched on and off: the network's outputs agree to fp32 round-off of the matrix products
-    (different summation orders), i.e. every switch computes the same function"""
-    from ws3d_amd import fastpath, stage1
-    from ws3d_amd.seeded import seeded_state_dict
-    cfg = stage1.RPNConfig(num_points=16384, rpn_pre_nms_top_n=1000, rpn_post_nms_top_n=20)
-    model = stage1.Stage1Net(mode="TEST", cfg=cfg)
-    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
-    model = model.cuda().eval()
-    pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS")
-    saved = {n: getattr(fastpath, n) for n in names}
-
-    def run(**kw):
-        for n, v in kw.items():
-            setattr(fastpath, n, v)
-        with torch.no_grad():
-            out = model.rpn_forward({"pts_input": pts})
-        return out["rpn_cls"].clone(), out["rpn_reg"].clone()
-    try:
-        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False, PER_POINT_FP=False, COMPACT_PAIRS=False)
-        scale = [float(t.abs().max()) for t in base]
-        for kw in ({"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 64}, {"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 128},
-                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
-                   {"FUSED_GATHER_GEMM3": True, "FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
-            for n, v in saved.items():
-                setattr(fastpath, n, v)
-            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False}, **kw))
-            for g, b, s in zip(got, base, scale):
-                assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
-    finally:
-        for n, v in saved.items():
-            setattr(fastpath, n, v)
-
-
-@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,r", [(2, 4096, 1024, 16, 96, 64, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 1.0), (1, 1024, 256, 16, 256, 128, 196, 1.0),
-                                              (2, 256, 64, 32, 512, 256, 384, 4.0), (1, 512, 128, 16, 8, 64, 20, 1.0)])
-def test_per_point_layer1_equals_the_grouped_product(ops, B, N, M, ns, C, O1, O2, r):
-    """ws3d_pgather_gemm2 / ws3d_pgather_rows (layer 1 as feats @ W_f over the POINTS, gathered per pair, + the centred xyz term)
-    against the float64 product over the grouped rows and against ws3d_gather_gemm(2); P carries a second scale's columns, so
-    the column offset and the row stride are exercised"""
-    rng = np.random.default_rng(16)
-    pc = synth.make_batch("lidar", B, 16384, 65)[:, :N, :3].copy()
-    xyz = dev(pc)
-    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
-    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
-    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
-    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
-    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
-    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
-    other = dev(rng.standard_normal((C, 64)).astype(np.float32))                  # another scale's columns in front
-    pmat = feats.view(B * N, C) @ torch.cat((other, w1[:C]), dim=1)
-    w1x = w1[C:].contiguous()
-    li = nbr.long()
-    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
-    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
-    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
-    h = torch.relu(x @ w1.double() + b1.double())
-    tol = 1e-5 * np.sqrt(max(C, 96) / 96)
-    rows = ops.c.pgather_rows(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True)
-    assert rows is not None and tuple(rows.shape) == (B * M * ns, O1)
-    assert (rows.double() - h).abs().max().item() <= tol * max(h.abs().max().item(), 1.0)
-    assert (rows - ops.c.gather_gemm(feats, xyz, new_xyz, nbr, w1, b1, True)).abs().max().item() <= 2 * tol * max(h.abs().max().item(), 1.0)
-    if O1 <= 128:
-        want = torch.relu(h @ w2.double() + b2.double())
-        got = ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True)
-        assert got is not None and tuple(got.shape) == (B * M * ns, O2)
-        assert (got.double() - want).abs().max().item() <= tol * max(want.abs().max().item(), 1.0)
-        no_act = ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, None, False, w2, None, False)
-        assert (no_act.double() - (x @ w1.double()) @ w2.double()).abs().max().item() <= 2 * tol * max(want.abs().max().item(), 1.0)
-    else:
-        assert ops.c.pgather_gemm2(pmat, 64, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True) is None
-
-
-@pytest.mark.parametrize("B,N,M,C2,C1,O", [(2, 4096, 1024, 256, 96, 256), (1, 16384, 4096, 128, 1, 128), (2, 1024, 256, 512, 256, 512),
-                                           (2, 256, 64, 512, 512, 512), (2, 1024, 256, 128, 0, 64), (1, 300, 70, 64, 3, 20)])
-def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
-    """ws3d_qinterp_rows (first FP layer as the interpolation of Q = known_feats @ W_a + the skip channels' product) against
-    three_interpolate + concat + float64 product, and against ws3d_interp_gemm where that applies; both skip forms (lin from
-    a GEMM, <= 4 channels evaluated inside), no skip, no bias"""
-    rng = np.random.default_rng(17)
-    pc = synth.make_batch("lidar", B, 16384, 66)[:, :N, :3].copy()
-    unknown = dev(pc)
-    known = unknown[:, ::max(N // M, 1)][:, :M].contiguous()
-    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
-    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
-    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
-    wt = dev((rng.standard_normal((C2 + C1, O)) / np.sqrt(C2 + C1)).astype(np.float32))
-    bias = dev(rng.standard_normal(O).astype(np.float32))
-    interp = torch.empty((B, N, C2), device="cuda")
-    ops.c.three_interpolate_nlc(kf, idx, weight, interp)
-    x = interp if uf is None else torch.cat((interp, uf), dim=2)
-    want = torch.relu(x.view(-1, C2 + C1).double() @ wt.double() + bias.double())
-    q = (kf.view(B * M, C2) @ wt[:C2]).view(B, M, O)
-    tol = 6e-6 * max(want.abs().max().item(), 1.0) * np.sqrt((C2 + C1) / 96)
-    if C1 > 4:
-        lin = torch.addmm(bias, uf.view(B * N, C1), wt[C2:].contiguous())
-        got = ops.c.qinterp_rows(q, idx, weight, lin=lin, relu=True)
-    else:
-        got = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=bias, relu=True)
-    assert got is not None and tuple(got.shape) == (B * N, O)
-    assert (got.double() - want).abs().max().item() <= tol
-    if O % 64 == 0 and (B * N) % 64 == 0:
-        fused = ops.c.interp_gemm(kf, uf, idx, weight, wt, bias, True)
-        if fused is not None:
-            assert (got - fused).abs().max().item() <= 2 * tol
-    if C1 <= 4:
-        nb = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=None, relu=False)
-        assert (nb.double() - x.view(-1, C2 + C1).double() @ wt.double()).abs().max().item() <= tol
-        assert ops.c.qinterp_rows(q[:, :, :O - 1].contiguous(), idx, weight, relu=True) is None if (O - 1) % 4 else True
-
-
-@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),
-                                                  (1, 1024, 256, 32, 256, 128, 196, 256, 2.0), (2, 4096, 1024, 32, 96, 64, 96, 128, 6.0),
-                                                  (2, 256, 64, 32, 512, 256, 384, 512, 4.0), (1, 512, 37, 16, 8, 64, 20, 64, 0.01)])
-def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, C, O1, O2, O3, r):
-    """the SharedMLP over the DISTINCT (centre, sample) pairs (ws3d_compact_pairs_* / ws3d_pgather_gemm2_compact /
-    ws3d_gemm_pool_compact) gives exactly the pooled rows of the dense kernels: padded rows repeat row 0 of their centre.  Radii
-    from "every list is one point" (0.01) over the network's to "every list is full" (6.0); the pair table itself is checked
-    against the lists"""
-    rng = np.random.default_rng(18)
-    pc = synth.make_batch("lidar", B, 16384, 67)[:, :N, :3].copy()
-    xyz = dev(pc)
-    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
-    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
-    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
-    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
-    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    rowc, rowsrc, total = ops.c.compact_pairs(nbr, ordered=True)
-    T = int(total.item())
-    want_pairs = []
-    nb = host(nbr).reshape(B * M, ns)
-    for c_ in range(B * M):
-        row = nb[c_]
-        k = 1 + int((row[1:] > row[:-1]).sum())
-        assert len(set(row[:k].tolist())) == k and set(row.tolist()) == set(row[:k].tolist())
-        want_pairs += [(c_, int(v)) for v in row[:k]]
-    assert T == len(want_pairs)
-    assert list(zip(host(rowc)[:T].tolist(), host(rowsrc)[:T].tolist())) == want_pairs
-    rc1, rs1, t1 = ops.c.compact_pairs(nbr)                          # one launch: same pairs, centres in arrival order
-    assert int(t1.item()) == T
-    got1 = list(zip(host(rc1)[:T].tolist(), host(rs1)[:T].tolist()))
-    assert sorted(got1) == sorted(want_pairs)
-    firsts = {}
-    for i_, (c_, _) in enumerate(got1):
-        firsts.setdefault(c_, []).append(i_)
-    assert all(v == list(range(v[0], v[0] + len(v))) for v in firsts.values())       # a centre's rows are contiguous
-    rowc, rowsrc, total = rc1, rs1, t1                                # the network uses this form
-    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
-    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
-    w3 = dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)); b3 = dev(rng.standard_normal(O3).astype(np.float32))
-    pmat = feats.view(B * N, C) @ w1[:C]
-    w1x = w1[C:].contiguous()
-    dense = torch.empty((B * M, O3), device="cuda")
-    y = ops.c.pgather_gemm2(pmat, 0, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True) if (M * ns) % 64 == 0 else None
-    if y is not None and ops.c.gemm_pool(y, w3, b3, True, ns, dense, 0):
-        pass
-    else:   # shapes the dense kernels decline: the float64 chain decides (round-off instead of bit-equality)
-        dense = None
-    out = torch.zeros((B * M, O3 + 64), device="cuda")
-    yc = ops.c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True)
-    assert yc is not None and ops.c.gemm_pool_compact(yc, (rowc, rowsrc, total), w3, b3, out, 64)
-    assert bool((out[:, :64] == 0).all())
-    if dense is not None:
-        assert torch.equal(out[:, 64:], dense)
-        # device-side dispatch (launch gates): both forms launched into the same buffers, the pair total decides in the kernels'
-        # prologues -- a limit below the total runs the dense form only, a limit at or above it the compact form only
-        for limit, runs in ((T - 1, "dense"), (0, "dense"), (T, "compact"), (B * M * ns, "compact")):
-            o2_ = torch.zeros((B * M, O3), device="cuda")
-            buf = ops.c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True, limit=limit)
-            buf.fill_(float("nan"))
-            ops.c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True, limit=limit)
-            if runs == "dense":
-                assert bool(torch.isnan(buf).all()), "the compact layers ran beyond their limit"
-            buf = yc.clone() if runs == "compact" else buf
-            assert ops.c.gemm_pool_compact(buf, (rowc, rowsrc, total), w3, b3, o2_, 0, limit=limit)
-            if runs == "dense":
-                assert bool((o2_ == 0).all())
-            yd = ops.c.pgather_gemm2(pmat, 0, O1, xyz, new_xyz, nbr, w1x, b1, True, w2, b2, True, out=buf, gate=(total, limit))
-            assert yd is buf and ops.c.gemm_pool(yd, w3, b3, True, ns, o2_, 0, gate=(total, limit))
-            assert torch.equal(o2_, dense), (limit, runs)
-            if runs == "compact":
-                assert torch.equal(buf, yc), "the gated-off dense layers wrote into the compact rows"
-    li = nbr.long()
-    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
-    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
-    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
     h = torch.relu(torch.relu(x @ w1.double() + b1.double()) @ w2.double() + b2.double())
     want = torch.relu(h @ w3.double() + b3.double()).view(B * M, ns, O3).amax(dim=1)
     assert (out[:, 64:].double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0) * np.sqrt(max(C, 96) / 96)
