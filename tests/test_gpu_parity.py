@@ -346,6 +346,53 @@ def test_ball_query_sorted_slab_equals_bruteforce(ops, oracle, N, M, r, ns, kind
     np.testing.assert_array_equal(host(bb), ref)
 
 
+@pytest.mark.parametrize("N,M,r,ns,kind", [(16384, 4096, 0.5, 32, "hdl64"), (16384, 4096, 0.1, 16, "hdl64"), (16384, 4096, 0.1, 64, "hdl64"),
+                                          (4096, 1024, 1.0, 32, "hdl64"), (4096, 1024, 0.5, 16, "hdl64"), (16384, 512, 2.5, 64, "hdl64"),
+                                          (16384, 777, 0.4, 32, "clump"), (16384, 300, 60.0, 32, "hdl64"), (8192, 500, 0.3, 5, "dups"),
+                                          (16384, 2048, 0.5, 1, "hdl64"), (16384, 1000, 0.5, 33, "narrow")])
+def test_ball_query_grid_one_wave_per_centre_dense_lists(ops, oracle, N, M, r, ns, kind):
+    """the fine-grid ball query with one WAVE per centre (threshold selection of the nsample smallest indices) on clouds with KITTI's
+    density -- tens to hundreds of hits per ball -- against the oracle: lists bit-exact, through the plain and the fill entry, the
+    fused grouping and the brute-force kernel.  'clump': 7000 points inside a 0.5 m cube (more hits than the wave's LDS list holds ->
+    the ordered 64-wide scan); r = 60: more candidates than the grid walk accepts; 'narrow': a 2 m wide strip (many grid rows per ball)"""
+    rng = np.random.default_rng(7)
+    if kind == "dups":
+        base = synth.hdl64_cloud(64, 3)[:, :3]
+        xyz = base[rng.integers(0, 64, N)][None].copy()
+    elif kind == "clump":
+        xyz = synth.hdl64_cloud(N, 41)[None, :, :3].copy()
+        where = rng.choice(N, 7000, replace=False)
+        xyz[0, where] = (np.array([3.0, 1.0, 12.0]) + rng.uniform(-0.25, 0.25, (7000, 3))).astype(np.float32)
+    elif kind == "narrow":
+        xyz = synth.hdl64_cloud(N, 43)[None, :, :3].copy()
+        xyz[0, :, 0] = (xyz[0, :, 0] * np.float32(0.025)).astype(np.float32)
+    else:
+        xyz = synth.hdl64_cloud(N, 40)[None, :, :3].copy() if N == 16384 else synth.hdl64_cloud(16384, 40)[None, :N, :3].copy()
+    xyz = np.ascontiguousarray(np.concatenate([xyz, xyz[:, ::-1]], 0))  # 2 scenes
+    cidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(2)])
+    ref = oracle.ball_query(r, ns, xyz, new_xyz)
+    distinct = (np.diff(ref, axis=2) > 0).sum(2) + 1
+    x, c = dev(xyz), dev(new_xyz)
+    grid = ops.c.sort_points_x(x, grid=True)
+    assert grid is not None
+    g = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, g, grid)
+    np.testing.assert_array_equal(host(g), ref)
+    np.testing.assert_array_equal(host(ops.c.ball_query_lists(r, ns, x, c, grid)), ref)
+    bb = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
+    ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, bb, None)
+    np.testing.assert_array_equal(host(bb), ref)
+    feat = dev(rng.standard_normal((2, N, 8)).astype(np.float32))
+    gl = ops.c.query_and_group_nlc(r, ns, x, c, feat, True, grid)                # fused emit behind the same search
+    li = torch.from_numpy(ref.astype(np.int64)).cuda().view(2, M * ns, 1)
+    want = torch.cat((torch.gather(x, 1, li.expand(2, M * ns, 3)).view(2, M, ns, 3) - c.unsqueeze(2),
+                      torch.gather(feat, 1, li.expand(2, M * ns, 8)).view(2, M, ns, 8)), dim=3)
+    assert torch.equal(gl, want)
+    if kind == "hdl64" and N == 16384 and r == 0.5 and ns == 32:
+        assert distinct.mean() > 8 and (distinct == ns).mean() > 0.05, "this cloud is supposed to be dense"
+
+
 def test_ball_query_no_hit_rows_untouched(ops, oracle):
     xyz = synth.uniform_cloud(300, 5)[None, :, :3].copy()
     far = (xyz[:, :10] + np.float32(1000.0)).copy()

@@ -15,6 +15,7 @@
 // of the contract -- and leave the chip with coalesced stores.  In the fused kernel the
 // rows never go back to global memory: the same workgroup emits the centred xyz and
 // the feature channels straight into the (B, 3+C, M, ns) tensor the SharedMLP consumes.
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 
@@ -821,6 +822,190 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 #endif
 }
 
+// ---- fine-grid flavour, one WAVE per centre (round 3).  The kernel above gives every centre one lane: fine while a list holds a
+// handful of candidates (the sparse `lidar` generator: 1-3 hits), but on a scan with KITTI's density (synth.hdl64_cloud) the
+// r = 0.5 m ball of a near-range centre holds 100-300 candidates and ~80 hits, the lane walks them one by one, keeps its 32 smallest
+// indices by insertion into an LDS row (a chain of dependent LDS round trips), and the wave waits for its slowest lane while
+// three of the workgroup's four waves idle: 736 us for level 1 of a batch of 8 (55 us on the sparse clouds).
+// Here a wave takes 16 of the workgroup's 64 centres in turn and works on ONE centre with all 64 lanes:
+//   1. ranges   lane (centre i, row q) reads the cell-start table for grid row iz0 + q of centre i: the first four rows of all
+//               16 centres in one round trip (more rows -- r / cell > 3 -- are fetched per centre, four at a time);
+//   2. test     the rows' candidate ranges are laid end to end and dealt out 64 at a time: one distance test per lane, the hits
+//               are appended to the wave's LDS list through ballot + mbcnt (order irrelevant);
+//   3. select   more than nsample hits: the nsample SMALLEST indices are the contract ("first nsample by index").  Their
+//               threshold T -- the nsample-th smallest -- is found bit by bit (log2 n rounds of "how many hits lie below T | bit":
+//               a compare, a ballot and an s_bcnt1 per 64 hits), then the hits <= T are compacted in place;
+//   4. order    <= nsample survivors: every lane ranks its own by counting the smaller ones (broadcast LDS reads) and stores it
+//               at its rank; the row is padded with its first entry as before.
+// No lane ever waits for another lane's longer list, the work per centre is O(candidates / 64 + log n * hits / 64 + nsample).
+// More than BQC_HCAP hits or BQC_MAX_CAND candidates (pathological density): the wave scans the scene in INDEX order, 64 points
+// per step, and stops at nsample hits -- the reference's own loop (ball_query_gpu.cu:29-44), 64 wide.
+// Same candidate bounds, same distance expression and operand order as above: bit-identical lists.
+constexpr int BQC_HCAP = 1024;        // hits kept per centre (uint16 in LDS, per wave)
+constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the ordered scan takes over
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
+                                                                   const float *__restrict__ xyz, const char *__restrict__ ws,
+                                                                   const float *__restrict__ new_xyz, const float *__restrict__ features,
+                                                                   int32_t *__restrict__ idx_out, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
+    int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
+    uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
+    const int rstride = nsample + 1;
+    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // 4 * BQC_HCAP
+    const int tiles = (m + 63) / 64;
+    int b, tile;
+    if ((nb & 7) == 0) {
+        const int g = blockIdx.x, j = g >> 3;
+        b = (j / tiles) * 8 + (g & 7);
+        tile = j - (j / tiles) * tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x - b * tiles;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = tile * 64;
+    xyz += (size_t)b * n * 3;
+    const char *base = ws + (size_t)b * bin_scene_stride(n);
+    const float4 *sorted = reinterpret_cast<const float4 *>(base);
+    const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)n * 16);
+    const uint16_t *start16 = reinterpret_cast<const uint16_t *>(base + (size_t)n * 16 + sizeof(BinHeader));
+    const int *params = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
+    new_xyz += (size_t)b * m * 3;
+    uint16_t *hits = hits_all + w * BQC_HCAP;
+    const float radius2 = radius * radius;
+    const float rabs = fabsf(radius);
+    const int gx = -hdr.pad, gz = params[2];
+    const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
+    const int id_bits = 32 - __builtin_clz(max(n - 1, 1));            // ids < n
+
+    // ---- 1. this lane's (centre, row) of the wave's 16 centres x first 4 grid rows
+    const int ci_l = lane >> 2, q_l = lane & 3;
+    const int mi_l = m0 + 16 * w + ci_l;
+    float lcx = 0.f, lcy = 0.f, lcz = 0.f;
+    if (mi_l < m) { lcx = new_xyz[mi_l * 3 + 0]; lcy = new_xyz[mi_l * 3 + 1]; lcz = new_xyz[mi_l * 3 + 2]; }
+    if (q_l == 0) cen[16 * w + ci_l] = make_float4(lcx, lcy, lcz, 0.f);
+    int l_ix0 = 0, l_ix1 = 0, l_iz0 = 0, l_nrows = 0, l_k0 = 0, l_ke = 0;
+    if (mi_l < m && lcx == lcx) {
+        // see ball_query_sorted_kernel for the bounds argument (hits lie within r (1 + 2^-23) of the centre on each axis)
+        const float sx = (fabsf(lcx) + rabs) * 6e-7f, sz = (fabsf(lcz) + rabs) * 6e-7f;
+        l_ix0 = grid_coord((lcx - rabs) - sx, hdr.xmin, hdr.inv_w, gx);
+        l_ix1 = grid_coord((lcx + rabs) + sx, hdr.xmin, hdr.inv_w, gx);
+        l_iz0 = grid_coord((lcz - rabs) - sz, zmin, inv_wz, gz);
+        l_nrows = grid_coord((lcz + rabs) + sz, zmin, inv_wz, gz) - l_iz0 + 1;
+        if (q_l < l_nrows) {
+            l_k0 = (int)start16[(l_iz0 + q_l) * gx + l_ix0];
+            l_ke = (int)start16[(l_iz0 + q_l) * gx + l_ix1 + 1];
+        }
+    }
+    for (int ci = 0; ci < 16; ++ci) {
+        const int c = 16 * w + ci;                                     // centre slot of the workgroup
+        uint16_t *row = rows + (size_t)c * rstride;
+        const int src = 4 * ci;
+        const float cx = readlane_f(lcx, src), cy = readlane_f(lcy, src), cz = readlane_f(lcz, src);
+        const int nrows = __builtin_amdgcn_readlane(l_nrows, src);
+        int cnt = 0;
+        if (nrows > 0) {
+            const int ix0 = __builtin_amdgcn_readlane(l_ix0, src), ix1 = __builtin_amdgcn_readlane(l_ix1, src);
+            const int iz0 = __builtin_amdgcn_readlane(l_iz0, src);
+            int H = 0, tested = 0;
+            bool ordered = false;
+            for (int rb = 0; rb < nrows && !ordered; rb += 4) {
+                int k0[4], len[4];
+                if (rb == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        k0[q] = __builtin_amdgcn_readlane(l_k0, src + q);
+                        len[q] = __builtin_amdgcn_readlane(l_ke, src + q) - k0[q];
+                    }
+                } else {
+                    int a = 0, e = 0;
+                    if (lane < 4 && rb + lane < nrows) {
+                        a = (int)start16[(iz0 + rb + lane) * gx + ix0];
+                        e = (int)start16[(iz0 + rb + lane) * gx + ix1 + 1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        k0[q] = __builtin_amdgcn_readlane(a, q);
+                        len[q] = __builtin_amdgcn_readlane(e, q) - k0[q];
+                    }
+                }
+                const int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
+                tested += L;
+                if (tested > BQC_MAX_CAND) { ordered = true; break; }
+                for (int j0 = 0; j0 < L; j0 += 64) {
+                    const int j = j0 + lane;
+                    // position j of the four ranges laid end to end
+                    const int k = j < p1 ? k0[0] + j : (j < p2 ? k0[1] + (j - p1) : (j < p3 ? k0[2] + (j - p2) : k0[3] + (j - p3)));
+                    const float4 p = sorted[j < L ? k : k0[0]];
+                    const float dx = cx - p.x;
+                    const bool hit = j < L && fabsf(dx) < rabs && sqdist3(dx, cy - p.y, cz - p.z) < radius2;
+                    const uint64_t mask = __ballot(hit);
+                    const int pos = H + mbcnt(mask);
+                    if (hit && pos < BQC_HCAP) hits[pos] = (uint16_t)__float_as_int(p.w);
+                    H += __popcll(mask);
+                }
+                if (H > BQC_HCAP) ordered = true;
+            }
+            if (ordered) {
+                // pathological density: the reference's ordered scan with early exit, 64 points per step
+                for (int q0 = 0; q0 < n && cnt < nsample; q0 += 64) {
+                    const int q = q0 + lane;
+                    bool hit = false;
+                    if (q < n) hit = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]) < radius2;
+                    const uint64_t mask = __ballot(hit);
+                    const int pos = cnt + mbcnt(mask);
+                    if (hit && pos < nsample) row[pos] = (uint16_t)q;
+                    cnt += __popcll(mask);
+                }
+                cnt = min(cnt, nsample);
+            } else {
+                // ---- 3. threshold: T = the nsample-th smallest index among the hits
+                if (H > nsample) {
+                    int T = 0;
+                    for (int bit = id_bits - 1; bit >= 0; --bit) {
+                        const int trial = T | (1 << bit);
+                        int below = 0;
+                        for (int u = 0; u < H; u += 64) {
+                            const int i = u + lane;
+                            below += __popcll(__ballot(i < H && (int)hits[i] < trial));
+                        }
+                        if (below < nsample) T = trial;                 // fewer than nsample hits below `trial`: the threshold is >= trial
+                    }
+                    int kept = 0;
+                    for (int u = 0; u < H; u += 64) {
+                        const int i = u + lane;
+                        const int v = i < H ? (int)hits[i] : 0x7fffffff;
+                        const bool keep = v <= T;
+                        const uint64_t mask = __ballot(keep);
+                        if (keep) hits[kept + mbcnt(mask)] = (uint16_t)v; // in place: a survivor moves to the left of every unread entry
+                        kept += __popcll(mask);
+                    }
+                    H = kept;                                           // == nsample (indices are distinct)
+                }
+                // ---- 4. order: rank of each survivor = number of smaller survivors
+                cnt = H;
+                if (lane < cnt) {
+                    const int v = (int)hits[lane];
+                    int rank = 0;
+                    for (int i = 0; i < cnt; ++i) rank += (int)hits[i] < v;
+                    row[rank] = (uint16_t)v;
+                }
+            }
+        }
+        // pad with the first (smallest) entry; rows of centres without a hit are never read by the emit unless FUSED (zeros)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint16_t first = cnt > 0 ? row[0] : (uint16_t)0;
+        for (int s2 = cnt + lane; s2 < nsample; s2 += 64) row[s2] = first;
+        if (lane == 0) cnt_s[c] = (m0 + c < m) ? cnt : 0;
+    }
+    __syncthreads();
+    bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
+}
+
 static size_t bq_smem(int nsample, size_t idx_bytes) {
     return sizeof(float4) * (BQ_NW * BQ_TILE + 64) + sizeof(int) * BQ_NW * 64 +
            idx_bytes * (size_t)BQ_NW * 64 * (nsample + 1);
@@ -853,6 +1038,13 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         while (gz < 64 && tiles * gz < 1024 && (64L * nsample) / (gz * 2) >= 64) gz *= 2;
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
+        static const int coop_env = getenv("WS3D_BQ_GRID_COOP") ? atoi(getenv("WS3D_BQ_GRID_COOP")) : 1;     // 0: one lane per centre (A/B runs)
+        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP);
+        if (coop_env && nsample <= 64 && smem_c <= 64 * 1024) {
+            hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
+                               radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out);
+            return check_launch(what);
+        }
         const size_t smem_g = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)64 * (nsample + 1);
         if (smem_g <= 64 * 1024) {
             hipLaunchKernelGGL((ball_query_grid_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_g, st, b, n, m, c,
