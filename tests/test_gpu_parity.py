@@ -357,7 +357,7 @@ def test_ball_query_grid_one_wave_per_centre_dense_lists(ops, oracle, N, M, r, n
     the ordered 64-wide scan); r = 60: more candidates than the grid walk accepts; 'narrow': a 2 m wide strip (many grid rows per ball)"""
     rng = np.random.default_rng(7)
     if kind == "dups":
-        base = synth.hdl64_cloud(64, 3)[:, :3]
+        base = synth.hdl64_cloud(16384, 3)[:64, :3]
         xyz = base[rng.integers(0, 64, N)][None].copy()
     elif kind == "clump":
         xyz = synth.hdl64_cloud(N, 41)[None, :, :3].copy()

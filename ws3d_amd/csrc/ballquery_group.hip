@@ -831,7 +831,9 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 //   1. ranges   lane (centre i, row q) reads the cell-start table for grid row iz0 + q of centre i: the first four rows of all
 //               16 centres in one round trip (more rows -- r / cell > 3 -- are fetched per centre, four at a time);
 //   2. test     the rows' candidate ranges are laid end to end and dealt out 64 at a time: one distance test per lane, the hits
-//               are appended to the wave's LDS list through ballot + mbcnt (order irrelevant);
+//               are appended to an LDS list through ballot + mbcnt (order irrelevant).  The FIRST 64 candidates of all 16 centres
+//               are loaded up front (16 loads in flight) and tested before the per-centre loop starts: a centre in a sparse
+//               neighbourhood (<= 64 candidates, most centres of an FPS-sampled scan) costs no memory round trip of its own;
 //   3. select   more than nsample hits: the nsample SMALLEST indices are the contract ("first nsample by index").  Their
 //               threshold T -- the nsample-th smallest -- is found bit by bit (log2 n rounds of "how many hits lie below T | bit":
 //               a compare, a ballot and an s_bcnt1 per 64 hits), then the hits <= T are compacted in place;
@@ -854,7 +856,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
     uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
     const int rstride = nsample + 1;
-    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // 4 * BQC_HCAP
+    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // 4 waves x BQC_HCAP
+    uint16_t *stage_all = hits_all + 4 * BQC_HCAP;                     // 4 waves x 16 centres x 64: the hits of each centre's first 64 candidates
     const int tiles = (m + 63) / 64;
     int b, tile;
     if ((nb & 7) == 0) {
@@ -875,6 +878,7 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     const int *params = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
     new_xyz += (size_t)b * m * 3;
     uint16_t *hits = hits_all + w * BQC_HCAP;
+    uint16_t *stage = stage_all + w * (16 * 64);
     const float radius2 = radius * radius;
     const float rabs = fabsf(radius);
     const int gx = -hdr.pad, gz = params[2];
@@ -900,70 +904,108 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
             l_ke = (int)start16[(l_iz0 + q_l) * gx + l_ix1 + 1];
         }
     }
+    // the four ranges of a centre laid end to end: position j -> index into `sorted`
+    auto locate = [&](const int j, const int (&k0)[4], const int p1, const int p2, const int p3) {
+        return j < p1 ? k0[0] + j : (j < p2 ? k0[1] + (j - p1) : (j < p3 ? k0[2] + (j - p2) : k0[3] + (j - p3)));
+    };
+    // ---- 2a. the first 64 candidates of all 16 centres: 16 independent loads in flight, then the tests; the hits of centre i go
+    //          to stage[i][..] (this is the whole search of a centre in a sparse neighbourhood -- no memory round trip per centre)
+    int l_h0 = 0;                                                       // lane i (< 16): hits among centre i's first 64 candidates
+    {
+        float4 pre[16];
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+            int k0[4], len[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                k0[q] = __builtin_amdgcn_readlane(l_k0, 4 * ci + q);
+                len[q] = __builtin_amdgcn_readlane(l_ke, 4 * ci + q) - k0[q];
+            }
+            const int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
+            pre[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < L) pre[ci] = sorted[locate(lane, k0, p1, p2, p3)];
+        }
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) {
+            const int L4 = (__builtin_amdgcn_readlane(l_ke, 4 * ci) - __builtin_amdgcn_readlane(l_k0, 4 * ci)) +
+                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 1) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 1)) +
+                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 2) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 2)) +
+                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 3) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 3));
+            const float cx = readlane_f(lcx, 4 * ci), cy = readlane_f(lcy, 4 * ci), cz = readlane_f(lcz, 4 * ci);
+            const float dx = cx - pre[ci].x;
+            const bool hit = lane < L4 && fabsf(dx) < rabs && sqdist3(dx, cy - pre[ci].y, cz - pre[ci].z) < radius2;
+            const uint64_t mask = __ballot(hit);
+            if (hit) stage[ci * 64 + mbcnt(mask)] = (uint16_t)__float_as_int(pre[ci].w);
+            if (lane == ci) l_h0 = __popcll(mask);
+        }
+    }
     for (int ci = 0; ci < 16; ++ci) {
         const int c = 16 * w + ci;                                     // centre slot of the workgroup
         uint16_t *row = rows + (size_t)c * rstride;
         const int src = 4 * ci;
-        const float cx = readlane_f(lcx, src), cy = readlane_f(lcy, src), cz = readlane_f(lcz, src);
         const int nrows = __builtin_amdgcn_readlane(l_nrows, src);
         int cnt = 0;
         if (nrows > 0) {
-            const int ix0 = __builtin_amdgcn_readlane(l_ix0, src), ix1 = __builtin_amdgcn_readlane(l_ix1, src);
-            const int iz0 = __builtin_amdgcn_readlane(l_iz0, src);
-            int H = 0, tested = 0;
-            bool ordered = false;
-            for (int rb = 0; rb < nrows && !ordered; rb += 4) {
-                int k0[4], len[4];
-                if (rb == 0) {
+            int k0[4], len[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        k0[q] = __builtin_amdgcn_readlane(l_k0, src + q);
-                        len[q] = __builtin_amdgcn_readlane(l_ke, src + q) - k0[q];
-                    }
-                } else {
-                    int a = 0, e = 0;
-                    if (lane < 4 && rb + lane < nrows) {
-                        a = (int)start16[(iz0 + rb + lane) * gx + ix0];
-                        e = (int)start16[(iz0 + rb + lane) * gx + ix1 + 1];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        k0[q] = __builtin_amdgcn_readlane(a, q);
-                        len[q] = __builtin_amdgcn_readlane(e, q) - k0[q];
-                    }
-                }
-                const int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
-                tested += L;
-                if (tested > BQC_MAX_CAND) { ordered = true; break; }
-                for (int j0 = 0; j0 < L; j0 += 64) {
-                    const int j = j0 + lane;
-                    // position j of the four ranges laid end to end
-                    const int k = j < p1 ? k0[0] + j : (j < p2 ? k0[1] + (j - p1) : (j < p3 ? k0[2] + (j - p2) : k0[3] + (j - p3)));
-                    const float4 p = sorted[j < L ? k : k0[0]];
-                    const float dx = cx - p.x;
-                    const bool hit = j < L && fabsf(dx) < rabs && sqdist3(dx, cy - p.y, cz - p.z) < radius2;
-                    const uint64_t mask = __ballot(hit);
-                    const int pos = H + mbcnt(mask);
-                    if (hit && pos < BQC_HCAP) hits[pos] = (uint16_t)__float_as_int(p.w);
-                    H += __popcll(mask);
-                }
-                if (H > BQC_HCAP) ordered = true;
+            for (int q = 0; q < 4; ++q) {
+                k0[q] = __builtin_amdgcn_readlane(l_k0, src + q);
+                len[q] = __builtin_amdgcn_readlane(l_ke, src + q) - k0[q];
             }
-            if (ordered) {
-                // pathological density: the reference's ordered scan with early exit, 64 points per step
-                for (int q0 = 0; q0 < n && cnt < nsample; q0 += 64) {
-                    const int q = q0 + lane;
-                    bool hit = false;
-                    if (q < n) hit = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]) < radius2;
-                    const uint64_t mask = __ballot(hit);
-                    const int pos = cnt + mbcnt(mask);
-                    if (hit && pos < nsample) row[pos] = (uint16_t)q;
-                    cnt += __popcll(mask);
+            int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
+            int H = __builtin_amdgcn_readlane(l_h0, ci);
+            const uint16_t *hl = stage + ci * 64;                       // this centre's hit list
+            bool ordered = false;
+            if (L > 64 || nrows > 4) {
+                // ---- 2b. a dense neighbourhood: the rest of the candidates, 64 per step, appended to the wave's long list
+                const float cx = readlane_f(lcx, src), cy = readlane_f(lcy, src), cz = readlane_f(lcz, src);
+                const int ix0 = __builtin_amdgcn_readlane(l_ix0, src), ix1 = __builtin_amdgcn_readlane(l_ix1, src);
+                const int iz0 = __builtin_amdgcn_readlane(l_iz0, src);
+                if (lane < H) hits[lane] = stage[ci * 64 + lane];
+                hl = hits;
+                int tested = 0;
+                for (int rb = 0; rb < nrows && !ordered; rb += 4) {
+                    if (rb > 0) {
+                        int a = 0, e = 0;
+                        if (lane < 4 && rb + lane < nrows) {
+                            a = (int)start16[(iz0 + rb + lane) * gx + ix0];
+                            e = (int)start16[(iz0 + rb + lane) * gx + ix1 + 1];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            k0[q] = __builtin_amdgcn_readlane(a, q);
+                            len[q] = __builtin_amdgcn_readlane(e, q) - k0[q];
+                        }
+                        p1 = len[0]; p2 = p1 + len[1]; p3 = p2 + len[2]; L = p3 + len[3];
+                    }
+                    tested += L;
+                    if (tested > BQC_MAX_CAND) { ordered = true; break; }
+                    for (int j0 = rb == 0 ? 64 : 0; j0 < L; j0 += 64) {
+                        const int j = j0 + lane;
+                        const float4 p = sorted[j < L ? locate(j, k0, p1, p2, p3) : k0[0]];
+                        const float dx = cx - p.x;
+                        const bool hit = j < L && fabsf(dx) < rabs && sqdist3(dx, cy - p.y, cz - p.z) < radius2;
+                        const uint64_t mask = __ballot(hit);
+                        const int pos = H + mbcnt(mask);
+                        if (hit && pos < BQC_HCAP) hits[pos] = (uint16_t)__float_as_int(p.w);
+                        H += __popcll(mask);
+                    }
+                    if (H > BQC_HCAP) ordered = true;
                 }
-                cnt = min(cnt, nsample);
-            } else {
-                // ---- 3. threshold: T = the nsample-th smallest index among the hits
-                if (H > nsample) {
+                if (ordered) {
+                    // pathological density: the reference's ordered scan with early exit, 64 points per step
+                    for (int q0 = 0; q0 < n && cnt < nsample; q0 += 64) {
+                        const int q = q0 + lane;
+                        bool hit = false;
+                        if (q < n) hit = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]) < radius2;
+                        const uint64_t mask = __ballot(hit);
+                        const int pos = cnt + mbcnt(mask);
+                        if (hit && pos < nsample) row[pos] = (uint16_t)q;
+                        cnt += __popcll(mask);
+                    }
+                    cnt = min(cnt, nsample);
+                } else if (H > nsample) {
+                    // ---- 3. threshold: T = the nsample-th smallest index among the hits
                     int T = 0;
                     for (int bit = id_bits - 1; bit >= 0; --bit) {
                         const int trial = T | (1 << bit);
@@ -985,17 +1027,27 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
                     }
                     H = kept;                                           // == nsample (indices are distinct)
                 }
+            } else if (H > nsample) {
+                // <= 64 candidates, more hits than the list takes (nsample < 64): the lane's own rank decides
+                const int v = lane < H ? (int)hl[lane] : 0x7fffffff;
+                int rank = 0;
+                for (int i = 0; i < H; ++i) rank += (int)hl[i] < v;
+                if (lane < H && rank < nsample) row[rank] = (uint16_t)v;
+                cnt = nsample;
+                ordered = true;                                         // (the row is written)
+            }
+            if (!ordered) {
                 // ---- 4. order: rank of each survivor = number of smaller survivors
                 cnt = H;
                 if (lane < cnt) {
-                    const int v = (int)hits[lane];
+                    const int v = (int)hl[lane];
                     int rank = 0;
-                    for (int i = 0; i < cnt; ++i) rank += (int)hits[i] < v;
+                    for (int i = 0; i < cnt; ++i) rank += (int)hl[i] < v;
                     row[rank] = (uint16_t)v;
                 }
             }
         }
-        // pad with the first (smallest) entry; rows of centres without a hit are never read by the emit unless FUSED (zeros)
+        // pad with the first (smallest) entry; a centre without a hit: zeros (only the fused emit reads them)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint16_t first = cnt > 0 ? row[0] : (uint16_t)0;
@@ -1039,7 +1091,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
         static const int coop_env = getenv("WS3D_BQ_GRID_COOP") ? atoi(getenv("WS3D_BQ_GRID_COOP")) : 1;     // 0: one lane per centre (A/B runs)
-        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP);
+        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP + 4 * 16 * 64);
         if (coop_env && nsample <= 64 && smem_c <= 64 * 1024) {
             hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
                                radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out);
