@@ -393,6 +393,20 @@ def test_ball_query_grid_one_wave_per_centre_dense_lists(ops, oracle, N, M, r, n
         assert distinct.mean() > 8 and (distinct == ns).mean() > 0.05, "this cloud is supposed to be dense"
 
 
+def test_ball_query_binned_buffer_of_another_flavour_on_a_noted_address(ops, oracle):
+    """the host picks the ball-query kernel from the flavour it noted per buffer ADDRESS; x-slab contents copied into a buffer noted
+    as fine-grid (a clone, a recycled allocation) must not be walked as a grid: the kernel reads the header and scans in order"""
+    xyz = synth.hdl64_cloud(16384, 44)[None, :, :3].copy()
+    cidx = oracle.furthest_point_sample(xyz, 300)
+    new_xyz = np.stack([xyz[0][cidx[0]]])
+    ref = oracle.ball_query(0.5, 32, xyz, new_xyz)
+    x, c = dev(xyz), dev(new_xyz)
+    grid = ops.c.sort_points_x(x, grid=True)
+    slabs = ops.c.sort_points_x(x, grid=False)
+    grid.copy_(slabs)
+    np.testing.assert_array_equal(host(ops.c.ball_query_lists(0.5, 32, x, c, grid)), ref)
+
+
 def test_ball_query_no_hit_rows_untouched(ops, oracle):
     xyz = synth.uniform_cloud(300, 5)[None, :, :3].copy()
     far = (xyz[:, :10] + np.float32(1000.0)).copy()

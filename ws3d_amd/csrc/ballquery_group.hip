@@ -773,7 +773,13 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
         if (active) { for (int q = 0; q < 40 && q < nsample; ++q) row[q] = (uint16_t)((mi * 7 + q * 13) % n); cnt = min(40, nsample); }
         if (false) {
 #else
-        if (active && cx == cx) {
+        if (active && cx == cx && hdr.pad >= 0) {
+            // not a fine-grid buffer (see ball_query_grid_coop_kernel): the reference's ordered scan
+            for (int q = 0; q < n && cnt < nsample; ++q) {
+                const float d2 = sqdist3(cx - xyz[q * 3 + 0], cy - xyz[q * 3 + 1], cz - xyz[q * 3 + 2]);
+                if (d2 < radius2) { row[cnt] = (uint16_t)q; ++cnt; }
+            }
+        } else if (active && cx == cx) {
 #endif
             // see ball_query_sorted_kernel for the bounds argument (hits lie within r (1 + 2^-23) of the centre on each axis)
             const int gx = -hdr.pad, gz = params[2];
@@ -881,7 +887,11 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     uint16_t *stage = stage_all + w * (16 * 64);
     const float radius2 = radius * radius;
     const float rabs = fabsf(radius);
-    const int gx = -hdr.pad, gz = params[2];
+    // the host picks this kernel from what the sort entry points noted per buffer ADDRESS; a buffer of another flavour that
+    // landed on a noted address (a copy, a recycled allocation) is recognised by its header and served by the ordered scan:
+    // slow, never wrong
+    const bool not_grid = hdr.pad >= 0;
+    const int gx = not_grid ? 1 : -hdr.pad, gz = not_grid ? 1 : params[2];
     const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
     const int id_bits = 32 - __builtin_clz(max(n - 1, 1));            // ids < n
 
@@ -899,7 +909,9 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
         l_ix1 = grid_coord((lcx + rabs) + sx, hdr.xmin, hdr.inv_w, gx);
         l_iz0 = grid_coord((lcz - rabs) - sz, zmin, inv_wz, gz);
         l_nrows = grid_coord((lcz + rabs) + sz, zmin, inv_wz, gz) - l_iz0 + 1;
-        if (q_l < l_nrows) {
+        if (not_grid) {
+            l_nrows = 1;
+        } else if (q_l < l_nrows) {
             l_k0 = (int)start16[(l_iz0 + q_l) * gx + l_ix0];
             l_ke = (int)start16[(l_iz0 + q_l) * gx + l_ix1 + 1];
         }
@@ -955,8 +967,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
             int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
             int H = __builtin_amdgcn_readlane(l_h0, ci);
             const uint16_t *hl = stage + ci * 64;                       // this centre's hit list
-            bool ordered = false;
-            if (L > 64 || nrows > 4) {
+            bool ordered = not_grid;
+            if (L > 64 || nrows > 4 || not_grid) {
                 // ---- 2b. a dense neighbourhood: the rest of the candidates, 64 per step, appended to the wave's long list
                 const float cx = readlane_f(lcx, src), cy = readlane_f(lcy, src), cz = readlane_f(lcz, src);
                 const int ix0 = __builtin_amdgcn_readlane(l_ix0, src), ix1 = __builtin_amdgcn_readlane(l_ix1, src);
