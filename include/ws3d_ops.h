@@ -106,6 +106,12 @@ WS3D_API int ws3d_ball_query(int b, int n, int m, float radius, int nsample, con
  * zero-initialised idx tensor, pointnet2_utils.py:201), so that idx need not be cleared first.  ws3d extension.           */
 WS3D_API int ws3d_ball_query_fill(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                          const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream);
+/* ws3d_ball_query_fill + ws3d_compact_pairs in ONE launch: the lists idx (b, m, nsample) and their distinct (centre, source) pairs
+ * rowc / rowsrc (b * m * nsample ints each, the first *total valid; *total must be ZERO on entry; compact rows of a centre
+ * contiguous, centres in arrival order of their 64-centre workgroups).  Needs the fine-grid buffer of ws3d_sort_points_grid and
+ * nsample <= 64 (the kernel that works with one wave per centre), else WS3D_E_UNSUPPORTED.  ws3d extension.                   */
+WS3D_API int ws3d_ball_query_pairs(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx,
+                          const void *sorted_grid, int32_t *rowc, int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);
 
 /* Optional accelerator for ws3d_ball_query / ws3d_query_and_group (no reference counterpart):
  * a per-scene copy of xyz counting-sorted into uniform x cells (float4 {x,y,z,index} x n, a
@@ -157,6 +163,10 @@ WS3D_API int ws3d_three_nn(int b, int n, int m, const float *unknown, const floa
 /* dist2 (rows,3) SQUARED distances from ws3d_three_nn -> weight (rows,3): the FP module's normalised
  * inverse-distance weights (pointnet2_modules.py:139-142) in one launch.  ws3d extension.            */
 WS3D_API int ws3d_three_nn_weights(long rows, const float *dist2, float *weight, ws3d_stream_t stream);
+/* ws3d_three_nn with ws3d_three_nn_weights folded into the search kernel's epilogue (same dist2 / idx, weight (b,n,3) as the
+ * two-launch form, bit for bit): what the FP modules of ws3d_amd/fastpath.py call.                              */
+WS3D_API int ws3d_three_nn_w(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
+                             const void *sorted_known, ws3d_stream_t stream);
 
 /* The SA module's pool over nsample (pointnet2_modules.py:50, F.max_pool2d(kernel_size=[1, nsample]))
  * with the position of the maximum kept for the backward pass.  x (rows, nsample) -- the contiguous

@@ -90,7 +90,7 @@ def test_two_ranks_c3_gather_equals_the_single_process_result(tmp_path):
     from bench_c3 import C3
     from ws3d_amd import dist as wdist
     for r in (0, 1):
-        wl = C3(8, r, 1, "lidar", depth=1)
+        wl = C3(8, r, 1, "hdl64", depth=1)
         wl.step()
         torch.cuda.synchronize()
         _, boxes, scores, count, _, _, _ = wl.last

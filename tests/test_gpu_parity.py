@@ -380,6 +380,19 @@ def test_ball_query_grid_one_wave_per_centre_dense_lists(ops, oracle, N, M, r, n
     ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, g, grid)
     np.testing.assert_array_equal(host(g), ref)
     np.testing.assert_array_equal(host(ops.c.ball_query_lists(r, ns, x, c, grid)), ref)
+    # lists + their distinct (centre, source) pairs in one launch == ball_query_lists + compact_pairs
+    both = ops.c.ball_query_pairs(r, ns, x, c, grid)
+    assert both is not None
+    np.testing.assert_array_equal(host(both[0]), ref)
+    rc_, rs_, tot_ = both[1]
+    T = int(tot_.item())
+    want_pairs = sorted((cm, int(v)) for cm in range(2 * M) for v in ref.reshape(2 * M, ns)[cm][:distinct.reshape(-1)[cm]])
+    got_pairs = list(zip(host(rc_)[:T].tolist(), host(rs_)[:T].tolist()))
+    assert T == len(want_pairs) and sorted(got_pairs) == want_pairs
+    pos = {}
+    for i_, (cm, _) in enumerate(got_pairs):
+        pos.setdefault(cm, []).append(i_)
+    assert all(v == list(range(v[0], v[0] + len(v))) for v in pos.values())        # a centre's compact rows are contiguous
     bb = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
     ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, bb, None)
     np.testing.assert_array_equal(host(bb), ref)

@@ -15,6 +15,7 @@ DIST_MODE = int(os.environ.get("WS3D_DIST_MODE", "0") or 0)
 LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B builds
     _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
+E_INVALID, E_LAUNCH, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4      # WS3D_E_* of include/ws3d_ops.h
 ABI_VERSION = 2     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
 
 _vp = C.c_void_p
@@ -35,6 +36,7 @@ SIGNATURES = {
     "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query_fill": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_ball_query_pairs": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_sorted_points_bytes": (_sz, [_i, _i]),
     "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_xz": (_i, [_i, _i, _vp, _vp, _vp]),
@@ -65,6 +67,7 @@ SIGNATURES = {
     "ws3d_decode_center_boxes": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ws3d_topk_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_three_nn_weights": (_i, [C.c_long, _vp, _vp, _vp]),
+    "ws3d_three_nn_w": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_rowmax_bias_act": (_i, [_i, _i, C.c_long, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

@@ -178,6 +178,29 @@ def ball_query_lists(radius, nsample, xyz, new_xyz, sorted_xyz=None):
     return idx
 
 
+def ball_query_pairs(radius, nsample, xyz, new_xyz, sorted_grid, total=None):
+    """ball_query_lists + compact_pairs in ONE launch: -> (idx (B, M, nsample) int32, (rowc, rowsrc, total)), or None when the
+    kernel that emits the pairs does not cover the call (no fine-grid buffer, nsample > 64).  `total`: a 1-element int32 tensor
+    that is ZERO (e.g. a slice of one cleared buffer shared by several calls); allocated and cleared here when None.  ws3d extension."""
+    if sorted_grid is None or nsample > 64 or not BQ_FINE_GRID:
+        return None
+    dev = _dev(xyz, new_xyz, sorted_grid)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+    idx = torch.empty((B, M, nsample), dtype=torch.int32, device=dev)
+    rowc = torch.empty(B * M * nsample, dtype=torch.int32, device=dev)
+    rowsrc = torch.empty(B * M * nsample, dtype=torch.int32, device=dev)
+    if total is None:
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().ws3d_ball_query_pairs(B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx), _p(sorted_grid), _p(rowc), _p(rowsrc),
+                                               _p(total), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "ball_query_pairs")
+    return idx, (rowc, rowsrc, total)
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
     """group_points.cpp:25-36"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)
@@ -229,7 +252,8 @@ def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=Tru
 
 def three_nn_with_weights(unknown, known, sorted_known=None):
     """unknown (B,N,3), known (B,M,3) -> (idx (B,N,3) int32, weight (B,N,3)): three_nn + the FP module's
-    normalised inverse-distance weights, two launches (ws3d extension)"""
+    normalised inverse-distance weights in ONE launch (ws3d_three_nn_w: the weights are the search kernel's epilogue; bit-identical
+    to three_nn_wrapper + ws3d_three_nn_weights).  ws3d extension."""
     dev = _dev(unknown, known)
     _f32(unknown, "unknown"); _f32(known, "known")
     B, N, M = unknown.size(0), unknown.size(1), known.size(1)
@@ -238,9 +262,8 @@ def three_nn_with_weights(unknown, known, sorted_known=None):
     w = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
     lib = _lib.load()
     with torch.cuda.device(dev):
-        check(lib.ws3d_three_nn(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx),
-                                _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn")
-        check(lib.ws3d_three_nn_weights(B * N, _p(d2), _p(w), _stream()), "three_nn_weights")
+        check(lib.ws3d_three_nn_w(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx), _p(w),
+                                  _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn_w")
     return idx, w
 
 

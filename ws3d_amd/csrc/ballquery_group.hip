@@ -856,7 +856,9 @@ template <bool FUSED>
 __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
                                                                    const float *__restrict__ xyz, const char *__restrict__ ws,
                                                                    const float *__restrict__ new_xyz, const float *__restrict__ features,
-                                                                   int32_t *__restrict__ idx_out, float *__restrict__ out) {
+                                                                   int32_t *__restrict__ idx_out, float *__restrict__ out,
+                                                                   int32_t *__restrict__ rowc, int32_t *__restrict__ rowsrc,
+                                                                   int32_t *__restrict__ total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
     int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
@@ -1067,6 +1069,30 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
         if (lane == 0) cnt_s[c] = (m0 + c < m) ? cnt : 0;
     }
     __syncthreads();
+    if (!FUSED && rowc) {
+        // ---- the compact (centre, source) pairs of these 64 lists (gemm_pool.hip pair_compact_kernel, here without a launch of
+        // its own): a centre contributes its distinct hits -- one pair (centre, point 0) when it has none, like its all-zero list --
+        // and the workgroup reserves its stretch of compact rows with ONE atomic add on *total (zero on entry)
+        int *pfx = reinterpret_cast<int *>(hits_all);                  // 65 ints: the hit lists are dead
+        if (w == 0) {
+            const int k = (m0 + lane < m) ? max(cnt_s[lane], 1) : 0;
+            int v = k;
+            for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
+            int base_row = 0;
+            if (lane == 63) base_row = atomicAdd(total, v);
+            base_row = __builtin_amdgcn_readlane(base_row, 63);
+            pfx[lane] = base_row + v - k;
+            if (lane == 63) pfx[64] = base_row + v;
+        }
+        __syncthreads();
+        const int c = tid >> 2;
+        const int first = pfx[c], k = pfx[c + 1] - first;
+        const int32_t cm = (int32_t)((size_t)b * m + m0 + c);
+        for (int s2 = tid & 3; s2 < k; s2 += 4) {
+            rowc[first + s2] = cm;
+            rowsrc[first + s2] = (int32_t)rows[(size_t)c * rstride + s2];
+        }
+    }
     bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
 }
 
@@ -1078,7 +1104,8 @@ static size_t bq_smem(int nsample, size_t idx_bytes) {
 template <bool FUSED>
 static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int use_xyz,
                      const float *xyz, const float *new_xyz, const float *features, int32_t *idx,
-                     float *out, const void *sorted, hipStream_t st, const char *what, int nlc = 0) {
+                     float *out, const void *sorted, hipStream_t st, const char *what, int nlc = 0,
+                     int32_t *rowc = nullptr, int32_t *rowsrc = nullptr, int32_t *total = nullptr) {
     if (b < 0 || n <= 0 || m < 0 || nsample <= 0 || c < 0 || !xyz || !new_xyz) {
         set_error("%s: invalid argument (b=%d n=%d m=%d nsample=%d c=%d)", what, b, n, m, nsample, c);
         return WS3D_E_INVALID;
@@ -1106,9 +1133,10 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP + 4 * 16 * 64);
         if (coop_env && nsample <= 64 && smem_c <= 64 * 1024) {
             hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
-                               radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out);
+                               radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
             return check_launch(what);
         }
+        if (rowc) { set_error("%s: nsample %d is not covered by the kernel that emits the pairs", what, nsample); return WS3D_E_UNSUPPORTED; }
         const size_t smem_g = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)64 * (nsample + 1);
         if (smem_g <= 64 * 1024) {
             hipLaunchKernelGGL((ball_query_grid_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_g, st, b, n, m, c,
@@ -1116,6 +1144,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
             return check_launch(what);
         }
     }
+    if (rowc) { set_error("%s: the pairs come out of the fine-grid kernel only (sort_points_grid buffer, n <= %d)", what, SORT_MAX_N); return WS3D_E_UNSUPPORTED; }
     if (sorted && n <= SORT_MAX_N && b <= 65535) {
         const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
                               sizeof(uint16_t) * (size_t)5 * 64 * (nsample + 1);
@@ -1284,6 +1313,14 @@ extern "C" int ws3d_ball_query_fill(int b, int n, int m, float radius, int nsamp
                                     const float *xyz, int32_t *idx, const void *sorted, ws3d_stream_t stream) {
     return ws3d::bq_launch<false>(b, n, m, 0, radius, nsample, 4, xyz, new_xyz, nullptr, idx, nullptr, sorted,
                                   ws3d::as_stream(stream), "ws3d_ball_query_fill");
+}
+
+extern "C" int ws3d_ball_query_pairs(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx,
+                                     const void *sorted_grid, int32_t *rowc, int32_t *rowsrc, int32_t *total, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (!rowc || !rowsrc || !total || !sorted_grid) { set_error("ws3d_ball_query_pairs: NULL argument"); return WS3D_E_INVALID; }
+    return bq_launch<false>(b, n, m, 0, radius, nsample, 4, xyz, new_xyz, nullptr, idx, nullptr, sorted_grid, as_stream(stream),
+                            "ws3d_ball_query_pairs", 0, rowc, rowsrc, total);
 }
 
 extern "C" int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample,

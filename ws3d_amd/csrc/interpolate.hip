@@ -18,6 +18,15 @@
 namespace ws3d {
 
 constexpr int NN_TILE = 1024;
+
+// inverse-distance weights of the FP module (pointnet2_modules.py:139-142) from three_nn's SQUARED distances:
+// w_k = (1 / (sqrt(d2_k) + 1e-8)) / sum_j (1 / (sqrt(d2_j) + 1e-8)), every operation a separate correctly rounded fp32 op like
+// the torch composition sqrt / add / reciprocal / sum / div
+__device__ __forceinline__ void nn_weights3(const float d0, const float d1, const float d2, float *__restrict__ w) {
+    const float r0 = 1.0f / (sqrtf(d0) + 1e-8f), r1 = 1.0f / (sqrtf(d1) + 1e-8f), r2 = 1.0f / (sqrtf(d2) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    w[0] = r0 / norm; w[1] = r1 / norm; w[2] = r2 / norm;
+}
 #ifndef NN_UNROLL
 #define NN_UNROLL 4   // candidates per side and trip in the binned 3-NN walk
 #endif
@@ -26,7 +35,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
                                                        const float *__restrict__ unknown,
                                                        const float *__restrict__ known,
                                                        float *__restrict__ dist2,
-                                                       int32_t *__restrict__ idx) {
+                                                       int32_t *__restrict__ idx, float *__restrict__ weight) {
     __shared__ float4 tile[NN_TILE];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
         int32_t *oi = idx + ((size_t)b * n + pi) * 3;
         od[0] = b1; od[1] = b2; od[2] = b3;
         oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        if (weight) nn_weights3(b1, b2, b3, weight + ((size_t)b * n + pi) * 3);
     }
 }
 
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(1024) void bin_points_xz_kernel(int n, const float 
 template <bool LDS>
 __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, const float *__restrict__ unknown,
                                                               const char *__restrict__ ws,
-                                                              float *__restrict__ dist2, int32_t *__restrict__ idx) {
+                                                              float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight) {
     extern __shared__ __attribute__((aligned(16))) char smem_nn[];
     const int b = blockIdx.y;
     const int pi = blockIdx.x * 512 + threadIdx.x;
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
     int32_t *oi = idx + ((size_t)b * n + pi) * 3;
     od[0] = b1; od[1] = b2; od[2] = b3;
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    if (weight) nn_weights3(b1, b2, b3, weight + ((size_t)b * n + pi) * 3);
 }
 
 constexpr int TI_CCH = 16;
@@ -635,10 +646,7 @@ __global__ __launch_bounds__(256) void nn_weights_kernel(long rows, const float 
     const long r = (long)blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     const float *d = dist2 + r * 3;
-    const float r0 = 1.0f / (sqrtf(d[0]) + 1e-8f), r1 = 1.0f / (sqrtf(d[1]) + 1e-8f), r2 = 1.0f / (sqrtf(d[2]) + 1e-8f);
-    const float norm = (r0 + r1) + r2;
-    float *w = weight + r * 3;
-    w[0] = r0 / norm; w[1] = r1 / norm; w[2] = r2 / norm;
+    nn_weights3(d[0], d[1], d[2], weight + r * 3);
 }
 
 }  // namespace ws3d
@@ -796,8 +804,22 @@ extern "C" int ws3d_sort_points_xz(int b, int n, const float *xyz, void *sorted,
     return check_launch("ws3d_sort_points_xz");
 }
 
+static int three_nn_launch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
+                           const void *sorted_known, ws3d_stream_t stream);
+
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
                              float *dist2, int32_t *idx, const void *sorted_known, ws3d_stream_t stream) {
+    return three_nn_launch(b, n, m, unknown, known, dist2, idx, nullptr, sorted_known, stream);
+}
+
+extern "C" int ws3d_three_nn_w(int b, int n, int m, const float *unknown, const float *known,
+                               float *dist2, int32_t *idx, float *weight, const void *sorted_known, ws3d_stream_t stream) {
+    if (!weight) { ws3d::set_error("ws3d_three_nn_w: weight is NULL"); return WS3D_E_INVALID; }
+    return three_nn_launch(b, n, m, unknown, known, dist2, idx, weight, sorted_known, stream);
+}
+
+static int three_nn_launch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
+                           const void *sorted_known, ws3d_stream_t stream) {
     using namespace ws3d;
     if (b < 0 || n < 0 || m < 0 || !unknown || (!known && m > 0) || !dist2 || !idx) {
         set_error("ws3d_three_nn: invalid argument (b=%d n=%d m=%d)", b, n, m);
@@ -814,15 +836,15 @@ extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const fl
                 attr = true;
             }
             hipLaunchKernelGGL(three_nn_sorted_kernel<true>, dim3((n + 511) / 512, b), dim3(512), lds, as_stream(stream),
-                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight);
         }
         else
             hipLaunchKernelGGL(three_nn_sorted_kernel<false>, dim3((n + 511) / 512, b), dim3(512), 0, as_stream(stream),
-                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx);
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight);
         return check_launch("ws3d_three_nn(sorted)");
     }
     hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m,
-                       unknown, known, dist2, idx);
+                       unknown, known, dist2, idx, weight);
     return check_launch("ws3d_three_nn");
 }
 

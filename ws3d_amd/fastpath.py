@@ -169,6 +169,35 @@ def list_fill(net, pointcloud: torch.Tensor):
     return rows
 
 
+class _ZeroArena:
+    """ONE cleared buffer per forward pass for everything that must start at zero -- the pooled outputs the compact SharedMLPs
+    reduce into with an atomic max, the pair totals, the heads' tickets -- instead of a fill launch each (13 per batch).  Cleared on
+    the caller's stream before the first sampling kernel, so the side streams (which start behind it) see it cleared."""
+
+    def __init__(self, numel: int, device):
+        self.buf = torch.zeros(max(int(numel), 4), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, shape, dtype=torch.float32):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if self.off + n > self.buf.numel():                     # (not sized for this caller: a fill of its own)
+            return torch.zeros(shape, dtype=dtype, device=self.buf.device)
+        v = self.buf[self.off:self.off + n]
+        self.off += (n + 3) & ~3                                 # 16-byte aligned pieces
+        return (v if dtype == torch.float32 else v.view(dtype)).view(shape)
+
+
+def _arena_for(net, B: int, device, extra: int = 0) -> _ZeroArena:
+    n = extra + 64
+    if COMPACT_PAIRS:
+        for sa in net.SA_modules:
+            n += B * sa.npoint * sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) + 4
+            n += 4 * len(sa.groupers)
+    return _ZeroArena(n, device)
+
+
 class _PairList:
     """a (B, M, ns) neighbour list together with its compact distinct pairs (rowc, rowsrc, total)"""
     __slots__ = ("nbr", "pairs")
@@ -196,7 +225,17 @@ def _per_point_l1(sa, feats: torch.Tensor, nbrs):
     return torch.mm(feats.view(B * N, C), cache[1]), cache[2], cache[3]
 
 
-def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
+def _lists_and_pairs(radius, nsample, xyz, new_xyz, sorted_xyz, zeros=None):
+    """(lists (B, M, nsample), (rowc, rowsrc, total)): one launch when the fine-grid kernel covers the call, else two"""
+    total = zeros.take((1,), torch.int32) if zeros is not None else None
+    both = _C.ball_query_pairs(radius, nsample, xyz, new_xyz, sorted_xyz, total)
+    if both is not None:
+        return both
+    nbr = _C.ball_query_lists(radius, nsample, xyz, new_xyz, sorted_xyz)
+    return nbr, _C.compact_pairs(nbr)
+
+
+def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
     """per grouper: the (B, npoint, nsample) neighbour list when its first layer gathers its own rows, else None"""
     B = xyz.size(0)
     lists = []
@@ -204,11 +243,12 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int):
         if not _gather_gemm_ok(sa, grouper, _blocks(mlp), c_feat, B):
             lists.append(None)
             continue
-        nbr = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
         if COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256 and len(_blocks(mlp)) == 3:
-            # the distinct pairs of the lists (coordinate-only work: with the lists on the search stream)
-            nbr = _PairList(nbr, _C.compact_pairs(nbr))
-        lists.append(nbr)
+            # the lists and their distinct pairs (coordinate-only work: on the search stream)
+            nbr, pairs = _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
+            lists.append(_PairList(nbr, pairs))
+        else:
+            lists.append(_C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz))
     return lists
 
 
@@ -239,7 +279,7 @@ class _Geometry:
     first action of the next pass is to wait for the caller's stream, so their reuse is ordered; passes issued from different
     caller streams share the side streams and are therefore ordered on them as well)."""
 
-    def __init__(self, net, xyz: torch.Tensor, c0: int):
+    def __init__(self, net, xyz: torch.Tensor, c0: int, zeros=None):
         sas = list(net.SA_modules)
         main = torch.cuda.current_stream(xyz.device)
         s_fps, s_search = _side_streams(main)
@@ -271,7 +311,7 @@ class _Geometry:
                 s_search.wait_event(fps_done[i])                                     # level i + 1 exists
                 srt = pn2_ops.sort_points_x(self.xyz[i])
                 self.sorted.append(srt)
-                self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i]))
+                self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i], zeros))
                 ev = torch.cuda.Event()
                 ev.record(s_search)
                 self.sa_ready.append(ev)
@@ -292,7 +332,7 @@ class _Geometry:
             s.wait_event(done)
 
 
-def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0):
+def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None):
     """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O)"""
     B = xyz.size(0)
     c_feat = 0 if feats is None else feats.size(2)
@@ -302,13 +342,18 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             geo.main.wait_event(geo.sa_ready[level])
             sorted_xyz, nbrs = geo.sorted[level], geo.nbr[level]
         else:
-            sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat)
+            sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat, zeros)
     else:
         _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
         sorted_xyz = pn2_ops.sort_points_x(xyz)
-        nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat)
+        nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat, zeros)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
-    out = (torch.zeros if COMPACT_PAIRS else torch.empty)((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)   # zeros: the atomic max
+    if not COMPACT_PAIRS:
+        out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
+    elif zeros is not None:
+        out = zeros.take((B * sa.npoint, sum(widths)))                               # zeros: the atomic max
+    else:
+        out = torch.zeros((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     col = 0
     pp = None
     for si, (grouper, mlp, width, nbr) in enumerate(zip(sa.groupers, sa.mlps, widths, nbrs)):
@@ -392,13 +437,13 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             # first level: lists only (no grouped tensor), the three layers chained in registers -- over the distinct pairs of the
             # lists (atomic max into the zeroed `out`) or over all their rows (pool in registers, stored), decided on the device
             layers = [_row_weights(b) for b in blocks]
-            nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
             if not COMPACT_PAIRS:
+                nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
                 if _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col):
                     col += width
                     continue
             else:
-                pairs1 = _C.compact_pairs(nbr1)
+                nbr1, pairs1 = _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
                 limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
                 if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
                     if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
@@ -463,17 +508,19 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
 
 
 @torch.no_grad()
-def backbone_forward(net, pointcloud: torch.Tensor):
+def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
     """Pointnet2MSG.forward on channels-last tensors -> xyz (B,N,3), features (B,N,C)"""
     xyz = pointcloud[..., 0:3].contiguous()
     feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None
+    if zeros is None:
+        zeros = _arena_for(net, xyz.size(0), xyz.device)
     # (not while a hipGraph is being captured: a graph with such branches replays slower than one stream on this runtime --
     # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
     ahead = GEOMETRY_AHEAD and not torch.cuda.is_current_stream_capturing()
-    geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2)) if ahead else None
+    geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats = [xyz], [feats]
     for level, sa in enumerate(net.SA_modules):
-        nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level)
+        nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros)
         l_xyz.append(nx)
         l_feats.append(nf)
     for i in range(-1, -(len(net.FP_modules) + 1), -1):
@@ -491,10 +538,11 @@ def backbone_forward(net, pointcloud: torch.Tensor):
 @torch.no_grad()
 def rpn_forward(model, pts_input: torch.Tensor) -> dict:
     rpn = model.rpn
-    xyz, feats = backbone_forward(rpn.backbone_net, pts_input)            # (B,N,3), (B,N,128)
+    zeros = _arena_for(rpn.backbone_net, pts_input.size(0), pts_input.device, extra=8)      # ONE fill for the whole pass
+    xyz, feats = backbone_forward(rpn.backbone_net, pts_input, zeros)     # (B,N,3), (B,N,128)
     B, N, C = feats.shape
     rows = feats.view(B * N, C)
-    tickets = torch.zeros(2, dtype=torch.int32, device=rows.device) if FUSED_MLP2_ROWS else (None, None)   # one fill for both heads
+    tickets = zeros.take((2,), torch.int32) if FUSED_MLP2_ROWS else (None, None)
     rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
     rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
     return {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz,
