@@ -219,12 +219,21 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         bq_log.append((xyz.size(1), _sha(idx.cpu().numpy().astype(np.int32))))
         return idx
 
+    orig_bqp = compat.ball_query_pairs
+
+    def bqp_tap(radius, nsample, xyz, new_xyz, sorted_grid, total=None):          # ... or with their compact pairs in the same launch
+        both = orig_bqp(radius, nsample, xyz, new_xyz, sorted_grid, total)
+        if both is not None:
+            bq_log.append((xyz.size(1), _sha(both[0].cpu().numpy().astype(np.int32))))
+        return both
+
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
     pn2_ops.furthest_point_sample_gather_nested = nested_tap
     compat.query_and_group_nlc = nlc_tap
     if channels_last:
         compat.ball_query_wrapper = bq_tap
         compat.ball_query_lists = bql_tap
+        compat.ball_query_pairs = bqp_tap
     prev = stage1.CHANNELS_LAST_FASTPATH
     stage1.CHANNELS_LAST_FASTPATH = channels_last
     try:
@@ -236,6 +245,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
         compat.query_and_group_nlc = orig_nlc
         compat.ball_query_wrapper = orig_bq
         compat.ball_query_lists = orig_bql
+        compat.ball_query_pairs = orig_bqp
         stage1.CHANNELS_LAST_FASTPATH = prev
     assert ("backbone_features_nlc" in out) == channels_last
     assert len(fps_log) == 4 and len(bq_log) == 8

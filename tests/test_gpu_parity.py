@@ -1283,6 +1283,19 @@ def test_three_nn_weights_kernel_equals_torch_composition(ops):
     assert torch.equal(idx, ref_idx)
     np.testing.assert_allclose(host(w), host(ref_w), rtol=3e-7, atol=0)
     np.testing.assert_allclose(host(w.sum(dim=2)), 1.0, rtol=1e-6)
+    # the one-launch form (weights in the search kernel's epilogue) == search + ws3d_three_nn_weights, bit for bit, behind every
+    # flavour of the binned known set (none: brute force; x slabs; the 3-NN (x, z) grid; the ball query's fine grid)
+    from ws3d_amd import _lib
+    big = dev(synth.make_batch("hdl64", 2, 16384, 13)[:, :, :3].copy())
+    for unknown, known in ((dev(pc), dev(kn)), (big, big[:, :4096].contiguous())):
+        B, n, m = unknown.size(0), unknown.size(1), known.size(1)
+        for srt in (None, ops.c.sort_points_x(known, min_n=256, grid=False), ops.c.sort_points_xz(known), ops.c.sort_points_x(known, min_n=256, grid=True)):
+            d2 = torch.empty((B, n, 3), device="cuda"); i3 = torch.empty((B, n, 3), dtype=torch.int32, device="cuda")
+            ops.c.three_nn_wrapper(B, n, m, unknown, known, d2, i3, srt)
+            w2 = torch.empty((B, n, 3), device="cuda")
+            _lib.check(_lib.load().ws3d_three_nn_weights(B * n, d2.data_ptr(), w2.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            i1, w1 = ops.c.three_nn_with_weights(unknown, known, srt)
+            assert torch.equal(i1, i3) and torch.equal(w1, w2)
 
 
 # ------------------------------------------------------------------------------- SA pool (training path)

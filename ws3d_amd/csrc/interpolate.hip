@@ -266,6 +266,7 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
         int32_t *oig = idx + ((size_t)b * n + pi) * 3;
         odg[0] = b1; odg[1] = b2; odg[2] = b3;
         oig[0] = i1; oig[1] = i2; oig[2] = i3;
+        if (weight) nn_weights3(b1, b2, b3, weight + ((size_t)b * n + pi) * 3);
         return;
     }
     if (hdr.pad < 0) {
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
         int32_t *oif = idx + ((size_t)b * n + pi) * 3;
         odf[0] = b1; odf[1] = b2; odf[2] = b3;
         oif[0] = i1; oif[1] = i2; oif[2] = i3;
+        if (weight) nn_weights3(b1, b2, b3, weight + ((size_t)b * n + pi) * 3);
         return;
     }
     const int c0 = x_cell(ux, hdr.xmin, hdr.inv_w);
