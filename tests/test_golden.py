@@ -347,3 +347,46 @@ def test_c5_gpu_roipool_and_nms_match_the_reference():
     assert _sha(got) == case["pooled_sha256"]
     keep = iou3d_ops.nms_gpu(dev(synth.boxes3d_to_bev(boxes[0])), dev(scores), case["nms_thresh"])
     np.testing.assert_array_equal(keep.cpu().numpy(), gold["nms_keep"])
+
+
+# ------------------------------------------------------------------------------- furthest point sampling vs the reference's getGreedyPerm
+def _greedyperm_cases():
+    """tests/golden/fps_greedyperm.npz: permutations of the reference's own lib/utils/greedFurthestPoint.getGreedyPerm (:11-37), run
+    on float64 distance matrices by tests/golden/make_golden_greedyperm.py -- the one reference-held CPU restatement of K1"""
+    g = np.load(os.path.join(G, "fps_greedyperm.npz"))
+    for key in g["cases"]:
+        kind, n, seed = str(key).rsplit("_", 2)
+        xyz = np.ascontiguousarray(synth.cloud(kind, 16384, int(seed))[:int(n), :3])
+        yield str(key), xyz, g[str(key) + "_perm"], g[str(key) + "_margin"]
+
+
+def _comparable_prefix(margin, tol=1e-6):
+    """steps [0, k): every pick before k won by a relative gap above tol -- float32 squared distances (sampling_gpu.cu:133) and
+    float64 Euclidean ones (getGreedyPerm) must order them alike; from the first closer call on the sequences may part for good"""
+    close = np.nonzero(margin[1:] < tol)[0]
+    return int(close[0]) + 1 if close.size else len(margin)
+
+
+def test_oracle_fps_follows_the_references_getGreedyPerm(oracle):
+    report = []
+    for key, xyz, perm, margin in _greedyperm_cases():
+        n = xyz.shape[0]
+        got = oracle.furthest_point_sample(xyz[None], n)[0]
+        k = _comparable_prefix(margin)
+        np.testing.assert_array_equal(got[:k], perm[:k], err_msg=key)
+        same = np.nonzero(got != perm)[0]
+        report.append((key, k, int(same[0]) if same.size else n))
+    # (case, comparable steps, matched steps): every case matches at least its comparable prefix; most match to the end
+    assert all(m >= k for _, k, m in report) and sum(m == int(key.split("_")[1]) for key, _, m in report) >= 6, report
+
+
+@pytest.mark.gpu
+def test_gpu_fps_follows_the_references_getGreedyPerm():
+    import torch
+    from ws3d_amd import pn2_ops
+    for key, xyz, perm, margin in _greedyperm_cases():
+        n = xyz.shape[0]
+        k = _comparable_prefix(margin)
+        for m in (n, max(n // 4, 1)):
+            got = pn2_ops.furthest_point_sample(torch.from_numpy(xyz[None]).cuda(), m)[0].cpu().numpy()
+            np.testing.assert_array_equal(got[:min(k, m)], perm[:min(k, m)], err_msg="%s m=%d" % (key, m))

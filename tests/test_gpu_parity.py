@@ -38,6 +38,7 @@ FPS_CASES = [
     (2, 4096, 1024, "lidar", 0.02), (1, 5000, 64, "uniform", 0.0), (1, 8192, 128, "lidar", 0.0),
     (2, 16384, 4096, "lidar", 0.02), (1, 16384, 4096, "uniform", 0.0), (1, 12345, 777, "lidar", 0.3),
     (1, 20000, 64, "lidar", 0.0), (1, 65536, 48, "uniform", 0.0),
+    (2, 16384, 4096, "hdl64", 0.0), (1, 4096, 1024, "hdl64", 0.0),      # KITTI's density (ray-cast scan): near-range rings, long empty stretches
 ]
 
 

@@ -72,7 +72,8 @@ def test_fps_batch_and_temp(oracle):
 
 def test_fps_loose_float64_crosscheck(oracle):
     """In the spirit of the reference's own getGreedyPerm (lib/utils/greedFurthestPoint.py:26-37):
-    float64 argmax-first FPS agrees when there are no near-ties."""
+    float64 argmax-first FPS agrees when there are no near-ties.  (The reference function ITSELF is run by
+    tests/golden/make_golden_greedyperm.py; tests/test_golden.py compares oracle and HIP kernel with its permutations.)"""
     xyz = synth.uniform_cloud(256, 123)[:, :3]
     got = oracle.furthest_point_sample(xyz[None], 32)[0]
     x = xyz.astype(np.float64)

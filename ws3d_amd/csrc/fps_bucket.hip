@@ -1,11 +1,13 @@
 // fps_bucket.hip -- pruned furthest point sampling for 4096 < n <= 16384 (gfx950).
 //
-// STATUS: experimental, selected only with WS3D_FPS_BUCKET=1.  Bit-exact (tests/
-// test_gpu_parity.py::test_fps_bucket_kernel_subprocess) but NOT faster than fps.hip on MI355X
-// (1.18 vs 1.17 us/step at n=16384): pruning removes most of the distance arithmetic, yet the
-// step is bounded by the cross-lane chain (DPP reductions, readlanes, VGPR-indexed moves, LDS
-// exchange), which pruning does not shorten, and the re-scan of the 32 cached per-lane values
-// costs half of the dense sweep.  Kept as the starting point for round 2.
+// STATUS: the DEFAULT kernel of furthest_point_sample for clouds of 8192 < n <= 16384 points whenever a scene gets a CU of its
+// own (batch <= 256; fps.hip fps_launch selects it -- WS3D_FPS_BUCKET=0 / 1 force the choice for A/B runs): level 1 of every
+// Stage-1 forward (16384 -> 4096, 8 scenes = 8 workgroups).  0.74 us per sampling step against 1.5 us of the dense sweep with one
+// scene per CU; batches above 256 scenes take the dense two-scenes-per-CU kernel of fps_v3.hip instead, which is VALU-bound and
+// fills the chip.  Bit-exact incl. the reference's tie order: tests/test_gpu_parity.py::test_fps_bit_exact (default dispatch, with
+// duplicated points), ::test_fps_ties, ::test_fps_bucket_kernel_subprocess (forced, every size class) and scripts/fuzz_parity.py.
+// The step is bound by its cross-lane chain (box test, bucket update, pick, record exchange: DESIGN.md 5.1 / 10.2), not by
+// arithmetic: pruning removes ~95 % of the distance evaluations of a step.
 //
 // Same contract as fps.hip (bit-exact indices incl. the reference's tie order), different
 // work per step.  After j samples the running min-distance of every point is <= G_j (the
