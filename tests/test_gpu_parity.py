@@ -1490,6 +1490,60 @@ def test_stage1_pipeline_equals_the_plain_step(ops):
         pipe.result(99)
 
 
+def test_every_launch_mode_of_the_step_gives_the_same_bits(ops):
+    """eager on one stream, eager with the coordinate-only work on side streams, a single-stream hipGraph and a hipGraph with the
+    side streams forked and joined INSIDE the capture produce bit-identical outputs -- also on their second and third replay and
+    with another stream hammering the chip (a missing dependency would show as a race).  Round 2 saw the fork/join graph return
+    other proposals: the compact / dense choice was then latched on the host per process (from whatever batch came first) and
+    SA4's dense form runs a library GEMM with another summation order; the choice is now taken on the device (launch gates) and the
+    same in every mode.  scripts/graph_fork_debug.py is the long form of this test (every SA / FP output, batch 8)."""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.seeded import seeded_state_dict
+    cfg = stage1.RPNConfig(rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=50)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg).eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    model = model.cuda()
+    pts = dev(np.stack([synth.cloud("hdl64", 16384, 5000 + j) for j in range(2)]))
+
+    @torch.no_grad()
+    def body():
+        out = model.rpn_forward({"pts_input": pts})
+        boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
+        return [out["rpn_cls"], out["rpn_reg"], out["backbone_features_nlc"], boxes, scores, count]
+
+    saved = (fastpath.GEOMETRY_AHEAD, fastpath.GEOMETRY_IN_CAPTURE)
+    try:
+        fastpath.GEOMETRY_AHEAD = False
+        body()
+        ref = [t.clone() for t in body()]
+        fastpath.GEOMETRY_AHEAD = True
+        for _ in range(3):
+            assert all(torch.equal(a, b) for a, b in zip(ref, body())), "eager side streams"
+        other = torch.cuda.Stream()
+        x = torch.randn(2048, 2048, device="cuda")
+        for fork in (False, True):
+            fastpath.GEOMETRY_IN_CAPTURE = fork
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                body()
+            s.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                res = body()
+            for load in (False, False, True, True):
+                if load:
+                    with torch.cuda.stream(other):
+                        for _ in range(10):
+                            x = x @ x * 1e-3
+                with torch.cuda.stream(s):
+                    g.replay()
+                torch.cuda.synchronize()
+                assert all(torch.equal(a, b) for a, b in zip(ref, res)), "graph, fork/join inside" if fork else "graph, single stream"
+    finally:
+        fastpath.GEOMETRY_AHEAD, fastpath.GEOMETRY_IN_CAPTURE = saved
+
+
 def test_roipool3d_fill_writes_every_element(ops, oracle):
     """ws3d_roipool3d_fill: outputs poisoned with NaN / garbage beforehand come out equal to the oracle,
     empty boxes included (zeros), for row widths that are and are not multiples of 16 bytes"""

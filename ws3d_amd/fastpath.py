@@ -34,6 +34,7 @@ FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + p
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+GEOMETRY_IN_CAPTURE = os.environ.get("WS3D_GEOMETRY_IN_CAPTURE", "0") != "0"  # ... also while a hipGraph is captured (fork / join inside the graph)
 # ws3d_gather_gemm3_pool: grouping + 3 layers + pool in one kernel.  OFF by default: at SA2 it is faster alone (62 vs 72 and 146 vs
 # 156 us per batch of 8) and 10-30 us off the latency, but the 20-deep pipeline loses 1.5 % with it (5,029 / 4,961 vs 5,076 / 5,092
 # scenes/s, ABAB on one box: 50 KB of LDS per workgroup leave less room beside the other streams' kernels); SA3 is slower either way
@@ -326,6 +327,8 @@ class _Geometry:
     def release(self):
         """every consumer of the side streams' tensors has been issued on the caller's stream: later side-stream work (of
         any caller) is ordered behind them, so the allocator may hand the blocks out again"""
+        if torch.cuda.is_current_stream_capturing():
+            return          # inside a capture the side streams are joined already (every product was waited for): nothing may follow the join
         done = torch.cuda.Event()
         done.record(self.main)
         for s in self.side:
@@ -516,7 +519,7 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
         zeros = _arena_for(net, xyz.size(0), xyz.device)
     # (not while a hipGraph is being captured: a graph with such branches replays slower than one stream on this runtime --
     # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
-    ahead = GEOMETRY_AHEAD and not torch.cuda.is_current_stream_capturing()
+    ahead = GEOMETRY_AHEAD and (GEOMETRY_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats = [xyz], [feats]
     for level, sa in enumerate(net.SA_modules):
