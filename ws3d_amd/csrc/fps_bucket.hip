@@ -30,6 +30,8 @@
 // more than once; if the global maximum is ambiguous the workgroup takes a (rare) resolution
 // round that enumerates all points holding the maximum and selects the smallest reference
 // rank  bitrev(k mod bs) * S + k / bs  -- the winner of the reference's reduction tree.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ws3d {
@@ -420,11 +422,370 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 #endif
 }
 
-size_t fps_bucket_smem() {
-    return sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * FB_NW * FB_SL * 6 +
-           sizeof(float4) * 2 * FB_NW + sizeof(unsigned) * (3 * FB_NW + 4) + sizeof(float4) + sizeof(float) * 4 * FB_NW +
-           sizeof(int) * FB_NW + 64;
+// ================================================================================================================================
+// fps_rounds_kernel (round 3): SEVERAL samples per record exchange, each CERTIFIED before it is applied.
+//
+// The step of the kernel above is a chain -- box test, bucket update, pick, record exchange -- of ~1,800 clk of which the arithmetic
+// is a small part; what it buys is ONE sample.  But late in the sweep consecutive samples are far apart (that is what furthest
+// point sampling does) and touch disjoint buckets: the records of one exchange already name the next few samples.  With every
+// wave publishing, next to its best point (value v_w), an upper bound s_w on ALL its other points, the candidate c of wave w is
+// the (k+1)-th sample of this round, with certainty, iff
+//   (a) v_c is the strict maximum of the v_w of the waves not yet used (an equal value, or a wave that flags a tie: stop);
+//   (b) v_c > s_a for every wave a already used this round (their remaining points cannot beat it, whatever the updates did);
+//   (c) fl|c - q_i|^2 >= v_c for every sample q_i accepted before it this round (the update with q_i leaves c's running minimum
+//       untouched: min(d, t) = t) -- the SAME fp32 expression, operands in the same order, as the update itself.
+// Running distances only fall, so under (a)-(c) c is the unique maximum of the state the sequential algorithm would have reached:
+// the accepted samples are exactly its next picks, in order (scripts/sim_fps_rounds.py: 3.1-3.3 samples per round at up to 4 per
+// round on the 16384 -> 4096 level, the sequence identical to the plain sweep).  Then ALL accepted samples are applied in one pass:
+// the box test of a bucket takes the minimum over the samples' bounds, an affected bucket one fused update min(t, d_1, .., d_K)
+// and ONE wave reduction, the wave one re-pick.  The certification is sequential and short; ONE wave does it (16 waves doing it
+// side by side would share four SIMDs) and hands the samples out through LDS: two LDS-only barriers per round.
+// Ties at the head of a round take the resolution round of the kernel above (one sample).  Bit-exact incl. the tie order.
+#ifndef FR_KMAX
+#define FR_KMAX 4
+#endif
+constexpr size_t FB_SMEM_BYTES = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * FB_NW * FB_SL * 6 +
+                                 sizeof(float4) * 2 * FB_NW + sizeof(unsigned) * (3 * FB_NW + 4) + sizeof(float4) + sizeof(float) * 4 * FB_NW +
+                                 sizeof(int) * FB_NW + 64;                   // the LDS layout both kernels share
+constexpr size_t FR_SAMPLES_OFF = (FB_SMEM_BYTES + 15) & ~(size_t)15;
+constexpr size_t FR_SAMPLES_MAX_M = 6144;      // m above this: the samples do not fit beside the sort tables (one sample per exchange then)
+static size_t fps_rounds_smem(int m) { return FR_SAMPLES_OFF + sizeof(float4) * (size_t)(m + FR_KMAX); }
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
+                                                           float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
+    static_assert(NW == 16 || NW == 8, "16 waves x 16 buckets or 8 waves x 32 buckets");
+    constexpr int SL = 256 / NW, NT = NW * 64;                     // buckets per wave, threads
+    constexpr unsigned SLMASK = SL == 32 ? 0xFFFFFFFFu : (1u << (SL & 31)) - 1u, WMASK = (1u << NW) - 1u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
+    int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
+    float *bbox = reinterpret_cast<float *>(hist + FB_CELLS);        // 256 * 6
+    float4 *rec = reinterpret_cast<float4 *>(bbox + 256 * 6);        // 16 records {v, x, y, z}, then 16 {s, pos, tie, -} (NW used)
+    float4 *aux = rec + 16;
+    unsigned *tiem = reinterpret_cast<unsigned *>(rec + 2 * 16);    // (layout of the kernel above: the launch shares its LDS size)
+    int *posr = reinterpret_cast<int *>(tiem + 4);                     // [0] = number of samples of this round (-1: tie at its head)
+    unsigned *tiekey = reinterpret_cast<unsigned *>(posr + 2 * 16);  // 16
+    float4 *tiept = reinterpret_cast<float4 *>(tiekey + 16);      // 1
+    float *red = reinterpret_cast<float *>(tiept + 1);               // 4 * NW: stage A; afterwards the round's samples (FR_KMAX float4)
+    int *wsum = reinterpret_cast<int *>(red + 4 * 16);            // 16
+    // every sample {x, y, z, sorted position}, in order: the certifying wave appends a round's samples, all waves read them from
+    // here, and idx / new_xyz leave the chip ONCE, after the loop (a global store per round kept its wave ~1,000 clk behind the others)
+    float4 *samples = reinterpret_cast<float4 *>(smem + FR_SAMPLES_OFF);   // m + FR_KMAX
+
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    if (temp) temp += (size_t)b * n;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // ---------------- stage A: Z-order counting sort of the scene into `order` (as above)
+    float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
+    for (int k = tid; k < n; k += NT) {
+        const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
+        if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
+        if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
+    }
+    xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
+    if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
+    for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
+    for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
+        zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
+    }
+    const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
+    const float ix = (xmn < xmx) ? 32.0f / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? 32.0f / (zmx - zmn) : 0.f;
+    for (int k = tid; k < n; k += NT)
+        atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FB_CELLS / NT;
+        int a[CPT], v = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
+        const int mine = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        int excl = off + v - mine;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += NT) {
+        const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+        order[pos] = (uint16_t)k;
+    }
+    __syncthreads();
+
+    // ---------------- registers: slot s of this lane = sorted position ((s*NW + w)*64 + lane)
+    float px[SL], py[SL], pz[SL], t[SL];
+    float bmax = -2.0f;                 // lane s < SL: the largest running distance of bucket s of this wave (-1: no point)
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int pos = ((s * NW + w) << 6) + lane;
+        const int k = (int)order[pos];
+        const bool valid = k != 0xFFFF;
+        px[s] = valid ? xyz[(size_t)k * 3 + 0] : 0.f;
+        py[s] = valid ? xyz[(size_t)k * 3 + 1] : 0.f;
+        pz[s] = valid ? xyz[(size_t)k * 3 + 2] : 0.f;
+        t[s] = valid ? (temp ? temp[k] : 1e10f) : -1.0f;
+        const float lx = wave_min(valid ? px[s] : INFINITY), hx = wave_max(valid ? px[s] : -INFINITY);
+        const float ly = wave_min(valid ? py[s] : INFINITY), hy = wave_max(valid ? py[s] : -INFINITY);
+        const float lz = wave_min(valid ? pz[s] : INFINITY), hz = wave_max(valid ? pz[s] : -INFINITY);
+        if (lane == 0) {
+            float *bb = bbox + (w * SL + s) * 6;
+            bb[0] = lx; bb[1] = hx; bb[2] = ly; bb[3] = hy; bb[4] = lz; bb[5] = hz;
+        }
+        const float bm0 = wave_max(t[s]);
+        bmax = lane == s ? bm0 : bmax;
+    }
+    __syncthreads();
+    float blx = INFINITY, bhx = -INFINITY, bly = INFINITY, bhy = -INFINITY, blz = INFINITY, bhz = -INFINITY;
+    if (lane < SL) {
+        const float *bb = bbox + (w * SL + lane) * 6;
+        blx = bb[0]; bhx = bb[1]; bly = bb[2]; bhy = bb[3]; blz = bb[4]; bhz = bb[5];
+    }
+    FbT32 tt;
+    { tt.v0 = t[0 % SL]; tt.v1 = t[1 % SL]; tt.v2 = t[2 % SL]; tt.v3 = t[3 % SL]; tt.v4 = t[4 % SL]; tt.v5 = t[5 % SL]; tt.v6 = t[6 % SL]; tt.v7 = t[7 % SL]; tt.v8 = t[8 % SL]; tt.v9 = t[9 % SL]; tt.v10 = t[10 % SL]; tt.v11 = t[11 % SL]; tt.v12 = t[12 % SL]; tt.v13 = t[13 % SL]; tt.v14 = t[14 % SL]; tt.v15 = t[15 % SL];
+      tt.v16 = SL > 16 ? t[16 % SL] : -1.f; tt.v17 = SL > 16 ? t[17 % SL] : -1.f; tt.v18 = SL > 16 ? t[18 % SL] : -1.f; tt.v19 = SL > 16 ? t[19 % SL] : -1.f; tt.v20 = SL > 16 ? t[20 % SL] : -1.f; tt.v21 = SL > 16 ? t[21 % SL] : -1.f; tt.v22 = SL > 16 ? t[22 % SL] : -1.f; tt.v23 = SL > 16 ? t[23 % SL] : -1.f;
+      tt.v24 = SL > 16 ? t[24 % SL] : -1.f; tt.v25 = SL > 16 ? t[25 % SL] : -1.f; tt.v26 = SL > 16 ? t[26 % SL] : -1.f; tt.v27 = SL > 16 ? t[27 % SL] : -1.f; tt.v28 = SL > 16 ? t[28 % SL] : -1.f; tt.v29 = SL > 16 ? t[29 % SL] : -1.f; tt.v30 = SL > 16 ? t[30 % SL] : -1.f; tt.v31 = SL > 16 ? t[31 % SL] : -1.f; }
+    if (tid < 4) tiem[tid] = 0u;
+    __syncthreads();
+
+    // the samples about to be applied (wave-uniform): the sweep starts from point 0 (sampling_gpu.cu:119)
+    int K = 1;
+    float q0x = xyz[0], q0y = xyz[1], q0z = xyz[2], q1x = 0.f, q1y = 0.f, q1z = 0.f, q2x = 0.f, q2y = 0.f, q2z = 0.f, q3x = 0.f, q3y = 0.f, q3z = 0.f;
+    float wv = -1.0f, wx = 0.f, wy = 0.f, wz = 0.f, ws2 = -1.0f;       // this wave's candidate and the bound on everything else it holds
+    int wpos = 0, wtie = 0, wslot = 0;
+    bool have = false;
+    int j = 1;                          // samples selected so far; the last K of them are not applied yet
+#ifdef FR_PROF      // scripts/ubench/fps_rounds_prof.sh: per-wave clocks per segment and the samples per round, returned through `temp`
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long pt = clock64();
+#define FRP(k) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
+#else
+#define FRP(k)
+#endif
+    for (;;) {
+#ifdef FR_PROF
+        if (j >= m) break;
+#endif
+        if (j >= m && !temp) break;                                    // nothing reads the running distances any more
+        // `temp` leaves the kernel as the reference leaves it: every sample applied but the last one picked (sampling_gpu.cu:118-208)
+        const int Ka = j >= m ? K - 1 : K;
+        // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
+        // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
+        unsigned need;
+#define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
+        {
+            float L = FR_BOX(q0x, q0y, q0z);                            // (independent chains: the samples' bounds overlap in the pipeline)
+            if (Ka > 1) L = min_f32(FR_BOX(q1x, q1y, q1z), L);
+            if (Ka > 2) L = min_f32(FR_BOX(q2x, q2y, q2z), L);
+            if (Ka > 3) L = min_f32(FR_BOX(q3x, q3y, q3z), L);
+            need = Ka > 0 ? (unsigned)__ballot(L < bmax) & SLMASK : 0u;
+        }
+#undef FR_BOX
+        FRP(0)
+        bool repick = !have;
+        if (need) {
+#define FR_UPD(S)                                                                                      \
+    if (need & (1u << (S))) {                                                                          \
+        float d = sqdist3(px[S] - q0x, py[S] - q0y, pz[S] - q0z);                                      \
+        if (Ka > 1) d = min_f32(sqdist3(px[S] - q1x, py[S] - q1y, pz[S] - q1z), d);                    \
+        if (Ka > 2) d = min_f32(sqdist3(px[S] - q2x, py[S] - q2y, pz[S] - q2z), d);                    \
+        if (Ka > 3) d = min_f32(sqdist3(px[S] - q3x, py[S] - q3y, pz[S] - q3z), d);                    \
+        fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
+        const float bm = wave_max(fb_t<S>(tt));                                                        \
+        bmax = lane == (S) ? bm : bmax;                                                                \
+    }
+#define FR_UPD8(G) if (need & (0xFFu << (G))) { FR_UPD(G) FR_UPD(G + 1) FR_UPD(G + 2) FR_UPD(G + 3) FR_UPD(G + 4) FR_UPD(G + 5) FR_UPD(G + 6) FR_UPD(G + 7) }
+            FR_UPD8(0) FR_UPD8(8)
+            if constexpr (SL == 32) { FR_UPD8(16 % SL) FR_UPD8(24 % SL) }
+#undef FR_UPD8
+#undef FR_UPD
+            repick = repick || ((need >> wslot) & 1u);
+        }
+        FRP(1)
+        if (j >= m) break;
+        if (repick) {
+            // the wave's candidate (the bucket holding the largest cached maximum, then the lane inside it) and the bound on the
+            // rest of the wave: the largest maximum of the OTHER buckets, the largest OTHER value of the candidate's bucket
+            const float wmax = SL <= 16 ? readlane_f(row16_max(bmax), 0) : wave_max(bmax);   // the cached maxima live in lanes 0 .. SL-1
+            const unsigned eqb = (unsigned)__ballot(bmax == wmax) & SLMASK;
+            wslot = (int)__builtin_ctz(eqb);
+            const float b2m = lane == wslot ? -2.0f : bmax;
+            const float b2 = SL <= 16 ? readlane_f(row16_max(b2m), 0) : wave_max(b2m);
+            uint64_t eql = 0;
+            float t2 = -2.0f;
+#define FR_PICK_BODY(S)                                                                                \
+    {                                                                                                  \
+        eql = __ballot(fb_t<S>(tt) == wmax);                                                           \
+        const int wl = (int)__builtin_ctzll(eql);                                                      \
+        wx = readlane_f(px[S], wl); wy = readlane_f(py[S], wl); wz = readlane_f(pz[S], wl);            \
+        wpos = ((S * NW + w) << 6) + wl;                                                               \
+        t2 = wave_max(lane == wl ? -2.0f : fb_t<S>(tt));                                               \
+    }
+#define FR_PICK(S) case S: FR_PICK_BODY(S) break;
+#define FR_PICK2(S) case S: if constexpr (SL == 32) { FR_PICK_BODY(S % SL) } break;
+            switch (wslot) {
+                FR_PICK(0) FR_PICK(1) FR_PICK(2) FR_PICK(3) FR_PICK(4) FR_PICK(5) FR_PICK(6) FR_PICK(7)
+                FR_PICK(8) FR_PICK(9) FR_PICK(10) FR_PICK(11) FR_PICK(12) FR_PICK(13) FR_PICK(14) FR_PICK(15)
+                FR_PICK2(16) FR_PICK2(17) FR_PICK2(18) FR_PICK2(19) FR_PICK2(20) FR_PICK2(21) FR_PICK2(22) FR_PICK2(23)
+                FR_PICK2(24) FR_PICK2(25) FR_PICK2(26) FR_PICK2(27) FR_PICK2(28) FR_PICK2(29) FR_PICK2(30) FR_PICK2(31)
+            }
+#undef FR_PICK2
+#undef FR_PICK
+            wtie = (__builtin_popcount(eqb) > 1 || __builtin_popcountll(eql) > 1) ? 1 : 0;
+            wv = wmax;
+            ws2 = max_f32(b2, t2);
+            have = true;
+        }
+        FRP(2)
+        // ---- publish, then ONE wave certifies the samples of the round
+        if (lane == 0) {
+            rec[w] = make_float4(wv, wx, wy, wz);
+            aux[w] = make_float4(ws2, __int_as_float(wpos), __int_as_float(wtie), 0.f);
+        }
+        FRP(3)
+        lds_barrier();
+        FRP(4)
+        if (w == 0) {
+            float4 *selq = samples + j;
+            const float4 r = rec[lane & (NW - 1)], a = aux[lane & (NW - 1)];
+            // every value compared below is >= 0 or a negative "nothing" mark (-1 no point, -2 / -3 unused): non-negative floats
+            // order like their bit patterns, so the uniform comparisons run on the scalar unit
+            float vcur = lane < NW ? r.x : -3.0f;     // candidates not used yet
+            const unsigned tiemask = (unsigned)__ballot(__float_as_int(a.z) != 0 && lane < NW);
+            int bound = __float_as_int(-3.0f);           // bits of the largest s_w of the waves used so far
+            float dmin = INFINITY;                        // lane l: the smallest distance of wave l's candidate to the samples accepted so far
+            int nk = 0;
+            const int cap = min(FR_KMAX, m - j);
+#pragma unroll
+            for (int k = 0; k < FR_KMAX; ++k) {
+                if (k >= cap) break;
+                const int vmb = __float_as_int(readlane_f(row16_max(vcur), 0));
+                if (vmb < 0) break;                                                   // no candidate left
+                const unsigned eq = (unsigned)__ballot(__float_as_int(vcur) == vmb) & WMASK;
+                const int sel = (int)__builtin_ctz(eq);
+                const bool tie = (eq & (eq - 1u)) != 0u || ((tiemask >> sel) & 1u) != 0u;
+                if (k == 0) {
+                    if (tie) { nk = -1; if (lane == 0) reinterpret_cast<int *>(selq)[0] = vmb; break; }
+                } else {
+                    // (b) beats everything the used waves still hold, (c) untouched by the samples accepted before it
+                    if (tie || !(vmb > bound) || !(__float_as_int(readlane_f(dmin, sel)) >= vmb)) break;
+                }
+                const float cx = readlane_f(r.y, sel), cy = readlane_f(r.z, sel), cz = readlane_f(r.w, sel);
+                if (k + 1 < FR_KMAX) {
+                    dmin = min_f32(sqdist3(r.y - cx, r.z - cy, r.w - cz), dmin);       // every candidate against this sample, lane-parallel
+                    vcur = lane == sel ? -3.0f : vcur;
+                }
+                bound = max(bound, __float_as_int(readlane_f(a.x, sel)));
+                {   // lanes 0-3 store one component each (a 16-byte store wants four consecutive registers: spills in this loop)
+                    const float pb = readlane_f(a.y, sel);
+                    const float comp = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? cz : pb));
+                    if (lane < 4) reinterpret_cast<float *>(selq + k)[lane] = comp;
+                }
+                nk = k + 1;
+            }
+            if (lane == 0) posr[0] = nk;
+        }
+        FRP(5)
+        lds_barrier();
+        FRP(6)
+        K = posr[0];
+        {   // (all five reads in flight before the first use)
+            const float4 s0 = samples[j], s1 = samples[j + 1], s2 = samples[j + 2], s3 = samples[j + 3];
+            q0x = s0.x; q0y = s0.y; q0z = s0.z;
+            q1x = s1.x; q1y = s1.y; q1z = s1.z;
+            q2x = s2.x; q2y = s2.y; q2z = s2.z;
+            q3x = s3.x; q3y = s3.y; q3z = s3.z;
+        }
+        if (K <= 0) {
+            // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
+            const float gmax = q0x;                              // (the certifying wave left the tied maximum in the first slot)
+            unsigned key = 0xFFFFFFFFu;
+            const float ta[32] = FB_T32_LIST(tt);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                if (ta[s] == gmax) {
+                    const int pos = ((s * NW + w) << 6) + lane;
+                    const int k = (int)order[pos];
+                    const unsigned rank = (unsigned)(fb_bitrev(k & (bs - 1), log2bs) * S + (k >> log2bs));
+                    key = min(key, (rank << 14) | (unsigned)pos);
+                }
+            }
+            const unsigned wkey = wave_min_u32(key);
+            if (lane == 0) tiekey[w] = wkey;
+            lds_barrier();
+            unsigned gk = tiekey[lane & (NW - 1)];
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR1, 0xF, 0xF, false));
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR2, 0xF, 0xF, false));
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
+            if constexpr (NW == 16) gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_MIRROR, 0xF, 0xF, false));
+            const int ipos = (int)(__builtin_amdgcn_readfirstlane(gk) & 0x3FFFu);
+            const int ob = ipos >> 6, ol = ipos & 63;           // owning bucket / lane
+            if ((ob & (NW - 1)) == w) {
+                const int os = ob / NW;                       // wave-uniform slot
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+#define FR_OWN(S) case S: ox = readlane_f(px[S], ol); oy = readlane_f(py[S], ol); oz = readlane_f(pz[S], ol); break;
+#define FR_OWN2(S) case S: if constexpr (SL == 32) { ox = readlane_f(px[S % SL], ol); oy = readlane_f(py[S % SL], ol); oz = readlane_f(pz[S % SL], ol); } break;
+                switch (os) {
+                    FR_OWN(0) FR_OWN(1) FR_OWN(2) FR_OWN(3) FR_OWN(4) FR_OWN(5) FR_OWN(6) FR_OWN(7)
+                    FR_OWN(8) FR_OWN(9) FR_OWN(10) FR_OWN(11) FR_OWN(12) FR_OWN(13) FR_OWN(14) FR_OWN(15)
+                    FR_OWN2(16) FR_OWN2(17) FR_OWN2(18) FR_OWN2(19) FR_OWN2(20) FR_OWN2(21) FR_OWN2(22) FR_OWN2(23)
+                    FR_OWN2(24) FR_OWN2(25) FR_OWN2(26) FR_OWN2(27) FR_OWN2(28) FR_OWN2(29) FR_OWN2(30) FR_OWN2(31)
+                }
+#undef FR_OWN2
+#undef FR_OWN
+                if (lane == 0) *tiept = make_float4(ox, oy, oz, 0.f);
+            }
+            lds_barrier();
+            const float4 c = *tiept;
+            q0x = c.x; q0y = c.y; q0z = c.z;
+            K = 1;
+            if (tid == NT - 64) samples[j] = make_float4(q0x, q0y, q0z, __int_as_float(ipos));
+        }
+        j += K;
+#ifdef FR_PROF
+        kh[K & 7] += 1;
+#endif
+        FRP(7)
+    }
+
+    // the samples leave the chip: sorted positions -> point indices, coordinates as stored (pure copies of xyz)
+    __syncthreads();
+    for (int jj = tid; jj < m; jj += NT) {
+        if (jj == 0) {
+            idx[0] = 0;
+            if (new_xyz) { new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
+        } else {
+            const float4 sm = samples[jj];
+            idx[jj] = (int)order[__float_as_int(sm.w)];
+            if (new_xyz) { new_xyz[jj * 3 + 0] = sm.x; new_xyz[jj * 3 + 1] = sm.y; new_xyz[jj * 3 + 2] = sm.z; }
+        }
+    }
+    if (temp) {
+        const float ta[32] = FB_T32_LIST(tt);
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int k = (int)order[((s * NW + w) << 6) + lane];
+            if (k != 0xFFFF) temp[k] = ta[s];
+        }
+    }
+#ifdef FR_PROF
+    __syncthreads();
+    if (temp && lane == 0)
+        for (int k = 0; k < 8; ++k) { temp[w * 8 + k] = (float)pc[k]; temp[128 + w * 8 + k] = (float)kh[k]; }
+#endif
 }
+
+size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
 
 int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
                       int bs, int log2bs, int S, hipStream_t st) {
@@ -434,6 +795,24 @@ int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_
                                   (int)fps_bucket_smem());
         attr_set = true;
     }
+#if FB_NW == 16 && !defined(FB_PROF)
+    // several certified samples per record exchange (fps_rounds_kernel); WS3D_FPS_ROUNDS=0: one sample per exchange (A/B runs)
+    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
+    if (rounds && (size_t)m <= FR_SAMPLES_MAX_M) {
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void *)fps_rounds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds_smem((int)FR_SAMPLES_MAX_M));
+            (void)hipFuncSetAttribute((const void *)fps_rounds_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds_smem((int)FR_SAMPLES_MAX_M));
+            attr2 = true;
+        }
+        static const int nw = getenv("WS3D_FPS_ROUNDS_WAVES") ? atoi(getenv("WS3D_FPS_ROUNDS_WAVES")) : 16;
+        if (nw == 8)
+            hipLaunchKernelGGL(fps_rounds_kernel<8>, dim3(b), dim3(512), fps_rounds_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
+        else
+            hipLaunchKernelGGL(fps_rounds_kernel<16>, dim3(b), dim3(1024), fps_rounds_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
+        return check_launch("furthest_point_sampling(rounds)");
+    }
+#endif
     hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FB_NT), fps_bucket_smem(), st, xyz, temp, idx, new_xyz, n,
                        m, bs, log2bs, S);
     return check_launch("furthest_point_sampling(bucket)");
