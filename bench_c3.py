@@ -191,7 +191,7 @@ class C3:
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
         try:
-            out = self.model.rpn_forward({'pts_input': self.pts})
+            out = self.model.rpn_forward({'pts_input': self.pts, 'defer_reg_join': True})      # proposals_from_rpn waits for rpn_reg
         finally:
             fastpath.GEOMETRY_AHEAD = ahead
         if timed:

@@ -1507,7 +1507,9 @@ def test_every_launch_mode_of_the_step_gives_the_same_bits(ops):
 
     @torch.no_grad()
     def body():
-        out = model.rpn_forward({"pts_input": pts})
+        # (defer_reg_join: in the side-stream mode the regression head runs beside the classification head and the top-k; the
+        # proposal stage waits for it -- reading rpn_reg below is ordered behind that wait)
+        out = model.rpn_forward({"pts_input": pts, "defer_reg_join": True})
         boxes, scores, count = stage1.proposals_from_rpn(out, cfg)
         return [out["rpn_cls"], out["rpn_reg"], out["backbone_features_nlc"], boxes, scores, count]
 

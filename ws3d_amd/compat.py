@@ -48,7 +48,35 @@ def _p(t):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of the current HIP stream of the current device (the C call behind torch.cuda.current_stream().cuda_stream: the
+    wrapper objects cost ~9 us per launch on the issuing thread, and an eager Stage-1 step makes ~100 launches)"""
+    return _raw_stream(_cur_device())
+
+
+try:
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:                                      # (another torch build: the public, slower way)
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+    def _cur_device():
+        return torch.cuda.current_device()
+
+
+class _SameDevice:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_SAME_DEVICE = _SameDevice()
+
+
+def _on(dev):
+    """context that makes `dev` the current device for the launch -- nothing to do (and nothing paid) when it already is"""
+    return _SAME_DEVICE if dev.index == _cur_device() else torch.cuda.device(dev)
 
 
 def _f32(t, name):
@@ -66,7 +94,7 @@ def furthest_point_sampling_wrapper(b, n, m, points_tensor, temp_tensor, idx_ten
     """sampling.cpp:36-46"""
     dev = _dev(points_tensor, temp_tensor, idx_tensor)
     _f32(points_tensor, "xyz"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_furthest_point_sampling(b, n, m, _p(points_tensor), _p(temp_tensor),
                                                         _p(idx_tensor), _stream()), "furthest_point_sampling")
     return 1
@@ -76,7 +104,7 @@ def furthest_point_sampling_gather(b, n, m, xyz, temp, idx, new_xyz):
     """fused a1+a2 (ws3d extension; no reference counterpart)"""
     dev = _dev(xyz, temp, idx, new_xyz)
     _f32(xyz, "xyz"); _i32(idx, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_furthest_point_sampling_gather(b, n, m, _p(xyz), _p(temp), _p(idx),
                                                                _p(new_xyz), _stream()), "fps_gather")
     return 1
@@ -87,7 +115,7 @@ def furthest_point_sampling_nested(b, n, m, xyz, idx, new_xyz):
     same results as furthest_point_sampling_gather, found by a parallel check instead of m dependent steps.  ws3d extension."""
     dev = _dev(xyz, idx, new_xyz)
     _f32(xyz, "xyz"); _i32(idx, "idx"); _f32(new_xyz, "new_xyz")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_furthest_point_sampling_nested(b, n, m, _p(xyz), _p(idx), _p(new_xyz), _stream()), "fps_nested")
     return 1
 
@@ -96,7 +124,7 @@ def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tenso
     """sampling.cpp:11-20"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)
     _f32(points_tensor, "points"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_points(b, c, n, npoints, _p(points_tensor), _p(idx_tensor),
                                               _p(out_tensor), _stream()), "gather_points")
     return 1
@@ -106,7 +134,7 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out_tensor, idx_tensor, gr
     """sampling.cpp:23-33"""
     dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
     _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_points_grad(b, c, n, npoints, _p(grad_out_tensor), _p(idx_tensor),
                                                    _p(grad_points_tensor), _stream()), "gather_points_grad")
     return 1
@@ -131,7 +159,7 @@ def sort_points_x(xyz, min_n=None, grid=None):
     if n < (SORTED_MIN_N if min_n is None else min_n) or nbytes == 0:
         return None
     out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         if BQ_FINE_GRID if grid is None else grid:
             check(lib.ws3d_sort_points_grid(b, n, _p(xyz), _p(out), _stream()), "sort_points_grid")
         else:
@@ -150,7 +178,7 @@ def sort_points_xz(xyz, min_n=256):
     if n < min_n or nbytes == 0:
         return None
     out = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_sort_points_xz(b, n, _p(xyz), _p(out), _stream()), "sort_points_xz")
     return out
 
@@ -159,7 +187,7 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx
     """ball_query.cpp:14-25 (sorted_xyz: optional output of sort_points_x for this xyz)"""
     dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz)
     _f32(xyz_tensor, "xyz"); _f32(new_xyz_tensor, "new_xyz"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_ball_query(b, n, m, float(radius), nsample, _p(new_xyz_tensor),
                                            _p(xyz_tensor), _p(idx_tensor), _p(sorted_xyz), _stream()), "ball_query")
     return 1
@@ -172,7 +200,7 @@ def ball_query_lists(radius, nsample, xyz, new_xyz, sorted_xyz=None):
     _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
     B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
     idx = torch.empty((B, M, nsample), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_ball_query_fill(B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx), _p(sorted_xyz), _stream()),
               "ball_query_fill")
     return idx
@@ -192,7 +220,7 @@ def ball_query_pairs(radius, nsample, xyz, new_xyz, sorted_grid, total=None):
     rowsrc = torch.empty(B * M * nsample, dtype=torch.int32, device=dev)
     if total is None:
         total = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rc = _lib.load().ws3d_ball_query_pairs(B, N, M, float(radius), nsample, _p(new_xyz), _p(xyz), _p(idx), _p(sorted_grid), _p(rowc), _p(rowsrc),
                                                _p(total), _stream())
     if rc == _lib.E_UNSUPPORTED:
@@ -205,7 +233,7 @@ def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, o
     """group_points.cpp:25-36"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)
     _f32(points_tensor, "points"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_group_points(b, c, n, npoints, nsample, _p(points_tensor), _p(idx_tensor),
                                              _p(out_tensor), _stream()), "group_points")
     return 1
@@ -215,7 +243,7 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out_tensor, idx_te
     """group_points.cpp:11-22"""
     dev = _dev(grad_out_tensor, idx_tensor, grad_points_tensor)
     _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_group_points_grad(b, c, n, npoints, nsample, _p(grad_out_tensor),
                                                   _p(idx_tensor), _p(grad_points_tensor), _stream()),
               "group_points_grad")
@@ -226,7 +254,7 @@ def query_and_group(b, n, m, c, radius, nsample, use_xyz, xyz, new_xyz, features
     """fused a5 (ws3d extension)"""
     dev = _dev(xyz, new_xyz, features, idx_out, out, sorted_xyz)
     _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_query_and_group(b, n, m, c, float(radius), nsample, int(bool(use_xyz)),
                                                 _p(xyz), _p(new_xyz), _p(features), _p(idx_out), _p(out),
                                                 _p(sorted_xyz), _stream()), "query_and_group")
@@ -243,7 +271,7 @@ def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=Tru
     if features_nlc is not None:
         _f32(features_nlc, "features")
     out = torch.empty((B, M, nsample, (3 if use_xyz else 0) + C), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_query_and_group_nlc(B, N, M, C, float(radius), nsample, int(bool(use_xyz)), _p(xyz),
                                                    _p(new_xyz), _p(features_nlc), _p(idx_out), _p(out),
                                                    _p(sorted_xyz), _stream()), "query_and_group_nlc")
@@ -261,7 +289,7 @@ def three_nn_with_weights(unknown, known, sorted_known=None):
     idx = torch.empty((B, N, 3), dtype=torch.int32, device=dev)
     w = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
     lib = _lib.load()
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_three_nn_w(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx), _p(w),
                                   _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn_w")
     return idx, w
@@ -277,7 +305,7 @@ def three_interpolate_nlc(feats_nlc, idx, weight, out=None):
     if out is None:
         out = torch.empty((B, N, C), dtype=torch.float32, device=dev)
     _f32(out, "out")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_three_interpolate_nlc(B, C, M, N, _p(feats_nlc), _p(idx), _p(weight), _p(out),
                                                      out.size(2), _stream()), "three_interpolate_nlc")
     return out
@@ -293,7 +321,7 @@ def rowmax_rows(y, ns, out=None, col0=0):
     if out is None:
         out = torch.empty((R, O), dtype=torch.float32, device=dev)
     view = out[:, col0:col0 + O]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_rowmax_rows(R, ns, O, _p(y), view.data_ptr(), out.size(1), _stream()), "rowmax_rows")
     return out
 
@@ -314,7 +342,7 @@ def bn_relu_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, 
     lib = _lib.load()
     nbytes = lib.ws3d_bn_workspace_bytes(b, c, l)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_bn_relu_train_fwd(b, c, l, _p(x), _p(gamma), _p(beta), float(eps), float(momentum), int(bool(relu)),
                                          _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(y), _p(mean), _p(invstd), _p(ws), nbytes,
                                          _stream()), "bn_relu_train_fwd")
@@ -333,7 +361,7 @@ def bn_relu_train_bwd(x, dy, gamma, beta, save_mean, save_invstd, relu=True):
     lib = _lib.load()
     nbytes = lib.ws3d_bn_workspace_bytes(b, c, l)
     ws = torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_bn_relu_train_bwd(b, c, l, _p(x), _p(dy), _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
                                          int(bool(relu)), _p(dx), _p(dgamma), _p(dbeta), _p(ws), nbytes, _stream()),
               "bn_relu_train_bwd")
@@ -353,7 +381,7 @@ def conv1x1_wgrad(grad_out, x, shape=None):
     lib = _lib.load()
     nbytes = lib.ws3d_conv1x1_wgrad_workspace_bytes(b, o, c, l)
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_conv1x1_wgrad(b, o, c, l, _p(grad_out), _p(x), _p(gw), _p(ws), nbytes, _stream()), "conv1x1_wgrad")
     return gw
 
@@ -377,7 +405,7 @@ def gemm_pool(x_rows, wt, bias, relu, nsample, out, col0=0, gate=None):
     if rows % 64 or rows // 64 > 65535 or o % 64 or k % 4 or nsample not in (16, 32) or wt.size(0) != k:
         return False
     view = out[:, col0:col0 + o]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gemm_pool(rows, nsample, k, o, _p(x_rows), _p(wt), _p(bias), int(bool(relu)), view.data_ptr(),
                                          out.size(1), *_gate(gate), _stream()), "gemm_pool")
     return True
@@ -396,7 +424,7 @@ def gather_gemm(feats, xyz, new_xyz, nbr, wt_feat_then_xyz, bias, relu):
     if C % 4 or O % 64 or rows % 64 or rows // 64 > 65535 or wt_feat_then_xyz.size(0) != C + 3 or not feats.is_contiguous():
         return None
     out = torch.empty((rows, O), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_gemm(B, N, M, ns, C, O, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(wt_feat_then_xyz), _p(bias),
                                            int(bool(relu)), _p(out), _stream()), "gather_gemm")
     return out
@@ -416,7 +444,7 @@ def gather_gemm2(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2t, b2
             not feats.is_contiguous() or not w2t.is_contiguous() or not w1t_feat_then_xyz.is_contiguous()):
         return None
     out = torch.empty((rows, O2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_gemm2(B, N, M, ns, C, O1, O2, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(w1t_feat_then_xyz), _p(b1),
                                             int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), _stream()), "gather_gemm2")
     return out
@@ -440,7 +468,7 @@ def gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2
             out2d.stride(1) != 1 or col_offset < 0 or col_offset + O3 > out2d.size(1) or not feats.is_contiguous() or
             not w1t_feat_then_xyz.is_contiguous() or not w2t.is_contiguous() or not w3t.is_contiguous()):
         return False
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_gemm3_pool(B, N, M, ns, C, O1, O2, O3, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(w1t_feat_then_xyz),
                                                  _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(w3t), _p(b3), int(bool(relu3)),
                                                  out2d.data_ptr() + 4 * col_offset, out2d.stride(0), _stream()), "gather_gemm3_pool")
@@ -463,7 +491,7 @@ def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, re
         out = torch.empty((B * M * ns, O2), dtype=torch.float32, device=dev)
     elif tuple(out.shape) != (B * M * ns, O2) or not out.is_contiguous():
         raise ValueError("pgather_gemm2: out must be a contiguous (B*M*ns, O2) tensor")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pgather_gemm2(B, N, M, ns, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(nbr), _p(w1x), _p(b1),
                                              int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out), *_gate(gate), _stream()), "pgather_gemm2")
     return out
@@ -479,7 +507,7 @@ def pgather_rows(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1):
             col0 + o1 > pmat.size(1) or tuple(w1x.shape) != (3, o1) or not w1x.is_contiguous() or pmat.data_ptr() % 16):
         return None
     out = torch.empty((B * M * ns, o1), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pgather_rows(B, N, M, ns, o1, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(nbr), _p(w1x), _p(b1),
                                             int(bool(relu1)), _p(out), _stream()), "pgather_rows")
     return out
@@ -498,7 +526,7 @@ def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=T
             (lin is None and c1 > 0 and (wb is None or tuple(wb.shape) != (c1, O) or not wb.is_contiguous() or not skip.is_contiguous()))):
         return None
     out = torch.empty((B * N, O), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_qinterp_rows(B, N, M, O, _p(q), _p(idx), _p(weight), _p(lin), _p(skip), c1, _p(wb), _p(bias), int(bool(relu)), _p(out),
                                             _stream()), "qinterp_rows")
     return out
@@ -517,7 +545,7 @@ def compact_pairs(nbr, ordered=False):
         rowc = torch.empty(B * M * ns, dtype=torch.int32, device=dev)
         rowsrc = torch.empty(B * M * ns, dtype=torch.int32, device=dev)
         total = torch.zeros(1, dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             check(_lib.load().ws3d_compact_pairs(B * M, ns, _p(nbr), _p(rowc), _p(rowsrc), _p(total), _stream()), "compact_pairs")
         return rowc, rowsrc, total
     dev = _dev(nbr)
@@ -528,7 +556,7 @@ def compact_pairs(nbr, ordered=False):
     rowc = torch.empty(centres * ns, dtype=torch.int32, device=dev)
     rowsrc = torch.empty(centres * ns, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         lib = _lib.load()
         check(lib.ws3d_compact_pairs_count(centres, ns, _p(nbr), _p(cnt), _stream()), "compact_pairs_count")
         incl = torch.cumsum(cnt, dim=0, dtype=torch.int32)
@@ -551,7 +579,7 @@ def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w
             tuple(w1x.shape) != (3, o1) or w2t.size(0) != o1 or not w1x.is_contiguous() or not w2t.is_contiguous()):
         return None
     out = torch.empty((rows, O2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pgather_gemm2_compact(B, N, M, rows, o1, O2, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc),
                                                      _p(rowsrc), _p(total), _p(w1x), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(out),
                                                      int(limit), _stream()), "pgather_gemm2_compact")
@@ -570,7 +598,7 @@ def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset, limit=-1):
     if (k % 4 or o % 64 or wt.size(0) != k or rows != rowc.numel() or not x_rows.is_contiguous() or not wt.is_contiguous() or out2d.dim() != 2 or
             out2d.stride(1) != 1 or col_offset < 0 or col_offset + o > out2d.size(1)):
         return False
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gemm_pool_compact(rows, k, o, _p(x_rows), _p(rowc), _p(total), _p(wt), _p(bias), out2d.data_ptr() + 4 * col_offset,
                                                  out2d.stride(0), int(limit), _stream()), "gemm_pool_compact")
     return True
@@ -590,7 +618,7 @@ def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
             (unknown_feats is not None and not unknown_feats.is_contiguous())):
         return None
     out = torch.empty((rows, O), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_interp_gemm(B, N, M, C2, C1, O, _p(known_feats), _p(unknown_feats), _p(idx), _p(weight), _p(wt), _p(bias),
                                            int(bool(relu)), _p(out), _stream()), "interp_gemm")
     return out
@@ -610,7 +638,7 @@ def mlp2_rows(x2d, w1t, b1, relu1, w2t, b2, relu2, ticket=None):
     out = torch.empty((R, O2), dtype=torch.float32, device=dev)
     if ticket is None:
         ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_mlp2_rows(R, K, O1, O2, _p(x2d), _p(w1t), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)),
                                          _p(out), _p(ticket), _stream()), "mlp2_rows")
     return out
@@ -624,7 +652,7 @@ def pool_nsample(x):
     ns = x.size(-1)
     out = torch.empty(x.shape[:-1], dtype=torch.float32, device=dev)
     arg = torch.empty(x.shape[:-1], dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pool_nsample(out.numel(), ns, _p(x), _p(out), _p(arg), _stream()), "pool_nsample")
     return out, arg
 
@@ -636,7 +664,7 @@ def pool_nsample_grad(grad_out, arg, nsample):
     if arg.dtype != torch.uint8 or not arg.is_contiguous():
         raise TypeError("arg must be a contiguous uint8 tensor")
     grad_x = torch.empty(tuple(grad_out.shape) + (nsample,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pool_nsample_grad(grad_out.numel(), nsample, _p(grad_out), _p(arg), _p(grad_x), _stream()),
               "pool_nsample_grad")
     return grad_x
@@ -655,7 +683,7 @@ def sa_mlp3_pool(x_rows4, nsample, layers, out, col0=0):
         return False
     dev = _dev(x_rows4, out)
     view = out[:, col0:col0 + widths[2]]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_sa_mlp3_pool(x_rows4.size(0), nsample, widths[0], widths[1], widths[2], _p(x_rows4),
                                             _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), int(bool(r3)),
                                             view.data_ptr(), out.size(1), _stream()), "sa_mlp3_pool")
@@ -675,7 +703,7 @@ def sa_mlp3_pool_compact(xyz, new_xyz, feat1, pairs, layers, out, col0=0, limit=
     dev = _dev(xyz, new_xyz, feat1, rowc, out)
     _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(feat1, "feat1"); _f32(out, "out")
     view = out[:, col0:col0 + widths[2]]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_sa_mlp3_pool_compact(xyz.size(0), xyz.size(1), new_xyz.size(1), rowc.numel(), widths[0], widths[1], widths[2], _p(xyz),
                                                     _p(new_xyz), _p(feat1), _p(rowc), _p(rowsrc), _p(total), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
                                                     _p(b3), view.data_ptr(), out.size(1), int(limit), _stream()), "sa_mlp3_pool_compact")
@@ -695,7 +723,7 @@ def sa_mlp3_pool_lists(xyz, new_xyz, feat1, nbr, layers, out, col0=0, gate=None)
     dev = _dev(xyz, new_xyz, feat1, nbr, out)
     _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(feat1, "feat1"); _i32(nbr, "nbr"); _f32(out, "out")
     view = out[:, col0:col0 + widths[2]]
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_sa_mlp3_pool_lists(xyz.size(0), xyz.size(1), new_xyz.size(1), ns, widths[0], widths[1], widths[2], _p(xyz), _p(new_xyz),
                                                   _p(feat1), _p(nbr), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3), _p(b3), int(bool(r3)), view.data_ptr(),
                                                   out.size(1), *_gate(gate), _stream()), "sa_mlp3_pool_lists")
@@ -706,7 +734,7 @@ def three_nn_wrapper(b, n, m, unknown_tensor, known_tensor, dist2_tensor, idx_te
     """interpolate.cpp:14-23 (+ optional x-binned copy of `known` from sort_points_x: same result)"""
     dev = _dev(unknown_tensor, known_tensor, dist2_tensor, idx_tensor)
     _f32(unknown_tensor, "unknown"); _f32(known_tensor, "known"); _i32(idx_tensor, "idx")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_three_nn(b, n, m, _p(unknown_tensor), _p(known_tensor), _p(dist2_tensor),
                                          _p(idx_tensor), _p(sorted_known) if sorted_known is not None else None,
                                          _stream()), "three_nn")
@@ -716,7 +744,7 @@ def three_interpolate_wrapper(b, c, m, n, points_tensor, idx_tensor, weight_tens
     """interpolate.cpp:26-39"""
     dev = _dev(points_tensor, idx_tensor, weight_tensor, out_tensor)
     _f32(points_tensor, "points"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_three_interpolate(b, c, m, n, _p(points_tensor), _p(idx_tensor),
                                                   _p(weight_tensor), _p(out_tensor), _stream()),
               "three_interpolate")
@@ -726,7 +754,7 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out_tensor, idx_tensor, weig
     """interpolate.cpp:41-53"""
     dev = _dev(grad_out_tensor, idx_tensor, weight_tensor, grad_points_tensor)
     _f32(grad_out_tensor, "grad_out"); _i32(idx_tensor, "idx"); _f32(weight_tensor, "weight")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_three_interpolate_grad(b, c, n, m, _p(grad_out_tensor), _p(idx_tensor),
                                                        _p(weight_tensor), _p(grad_points_tensor), _stream()),
               "three_interpolate_grad")
@@ -740,7 +768,7 @@ def group_points_grad_det(b, c, n, npoints, nsample, grad_out_tensor, idx_tensor
     lib = _lib.load()
     nbytes = lib.ws3d_scatter_workspace_bytes(b, c, n, npoints * nsample)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_group_points_grad_det(b, c, n, npoints, nsample, _p(grad_out_tensor), _p(idx_tensor),
                                              _p(grad_points_tensor), _p(ws), nbytes, _stream()), "group_points_grad_det")
     return 1
@@ -753,7 +781,7 @@ def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_t
     lib = _lib.load()
     nbytes = lib.ws3d_scatter_workspace_bytes(b, c, m, n * 3)
     ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_three_interpolate_grad_det(b, c, n, m, _p(grad_out_tensor), _p(idx_tensor), _p(weight_tensor),
                                                   _p(grad_points_tensor), _p(ws), nbytes, _stream()),
               "three_interpolate_grad_det")
@@ -768,7 +796,7 @@ def topk_sorted(scores, k):
     B, N = scores.shape
     vals = torch.empty((B, k), dtype=torch.float32, device=dev)
     idx = torch.empty((B, k), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_topk_sorted(B, N, k, _p(scores), _p(vals), _p(idx), _stream()), "topk_sorted")
     return vals, idx
 
@@ -783,7 +811,7 @@ def decode_center_boxes(xyz, rpn_reg, loc_scope, loc_bin_size, mean_size):
         raise ValueError("decode_center_boxes: rpn_reg must be contiguous (B,N,%d)" % (4 * bins))
     boxes = torch.empty((B, N, 7), dtype=torch.float32, device=dev)
     h, w, l = mean_size
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_decode_center_boxes(B, N, bins, float(loc_scope), float(loc_bin_size), float(h), float(w),
                                                    float(l), _p(xyz), _p(rpn_reg), _p(boxes), _stream()), "decode_center_boxes")
     return boxes
@@ -798,7 +826,7 @@ def gather_boxes_bev(box, order):
     B, N, top = box.size(0), box.size(1), order.size(1)
     box_sorted = torch.empty((B, top, 7), dtype=torch.float32, device=dev)
     bev = torch.empty((B, top, 5), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_gather_boxes_bev(B, N, top, _p(box), _p(order), _p(box_sorted), _p(bev), _stream()), "gather_boxes_bev")
     return box_sorted, bev
 
@@ -815,7 +843,7 @@ def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None):
     scores = torch.empty((B, k), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=torch.int64, device=dev)
     pooled = torch.empty((B, k, 7), dtype=torch.float32, device=dev) if extra_width is not None else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_select_proposals(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
                                                 _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
                                                 _stream()), "select_proposals")
@@ -828,7 +856,7 @@ def bias_act_inplace(y, bias, relu=True):
     _f32(y, "y"); _f32(bias, "bias")
     B, O = y.size(0), y.size(1)
     L = y.numel() // max(B * O, 1)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_bias_act_inplace(B, O, L, int(bool(relu)), _p(y), _p(bias), _stream()), "bias_act")
     return y
 
@@ -841,7 +869,7 @@ def rowmax_bias_act(y, bias=None, relu=True):
         _f32(bias, "bias")
     B, O, M, S = y.shape
     out = torch.empty((B, O, M), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_rowmax_bias_act(B, O, M, S, int(bool(relu)), _p(y), _p(bias) if bias is not None else None,
                                                _p(out), _stream()), "rowmax_bias_act")
     return out
@@ -852,7 +880,7 @@ def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans_overlap):
     """iou3d.cpp:31-50"""
     dev = _dev(boxes_a, boxes_b, ans_overlap)
     _f32(boxes_a, "boxes_a"); _f32(boxes_b, "boxes_b"); _f32(ans_overlap, "ans")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_boxes_overlap_bev(boxes_a.size(0), _p(boxes_a), boxes_b.size(0), _p(boxes_b),
                                                   _p(ans_overlap), _stream()), "boxes_overlap_bev")
     return 1
@@ -862,7 +890,7 @@ def boxes_iou_bev_gpu(boxes_a, boxes_b, ans_iou):
     """iou3d.cpp:52-71"""
     dev = _dev(boxes_a, boxes_b, ans_iou)
     _f32(boxes_a, "boxes_a"); _f32(boxes_b, "boxes_b"); _f32(ans_iou, "ans")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_boxes_iou_bev(boxes_a.size(0), _p(boxes_a), boxes_b.size(0), _p(boxes_b),
                                               _p(ans_iou), _stream()), "boxes_iou_bev")
     return 1
@@ -880,7 +908,7 @@ def nms_device(boxes, thresh, normal=False, max_keep=0):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     keep = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
     num = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_nms(n, _p(boxes), float(thresh), int(bool(normal)), int(max_keep), _p(ws), ws_bytes,
                            _p(keep), _p(num), _stream()), "nms")
     return keep, num
@@ -897,7 +925,7 @@ def nms_device_batched(boxes, thresh, normal=False, max_keep=0):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     keep = torch.empty((B, max(n, 1)), dtype=torch.int64, device=dev)
     num = torch.zeros(B, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_nms_batched(B, n, _p(boxes), float(thresh), int(bool(normal)), int(max_keep), _p(ws),
                                    ws_bytes, _p(keep), _p(num), _stream()), "nms_batched")
     return keep, num
@@ -914,7 +942,7 @@ def radius_nms_device_batched(centers, radius, max_keep=0):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     keep = torch.empty((B, max(n, 1)), dtype=torch.int64, device=dev)
     num = torch.zeros(B, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.ws3d_radius_nms_batched(B, n, _p(centers), float(radius), int(max_keep), _p(ws), ws_bytes,
                                           _p(keep), _p(num), _stream()), "radius_nms")
     return keep, num
@@ -945,7 +973,7 @@ def nms_mask(boxes, thresh, normal=False, full_grid=False):
     _f32(boxes, "boxes")
     n = boxes.size(0)
     mask = torch.zeros((n, (n + 63) // 64), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_nms_mask(n, _p(boxes), float(thresh), int(bool(normal)), int(bool(full_grid)),
                                          _p(mask), _stream()), "nms_mask")
     return mask
@@ -957,7 +985,7 @@ def roipool3d_forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_f
     dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
     _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
     _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_roipool3d(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
                                           pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
                                           _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
@@ -970,7 +998,7 @@ def roipool3d_forward_fill(xyz, boxes3d, pts_feature, pooled_features, pooled_em
     dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
     _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
     _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_roipool3d_fill(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
                                                pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
                                                _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
@@ -983,7 +1011,7 @@ def pts_in_boxes3d_device(pts, boxes3d):
     dev = _dev(pts, boxes3d)
     _f32(pts, "pts"); _f32(boxes3d, "boxes3d")
     flag = torch.empty((boxes3d.size(0), pts.size(0)), dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(_lib.load().ws3d_pts_in_boxes3d(boxes3d.size(0), pts.size(0), _p(pts), _p(boxes3d), _p(flag),
                                                _stream()), "pts_in_boxes3d")
     return flag

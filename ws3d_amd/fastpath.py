@@ -54,6 +54,8 @@ PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: fi
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
+PARALLEL_SCALES = os.environ.get("WS3D_PARALLEL_SCALES", "1") != "0"  # eager side-stream mode: the second scale of a level beside the first
+PARALLEL_HEADS = os.environ.get("WS3D_PARALLEL_HEADS", "1") != "0"  # ... and the regression head beside the classification head + top-k
 
 
 def _row_weights(block):
@@ -253,22 +255,21 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
     return lists
 
 
-_SIDE_STREAMS = {}
-
-
 def _side_streams(main: torch.cuda.Stream):
-    """the two side streams of a device: the sampling chain and the searches.  ONE pair per device, shared by every caller
-    stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has
-    descriptors gets time-sliced (measured: a pair per Stage1Pipeline slot, 60 streams, ran every kernel of the process
-    ~1.6x slower -- FPS of the c2 block 0.30 instead of 0.54 of the VALU peak; the limit sits at 24 queues: 20 pipeline
-    slots + the null stream + this pair = 23 is fine, a third side stream -- tried for the second scale of the multi-scale
-    levels and one of the two heads, worth 0.1 ms of latency with a 16-deep pipeline -- made the eager step 7.5 instead of
-    5.4 ms)."""
-    key = main.device.index
-    pair = _SIDE_STREAMS.get(key)
-    if pair is None:
-        pair = _SIDE_STREAMS[key] = (torch.cuda.Stream(device=main.device), torch.cuda.Stream(device=main.device))
-    return pair
+    """the three side streams of a forward pass: the sampling chain, the searches, and one for the second scale of a level / the
+    second head.  Taken from the per-device pool that Stage1Pipeline's slots use (ws3d_amd/streams.py) -- never the caller's own
+    stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has descriptors
+    gets time-sliced (measured: a pair per Stage1Pipeline slot, 60 streams, ran every kernel of the process ~1.6x slower; the
+    limit sits at 24 queues: 20 pipeline slots + the null stream + a pair of its own = 23 was fine, a third one was not).
+    Sharing the pool costs nothing: a pass that runs eagerly beside a pipeline in flight merely queues behind its slots."""
+    from .streams import pooled_stream
+    picked, j = [], 0
+    while len(picked) < 3:
+        st = pooled_stream(main.device, j)
+        j += 1
+        if st.cuda_stream != main.cuda_stream:
+            picked.append(st)
+    return tuple(picked)
 
 
 class _Geometry:
@@ -283,7 +284,8 @@ class _Geometry:
     def __init__(self, net, xyz: torch.Tensor, c0: int, zeros=None):
         sas = list(net.SA_modules)
         main = torch.cuda.current_stream(xyz.device)
-        s_fps, s_search = _side_streams(main)
+        s_fps, s_search, s_aux = _side_streams(main)
+        self.aux = s_aux
         self.xyz = [xyz]
         # (binning the input cloud on the side stream BESIDE this kernel instead of behind it was measured: 5.22-5.26 vs 5.19-5.20 ms
         # per batch -- anything that shares the memory path slows the sampling chain by more than the 30 us it hides)
@@ -322,7 +324,7 @@ class _Geometry:
                 ev = torch.cuda.Event()
                 ev.record(s_search)
                 self.nn_ready[i] = ev
-        self.main, self.side = main, (s_fps, s_search)
+        self.main, self.side = main, (s_fps, s_search, s_aux)
 
     def release(self):
         """every consumer of the side streams' tensors has been issued on the caller's stream: later side-stream work (of
@@ -357,9 +359,12 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         out = zeros.take((B * sa.npoint, sum(widths)))                               # zeros: the atomic max
     else:
         out = torch.zeros((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
-    col = 0
-    pp = None
-    for si, (grouper, mlp, width, nbr) in enumerate(zip(sa.groupers, sa.mlps, widths, nbrs)):
+    cols = [sum(widths[:i]) for i in range(len(widths))]
+    pp = [None]
+
+    def run_scale(si: int) -> None:
+        """the SharedMLP + pool of scale si into its column slice of `out`"""
+        grouper, mlp, width, nbr, col = sa.groupers[si], sa.mlps[si], widths[si], nbrs[si], cols[si]
         blocks = _blocks(mlp)
         pairs = None
         if isinstance(nbr, _PairList):
@@ -370,9 +375,9 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             if PER_POINT_L1 and len(blocks) >= 3:
                 # layer 1 is linear in the grouped row: its feature part is ONE product over the level's points (both scales in
                 # one GEMM), the pairs only gather that row and add the xyz term
-                if pp is None:
-                    pp = _per_point_l1(sa, feats, nbrs)
-                pmat, offs, w1xs = pp
+                if pp[0] is None:
+                    pp[0] = _per_point_l1(sa, feats, nbrs)
+                pmat, offs, w1xs = pp[0]
                 o1 = blocks[0].conv.out_channels
                 y = None
                 wt3, b3, r3 = _row_weights(blocks[-1])
@@ -393,8 +398,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                             yd = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2, out=yc, gate=gate)
                             if yd is None or not _C.gemm_pool(yd, wt3, b3, r3, ns, out, col, gate=gate):
                                 raise RuntimeError("the gated dense kernels declined a shape _pair_limit accepted")
-                        col += width
-                        continue
+                        return
                 if o1 <= 128:
                     wt2, b2, r2 = _row_weights(blocks[1])
                     y = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2)
@@ -408,12 +412,10 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     wt, bias, relu = _row_weights(blocks[-1])
                     if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
                         _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
-                    col += width
-                    continue
+                    return
             if (FUSED_GATHER_GEMM3 and len(blocks) == 3 and blocks[0].conv.out_channels <= FUSED_GATHER_GEMM3_MAX_O1 and
                     _C.gather_gemm3_pool(feats, xyz, new_xyz, nbr, wt1, b1, r1, *_row_weights(blocks[1]), *_row_weights(blocks[2]), out, col)):
-                col += width       # the whole SharedMLP + pool in one kernel: only the pooled rows reach HBM
-                continue
+                return       # the whole SharedMLP + pool in one kernel: only the pooled rows reach HBM
             y = None
             rest = blocks[1:-1]
             if FUSED_GATHER_GEMM2 and len(blocks) >= 3 and blocks[0].conv.out_channels <= 128:
@@ -434,8 +436,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             wt, bias, relu = _row_weights(blocks[-1])
             if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
                 _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
-            col += width
-            continue
+            return
         if FUSED_SA_MLP and SA1_FROM_LISTS and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
             # first level: lists only (no grouped tensor), the three layers chained in registers -- over the distinct pairs of the
             # lists (atomic max into the zeroed `out`) or over all their rows (pool in registers, stored), decided on the device
@@ -443,16 +444,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             if not COMPACT_PAIRS:
                 nbr1 = _C.ball_query_lists(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz)
                 if _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col):
-                    col += width
-                    continue
+                    return
             else:
                 nbr1, pairs1 = _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
                 limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
                 if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
                     if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
                         raise RuntimeError("ws3d_sa_mlp3_pool_lists declined a shape ws3d_sa_mlp3_pool_compact accepted")
-                    col += width
-                    continue
+                    return
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
         # 4-channel level (dx,dy,dz,intensity): three layers + pool in one kernel, nothing but the
@@ -467,7 +466,25 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             # cover: GEMM with fused bias + ReLU, then the pool kernel into the column slice
             if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
                 _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
-        col += width
+
+    if geo is not None and geo.aux is not None and PARALLEL_SCALES and len(widths) == 2:
+        # the two scales of a multi-scale level are independent and neither fills the chip at batch 8: the second one on a side
+        # stream beside the first.  What both read is ready on the caller's stream at this point (the level's features, the
+        # per-point product of layer 1 -- taken here, once, for both -- and, waited for above, the neighbour lists)
+        if PER_POINT_L1 and any(n is not None and len(_blocks(m)) >= 3 for n, m in zip(nbrs, sa.mlps)):
+            pp[0] = _per_point_l1(sa, feats, nbrs)
+        fork = torch.cuda.Event()
+        fork.record(geo.main)
+        geo.aux.wait_event(fork)
+        with torch.cuda.stream(geo.aux):
+            run_scale(1)
+            join = torch.cuda.Event()
+            join.record(geo.aux)
+        run_scale(0)
+        geo.main.wait_event(join)
+    else:
+        for si in range(len(widths)):
+            run_scale(si)
     return new_xyz, out.view(B, sa.npoint, -1)
 
 
@@ -539,15 +556,37 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
 
 
 @torch.no_grad()
-def rpn_forward(model, pts_input: torch.Tensor) -> dict:
+def rpn_forward(model, pts_input: torch.Tensor, defer_reg_join: bool = False) -> dict:
+    """defer_reg_join (eager side-stream mode only): the regression head runs on a side stream beside the classification head;
+    with the flag set the caller's stream is NOT made to wait for it here -- the dict then carries the event ``rpn_reg_ready`` that a
+    consumer of ``rpn_reg`` must wait for (stage1.proposals_from_rpn does: the top-k over the scores runs beside the head)."""
     rpn = model.rpn
     zeros = _arena_for(rpn.backbone_net, pts_input.size(0), pts_input.device, extra=8)      # ONE fill for the whole pass
     xyz, feats = backbone_forward(rpn.backbone_net, pts_input, zeros)     # (B,N,3), (B,N,128)
     B, N, C = feats.shape
     rows = feats.view(B * N, C)
     tickets = zeros.take((2,), torch.int32) if FUSED_MLP2_ROWS else (None, None)
-    rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
-    rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
-    return {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz,
-            "backbone_features": feats.transpose(1, 2),                   # (B,C,N) view of the (B,N,C) tensor
-            "backbone_features_nlc": feats}
+    reg_ready = None
+    if PARALLEL_HEADS and GEOMETRY_AHEAD and not torch.cuda.is_current_stream_capturing():
+        main = torch.cuda.current_stream(rows.device)
+        aux = _side_streams(main)[2]
+        fork = torch.cuda.Event()
+        fork.record(main)
+        aux.wait_event(fork)
+        with torch.cuda.stream(aux):
+            rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
+            reg_ready = torch.cuda.Event()
+            reg_ready.record(aux)
+        rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
+        if not defer_reg_join:
+            main.wait_event(reg_ready)
+            reg_ready = None
+    else:
+        rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
+        rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
+    out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz,
+           "backbone_features": feats.transpose(1, 2),                   # (B,C,N) view of the (B,N,C) tensor
+           "backbone_features_nlc": feats}
+    if reg_ready is not None:
+        out["rpn_reg_ready"] = reg_ready
+    return out

@@ -46,18 +46,12 @@ def _hw_queue_cap() -> int:
         return 4
 
 
-_SLOT_STREAMS = {}      # device index -> the slot streams handed out so far
-
-
 def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
-    """stream of slot j on `device`: ONE pool per device, shared by every Stage1Pipeline of the process.  A HIP stream may claim
-    a hardware queue for as long as it lives, and beyond 23 queues in one process this runtime time-slices them (every kernel
-    1.4-1.6 x slower, measured); a second pipeline (another model, a re-capture, bench.py's side runs) therefore reuses the
-    streams of the first instead of adding `depth` more.  Pipelines that share streams simply serialise on them."""
-    pool = _SLOT_STREAMS.setdefault(device.index if device.index is not None else torch.cuda.current_device(), [])
-    while len(pool) <= j:
-        pool.append(torch.cuda.Stream(device=device))
-    return pool[j]
+    """stream of slot j on `device`: from the package's per-device pool (ws3d_amd/streams.py), shared by every Stage1Pipeline of
+    the process and by the eager forward's side streams -- a second pipeline (another model, a re-capture, bench.py's side runs)
+    reuses the streams of the first instead of adding `depth` more hardware queues."""
+    from .streams import pooled_stream
+    return pooled_stream(device, j)
 
 
 class Stage1Pipeline:
@@ -94,7 +88,7 @@ class Stage1Pipeline:
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
     def body(self, pts: torch.Tensor) -> dict:
-        out = self.model.rpn_forward({"pts_input": pts})
+        out = self.model.rpn_forward({"pts_input": pts, "defer_reg_join": True})     # (proposals_from_rpn waits for rpn_reg)
         boxes, scores, count, enlarged = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True)
         res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count}
         if self.roipool:

@@ -159,7 +159,8 @@ class Stage1Net(nn.Module):
             if ok is None:
                 ok = self.__dict__["_fastpath_ok"] = fastpath.supported(self)
             if ok:
-                return fastpath.rpn_forward(self, pts)
+                # 'defer_reg_join': see fastpath.rpn_forward (the caller promises to wait for out['rpn_reg_ready'] before reading rpn_reg)
+                return fastpath.rpn_forward(self, pts, bool(input_data.get('defer_reg_join', False)))
         with torch.set_grad_enabled(self.training):
             return dict(self.rpn(input_data))
 
@@ -205,6 +206,14 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
     K = cfg.rpn_post_nms_top_n
     h, w, l = cfg.cls_mean_size
     score = torch.sigmoid(cls[:, :, 0])                                                   # (B,N)
+    top = min(cfg.rpn_pre_nms_top_n, N)
+    sc = order = None
+    if xyz.is_cuda and N <= 16384:     # one LDS-resident sort per scene instead of topk's select + gather + merge sort
+        from . import compat as _C
+        sc, order = _C.topk_sorted(score.contiguous(), top)      # (scores only: runs beside the regression head when that is deferred)
+    ready = out.get('rpn_reg_ready')
+    if ready is not None:
+        torch.cuda.current_stream(xyz.device).wait_event(ready)   # fastpath.rpn_forward(defer_reg_join=True): rpn_reg comes from a side stream
     if xyz.is_cuda:
         from . import compat as _C        # one kernel instead of ~25 tiny torch launches; bit-identical
         box = _C.decode_center_boxes(xyz.contiguous(), reg.contiguous(), cfg.loc_scope, cfg.loc_bin_size, (h, w, l))
@@ -214,10 +223,7 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
         ry = synthetic_orientation(N, xyz.device).unsqueeze(0).expand(B, N)
         box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h),
                            torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
-    top = min(cfg.rpn_pre_nms_top_n, N)
-    if xyz.is_cuda and N <= 16384:     # one LDS-resident sort per scene instead of topk's select + gather + merge sort
-        sc, order = _C.topk_sorted(score.contiguous(), top)
-    else:
+    if sc is None:
         sc, order = torch.topk(score, top, dim=1, sorted=True)                            # (B,top)
     if xyz.is_cuda and top >= K and fused:
         # two launches instead of ~25: rows in score order + BEV rectangles, NMS, then the padded survivors (+ the rows
