@@ -57,7 +57,7 @@ FAMILIES = {
     "sa_mlp3_pool_lists": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
     "pgather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "pgather_gemm2_compact": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
     "pgather_rows": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "gather_gemm": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
-    "gather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "gather_gemm3_pool": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
+    "gather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
     "gemm_pool": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)", "gemm_pool_compact": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
     "rowmax_rows": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
     "three_nn_wrapper": "three_nn (+ weights)", "three_nn_with_weights": "three_nn (+ weights)",

@@ -204,16 +204,6 @@ WS3D_API int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, int
                       const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1, const float *w2t,
                       const float *b2, int relu2, float *out, ws3d_stream_t stream);
 
-/* A whole three-layer SharedMLP of a set-abstraction scale with the grouping in front and the max over nsample behind, in one
- * kernel: ws3d_gather_gemm2 followed by layer 3 (w3t (o2, o3)) and the pool of ws3d_gemm_pool; both activations stay in LDS,
- *   out[(scene, centre), 0:o3] = relu3?( max_s ( layer3(layer2(layer1(grouped row))) ) + b3 )      (out row stride out_stride)
- * nsample 16 | 32, o1 in {64, 128}, o3 % 128 == 0, a tile of (o1 + o2) x 65 floats + 8 KB within 150 KB of LDS; other shapes return
- * WS3D_E_UNSUPPORTED (the caller uses ws3d_gather_gemm2 + ws3d_gemm_pool).  ws3d extension, used by ws3d_amd/fastpath.py.   */
-WS3D_API int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_feat, int o1, int o2, int o3, const float *feats, const float *xyz,
-                           const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1,
-                           const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3, int relu3,
-                           float *out, int out_stride, ws3d_stream_t stream);
-
 /* Layer 1 of a set-abstraction SharedMLP without its per-pair product: W [f_j ; x_j - c] = W_f f_j + W_x (x_j - c), and
  * P = feats @ W_f (b * n rows, o1 columns at row stride p_stride: ONE GEMM over the points of a scene, by the caller) replaces the
  * product over the b * m * nsample (centre, sample) pairs.  Per pair: gather P's row of the neighbour, add the three-term xyz

@@ -194,7 +194,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
 
     def qg_tap(radius, nsample, xyz, new_xyz, features=None, use_xyz=True, return_idx=False, sorted_xyz=None):
         out, idx = orig_qg(radius, nsample, xyz, new_xyz, features, use_xyz, return_idx=True, sorted_xyz=sorted_xyz)
-        bq_log.append((xyz.size(1), _sha(idx.cpu().numpy().astype(np.int32))))
+        bq_log.append((xyz.size(1), nsample, _sha(idx.cpu().numpy().astype(np.int32))))
         return (out, idx) if return_idx else out
 
     orig_nlc = compat.query_and_group_nlc
@@ -202,21 +202,21 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     def nlc_tap(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=True, sorted_xyz=None, idx_out=None):
         idx = torch.empty((xyz.size(0), new_xyz.size(1), nsample), dtype=torch.int32, device=xyz.device)
         out = orig_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz, sorted_xyz, idx)
-        bq_log.append((xyz.size(1), _sha(idx.cpu().numpy().astype(np.int32))))
+        bq_log.append((xyz.size(1), nsample, _sha(idx.cpu().numpy().astype(np.int32))))
         return out
 
     orig_bq = compat.ball_query_wrapper
 
     def bq_tap(b, n, m, radius, nsample, new_xyz, xyz, idx, sorted_xyz=None):     # the gather-GEMM path asks for the lists only
         r = orig_bq(b, n, m, radius, nsample, new_xyz, xyz, idx, sorted_xyz)
-        bq_log.append((n, _sha(idx.cpu().numpy().astype(np.int32))))
+        bq_log.append((n, nsample, _sha(idx.cpu().numpy().astype(np.int32))))
         return r
 
     orig_bql = compat.ball_query_lists
 
     def bql_tap(radius, nsample, xyz, new_xyz, sorted_xyz=None):                  # ... through the entry that needs no cleared idx
         idx = orig_bql(radius, nsample, xyz, new_xyz, sorted_xyz)
-        bq_log.append((xyz.size(1), _sha(idx.cpu().numpy().astype(np.int32))))
+        bq_log.append((xyz.size(1), nsample, _sha(idx.cpu().numpy().astype(np.int32))))
         return idx
 
     orig_bqp = compat.ball_query_pairs
@@ -224,7 +224,7 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     def bqp_tap(radius, nsample, xyz, new_xyz, sorted_grid, total=None):          # ... or with their compact pairs in the same launch
         both = orig_bqp(radius, nsample, xyz, new_xyz, sorted_grid, total)
         if both is not None:
-            bq_log.append((xyz.size(1), _sha(both[0].cpu().numpy().astype(np.int32))))
+            bq_log.append((xyz.size(1), nsample, _sha(both[0].cpu().numpy().astype(np.int32))))
         return both
 
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
@@ -251,8 +251,9 @@ def test_gpu_stage1_forward_matches_reference_harness(meta, channels_last):
     assert len(fps_log) == 4 and len(bq_log) == 8
     for i in range(4):
         np.testing.assert_array_equal(fps_log[i], gold[f"fps_idx_{i}"])
-    # the channels-last path issues the searches of levels 2-4 ahead of level 1's (side streams): back into level order
-    assert [h for _, h in sorted(bq_log, key=lambda e: -e[0])] == case["ball_query_sha256"]
+    # the channels-last path issues the searches of levels 2-4 ahead of level 1's and the second scale of a level ahead of the
+    # first (side streams): back into level / scale order (nsample 16, then 32)
+    assert [h for _, _, h in sorted(bq_log, key=lambda e: (-e[0], e[1]))] == case["ball_query_sha256"]
     for name in ("rpn_cls", "rpn_reg", "backbone_xyz", "backbone_features"):
         arr = out[name].cpu().numpy()
         assert list(arr.shape) == case["outputs"][name]["shape"]

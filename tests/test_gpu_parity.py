@@ -1906,51 +1906,6 @@ def test_interp_gemm_tile_variants_subprocess(tile):
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),
-                                                  (1, 1024, 256, 16, 256, 128, 196, 256, 1.0), (1, 1024, 256, 32, 256, 128, 196, 256, 2.0),
-                                                  (1, 512, 64, 16, 8, 64, 20, 128, 1.0)])
-def test_gather_gemm3_pool_equals_three_layers_and_pool(ops, B, N, M, ns, C, O1, O2, O3, r):
-    """ws3d_gather_gemm3_pool (grouping + the three SharedMLP layers + max over nsample in one kernel, both activations in LDS)
-    against the float64 chain, and against ws3d_gather_gemm2 + ws3d_gemm_pool; written into a column slice of a wider matrix;
-    O2 off the k-tile (196, 20: the zero-padded tail of layer 3's k dimension)"""
-    rng = np.random.default_rng(15)
-    pc = synth.make_batch("lidar", B, 16384, 64)[:, :N, :3].copy()
-    xyz = dev(pc)
-    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
-    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
-    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
-    nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
-    ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, ops.c.sort_points_x(xyz))
-    w1 = dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)); b1 = dev(rng.standard_normal(O1).astype(np.float32))
-    w2 = dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)); b2 = dev(rng.standard_normal(O2).astype(np.float32))
-    w3 = dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)); b3 = dev(rng.standard_normal(O3).astype(np.float32))
-    out = torch.full((B * M, O3 + 64), 7.0, device="cuda")
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True, w3, b3, True, out, 64)
-    assert bool((out[:, :64] == 7.0).all())
-    li = nbr.long()
-    gx = torch.gather(xyz, 1, li.view(B, M * ns, 1).expand(B, M * ns, 3)).view(B, M, ns, 3) - new_xyz.unsqueeze(2)
-    gf = torch.gather(feats, 1, li.view(B, M * ns, 1).expand(B, M * ns, C)).view(B, M, ns, C)
-    x = torch.cat((gf, gx), dim=3).view(-1, C + 3).double()
-    h = torch.relu(x @ w1.double() + b1.double())
-    h = torch.relu(h @ w2.double() + b2.double())
-    want = torch.relu(h @ w3.double() + b3.double()).view(B * M, ns, O3).amax(dim=1)
-    err = (out[:, 64:].double() - want).abs().max().item()
-    scale = max(want.abs().max().item(), 1.0)
-    assert err <= 1.5e-5 * scale * np.sqrt(max(C, 96) / 96), (err, scale)
-    if O2 % 4 == 0 and O3 % 64 == 0:
-        two = ops.c.gather_gemm2(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True)
-        ref = torch.empty((B * M, O3), device="cuda")
-        assert ops.c.gemm_pool(two, w3, b3, True, ns, ref, 0)
-        assert (out[:, 64:] - ref).abs().max().item() <= 2e-5 * scale
-    # no bias, no activation on the last layer
-    out2 = torch.empty((B * M, O3), device="cuda")
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1, b1, True, w2, b2, True, w3, None, False, out2, 0)
-    want2 = (h @ w3.double()).view(B * M, ns, O3).amax(dim=1)
-    assert (out2.double() - want2).abs().max().item() <= 1.5e-5 * max(want2.abs().max().item(), 1.0) * np.sqrt(max(C, 96) / 96)
-    # declined shapes
-    assert ops.c.gather_gemm3_pool(feats, xyz, new_xyz, nbr[:, :, :ns - 1].contiguous(), w1, b1, True, w2, b2, True, w3, b3, True, out2, 0) is False
-
-
 def test_fast_path_switches_agree(ops):
     """the optional fusions of the inference fast path (whole-SharedMLP kernel at SA2 / SA3, two-layer heads, two-layer
     gather-GEMM, fused interpolation) switched on and off: the network's outputs agree to fp32 round-off of the matrix products
@@ -1962,7 +1917,7 @@ def test_fast_path_switches_agree(ops):
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_GATHER_GEMM3", "FUSED_GATHER_GEMM3_MAX_O1", "FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS")
+    names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -1972,14 +1927,16 @@ def test_fast_path_switches_agree(ops):
             out = model.rpn_forward({"pts_input": pts})
         return out["rpn_cls"].clone(), out["rpn_reg"].clone()
     try:
-        base = run(FUSED_GATHER_GEMM3=False, FUSED_MLP2_ROWS=False, FUSED_GATHER_GEMM2=False, FUSED_INTERP_GEMM=False, PER_POINT_L1=False, PER_POINT_FP=False, COMPACT_PAIRS=False)
+        off = {"FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False,
+               "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False}
+        base = run(**off)
         scale = [float(t.abs().max()) for t in base]
-        for kw in ({"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 64}, {"FUSED_GATHER_GEMM3": True, "FUSED_GATHER_GEMM3_MAX_O1": 128},
-                   {"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
-                   {"FUSED_GATHER_GEMM3": True, "FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
+        for kw in ({"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
+                   {"SA1_FROM_LISTS": True}, {"SA1_FROM_LISTS": True, "COMPACT_PAIRS": True, "PER_POINT_L1": True}, {"PARALLEL_SCALES": True, "PARALLEL_HEADS": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True},
+                   {"FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
-            got = run(**dict({"FUSED_GATHER_GEMM3": False, "FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False}, **kw))
+            got = run(**dict(off, **kw))
             for g, b, s in zip(got, base, scale):
                 assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
     finally:

@@ -79,7 +79,6 @@ SIGNATURES = {
     "ws3d_radius_nms_batched": (_i, [_i, _i, _vp, _f, _i, _vp, _sz, _vp, _vp, _vp]),
     "ws3d_gather_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_gather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
-    "ws3d_gather_gemm3_pool": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "ws3d_pgather_gemm2": (_i, [_i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, C.c_long, _vp]),
     "ws3d_pgather_rows": (_i, [_i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_qinterp_rows": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),

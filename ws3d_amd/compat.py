@@ -450,31 +450,6 @@ def gather_gemm2(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2t, b2
     return out
 
 
-def gather_gemm3_pool(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, b1, relu1, w2t, b2, relu2, w3t, b3, relu3, out2d, col_offset):
-    """a whole three-layer SharedMLP with the grouping in front and the max over nsample behind: writes
-    out2d[:, col_offset : col_offset + O3] (out2d (B*M, W) row-major) and returns True, or False when the shape is not covered
-    (ns 16 | 32, C % 4, O1 in {64, 128}, O2 % 4, O3 % 128, LDS tile <= 150 KB).  ws3d extension."""
-    dev = _dev(feats, xyz, new_xyz, nbr, w1t_feat_then_xyz, w2t, w3t, out2d)
-    _f32(feats, "feats"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _i32(nbr, "nbr"); _f32(w1t_feat_then_xyz, "w1t"); _f32(w2t, "w2t")
-    _f32(w3t, "w3t"); _f32(out2d, "out2d")
-    B, N, C = feats.shape
-    M, ns = nbr.size(1), nbr.size(2)
-    O1, O2, O3 = w1t_feat_then_xyz.size(1), w2t.size(1), w3t.size(1)
-    rows = B * M * ns
-    o2p = -(-O2 // 16) * 16
-    lds = 4 * max(2 * 16 * 65 + 2 * 16 * O1, (O1 + o2p) * 65 + 2 * 16 * 64)
-    if (ns not in (16, 32) or C % 4 or O1 not in (64, 128) or O2 % 4 or O3 % 128 or rows % 64 or lds > 150 * 1024 or
-            w1t_feat_then_xyz.size(0) != C + 3 or w2t.size(0) != O1 or w3t.size(0) != O2 or out2d.dim() != 2 or out2d.size(0) != B * M or
-            out2d.stride(1) != 1 or col_offset < 0 or col_offset + O3 > out2d.size(1) or not feats.is_contiguous() or
-            not w1t_feat_then_xyz.is_contiguous() or not w2t.is_contiguous() or not w3t.is_contiguous()):
-        return False
-    with _on(dev):
-        check(_lib.load().ws3d_gather_gemm3_pool(B, N, M, ns, C, O1, O2, O3, _p(feats), _p(xyz), _p(new_xyz), _p(nbr), _p(w1t_feat_then_xyz),
-                                                 _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(w3t), _p(b3), int(bool(relu3)),
-                                                 out2d.data_ptr() + 4 * col_offset, out2d.stride(0), _stream()), "gather_gemm3_pool")
-    return True
-
-
 def pgather_gemm2(pmat, col0, o1, xyz, new_xyz, nbr, w1x, b1, relu1, w2t, b2, relu2, out=None, gate=None):
     """layer 1 from the per-point product P = feats @ W_f (pmat (B*N, W) row-major, this scale's columns col0 .. col0 + o1) +
     the xyz term (w1x (3, o1)) + bias + ReLU, then layer 2 (w2t (o1, O2)): -> (B*M*ns, O2), or None when the shape is not

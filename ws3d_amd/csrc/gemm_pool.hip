@@ -1308,38 +1308,6 @@ extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, i
     return check_launch("ws3d_gather_gemm2");
 }
 
-extern "C" int ws3d_gather_gemm3_pool(int b, int n, int m, int nsample, int c_feat, int o1, int o2, int o3, const float *feats, const float *xyz,
-                                      const float *new_xyz, const int32_t *nbr, const float *w1t, const float *b1, int relu1,
-                                      const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3, int relu3,
-                                      float *out, int out_stride, ws3d_stream_t stream) {
-    using namespace ws3d;
-    const long rows = (long)b * m * nsample;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(w1t) | reinterpret_cast<uintptr_t>(w2t) |
-                         reinterpret_cast<uintptr_t>(w3t);
-    const size_t o2p = (size_t)(o2 + GP_KT - 1) / GP_KT * GP_KT;
-    const size_t p1 = (size_t)2 * GP_KT * GP_XS + (size_t)2 * GP_KT * o1, p2 = ((size_t)o1 + o2p) * GP_XS + (size_t)2 * GP_KT * 64;
-    const size_t lds = sizeof(float) * (p1 > p2 ? p1 : p2);
-    if (b < 0 || n <= 0 || m <= 0 || (nsample != 16 && nsample != 32) || c_feat <= 0 || (c_feat & 3) || (o1 != 64 && o1 != 128) || o2 <= 0 ||
-        (o2 & 3) || o3 <= 0 || (o3 & 127) || (rows & 63) || !feats || !xyz || !new_xyz || !nbr || !w1t || !w2t || !w3t || !out ||
-        out_stride < o3 || (al & 15) || lds > 150 * 1024) {
-        set_error("ws3d_gather_gemm3_pool: unsupported shape (b=%d n=%d m=%d ns=%d c=%d o1=%d o2=%d o3=%d; ns 16|32, c, o2 %% 4, o1 in {64,128}, "
-                  "o3 %% 128, rows %% 64, tile <= 150 KB of LDS)", b, n, m, nsample, c_feat, o1, o2, o3);
-        return WS3D_E_UNSUPPORTED;
-    }
-    if (rows == 0) return WS3D_OK;
-#define WS3D_GG3(NB, NS)                                                                                                               \
-    {                                                                                                                                  \
-        if (lds > 64 * 1024)                                                                                                           \
-            (void)hipFuncSetAttribute((const void *)gather_gemm2_kernel<NB, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((gather_gemm2_kernel<NB, NS>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), c_feat, o2, n, m, nsample, \
-                           feats, xyz, new_xyz, nbr, w1t, b1, relu1, w2t, b2, relu2, out, o3, w3t, b3, relu3, out_stride);              \
-    }
-    if (o1 == 64) { if (nsample == 16) WS3D_GG3(1, 16) else WS3D_GG3(1, 32) }
-    else          { if (nsample == 16) WS3D_GG3(2, 16) else WS3D_GG3(2, 32) }
-#undef WS3D_GG3
-    return check_launch("ws3d_gather_gemm3_pool");
-}
-
 extern "C" int ws3d_pgather_gemm2(int b, int n, int m, int nsample, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                   const float *new_xyz, const int32_t *nbr, const float *w1x, const float *b1, int relu1,
                                   const float *w2t, const float *b2, int relu2, float *out, const int32_t *gate, long gate_limit, ws3d_stream_t stream) {

@@ -35,11 +35,6 @@ FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
 GEOMETRY_IN_CAPTURE = os.environ.get("WS3D_GEOMETRY_IN_CAPTURE", "0") != "0"  # ... also while a hipGraph is captured (fork / join inside the graph)
-# ws3d_gather_gemm3_pool: grouping + 3 layers + pool in one kernel.  OFF by default: at SA2 it is faster alone (62 vs 72 and 146 vs
-# 156 us per batch of 8) and 10-30 us off the latency, but the 20-deep pipeline loses 1.5 % with it (5,029 / 4,961 vs 5,076 / 5,092
-# scenes/s, ABAB on one box: 50 KB of LDS per workgroup leave less room beside the other streams' kernels); SA3 is slower either way
-FUSED_GATHER_GEMM3 = os.environ.get("WS3D_FUSED_GATHER_GEMM3", "0") != "0"
-FUSED_GATHER_GEMM3_MAX_O1 = int(os.environ.get("WS3D_FUSED_GATHER_GEMM3_MAX_O1", "64"))  # widest first layer it takes (SA2: 64, SA3: 128)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
 COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # lists fuller than this (distinct rows / all rows) take the dense kernels
 COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # the SharedMLPs over the distinct (centre, sample) pairs only (0: all m * nsample rows)
@@ -413,9 +408,6 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
                         _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
                     return
-            if (FUSED_GATHER_GEMM3 and len(blocks) == 3 and blocks[0].conv.out_channels <= FUSED_GATHER_GEMM3_MAX_O1 and
-                    _C.gather_gemm3_pool(feats, xyz, new_xyz, nbr, wt1, b1, r1, *_row_weights(blocks[1]), *_row_weights(blocks[2]), out, col)):
-                return       # the whole SharedMLP + pool in one kernel: only the pooled rows reach HBM
             y = None
             rest = blocks[1:-1]
             if FUSED_GATHER_GEMM2 and len(blocks) >= 3 and blocks[0].conv.out_channels <= 128:
