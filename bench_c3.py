@@ -33,6 +33,16 @@ def _qg_bytes(cfg):
     return tot
 
 
+def _bq_bytes(cfg):
+    """lists only (+ their pair table): points and centres in, nsample indices per centre out, up to two ints per list entry of pairs"""
+    n, tot = cfg.num_points, 0
+    for k, m in enumerate(cfg.npoints):
+        for ns in cfg.nsample[k]:
+            tot += (n + m) * 12 + m * ns * 4 * 3
+        n = m
+    return tot
+
+
 def _interp_bytes(cfg):
     pts = [cfg.num_points] + list(cfg.npoints)
     chans = [sum(mm[-1] for mm in cfg.mlps[k]) for k in range(4)]      # 96, 256, 512, 1024
@@ -51,7 +61,7 @@ def _interp_bytes(cfg):
 FAMILIES = {
     "furthest_point_sampling_gather": "fps level 1 (16384 -> 4096)", "furthest_point_sampling_nested": "fps levels 2-4 (verified prefix)",
     "sort_points_x": "binning (grid / x slabs / xz grid)", "sort_points_xz": "binning (grid / x slabs / xz grid)",
-    "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
+    "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "ball_query_pairs": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
     "compact_pairs": "pair compaction",
     "sa_mlp3_pool": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)", "sa_mlp3_pool_compact": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
     "sa_mlp3_pool_lists": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
@@ -260,7 +270,7 @@ class C3:
         n1, m1 = cfg.num_points, cfg.npoints[0]
         fps1_b = (m1 - 1) * n1 * 12 + m1 * 4
         alg = {"fps level 1 (16384 -> 4096)": fps1_b * B, "fps levels 2-4 (verified prefix)": (_fps_model_bytes(cfg) - fps1_b) * B,
-               "ball_query": _qg_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn (+ weights)": nn_b * B,
+               "ball_query": _bq_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn (+ weights)": nn_b * B,
                "FP first layer (interpolate + add, own kernels)": interp_b * B, "roipool3d": roi_b * B,
                "nms(mask+sweep)": (cfg.rpn_pre_nms_top_n * 20 + cfg.rpn_pre_nms_top_n * 141 * 8) * B}
         rows = []

@@ -49,6 +49,9 @@ PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: fi
 FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
+# levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
+# the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
+GRID_MIN_N = int(os.environ.get("WS3D_GRID_MIN_N", "256"))
 PARALLEL_SCALES = os.environ.get("WS3D_PARALLEL_SCALES", "1") != "0"  # eager side-stream mode: the second scale of a level beside the first
 PARALLEL_HEADS = os.environ.get("WS3D_PARALLEL_HEADS", "1") != "0"  # ... and the regression head beside the classification head + top-k
 
@@ -307,7 +310,7 @@ class _Geometry:
             # after level 1's sampling, and the 3-NN of FP1 (131072 queries) in front of level 2's lists was on its path
             for i in range(1, len(sas)):
                 s_search.wait_event(fps_done[i])                                     # level i + 1 exists
-                srt = pn2_ops.sort_points_x(self.xyz[i])
+                srt = pn2_ops.sort_points_x(self.xyz[i], GRID_MIN_N)
                 self.sorted.append(srt)
                 self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i], zeros))
                 ev = torch.cuda.Event()
@@ -345,7 +348,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat, zeros)
     else:
         _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
-        sorted_xyz = pn2_ops.sort_points_x(xyz)
+        sorted_xyz = pn2_ops.sort_points_x(xyz, GRID_MIN_N)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat, zeros)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
     if not COMPACT_PAIRS:
