@@ -221,6 +221,7 @@ class C2:
         from ws3d_amd import compat, synth
         self.c = compat
         self.B = batch
+        self.kind = kind
         pc = np.empty((batch, N_PTS, 4), dtype=np.float32)
         for s in range(batch):
             seed = 1000 * 2 + rank * batch + s
@@ -256,20 +257,22 @@ class C2:
     def kernel_table(self):
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
-        pair = self.B > 256
-        fps_row = {"name": ("fps_v3_kernel<32,512,ZLDS> (dense sweep, two scenes per CU)" if pair else "fps_bucket_kernel (pruned, one scene per CU)") +
-                           " (furthest_point_sample + gather)", "ms_per_step": fps,
+        # round 3: fps_rounds_kernel (fps_bucket.hip) at every batch size -- one scene per CU, ceil(B / 256) waves of workgroups; 4.96 ms
+        # per 512 scenes against 6.10 ms of the dense two-scenes-per-CU kernel (profiles/r03_fps_rounds_ab.txt)
+        pmc = fps_valu_pmc(self.B, self.kind)
+        fps_row = {"name": "fps_rounds_kernel<16> (exact pruned sampling, several certified samples per record exchange; one scene per CU, "
+                           "%d wave(s) of workgroups) (furthest_point_sample + gather)" % -(-self.B // 256), "ms_per_step": fps,
                    "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
+                   "physical_lane_instr_per_step": None if pmc is None else pmc["sq_insts_valu_per_launch"] * 64.0,
+                   "us_per_sample": fps * 1e3 / (M_PTS - 1) / -(-self.B // 256),
                    "alg_bytes_per_step": a_model_fps() * self.B,
-                   "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_v3_pair_kernel" if pair else "fps_bucket_kernel",
-                   "comment": "VALU-issue-bound: (M-1) dependent argmax steps over a scene that stays on chip (x, y, min-dist in VGPRs, z in LDS "
-                              "when two scenes share a CU); frac = %d VALU lane-instructions per point and step / (1024 SIMDs x 32 lanes/clk x 2.4 GHz). "
-                              "alg_bytes_per_step is SURVEY 8d's A_model (xyz re-read every step) -> effective_frac; real HBM traffic is ~A_min "
-                              "(traffic_bytes_per_launch)" % FPS_VALU_PER_POINT}
-        if not pair:
-            fps_row["comment"] = ("the exact PRUNED kernel (fps_bucket.hip): a step updates ~6 of 256 buckets, so lane_instr_per_step -- the dense "
-                                  "sweep's count -- overstates what is issued and valu_frac is a dense-equivalent rate, not occupancy; the step is "
-                                  "bound by its cross-lane chain (0.76 us).  The physical VALU roofline is that of the dense kernel (batch > 256)")
+                   "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_rounds_kernel",
+                   "comment": "chain-bound, not VALU-bound: a round of the kernel is box tests, bucket updates, a re-pick, a record exchange and the "
+                              "certification of up to 4 samples (fps_bucket.hip); pruning leaves ~1/4 of the dense sweep's instructions.  valu_frac = "
+                              "ISSUED wave64 VALU instructions x 64 lanes (SQ_INSTS_VALU of the committed --pmc pass of this batch and generator, "
+                              "profiles/traffic_fps_valu.json) / the duration measured here / the VALU issue roof; dense_equivalent_valu_frac counts "
+                              "the dense sweep's %d lane-instructions per point and step instead (what the VALU-bound dense kernel issues: 0.55-0.57 "
+                              "of the roof at 6.1 ms per 512 scenes, 1.23 x slower than this kernel)" % FPS_VALU_PER_POINT}
         return [
             fps_row,
             {"name": "bin_points_grid + ball_query_grid_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
@@ -328,7 +331,7 @@ class C5:
 
     def __init__(self, batch, rank, kind="lidar"):
         from ws3d_amd import compat, kitti_utils, synth
-        self.c, self.B = compat, batch
+        self.c, self.B, self.kind = compat, batch, kind
         pc = np.stack([synth.cloud(kind, self.N, 1000 * 5 + rank * batch + s) for s in range(batch)])
         boxes = synth.proposal_boxes(batch, self.M, 5)
         for b in range(batch):   # half of the proposals sit exactly on the synthetic cars (non-empty RoIs)
@@ -530,6 +533,17 @@ def step_percentiles(wl):
             "n": int(t.size)}
 
 
+def fps_valu_pmc(batch, kind):
+    """SQ_INSTS_VALU (wave64 VALU instructions per launch) of the level-1 sampling kernel at this batch and generator from the committed
+    --pmc pass (scripts/pmc_fps_valu.sh -> profiles/traffic_fps_valu.json), or None.  The count is a property of the data (same seeds
+    here and there), the duration is measured live."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "traffic_fps_valu.json"))).get("b%d_%s" % (batch, kind))
+        return e if e and e.get("sq_insts_valu_per_launch") else None
+    except Exception:
+        return None
+
+
 def _traffic_file(kernel_key):
     """'fps_zlds_kernel' -> (profiles/traffic.json, key); 'c5:roipool3d_kernel' -> (profiles/traffic_c5.json, key);
     'fps_bucket_valu:hdl64' -> (profiles/traffic_fps_bucket_valu.json, 'hdl64')"""
@@ -566,7 +580,12 @@ def finish_kernel_rows(kernels, scenes):
         k["achieved_GBps"] = k["alg_bytes_per_step"] / sec / 1e9 if sec > 0 else 0.0
         k["frac_of_8TBps"] = k["achieved_GBps"] * 1e9 / HBM_PEAK
         if k.get("bound") == "valu" and sec > 0:
-            k["valu_lane_instr_per_s"] = k["lane_instr_per_step"] / sec
+            k["dense_equivalent_valu_frac"] = k["lane_instr_per_step"] / sec / VALU_PEAK
+            phys = k.get("physical_lane_instr_per_step")
+            # physical = instructions actually issued (hardware counter of the committed pass) / the duration measured in this run;
+            # without a committed pass for this batch and generator only the dense-equivalent figure exists
+            k["valu_frac_is"] = "physical (SQ_INSTS_VALU x 64 / duration / roof)" if phys else "dense-equivalent (no committed --pmc pass for this batch / generator)"
+            k["valu_lane_instr_per_s"] = (phys if phys else k["lane_instr_per_step"]) / sec
             k["valu_frac"] = k["valu_lane_instr_per_s"] / VALU_PEAK
         tkey = k.pop("traffic_key", None)
         tr = load_traffic(tkey)
@@ -583,15 +602,19 @@ def roofline_of(k, where):
     r = {"kernel": k["name"], "measured_in": where, "ms_per_launch": k["ms_per_step"] / launches, "traffic": traffic}
     if k.get("bound") == "valu":
         r.update({"bound": "valu", "achieved": k["valu_lane_instr_per_s"] / 1e12, "peak": VALU_PEAK / 1e12, "unit": "Tlane-instr/s",
-                  "frac": k["valu_frac"], "lane_instr_per_launch": k["lane_instr_per_step"] / launches,
-                  "valu_instr_per_point_and_step": FPS_VALU_PER_POINT,
+                  "frac": k["valu_frac"], "frac_is": k.get("valu_frac_is"), "lane_instr_per_launch": k["valu_lane_instr_per_s"] * sec / launches,
+                  "dense_equivalent_frac": k.get("dense_equivalent_valu_frac"), "dense_sweep_lane_instr_per_launch": k["lane_instr_per_step"] / launches,
+                  "us_per_sample": k.get("us_per_sample"), "valu_instr_per_point_and_step_of_the_dense_sweep": FPS_VALU_PER_POINT,
                   "effective_frac": k["frac_of_8TBps"], "effective_GBps_a_model": k["achieved_GBps"],
                   "alg_bytes_per_launch_a_model": k["alg_bytes_per_step"] / launches,
                   "hbm_frac_physical": (traffic / (sec / launches) / HBM_PEAK) if traffic else None,
-                  "note": "FPS never re-reads the scene, so HBM does not bound it: frac = algorithmic VALU lane-instructions (8 per point "
-                          "and step) / duration / the VALU issue roof of MI355X_MICROARCH.md (wave64 instruction = 2 clk on a SIMD-32). "
-                          "effective_frac = SURVEY 8d's A_model bytes / duration / 8 TB/s (the north-star's accounting; may exceed 1 "
-                          "because nothing is re-read). traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json or null"})
+                  "note": "FPS never re-reads the scene, so HBM does not bound it; the roof that applies is VALU issue (MI355X_MICROARCH.md: a wave64 "
+                          "instruction = 2 clk on a SIMD-32).  frac = VALU lane-instructions ISSUED (hardware counter) / duration / that roof: the "
+                          "physical utilisation of a kernel that is deliberately NOT VALU-bound -- the sampling kernel of round 3 prunes ~3/4 of the "
+                          "dense sweep's instructions and is bound by its cross-lane chain; its figure of merit is us_per_sample.  dense_equivalent_frac "
+                          "= the dense sweep's instruction count (8 per point and step) / duration / roof: what a VALU-bound kernel would need to reach "
+                          "for the same speed.  effective_frac = SURVEY 8d's A_model bytes / duration / 8 TB/s (the north-star's accounting; exceeds 1 "
+                          "because nothing is re-read).  traffic = FETCH_SIZE+WRITE_SIZE per launch from profiles/traffic*.json or null"})
     else:
         r.update({"bound": "hbm", "achieved": k["achieved_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": k["frac_of_8TBps"],
                   "alg_bytes_per_launch": k["alg_bytes_per_step"] / launches,
@@ -786,15 +809,18 @@ def main():
             c3fps = next((k for k in kernels if k.get("bound") == "valu"), None)
             if c3fps is not None:
                 us = c3fps.get("us_per_fps_step")
-                pmc = load_traffic("fps_bucket_valu:" + args.kind)
+                e8 = fps_valu_pmc(wl.scenes(), args.kind)
+                pmc = None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0 / (c3fps["ms_per_step"] * 1e-3) / (VALU_PEAK * wl.scenes() / 256.0)
                 out["roofline"]["same_kernel_family_in_the_timed_c3_step"] = {
-                    "kernel": "fps_bucket_kernel (exact pruned sampling, level 1: 16384 -> 4096)", "ms_per_step_eager": c3fps["ms_per_step"],
-                    "workgroups": wl.scenes(), "us_per_fps_step": us, "clk_per_fps_step_at_2.4GHz": None if us is None else us * 2400.0,
+                    "kernel": "fps_rounds_kernel<16> (exact pruned sampling, several certified samples per exchange; level 1: 16384 -> 4096)",
+                    "ms_per_step_eager": c3fps["ms_per_step"],
+                    "workgroups": wl.scenes(), "us_per_sample": us, "clk_per_sample_at_2.4GHz": None if us is None else us * 2400.0,
                     "valu_share_of_occupied_CUs_pmc": pmc,
                     "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs (throughput mode overlaps 20 batches).  This kernel is "
-                            "chain-bound, not VALU-bound: its figure is the length of one sampling step (box test, bucket update, pick, record "
-                            "exchange), in us and clk; valu_share_of_occupied_CUs_pmc = SQ_INSTS_VALU x 2 clk / (4 SIMDs x busy clk) of the CUs it "
-                            "runs on, from the committed --pmc pass of this generator (profiles/traffic_fps_bucket_valu.json) or null"}
+                            "chain-bound, not VALU-bound: its figure is the time per sample (a round = box tests, bucket updates, re-pick, record "
+                            "exchange, certification of up to 4 samples; ~3.1 samples per round), in us and clk; valu_share_of_occupied_CUs_pmc = "
+                            "SQ_INSTS_VALU x 64 lanes / duration / the VALU roof of the 8 CUs it runs on, from the committed --pmc pass of this batch "
+                            "and generator (profiles/traffic_fps_valu.json) or null"}
             out["c2"] = c2blk
         else:
             out["roofline"] = roofline_of(dom, "the timed region (HIP events on the launch stream)")

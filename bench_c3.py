@@ -280,11 +280,14 @@ class C3:
                    "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None, "bound": "hbm"}
             if key.startswith("fps level 1"):
                 from bench import fps_lane_instr
+                from bench import fps_valu_pmc
+                e8 = fps_valu_pmc(B, self.kind)
                 row.update({"bound": "valu", "lane_instr_per_step": fps_lane_instr(n1, m1) * B, "us_per_fps_step": ms * 1e3 / (m1 - 1),
-                            "comment": "one workgroup per scene (8 of 256 CUs): the exact pruned kernel (fps_bucket.hip) on clouds this size.  "
-                                       "lane_instr_per_step is the DENSE sweep's count (8 per point and step) and valu_frac therefore a "
-                                       "dense-equivalent rate, not issue-slot occupancy: a step updates a few of 256 buckets and is bound by "
-                                       "its cross-lane chain -- us_per_fps_step is the figure to watch"})
+                            "physical_lane_instr_per_step": None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0,
+                            "comment": "one workgroup per scene (8 of 256 CUs): fps_rounds_kernel (fps_bucket.hip), exact pruned sampling with several "
+                                       "certified samples per record exchange.  Chain-bound: us_per_fps_step (time per sample) is the figure to "
+                                       "watch; valu_frac = issued VALU lane-instructions (committed --pmc pass) / duration / the WHOLE chip's roof, "
+                                       "lane_instr_per_step the dense sweep's count (8 per point and step)"})
             elif key.startswith("fps levels"):
                 row["comment"] = "1024 + 256 + 64 picks verified as the leading prefix of the previous level's order (fps_nested.hip)"
             elif key.startswith(("three_nn", "nms", "ball_query")):

@@ -647,8 +647,8 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             have = true;
         }
         FRP(2)
-        // ---- publish, then ONE wave certifies the samples of the round
-        if (lane == 0) {
+        // ---- publish (only a wave whose candidate changed: the records persist), then ONE wave certifies the samples of the round
+        if (repick && lane == 0) {
             rec[w] = make_float4(wv, wx, wy, wz);
             aux[w] = make_float4(ws2, __int_as_float(wpos), __int_as_float(wtie), 0.f);
         }
@@ -657,7 +657,9 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         FRP(4)
         if (w == 0) {
             float4 *selq = samples + j;
-            const float4 r = rec[lane & (NW - 1)], a = aux[lane & (NW - 1)];
+            const float4 r = rec[lane & (NW - 1)];                 // (both reads in flight before the first use)
+            const float4 a = aux[lane & (NW - 1)];
+            __builtin_amdgcn_sched_barrier(0);
             // every value compared below is >= 0 or a negative "nothing" mark (-1 no point, -2 / -3 unused): non-negative floats
             // order like their bit patterns, so the uniform comparisons run on the scalar unit
             float vcur = lane < NW ? r.x : -3.0f;     // candidates not used yet
@@ -786,6 +788,17 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 }
 
 size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
+
+// does the multi-sample kernel take this launch?  (fps.hip: it then serves every batch size -- 512 scenes in two waves of
+// workgroups take 4.96 ms against 6.10 ms of the dense two-scenes-per-CU kernel)
+bool fps_rounds_covers(int m) {
+#if FB_NW == 16 && !defined(FB_PROF)
+    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
+    return rounds != 0 && (size_t)m <= FR_SAMPLES_MAX_M;
+#else
+    return false;
+#endif
+}
 
 int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
                       int bs, int log2bs, int S, hipStream_t st) {
