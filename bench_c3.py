@@ -316,7 +316,7 @@ class C3:
     def scenes(self):
         return self.B
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, min_seconds=6.0):
         """The custom ops of ONE scene's Stage-1 forward on the CPU oracle port (the MLPs are
         torch/BLAS on both sides and are excluded): 4x FPS, 8x ball_query+group, 4x three_nn."""
         import oracle
@@ -337,7 +337,7 @@ class C3:
                 levels.append(new)
             for k in range(4, 0, -1):
                 oracle.three_nn_dist2(levels[k - 1], levels[k])
-        _, dt, reps = repeat_for(one_pass)
+        _, dt, reps = repeat_for(one_pass, min_seconds)
         oracle.set_threads(1)
         return {"value": ns * reps / dt, "unit": "scenes/s", "cores": threads, "kind": "port", "host": host_info(threads),
                 "sample": f"{ns} scenes (the batch tiled {reps_of_batch}x) x {reps} pass(es): the search ops of the Stage-1 forward "

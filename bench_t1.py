@@ -103,7 +103,7 @@ class T1:
     def path_gbps(self, scenes_per_s_per_gpu):
         return {"loss_last_step": None if self.last is None else self.last["loss"]}
 
-    def cpu_baseline(self):
+    def cpu_baseline(self, min_seconds=6.0):
         return {"value": None, "unit": "scenes/s", "cores": 0, "kind": "port",
                 "sample": "none: the oracle restates the operators (timed under --workload c2/c3), not the network's "
                           "library convolutions, so there is no CPU leg for a training iteration"}

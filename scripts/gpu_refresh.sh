@@ -1,8 +1,8 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun): full GPU test suite, the bench lines and the rocprofv3
 # evidence of one code state.  Everything lands in gpurun_out/refresh/; copy what should be
-# judged into profiles/ afterwards (see profiles/README.md).  Round 2: the default bench line is the
-# BASELINE headline (c3 + the c2 block).
+# judged into profiles/ afterwards (see profiles/README.md).  The default bench line is the BASELINE headline (c3 + the c2 block)
+# on the hdl64 generator (round 3); `--kind lidar` is the sparse generator of rounds 1-2.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/refresh
@@ -11,9 +11,10 @@ export TMPDIR=/tmp
 T="timeout 900"
 $T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 $T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-$T python bench.py --steps 160 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
-$T python bench.py --pipeline-depth 1 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
-GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
+$T python bench.py --kind lidar                               2>$OUT/bench_default_lidar.err | tail -1 > $OUT/bench_default_lidar.json
+$T python bench.py --steps 160 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
+$T python bench.py --pipeline-depth 1 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
+GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
 $T python bench.py --workload c2                              2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b512.json
 for b in 1 8 64 256 1024; do
   $T python bench.py --workload c2 --batch $b --no-cpu-baseline 2>>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b$b.json
@@ -49,9 +50,15 @@ for wl in c5:8; do
     $OUT/traffic_$w.json "$w batch $nb, bytes per launch, rocprofv3 --pmc in separate passes" $nb > /dev/null 2>>$OUT/pmc_${w}_WRITE_SIZE.log
 done
 # round-2 extras: FPS kernels side by side, the eager step's kernel timeline (side streams), roipool3d ablation, ubenches
-{ python scripts/ab_fps.py default; WS3D_FPS_BUCKET=0 python scripts/ab_fps.py dense 8x16384x4096 256x16384x4096 8x12345x3000; WS3D_FPS_BUCKET=1 python scripts/ab_fps.py pruned 512x16384x4096 256x8192x2048; } > $OUT/fps_ab.txt 2>/dev/null
+{ python scripts/ab_fps.py default; WS3D_FPS_BUCKET=0 python scripts/ab_fps.py dense 8x16384x4096 256x16384x4096 512x16384x4096 8x12345x3000; WS3D_FPS_ROUNDS=0 python scripts/ab_fps.py one-sample-per-exchange 8x16384x4096 256x16384x4096 512x16384x4096; } > $OUT/fps_ab.txt 2>/dev/null
+$T bash scripts/pmc_fps_valu.sh $OUT/pmc_fps hdl64 > $OUT/pmc_fps_valu.txt 2>&1
+$T bash scripts/ubench/fps_rounds_prof.sh > $OUT/fps_rounds_segments.txt 2>&1
+$T python scripts/graph_fork_debug.py > $OUT/graph_fork_join_stress.txt 2>&1
+$T python scripts/ubench/compact_vs_dense.py > $OUT/compact_vs_dense_dispatch.txt 2>&1
+for coop in 1 0; do WS3D_BQ_GRID_COOP=$coop $T python bench.py --no-cpu-baseline --no-side-runs --c2-batch 512 2>/dev/null | tail -1 > $OUT/bench_ab_ball_query_coop$coop.json; done
 rm -rf /tmp/tl; (cd /tmp && $T rocprofv3 --kernel-trace -d /tmp/tl -o t -- python $OLDPWD/scripts/host_issue_time.py > $OLDPWD/$OUT/host_issue_time.txt 2>&1)
-python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_bucket_kernel $OUT/c3_eager_timeline.txt > /dev/null 2>>$OUT/host_issue_time.txt
+python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_rounds_kernel $OUT/c3_eager_timeline.txt > /dev/null 2>>$OUT/host_issue_time.txt
+python scripts/host_issue_time.py > $OUT/host_issue_time_untraced.txt 2>&1
 $T bash scripts/ablate_roi.sh > $OUT/roipool3d_ablation.txt 2>&1
 $T bash scripts/ubench/fps_bucket_prof.sh > $OUT/fps_bucket_segments.txt 2>&1
 (cd scripts/ubench && hipcc -O3 --offload-arch=gfx950 row_copy.hip -o /tmp/row_copy 2>/dev/null && timeout 120 /tmp/row_copy) > $OUT/ubench_row_copy.txt 2>&1

@@ -1,5 +1,8 @@
 """SharedMLP of an SA2-shaped scale over the compact (distinct) pairs vs over all m * nsample rows, from sparse to full ball-query lists
-(the radius sets the fill): ws3d_pgather_gemm2(_compact) + ws3d_gemm_pool(_compact), incl. ws3d_compact_pairs."""
+(the radius sets the fill): ws3d_pgather_gemm2(_compact) + ws3d_gemm_pool(_compact), incl. the pair table -- and the device-side
+dispatch of round 3: both forms launched with their launch gates, the pair total of the batch decides in the kernels' prologues."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from ws3d_amd import compat as c, synth
 def timeit(f, n=20):
@@ -30,6 +33,16 @@ for r in (1.0, 3.0, 6.0, 12.0, 40.0):
     def run_compact():
         p = c.compact_pairs(nbr); comp.zero_()
         y = c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, p, w1x, b1, True, w2, b2, True); c.gemm_pool_compact(y, p, w3, b3, comp, 0)
-    run_dense(); run_compact(); torch.cuda.synchronize()
-    assert torch.equal(dense, comp)
-    print(f"radius {r:5.1f}: {100 * fill:5.1f} % of the rows distinct: dense {timeit(run_dense):6.1f} us, compact (incl. pair table + zeroing) {timeit(run_compact):6.1f} us, bit-identical")
+    disp = torch.zeros((B * M, O3), device="cuda")
+    limit = int(0.55 * B * M * ns)
+    def run_dispatch():     # what fastpath.sa_forward issues: lists + pair table in one launch, then both forms, gated
+        nb, p = c.ball_query_pairs(r, ns, xyz, new_xyz, srt); disp.zero_()
+        y = c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, p, w1x, b1, True, w2, b2, True, limit=limit); c.gemm_pool_compact(y, p, w3, b3, disp, 0, limit=limit)
+        c.pgather_gemm2(pmat, 0, O1, xyz, new_xyz, nb, w1x, b1, True, w2, b2, True, out=y, gate=(p[2], limit)); c.gemm_pool(y, w3, b3, True, ns, disp, 0, gate=(p[2], limit))
+    def run_lists():        # the search alone (its time is inside run_dispatch, not inside the two columns before it)
+        c.ball_query_pairs(r, ns, xyz, new_xyz, srt)
+    run_dense(); run_compact(); run_dispatch(); torch.cuda.synchronize()
+    assert torch.equal(dense, comp) and torch.equal(dense, disp)
+    td, tc, tx, tl = timeit(run_dense), timeit(run_compact), timeit(run_dispatch), timeit(run_lists)
+    print(f"radius {r:5.1f}: {100 * fill:5.1f} % of the rows distinct: dense {td:6.1f} us, compact (incl. pair table + zeroing) {tc:6.1f} us, "
+          f"device-side dispatch {tx - tl:6.1f} us (+ {tl:5.1f} us of search with the pair table; runs the {'compact' if fill <= 0.55 else 'dense'} form), bit-identical")

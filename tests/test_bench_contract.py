@@ -25,7 +25,13 @@ def run_bench(*flags):
 def test_default_line_is_the_baseline_headline():
     """no --workload: BASELINE.json's metric on configs[2] (c3) with latency + throughput modes, the c2 block and a
     physical roofline fraction"""
-    out = run_bench("--no-cpu-baseline", "--c2-batch", "64", "--pipeline-depth", "3")
+    out = run_bench("--cpu-baseline-seconds", "1", "--c2-batch", "64", "--pipeline-depth", "3")
+    for cpu in (out["cpu_baseline"], out["c2"]["cpu_baseline"]):
+        assert "error" not in cpu and cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1, cpu
+    assert out["c2"]["cpu_baseline"]["gpu_matches_oracle_on_sample"] is True
+    assert out["value_all_rows"] == out["all_rows"]["value"] > 0 and out["other_generator"]["generator"] == "lidar"
+    assert len(out["list_fill"]["scales"]) == 8 and all(0 < s_["fill"] <= 1 for s_ in out["list_fill"]["scales"])
+    assert "hdl64" in out["data"]
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert out["metric"] == base["metric"] and out["config"]["workload"].startswith("c3") and out["config"]["batch_per_gpu"] == 8
     assert out["throughput_mode"]["value"] == out["value"] and out["throughput_mode"]["batches_in_flight"] == 3
