@@ -275,8 +275,8 @@ class C2:
                               "of the roof at 6.1 ms per 512 scenes, 1.23 x slower than this kernel)" % FPS_VALU_PER_POINT}
         return [
             fps_row,
-            {"name": "bin_points_grid + ball_query_grid_kernel<fused> (ball_query + group + centre + cat)", "ms_per_step": qg,
-             "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_grid_kernel",
+            {"name": "bin_points_grid + ball_query_grid_coop_kernel<fused> (ball_query, one wave per centre, + group + centre + cat)", "ms_per_step": qg,
+             "launches_per_step": 2, "bound": "hbm", "alg_bytes_per_step": a_rest() * self.B, "traffic_key": "ball_query_grid_coop_kernel",
              "comment": "A_model == A_min for this kernel (every input read once, every output written once)"},
         ]
 

@@ -51,7 +51,7 @@ for wl in c5:8; do
 done
 # round-2 extras: FPS kernels side by side, the eager step's kernel timeline (side streams), roipool3d ablation, ubenches
 { python scripts/ab_fps.py default; WS3D_FPS_BUCKET=0 python scripts/ab_fps.py dense 8x16384x4096 256x16384x4096 512x16384x4096 8x12345x3000; WS3D_FPS_ROUNDS=0 python scripts/ab_fps.py one-sample-per-exchange 8x16384x4096 256x16384x4096 512x16384x4096; } > $OUT/fps_ab.txt 2>/dev/null
-$T bash scripts/pmc_fps_valu.sh $OUT/pmc_fps hdl64 > $OUT/pmc_fps_valu.txt 2>&1
+$T bash scripts/pmc_fps_valu.sh $OUT/pmc_fps > $OUT/pmc_fps_valu.txt 2>&1
 $T bash scripts/ubench/fps_rounds_prof.sh > $OUT/fps_rounds_segments.txt 2>&1
 $T python scripts/graph_fork_debug.py > $OUT/graph_fork_join_stress.txt 2>&1
 $T python scripts/ubench/compact_vs_dense.py > $OUT/compact_vs_dense_dispatch.txt 2>&1

@@ -6,13 +6,14 @@
 #   -> <out>/traffic_fps_valu.json  (copy to profiles/: bench.py reads profiles/traffic_fps_valu.json)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=${1:-gpurun_out/pmc_fps}; mkdir -p $OUT; export TMPDIR=/tmp
-KIND=${2:-hdl64}
+KINDS=${2:-"hdl64 lidar"}
 rm -f $OUT/fps_valu_rows.txt
+for KIND in $KINDS; do
 for b in 512 8; do
   for c in SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE; do
     rm -rf /tmp/pv_$c
     (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pv_$c -o pv -- python $OLDPWD/bench.py --workload c2 --kind $KIND --batch $b --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/log_${b}_$c.txt 2>&1)
-    python - "$(find /tmp/pv_$c -name '*.db' | head -1)" $c $b >> $OUT/fps_valu_rows.txt <<'PY'
+    python - "$(find /tmp/pv_$c -name '*.db' | head -1)" $c $b $KIND >> $OUT/fps_valu_rows.txt <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); c, b = sys.argv[2], sys.argv[3]
 try:
@@ -22,20 +23,21 @@ except Exception as e:
 dur = {r[0]: r[1] for r in db.execute("select name, avg(end-start) from kernels group by name").fetchall()}
 for name, v, n in rows:
     if "fps" in name:
-        print("%s\t%s\t%s\t%.6g\t%d\t%.4f" % (b, c, name.split("(")[0][:60], v, n, dur.get(name, 0) / 1e6))
+        print("%s\t%s\t%s\t%.6g\t%d\t%.4f\t%s" % (b, c, name.split("(")[0][:60], v, n, dur.get(name, 0) / 1e6, sys.argv[4]))
 PY
   done
 done
-python - $OUT $KIND <<'PY'
+done
+python - $OUT <<'PY'
 import json, sys
-out, kind = sys.argv[1], sys.argv[2]
-res = {"_note": "rocprofv3 --pmc, one counter per pass, bench.py --workload c2 --kind %s --batch B; values per launch (average over the traced launches); "
-                "sq_insts_valu = wave64 VALU instructions; physical VALU share = sq_insts_valu * 64 / duration / (1024 * 32 * 2.4e9)" % kind}
+out = sys.argv[1]
+res = {"_note": "rocprofv3 --pmc, one counter per pass, bench.py --workload c2 --kind K --batch B -> key bB_K; values per launch (average over the traced launches); "
+                "sq_insts_valu = wave64 VALU instructions; physical VALU share = sq_insts_valu * 64 / duration / (1024 * 32 * 2.4e9)"}
 for ln in open(out + "/fps_valu_rows.txt"):
     p = ln.rstrip("\n").split("\t")
-    if len(p) != 6:
+    if len(p) != 7:
         continue
-    b, c, name, v, n, ms = p
+    b, c, name, v, n, ms, kind = p
     e = res.setdefault("b%s_%s" % (b, kind), {"kernel": name})
     e[c.lower() + "_per_launch"] = float(v)
     e["traced_ms"] = float(ms)
