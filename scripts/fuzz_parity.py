@@ -14,8 +14,14 @@ host = lambda t: t.detach().cpu().numpy()
 
 
 def cloud(rng, B, N):
-    kind = rng.choice(["lidar", "uniform", "grid", "line"])
-    if kind in ("lidar", "uniform"):
+    kind = rng.choice(["lidar", "uniform", "grid", "line", "hdl64", "hdl64", "clump"])
+    if kind in ("hdl64", "clump"):     # KITTI's density (a prefix of a shuffled ray-cast scan is a uniform sub-sample of it); clump: thousands of points in a small cube
+        pc = np.stack([synth.hdl64_cloud(16384, int(rng.integers(1, 10 ** 6)))[np.arange(N) % 16384, :3] for _ in range(B)])
+        if kind == "clump" and N >= 64:
+            k = int(rng.integers(N // 8, N // 2))
+            for b_ in range(B):
+                pc[b_, rng.choice(N, k, replace=False)] = (np.array([3.0, 1.0, 12.0]) + rng.uniform(-0.3, 0.3, (k, 3))).astype(np.float32)
+    elif kind in ("lidar", "uniform"):
         pc = synth.make_batch(kind, B, N, int(rng.integers(1, 10 ** 6)), dup_frac=float(rng.choice([0, 0, 0.05, 0.5])))[:, :, :3].copy()
     elif kind == "grid":    # quantised coordinates: masses of exact distance ties
         pc = (rng.integers(0, 12, (B, N, 3)) * rng.choice([0.25, 0.5, 1.0])).astype(np.float32)
@@ -39,7 +45,15 @@ def one_round(rng):
     C = int(rng.choice([0, 1, 3, 8, 96]))
     feat = rng.standard_normal((B, C, N)).astype(np.float32) if C else None
     ref_bq = oracle.ball_query(r, ns, pc, cen)
-    srt = c.sort_points_x(dev(pc))
+    srt = c.sort_points_x(dev(pc), min_n=int(rng.choice([64, 2048])))
+    if srt is not None and ns <= 64:      # lists + compact pair table in one launch (fine-grid kernel): the lists, and the pairs as a multiset
+        both = c.ball_query_pairs(r, ns, dev(pc), dev(cen), srt)
+        assert both is not None and np.array_equal(host(both[0]), ref_bq), ("ball_query_pairs lists", B, N, M, r, ns)
+        T = int(both[1][2].item())
+        distinct = (np.diff(ref_bq.reshape(-1, ns), axis=1) > 0).sum(1) + 1
+        want = np.concatenate([np.stack([np.full(int(k_), c_), ref_bq.reshape(-1, ns)[c_, :int(k_)]], 1) for c_, k_ in enumerate(distinct)]) if M else np.zeros((0, 2))
+        got = np.stack([host(both[1][0])[:T], host(both[1][1])[:T]], 1)
+        assert T == len(want) and np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))]), ("ball_query_pairs table", B, N, M, r, ns)
     for s in ([None, srt] if srt is not None else [None]):
         out, nb = pn2_ops.query_and_group(r, ns, dev(pc), dev(cen), None if feat is None else dev(feat), True, return_idx=True, sorted_xyz=s)
         assert np.array_equal(host(nb), ref_bq), ("ball_query", B, N, M, r, ns, s is not None)
@@ -57,6 +71,9 @@ def one_round(rng):
             d2 = torch.empty((B, N, 3), device="cuda"); i3 = torch.empty((B, N, 3), dtype=torch.int32, device="cuda")
             c.three_nn_wrapper(B, N, M, dev(pc), dev(cen), d2, i3, s)
             assert np.array_equal(host(i3), ir) and np.array_equal(host(d2), d2r), ("three_nn", B, N, M, s is not None)
+            iw, ww_ = c.three_nn_with_weights(dev(pc), dev(cen), s)          # the one-launch form: same indices, weights of the same distances
+            rcp = 1.0 / (torch.sqrt(d2) + 1e-8)
+            assert torch.equal(iw, i3) and torch.equal(ww_, rcp / ((rcp[..., 0] + rcp[..., 1]) + rcp[..., 2]).unsqueeze(-1)), ("three_nn_w", B, N, M)
         Ck = int(rng.choice([4, 20, 128]))
         kf = rng.standard_normal((B, Ck, M)).astype(np.float32)
         w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)

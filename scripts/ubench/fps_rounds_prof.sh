@@ -21,6 +21,6 @@ for kind in ("hdl64", "lidar"):
     rounds = kh.sum()
     print("%s: %d rounds for %d samples = %.2f samples per round; rounds by number of samples (tie-round, 1, 2, 3, 4): %s" % (kind, rounds, M - 1, (M - 1) / rounds, [int(kh[k]) for k in (0, 1, 2, 3, 4)]))
     names = ["box tests", "updates", "re-pick", "publish", "wait A", "certify / idle", "wait B", "read samples"]
-    for w in (0, 1, 5, 15):
+    for w in (0, 5, 15):
         print("  wave %2d, clk per round: " % w + "  ".join("%s %.0f" % (names[k], t[w, k] / rounds) for k in range(8)) + "  | sum %.0f" % (t[w].sum() / rounds))
 PY

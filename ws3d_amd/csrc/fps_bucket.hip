@@ -568,7 +568,10 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #ifdef FR_PROF      // scripts/ubench/fps_rounds_prof.sh: per-wave clocks per segment and the samples per round, returned through `temp`
     long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long pt = clock64();
-#define FRP(k) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
+    // (only three waves carry the hooks: sixteen waves executing s_memtime at the same moment queue on the scalar memory path and
+    // the last one reads ~900 clk more than the first -- an artefact that would look like SIMD contention)
+    const bool prof_wave = w == 0 || w == 5 || w == 15;
+#define FRP(k) if (prof_wave) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
 #else
 #define FRP(k)
 #endif
