@@ -449,7 +449,7 @@ constexpr size_t FB_SMEM_BYTES = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_C
                                  sizeof(int) * FB_NW + 64;                   // the LDS layout both kernels share
 constexpr size_t FR_SAMPLES_OFF = (FB_SMEM_BYTES + 15) & ~(size_t)15;
 constexpr size_t FR_SAMPLES_MAX_M = 6144;      // m above this: the samples do not fit beside the sort tables (one sample per exchange then)
-static size_t fps_rounds_smem(int m) { return FR_SAMPLES_OFF + sizeof(float4) * (size_t)(m + FR_KMAX); }
+static size_t fps_rounds_smem(int m) { return FR_SAMPLES_OFF + sizeof(float4) * (size_t)(m + 8); }   // (the certification parks candidates up to 7 slots ahead)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
                                                            float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
     uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
     int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
     float *bbox = reinterpret_cast<float *>(hist + FB_CELLS);        // 256 * 6
-    float4 *rec = reinterpret_cast<float4 *>(bbox + 256 * 6);        // 16 records {v, x, y, z}, then 16 {s, pos, tie, -} (NW used)
+    float4 *rec = reinterpret_cast<float4 *>(bbox + 256 * 6);        // 16 records {x, y, z, sorted position}, then 16 {v, s, tie, -} (NW used)
     float4 *aux = rec + 16;
     unsigned *tiem = reinterpret_cast<unsigned *>(rec + 2 * 16);    // (layout of the kernel above: the launch shares its LDS size)
     int *posr = reinterpret_cast<int *>(tiem + 4);                     // [0] = number of samples of this round (-1: tie at its head)
@@ -575,6 +575,13 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #else
 #define FRP(k)
 #endif
+#ifdef FR_DUP       // scripts/ubench/fps_rounds_dup.sh: segment FR_DUP of every round is executed TWICE (each is idempotent: same results); the
+    // rise of the launch time over the plain build / the number of rounds = what that segment contributes to the round's critical path.
+    // (compile-time constant: the loop unrolls into a second copy of the segment, the asm keeps the copies from being merged)
+#define FR_REP(k) _Pragma("unroll") for (int rep_ = 0; rep_ < (FR_DUP == (k) ? 2 : 1); ++rep_, ({ asm volatile("" : "+v"(q0x), "+v"(q1x), "+v"(q2x), "+v"(q3x), "+v"(bmax) :: "memory"); }))
+#else
+#define FR_REP(k)
+#endif
     for (;;) {
 #ifdef FR_PROF
         if (j >= m) break;
@@ -584,9 +591,9 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         const int Ka = j >= m ? K - 1 : K;
         // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
         // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
-        unsigned need;
+        unsigned need = 0u;
 #define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
-        {
+        FR_REP(0) {
             float L = FR_BOX(q0x, q0y, q0z);                            // (independent chains: the samples' bounds overlap in the pipeline)
             if (Ka > 1) L = min_f32(FR_BOX(q1x, q1y, q1z), L);
             if (Ka > 2) L = min_f32(FR_BOX(q2x, q2y, q2z), L);
@@ -596,7 +603,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #undef FR_BOX
         FRP(0)
         bool repick = !have;
-        if (need) {
+        FR_REP(1) if (need) {
 #define FR_UPD(S)                                                                                      \
     if (need & (1u << (S))) {                                                                          \
         float d = sqdist3(px[S] - q0x, py[S] - q0y, pz[S] - q0z);                                      \
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         }
         FRP(1)
         if (j >= m) break;
-        if (repick) {
+        FR_REP(2) if (repick) {
             // the wave's candidate (the bucket holding the largest cached maximum, then the lane inside it) and the bound on the
             // rest of the wave: the largest maximum of the OTHER buckets, the largest OTHER value of the candidate's bucket
             const float wmax = SL <= 16 ? readlane_f(row16_max(bmax), 0) : wave_max(bmax);   // the cached maxima live in lanes 0 .. SL-1
@@ -652,59 +659,84 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         FRP(2)
         // ---- publish (only a wave whose candidate changed: the records persist), then ONE wave certifies the samples of the round
         if (repick && lane == 0) {
-            rec[w] = make_float4(wv, wx, wy, wz);
-            aux[w] = make_float4(ws2, __int_as_float(wpos), __int_as_float(wtie), 0.f);
+            rec[w] = make_float4(wx, wy, wz, __int_as_float(wpos));
+            aux[w] = make_float4(wv, ws2, __int_as_float(wtie), 0.f);
         }
         FRP(3)
-        lds_barrier();
+        FR_REP(4) lds_barrier();
         FRP(4)
-        if (w == 0) {
+        FR_REP(5) if (tid < NW) {
+            // ---- certification, by the first NW lanes of wave 0 (lane c = the candidate of wave c), on the vector unit and LDS only:
+            // every hop vector -> scalar -> vector (ballot, readlane with a computed lane, a compare feeding a select) costs a lone
+            // wave ~20 clk, and the sequential form of this block had ~40 of them (1,360 of a round's 4,600 clk).
             float4 *selq = samples + j;
-            const float4 r = rec[lane & (NW - 1)];                 // (both reads in flight before the first use)
-            const float4 a = aux[lane & (NW - 1)];
+            float4 *auxs = reinterpret_cast<float4 *>(red);        // the {v, s, tie} of the candidates in rank order
+            const float4 r = rec[lane];                            // {x, y, z, sorted position} (both reads in flight before the first use)
+            const float4 a = aux[lane];                            // {v, s, tie, -}
             __builtin_amdgcn_sched_barrier(0);
             // every value compared below is >= 0 or a negative "nothing" mark (-1 no point, -2 / -3 unused): non-negative floats
-            // order like their bit patterns, so the uniform comparisons run on the scalar unit
-            float vcur = lane < NW ? r.x : -3.0f;     // candidates not used yet
-            const unsigned tiemask = (unsigned)__ballot(__float_as_int(a.z) != 0 && lane < NW);
-            int bound = __float_as_int(-3.0f);           // bits of the largest s_w of the waves used so far
-            float dmin = INFINITY;                        // lane l: the smallest distance of wave l's candidate to the samples accepted so far
-            int nk = 0;
-            const int cap = min(FR_KMAX, m - j);
+            // order like their bit patterns, so all comparisons are integer comparisons -- done as sign bits of differences (marks
+            // clamped to -1: no overflow).
+            const int key = __float_as_int(a.x);
+            const int keyc = max(key, -1);
+            // rank of my candidate = the number of candidates above it: 15 row rotations, one sign bit each (equal values share a rank:
+            // a tie, the round stops there)
+            // (explicit v_sub_u32_dpp = rotated - own, checked on the device: the compiler folds `own - update_dpp(..)` into
+            // v_subrev_u32_dpp, which on this chip ALSO returns rotated - own -- the ranks came out upside down.  The order is
+            // reversed by complementing the keys instead: ~a < ~b <=> a > b.)
+            const int nkey = ~keyc;
+            unsigned above = 0u;
+#define FR_RANK(N, NOP)                                                                                                           \
+    {                                                                                                                             \
+        unsigned d_;                                                                                                              \
+        asm(NOP "v_sub_u32_dpp %0, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(d_) : "v"(nkey));                     \
+        above = __builtin_amdgcn_alignbit(above, d_, 31u);                                                                        \
+    }
+            FR_RANK(1, "s_nop 1\n\t") FR_RANK(2, "") FR_RANK(3, "") FR_RANK(4, "") FR_RANK(5, "") FR_RANK(6, "") FR_RANK(7, "") FR_RANK(8, "")
+            FR_RANK(9, "") FR_RANK(10, "") FR_RANK(11, "") FR_RANK(12, "") FR_RANK(13, "") FR_RANK(14, "") FR_RANK(15, "")
+#undef FR_RANK
+            const unsigned valid = ~(unsigned)(key >> 31);         // all ones for a candidate, 0 for a mark
+            const unsigned rk = min((unsigned)__builtin_popcount(above) | (~valid & 7u), 7u);   // marks and ranks >= 7 share slot 7, which nothing reads
+            static_assert(FR_KMAX <= 7, "rank slots");
+            // the candidates in rank order through LDS: the first FR_KMAX are the round's samples if they pass (slots past the
+            // accepted ones are never read as samples), all lanes read the leading ones back
+            selq[rk] = r;
+            auxs[rk] = a;
+            float dm = INFINITY;                                    // my candidate's smallest distance to the candidates of rank < i
+            int bound = -1;                                         // the largest s_w of the waves of rank < i
+            unsigned okw = 1u;                                      // bit i: my candidate would pass (b) and (c) AS rank i
 #pragma unroll
-            for (int k = 0; k < FR_KMAX; ++k) {
-                if (k >= cap) break;
-                const int vmb = __float_as_int(readlane_f(row16_max(vcur), 0));
-                if (vmb < 0) break;                                                   // no candidate left
-                const unsigned eq = (unsigned)__ballot(__float_as_int(vcur) == vmb) & WMASK;
-                const int sel = (int)__builtin_ctz(eq);
-                const bool tie = (eq & (eq - 1u)) != 0u || ((tiemask >> sel) & 1u) != 0u;
-                if (k == 0) {
-                    if (tie) { nk = -1; if (lane == 0) reinterpret_cast<int *>(selq)[0] = vmb; break; }
-                } else {
-                    // (b) beats everything the used waves still hold, (c) untouched by the samples accepted before it
-                    if (tie || !(vmb > bound) || !(__float_as_int(readlane_f(dmin, sel)) >= vmb)) break;
-                }
-                const float cx = readlane_f(r.y, sel), cy = readlane_f(r.z, sel), cz = readlane_f(r.w, sel);
-                if (k + 1 < FR_KMAX) {
-                    dmin = min_f32(sqdist3(r.y - cx, r.z - cy, r.w - cz), dmin);       // every candidate against this sample, lane-parallel
-                    vcur = lane == sel ? -3.0f : vcur;
-                }
-                bound = max(bound, __float_as_int(readlane_f(a.x, sel)));
-                {   // lanes 0-3 store one component each (a 16-byte store wants four consecutive registers: spills in this loop)
-                    const float pb = readlane_f(a.y, sel);
-                    const float comp = lane == 0 ? cx : (lane == 1 ? cy : (lane == 2 ? cz : pb));
-                    if (lane < 4) reinterpret_cast<float *>(selq + k)[lane] = comp;
-                }
-                nk = k + 1;
+            for (int i = 0; i + 1 < FR_KMAX; ++i) {
+                const float4 c = selq[i];
+                dm = min_f32(sqdist3(r.x - c.x, r.y - c.y, r.z - c.z), dm);
+                bound = max(bound, __float_as_int(auxs[i].y));
+                // (b) beats everything the waves of smaller rank still hold: key > bound; (c) untouched by the samples before it: dm >= key
+                okw |= ((((unsigned)bound - (unsigned)key) >> 31) & ~(((unsigned)__float_as_int(dm) - (unsigned)key) >> 31)) << (i + 1);   // (unsigned: wraps, stays arithmetic)
+            }
+            // per rank slot (a nibble): how many candidates hold it; 1 if its candidate passes, +2 if its wave flags a tie
+            unsigned w1 = (valid & 1u) << (4u * rk);
+            unsigned w2 = (((okw >> rk) & 1u) | (((unsigned)__float_as_int(a.z) & 1u) << 1)) << (4u * rk);      // (the flag is 0 or 1)
+#define FR_ROWSUM(CTRL)                                                                                           \
+    w1 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w1, CTRL, 0xF, 0xF, false);                             \
+    w2 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w2, CTRL, 0xF, 0xF, false);
+            FR_ROWSUM(DPP_QUAD_XOR1) FR_ROWSUM(DPP_QUAD_XOR2) FR_ROWSUM(DPP_ROW_HALF_MIRROR) FR_ROWSUM(DPP_ROW_MIRROR)
+#undef FR_ROWSUM
+            // a slot is good iff exactly one candidate holds it (a), it passes and its wave flags no tie: both nibbles == 1
+            unsigned bad = (w1 ^ 0x11111111u) | (w2 ^ 0x11111111u);
+            bad = (bad | (bad >> 1) | (bad >> 2) | (bad >> 3)) & 0x11111111u;
+            const int cap = min(FR_KMAX, m - j);
+            int nk = (int)__builtin_ctz(bad | (1u << (4 * cap))) >> 2;     // leading good slots
+            if (nk == 0 && w1 != 0u) {                              // (w1 != 0: there is a candidate, and the best one holds slot 0)
+                nk = -1;                                            // a tie at the head of the round: the tied maximum goes into the first slot
+                if (lane == 0) reinterpret_cast<int *>(selq)[0] = __float_as_int(auxs[0].x);
             }
             if (lane == 0) posr[0] = nk;
         }
         FRP(5)
-        lds_barrier();
+        FR_REP(6) lds_barrier();
         FRP(6)
-        K = posr[0];
-        {   // (all five reads in flight before the first use)
+        FR_REP(7) K = posr[0];
+        FR_REP(7) {   // (all five reads in flight before the first use)
             const float4 s0 = samples[j], s1 = samples[j + 1], s2 = samples[j + 2], s3 = samples[j + 3];
             q0x = s0.x; q0y = s0.y; q0z = s0.z;
             q1x = s1.x; q1y = s1.y; q1z = s1.z;
