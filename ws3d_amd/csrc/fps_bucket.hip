@@ -560,7 +560,11 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 
     // the samples about to be applied (wave-uniform): the sweep starts from point 0 (sampling_gpu.cu:119)
     int K = 1;
-    float q0x = xyz[0], q0y = xyz[1], q0z = xyz[2], q1x = 0.f, q1y = 0.f, q1z = 0.f, q2x = 0.f, q2y = 0.f, q2z = 0.f, q3x = 0.f, q3y = 0.f, q3z = 0.f;
+    // (always FR_KMAX of them: the slots past the round's K hold a point FR_FAR away on every axis -- its distance to anything is ~3e36,
+    // finite and above every running distance, so min() ignores it and the box test never fires: no branch on K in the round)
+    constexpr float FR_FAR = 1e18f;
+    float q0x = xyz[0], q0y = xyz[1], q0z = xyz[2], q1x = FR_FAR, q1y = FR_FAR, q1z = FR_FAR, q2x = FR_FAR, q2y = FR_FAR, q2z = FR_FAR,
+          q3x = FR_FAR, q3y = FR_FAR, q3z = FR_FAR;
     float wv = -1.0f, wx = 0.f, wy = 0.f, wz = 0.f, ws2 = -1.0f;       // this wave's candidate and the bound on everything else it holds
     int wpos = 0, wtie = 0, wslot = 0;
     bool have = false;
@@ -588,34 +592,40 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #endif
         if (j >= m && !temp) break;                                    // nothing reads the running distances any more
         // `temp` leaves the kernel as the reference leaves it: every sample applied but the last one picked (sampling_gpu.cu:118-208)
-        const int Ka = j >= m ? K - 1 : K;
+        if (j >= m) {
+            if (K == 1) { q0x = q0y = q0z = FR_FAR; }
+            else if (K == 2) { q1x = q1y = q1z = FR_FAR; }
+            else if (K == 3) { q2x = q2y = q2z = FR_FAR; }
+            else { q3x = q3y = q3z = FR_FAR; }
+        }
         // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
         // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
         unsigned need = 0u;
 #define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
         FR_REP(0) {
             float L = FR_BOX(q0x, q0y, q0z);                            // (independent chains: the samples' bounds overlap in the pipeline)
-            if (Ka > 1) L = min_f32(FR_BOX(q1x, q1y, q1z), L);
-            if (Ka > 2) L = min_f32(FR_BOX(q2x, q2y, q2z), L);
-            if (Ka > 3) L = min_f32(FR_BOX(q3x, q3y, q3z), L);
-            need = Ka > 0 ? (unsigned)__ballot(L < bmax) & SLMASK : 0u;
+            L = min_f32(FR_BOX(q1x, q1y, q1z), L);
+            L = min_f32(FR_BOX(q2x, q2y, q2z), L);
+            L = min_f32(FR_BOX(q3x, q3y, q3z), L);
+            need = (unsigned)__ballot(L < bmax) & SLMASK;
         }
 #undef FR_BOX
         FRP(0)
         bool repick = !have;
-        FR_REP(1) if (need) {
+        if (need) {
 #define FR_UPD(S)                                                                                      \
     if (need & (1u << (S))) {                                                                          \
         float d = sqdist3(px[S] - q0x, py[S] - q0y, pz[S] - q0z);                                      \
-        if (Ka > 1) d = min_f32(sqdist3(px[S] - q1x, py[S] - q1y, pz[S] - q1z), d);                    \
-        if (Ka > 2) d = min_f32(sqdist3(px[S] - q2x, py[S] - q2y, pz[S] - q2z), d);                    \
-        if (Ka > 3) d = min_f32(sqdist3(px[S] - q3x, py[S] - q3y, pz[S] - q3z), d);                    \
+        d = min_f32(sqdist3(px[S] - q1x, py[S] - q1y, pz[S] - q1z), d);                                \
+        d = min_f32(sqdist3(px[S] - q2x, py[S] - q2y, pz[S] - q2z), d);                                \
+        d = min_f32(sqdist3(px[S] - q3x, py[S] - q3y, pz[S] - q3z), d);                                \
         fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
         const float bm = wave_max(fb_t<S>(tt));                                                        \
         bmax = lane == (S) ? bm : bmax;                                                                \
     }
 #define FR_UPD8(G) if (need & (0xFFu << (G))) { FR_UPD(G) FR_UPD(G + 1) FR_UPD(G + 2) FR_UPD(G + 3) FR_UPD(G + 4) FR_UPD(G + 5) FR_UPD(G + 6) FR_UPD(G + 7) }
-            FR_UPD8(0) FR_UPD8(8)
+            FR_REP(1) { FR_UPD8(0) }
+            FR_REP(3) { FR_UPD8(8) }
             if constexpr (SL == 32) { FR_UPD8(16 % SL) FR_UPD8(24 % SL) }
 #undef FR_UPD8
 #undef FR_UPD
@@ -729,6 +739,11 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             if (nk == 0 && w1 != 0u) {                              // (w1 != 0: there is a candidate, and the best one holds slot 0)
                 nk = -1;                                            // a tie at the head of the round: the tied maximum goes into the first slot
                 if (lane == 0) reinterpret_cast<int *>(selq)[0] = __float_as_int(auxs[0].x);
+            }
+            {   // the slots past the accepted samples become the far point (in-order LDS: after the candidates parked there)
+                const int first = max(nk, 1);
+                const int park = ((first - 1 - lane) >> 31) & ((lane - 4) >> 31);            // all ones: first <= lane < 4 (the slots every wave reads)
+                selq[(lane & park) | (7 & ~park)] = make_float4(FR_FAR, FR_FAR, FR_FAR, 0.f);
             }
             if (lane == 0) posr[0] = nk;
         }
