@@ -444,6 +444,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 #ifndef FR_KMAX
 #define FR_KMAX 4
 #endif
+#define FR_Q (FR_KMAX < 4 ? 4 : FR_KMAX)      // sample slots every wave reads and applies per round
 constexpr size_t FB_SMEM_BYTES = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * FB_NW * FB_SL * 6 +
                                  sizeof(float4) * 2 * FB_NW + sizeof(unsigned) * (3 * FB_NW + 4) + sizeof(float4) + sizeof(float) * 4 * FB_NW +
                                  sizeof(int) * FB_NW + 64;                   // the LDS layout both kernels share
@@ -563,8 +564,9 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
     // (always FR_KMAX of them: the slots past the round's K hold a point FR_FAR away on every axis -- its distance to anything is ~3e36,
     // finite and above every running distance, so min() ignores it and the box test never fires: no branch on K in the round)
     constexpr float FR_FAR = 1e18f;
-    float q0x = xyz[0], q0y = xyz[1], q0z = xyz[2], q1x = FR_FAR, q1y = FR_FAR, q1z = FR_FAR, q2x = FR_FAR, q2y = FR_FAR, q2z = FR_FAR,
-          q3x = FR_FAR, q3y = FR_FAR, q3z = FR_FAR;
+    float qx[FR_Q], qy[FR_Q], qz[FR_Q];
+#pragma unroll
+    for (int i = 0; i < FR_Q; ++i) { qx[i] = i ? FR_FAR : xyz[0]; qy[i] = i ? FR_FAR : xyz[1]; qz[i] = i ? FR_FAR : xyz[2]; }
     float wv = -1.0f, wx = 0.f, wy = 0.f, wz = 0.f, ws2 = -1.0f;       // this wave's candidate and the bound on everything else it holds
     int wpos = 0, wtie = 0, wslot = 0;
     bool have = false;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #ifdef FR_DUP       // scripts/ubench/fps_rounds_dup.sh: segment FR_DUP of every round is executed TWICE (each is idempotent: same results); the
     // rise of the launch time over the plain build / the number of rounds = what that segment contributes to the round's critical path.
     // (compile-time constant: the loop unrolls into a second copy of the segment, the asm keeps the copies from being merged)
-#define FR_REP(k) _Pragma("unroll") for (int rep_ = 0; rep_ < (FR_DUP == (k) ? 2 : 1); ++rep_, ({ asm volatile("" : "+v"(q0x), "+v"(q1x), "+v"(q2x), "+v"(q3x), "+v"(bmax) :: "memory"); }))
+#define FR_REP(k) _Pragma("unroll") for (int rep_ = 0; rep_ < (FR_DUP == (k) ? 2 : 1); ++rep_, ({ asm volatile("" : "+v"(qx[0]), "+v"(qx[1]), "+v"(qx[2]), "+v"(qx[3]), "+v"(bmax) :: "memory"); }))
 #else
 #define FR_REP(k)
 #endif
@@ -593,20 +595,18 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         if (j >= m && !temp) break;                                    // nothing reads the running distances any more
         // `temp` leaves the kernel as the reference leaves it: every sample applied but the last one picked (sampling_gpu.cu:118-208)
         if (j >= m) {
-            if (K == 1) { q0x = q0y = q0z = FR_FAR; }
-            else if (K == 2) { q1x = q1y = q1z = FR_FAR; }
-            else if (K == 3) { q2x = q2y = q2z = FR_FAR; }
-            else { q3x = q3y = q3z = FR_FAR; }
+#pragma unroll
+            for (int i = 0; i < FR_Q; ++i)
+                if (i == K - 1) { qx[i] = qy[i] = qz[i] = FR_FAR; }
         }
         // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
         // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
         unsigned need = 0u;
 #define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
         FR_REP(0) {
-            float L = FR_BOX(q0x, q0y, q0z);                            // (independent chains: the samples' bounds overlap in the pipeline)
-            L = min_f32(FR_BOX(q1x, q1y, q1z), L);
-            L = min_f32(FR_BOX(q2x, q2y, q2z), L);
-            L = min_f32(FR_BOX(q3x, q3y, q3z), L);
+            float L = FR_BOX(qx[0], qy[0], qz[0]);                      // (independent chains: the samples' bounds overlap in the pipeline)
+#pragma unroll
+            for (int i = 1; i < FR_Q; ++i) L = min_f32(FR_BOX(qx[i], qy[i], qz[i]), L);
             need = (unsigned)__ballot(L < bmax) & SLMASK;
         }
 #undef FR_BOX
@@ -615,13 +615,11 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         if (need) {
 #define FR_UPD(S)                                                                                      \
     if (need & (1u << (S))) {                                                                          \
-        float d = sqdist3(px[S] - q0x, py[S] - q0y, pz[S] - q0z);                                      \
-        d = min_f32(sqdist3(px[S] - q1x, py[S] - q1y, pz[S] - q1z), d);                                \
-        d = min_f32(sqdist3(px[S] - q2x, py[S] - q2y, pz[S] - q2z), d);                                \
-        d = min_f32(sqdist3(px[S] - q3x, py[S] - q3y, pz[S] - q3z), d);                                \
+        float d = sqdist3(px[S] - qx[0], py[S] - qy[0], pz[S] - qz[0]);                                \
+        _Pragma("unroll") for (int i_ = 1; i_ < FR_Q; ++i_) d = min_f32(sqdist3(px[S] - qx[i_], py[S] - qy[i_], pz[S] - qz[i_]), d); \
         fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
         const float bm = wave_max(fb_t<S>(tt));                                                        \
-        bmax = lane == (S) ? bm : bmax;                                                                \
+        bmax = lane == (S) ? bm : bmax;                 /* (v_writelane instead: same time) */         \
     }
 #define FR_UPD8(G) if (need & (0xFFu << (G))) { FR_UPD(G) FR_UPD(G + 1) FR_UPD(G + 2) FR_UPD(G + 3) FR_UPD(G + 4) FR_UPD(G + 5) FR_UPD(G + 6) FR_UPD(G + 7) }
             FR_REP(1) { FR_UPD8(0) }
@@ -742,7 +740,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             }
             {   // the slots past the accepted samples become the far point (in-order LDS: after the candidates parked there)
                 const int first = max(nk, 1);
-                const int park = ((first - 1 - lane) >> 31) & ((lane - 4) >> 31);            // all ones: first <= lane < 4 (the slots every wave reads)
+                const int park = ((first - 1 - lane) >> 31) & ((lane - FR_Q) >> 31);         // all ones: first <= lane < FR_Q (the slots every wave reads)
                 selq[(lane & park) | (7 & ~park)] = make_float4(FR_FAR, FR_FAR, FR_FAR, 0.f);
             }
             if (lane == 0) posr[0] = nk;
@@ -752,15 +750,15 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         FRP(6)
         FR_REP(7) K = posr[0];
         FR_REP(7) {   // (all five reads in flight before the first use)
-            const float4 s0 = samples[j], s1 = samples[j + 1], s2 = samples[j + 2], s3 = samples[j + 3];
-            q0x = s0.x; q0y = s0.y; q0z = s0.z;
-            q1x = s1.x; q1y = s1.y; q1z = s1.z;
-            q2x = s2.x; q2y = s2.y; q2z = s2.z;
-            q3x = s3.x; q3y = s3.y; q3z = s3.z;
+            float4 sq[FR_Q];
+#pragma unroll
+            for (int i = 0; i < FR_Q; ++i) sq[i] = samples[j + i];
+#pragma unroll
+            for (int i = 0; i < FR_Q; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
         }
         if (K <= 0) {
             // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
-            const float gmax = q0x;                              // (the certifying wave left the tied maximum in the first slot)
+            const float gmax = qx[0];                              // (the certifying wave left the tied maximum in the first slot)
             unsigned key = 0xFFFFFFFFu;
             const float ta[32] = FB_T32_LIST(tt);
 #pragma unroll
@@ -799,9 +797,9 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             }
             lds_barrier();
             const float4 c = *tiept;
-            q0x = c.x; q0y = c.y; q0z = c.z;
+            qx[0] = c.x; qy[0] = c.y; qz[0] = c.z;
             K = 1;
-            if (tid == NT - 64) samples[j] = make_float4(q0x, q0y, q0z, __int_as_float(ipos));
+            if (tid == NT - 64) samples[j] = make_float4(qx[0], qy[0], qz[0], __int_as_float(ipos));
         }
         j += K;
 #ifdef FR_PROF
