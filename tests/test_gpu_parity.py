@@ -753,6 +753,37 @@ def test_nms_mask_and_keep(ops, oracle, n, thresh, normal, spread):
     np.testing.assert_array_equal(keep_cpu.numpy()[:cnt], ref_keep)
 
 
+@pytest.mark.parametrize("thresh", [0.3, 0.5, 0.7, 0.8, 0.9])
+@pytest.mark.parametrize("same_size", [True, False])
+def test_nms_mask_of_near_threshold_clusters(ops, oracle, thresh, same_size):
+    """the mask kernel drops a pair without running the polygon clipping when an upper bound of the intersection area proves
+    iou <= thresh (iou3d.hip iou_surely_not_above): clusters of car-sized boxes a few centimetres to decimetres and a few degrees
+    apart put thousands of pairs right at the threshold -- every bit must still be the oracle's"""
+    rng = np.random.default_rng(int(thresh * 100) + (7 if same_size else 0))
+    n, per = 640, 40
+    centres = rng.uniform(-8, 8, (n // per, 2)) + np.array([0.0, 30.0])
+    b3 = np.zeros((n, 7), np.float32)
+    for c in range(n // per):
+        sl = slice(c * per, (c + 1) * per)
+        spread = [0.05, 0.15, 0.4, 1.0][c % 4]
+        b3[sl, 0] = centres[c, 0] + rng.normal(0, spread, per)
+        b3[sl, 2] = centres[c, 1] + rng.normal(0, spread, per)
+        b3[sl, 1] = 1.0
+        b3[sl, 3] = 1.5
+        b3[sl, 4] = 1.6 if same_size else 1.6 * rng.uniform(0.85, 1.15, per)
+        b3[sl, 5] = 3.9 if same_size else 3.9 * rng.uniform(0.85, 1.15, per)
+        b3[sl, 6] = rng.uniform(-np.pi, np.pi) + rng.normal(0, [0.02, 0.1, 0.3, 1.0][(c // 4) % 4], per) + (np.pi / 2) * rng.integers(0, 2, per)
+    boxes = np.ascontiguousarray(synth.boxes3d_to_bev(b3)[rng.permutation(n)])
+    ref_mask = oracle.nms_mask(boxes, thresh, False)
+    got = host(ops.c.nms_mask(dev(boxes), thresh, False, full_grid=True)).view(np.uint64)
+    np.testing.assert_array_equal(got, ref_mask)
+    bits = int(sum(bin(int(w)).count("1") for w in ref_mask.ravel()))
+    assert bits > 40                                         # (the clusters do suppress each other: the test is not vacuous)
+    ref_keep = oracle.nms_sorted(boxes, thresh, False)
+    keep, num = ops.c.nms_device(dev(boxes), thresh, False)
+    np.testing.assert_array_equal(host(keep)[:int(num.item())], ref_keep)
+
+
 def test_nms_batched_and_proposal_stage(ops, oracle):
     """one launch pair for a batch of scenes == per-scene NMS == oracle; the vectorised proposal
     stage == a per-scene composition of the reference-named wrappers"""

@@ -264,3 +264,49 @@ def test_radius_nms(oracle, n, r, seed):
         if d[keep, i].min() > np.float32(r):
             keep.append(i)
     np.testing.assert_array_equal(oracle.radius_nms_sorted(c, r), np.asarray(keep))
+
+
+def _intersection_upper_bounds(A, B):
+    """numpy (float64) restatement of the two upper bounds of ws3d_amd/csrc/iou3d.hip iou_surely_not_above on the intersection area of
+    two rotated BEV rectangles (rows x1, y1, x2, y2, ry): (1) overlap of the projections on the centre line x the narrower extent
+    across it, (2) the parallelogram of one strip of each box"""
+    A = A.astype(np.float64)[:, None, :]
+    B = B.astype(np.float64)[None, :, :]
+    hxa, hya = (A[..., 2] - A[..., 0]) / 2, (A[..., 3] - A[..., 1]) / 2
+    hxb, hyb = (B[..., 2] - B[..., 0]) / 2, (B[..., 3] - B[..., 1]) / 2
+    ca, sa, cb, sb = np.cos(-A[..., 4]), np.sin(-A[..., 4]), np.cos(-B[..., 4]), np.sin(-B[..., 4])
+    sn, cs = np.abs(ca * sb - sa * cb), np.abs(ca * cb + sa * sb)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b2 = np.minimum(np.minimum(4 * hya * hyb / sn, 4 * hxa * hxb / sn), np.minimum(4 * hya * hxb / cs, 4 * hxa * hyb / cs))
+        vx = (B[..., 0] + B[..., 2]) / 2 - (A[..., 0] + A[..., 2]) / 2
+        vy = (B[..., 1] + B[..., 3]) / 2 - (A[..., 1] + A[..., 3]) / 2
+        d2 = vx * vx + vy * vy
+        va1, va2 = np.abs(vx * ca + vy * sa), np.abs(vy * ca - vx * sa)
+        vb1, vb2 = np.abs(vx * cb + vy * sb), np.abs(vy * cb - vx * sb)
+        E = hxa * va1 + hya * va2 + hxb * vb1 + hyb * vb2 - d2
+        P = np.minimum(hxa * va2 + hya * va1, hxb * vb2 + hyb * vb1)
+        b1 = np.where(d2 > 0, 2 * np.maximum(E, 0) * P / d2, np.inf)
+    return np.minimum(b1, b2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_overlap_never_exceeds_the_bounds_the_nms_kernel_prunes_with(oracle, seed):
+    """the HIP mask kernel clears a bit without clipping polygons when bound < thresh * (SA + SB) / (1 + thresh) minus a margin
+    (2e-3 relative + 1e-3): sound iff the overlap the reference algorithm computes never exceeds the bound by more than that"""
+    rng = np.random.default_rng(seed)
+    n = 100
+    b3 = np.zeros((n, 7), np.float32)
+    spread = [0.05, 0.2, 0.6, 2.0, 6.0][seed % 5]
+    b3[:, 0] = rng.normal(0, spread, n)
+    b3[:, 2] = 30 + rng.normal(0, spread, n)
+    b3[:, 1], b3[:, 3] = 1.0, 1.5
+    if seed % 2:
+        b3[:, 4], b3[:, 5] = 1.6, 3.9
+    else:
+        b3[:, 4], b3[:, 5] = rng.uniform(0.3, 3, n), rng.uniform(0.3, 6, n)
+    b3[:, 6] = rng.uniform(-np.pi, np.pi, n) if seed % 3 else rng.normal(0.3, 0.1, n)
+    bev = synth.boxes3d_to_bev(b3)
+    ov = oracle.boxes_overlap_bev(bev, bev).astype(np.float64)
+    bound = _intersection_upper_bounds(bev, bev)
+    np.fill_diagonal(bound, np.inf)
+    assert float((ov - bound).max()) < 2e-4

@@ -114,6 +114,36 @@ __device__ __forceinline__ bool far_apart(float acx, float acy, float arad, floa
     return dx * dx + dy * dy > rr * rr * 1.0001f;
 }
 
+// NMS only needs the BIT iou > thresh, and most pairs that survive the circle test above are nowhere near the threshold (the
+// Stage-1 proposals are thousands of car-sized boxes a few decimetres apart under every heading).  Two upper bounds on the
+// intersection area of two rectangles, from the frames alone (no corner, no division):
+//   (1) along the line through the centres the projections overlap by at most ext = hA(u) + hB(u) - d, across it the
+//       intersection is no wider than the narrower box's extent: I <= ext * min(pA, pB)  (all lengths scaled by d: no sqrt);
+//   (2) the intersection lies in one strip of A and one strip of B: I <= wA * wB / |sin of the angle between the strips|.
+// The reference's polygon is spanned by points ON the boundary of the true intersection (edge crossings, corners inside the
+// other box up to its 1e-5 margin): its area is <= I + ~1e-4.  So `bound < T`, T = thresh * (SA + SB) / (1 + thresh), with
+// a 2e-3 relative and 1e-3 absolute margin (rounding here is ~1e-6) proves that the reference computes iou <= thresh: the
+// bit is clear, exactly.  Degenerate boxes (a non-positive side) and thresh <= 0 never take the shortcut.
+__device__ __forceinline__ bool iou_surely_not_above(const float *a, const float *b, float thresh) {
+    const float hxa = (a[2] - a[0]) * 0.5f, hya = (a[3] - a[1]) * 0.5f, hxb = (b[2] - b[0]) * 0.5f, hyb = (b[3] - b[1]) * 0.5f;
+    if (!(hxa > 0.f && hya > 0.f && hxb > 0.f && hyb > 0.f && thresh > 0.f)) return false;
+    const float T = thresh * (a[8] + b[8]) / (1.0f + thresh);
+    const float Tm = T * (1.0f - 2e-3f) - 1e-3f;
+    if (!(Tm > 0.f)) return false;
+    const float ca = a[6], sa = a[7], cb = b[6], sb = b[7];       // e1 = (c, s): the box's x side, e2 = (-s, c)
+    // (2) strips
+    const float sn = fabsf(ca * sb - sa * cb), cs = fabsf(ca * cb + sa * sb);
+    if (4.f * hya * hyb < Tm * sn || 4.f * hxa * hxb < Tm * sn || 4.f * hya * hxb < Tm * cs || 4.f * hxa * hyb < Tm * cs) return true;
+    // (1) slab along the centre line, v = cB - cA (not normalised: every length below carries a factor |v|)
+    const float vx = b[4] - a[4], vy = b[5] - a[5];
+    const float d2 = vx * vx + vy * vy;
+    const float va1 = fabsf(vx * ca + vy * sa), va2 = fabsf(vy * ca - vx * sa);     // |v . e1A|, |v . e2A| (= |v_perp . e1A|)
+    const float vb1 = fabsf(vx * cb + vy * sb), vb2 = fabsf(vy * cb - vx * sb);
+    const float E = hxa * va1 + hya * va2 + hxb * vb1 + hyb * vb2 - d2;             // |v| * (hA(u) + hB(u) - d)
+    const float P = fminf(hxa * va2 + hya * va1, hxb * vb2 + hyb * vb1);            // |v| * half the narrower extent across u
+    return 2.f * fmaxf(E, 0.f) * P < Tm * d2;
+}
+
 // iou3d_kernel.cu:108-212.  vx/vy/va: this lane's polygon scratch in LDS, element v at
 // [v * LS] (LS = lanes sharing the scratch; the caller passes pointers offset by its lane id).
 template <int LS>
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
         if (cand) {
             const float *fr = s.frames[0] + r * FRAME_F, *fc = s.frames[1] + c * FRAME_F;
             // a far pair has overlap 0 => IoU 0: its bit is clear unless 0 > thresh
-            cand = !(thresh >= 0.0f) || !far_apart(fr[4], fr[5], fr[9], fc[4], fc[5], fc[9]);
+            cand = !(thresh >= 0.0f) || !(far_apart(fr[4], fr[5], fr[9], fc[4], fc[5], fc[9]) || iou_surely_not_above(fr, fc, thresh));
         }
         const uint64_t bal = __ballot(cand);
         if (bal) {
