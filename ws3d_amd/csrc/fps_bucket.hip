@@ -438,9 +438,16 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 // the accepted samples are exactly its next picks, in order (scripts/sim_fps_rounds.py: 3.1-3.3 samples per round at up to 4 per
 // round on the 16384 -> 4096 level, the sequence identical to the plain sweep).  Then ALL accepted samples are applied in one pass:
 // the box test of a bucket takes the minimum over the samples' bounds, an affected bucket one fused update min(t, d_1, .., d_K)
-// and ONE wave reduction, the wave one re-pick.  The certification is sequential and short; ONE wave does it (16 waves doing it
-// side by side would share four SIMDs) and hands the samples out through LDS: two LDS-only barriers per round.
+// and ONE wave reduction, the wave one re-pick.  ONE wave certifies (16 waves doing it side by side would share four SIMDs)
+// and hands the samples out through LDS: two LDS-only barriers per round.  The certification runs on 16 lanes (lane c = the
+// candidate of wave c) and never leaves the vector unit: the candidates' order from 15 row rotations (lane c counts the
+// candidates above its own), the candidates in rank order through LDS, conditions (b) and (c) of ALL ranks at once as sign
+// bits of integer differences, "exactly one candidate per rank and it passes" from two row sums of nibble counters.  The
+// sequential form (max, ballot, ctz, readlane per sample) cost 1,360 of the round's 4,600 clk: every vector -> scalar ->
+// vector hop stalls a lone wave ~20 clk; this form costs ~830.  The unused sample slots of a round hold a far point
+// (distance ~3e36 to everything: min() ignores it, its box bound never fires), so the round has no branch on K.
 // Ties at the head of a round take the resolution round of the kernel above (one sample).  Bit-exact incl. the tie order.
+// Anatomy without clock hooks: scripts/ubench/fps_rounds_dup.sh (one segment of the round executed twice per build).
 #ifndef FR_KMAX
 #define FR_KMAX 4
 #endif
