@@ -207,15 +207,11 @@ class C3:
         self._timed = timed
         e = None
         from ws3d_amd import fastpath
-        ahead = fastpath.GEOMETRY_AHEAD
         if timed:           # per-operator timers: one stream, so that an operator's time is its own
-            fastpath.GEOMETRY_AHEAD = False
             e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             e[0].record()
-        try:
+        with fastpath.geometry_ahead(False if timed else fastpath.GEOMETRY_AHEAD):
             out = self.model.rpn_forward({'pts_input': self.pts, 'defer_reg_join': True})      # proposals_from_rpn waits for rpn_reg
-        finally:
-            fastpath.GEOMETRY_AHEAD = ahead
         if timed:
             e[1].record()
         boxes, scores, count, enlarged = proposals_from_rpn(out, self.cfg, with_pool_boxes=True)

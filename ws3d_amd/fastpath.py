@@ -19,6 +19,8 @@ eval mode on the GPU unless ``stage1.CHANNELS_LAST_FASTPATH`` is cleared.
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import os
 
 import torch
@@ -34,6 +36,23 @@ FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + p
 FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
 NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
 GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+_AHEAD_OVERRIDE = contextvars.ContextVar("ws3d_geometry_ahead", default=None)
+
+
+@contextlib.contextmanager
+def geometry_ahead(on: bool):
+    """the forward passes issued inside this block (by this thread / task only) use / do not use the side streams, whatever the
+    module default says: Stage1Pipeline primes its slots on ONE stream, bench_c3's per-operator timers want one stream"""
+    token = _AHEAD_OVERRIDE.set(bool(on))
+    try:
+        yield
+    finally:
+        _AHEAD_OVERRIDE.reset(token)
+
+
+def _geometry_ahead_now() -> bool:
+    v = _AHEAD_OVERRIDE.get()
+    return GEOMETRY_AHEAD if v is None else v
 GEOMETRY_IN_CAPTURE = os.environ.get("WS3D_GEOMETRY_IN_CAPTURE", "0") != "0"  # ... also while a hipGraph is captured (fork / join inside the graph)
 PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
 COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # lists fuller than this (distinct rows / all rows) take the dense kernels
@@ -137,7 +156,8 @@ def supported(model) -> bool:
 
 def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
     return (FUSED_GATHER_GEMM and c_feat >= 16 and c_feat % 4 == 0 and grouper.use_xyz and len(blocks) >= 2 and
-            blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0)
+            blocks[0].conv.out_channels % 64 == 0 and (B * sa.npoint * grouper.nsample) % 64 == 0 and
+            (B * sa.npoint * grouper.nsample) // 64 <= 65535)        # (the gather-GEMM kernels' grid: one row tile of 64 per workgroup, 16-bit y)
 
 
 def _pair_limit(rows: int, dense_available: bool) -> int:
@@ -424,14 +444,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     rest = blocks[2:-1]
             if y is None:
                 y = _C.gather_gemm(feats, xyz, new_xyz, nbr, wt1, b1, r1)
-            if y is None:
-                raise RuntimeError("ws3d_gather_gemm declined a shape _gather_gemm_ok accepted")
-            for blk in rest:
-                y = _layer(y, blk)
-            wt, bias, relu = _row_weights(blocks[-1])
-            if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
-                _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
-            return
+            if y is not None:
+                for blk in rest:
+                    y = _layer(y, blk)
+                wt, bias, relu = _row_weights(blocks[-1])
+                if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
+                    _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
+                return
+            # (the kernel declined -- e.g. a non-contiguous feature tensor: the grouped path below covers every shape)
         if FUSED_SA_MLP and SA1_FROM_LISTS and feats is not None and feats.size(2) == 1 and grouper.use_xyz and len(blocks) == 3:
             # first level: lists only (no grouped tensor), the three layers chained in registers -- over the distinct pairs of the
             # lists (atomic max into the zeroed `out`) or over all their rows (pool in registers, stored), decided on the device
@@ -531,22 +551,24 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
         zeros = _arena_for(net, xyz.size(0), xyz.device)
     # (not while a hipGraph is being captured: a graph with such branches replays slower than one stream on this runtime --
     # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
-    ahead = GEOMETRY_AHEAD and (GEOMETRY_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())
+    ahead = _geometry_ahead_now() and (GEOMETRY_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats = [xyz], [feats]
-    for level, sa in enumerate(net.SA_modules):
-        nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros)
-        l_xyz.append(nx)
-        l_feats.append(nf)
-    for i in range(-1, -(len(net.FP_modules) + 1), -1):
-        nn3 = None
-        if geo is not None:
-            lvl = len(l_xyz) + i - 1                                   # unknown level of this module
-            geo.main.wait_event(geo.nn_ready[lvl])
-            nn3 = geo.nn[lvl]
-        l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3)
-    if geo is not None:
-        geo.release()
+    try:
+        for level, sa in enumerate(net.SA_modules):
+            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros)
+            l_xyz.append(nx)
+            l_feats.append(nf)
+        for i in range(-1, -(len(net.FP_modules) + 1), -1):
+            nn3 = None
+            if geo is not None:
+                lvl = len(l_xyz) + i - 1                                   # unknown level of this module
+                geo.main.wait_event(geo.nn_ready[lvl])
+                nn3 = geo.nn[lvl]
+            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3)
+    finally:
+        if geo is not None:       # also when a layer raised: the side streams' tensors go back to their pools behind the caller's stream
+            geo.release()
     return l_xyz[0], l_feats[0]
 
 
@@ -562,7 +584,7 @@ def rpn_forward(model, pts_input: torch.Tensor, defer_reg_join: bool = False) ->
     rows = feats.view(B * N, C)
     tickets = zeros.take((2,), torch.int32) if FUSED_MLP2_ROWS else (None, None)
     reg_ready = None
-    if PARALLEL_HEADS and GEOMETRY_AHEAD and not torch.cuda.is_current_stream_capturing():
+    if PARALLEL_HEADS and _geometry_ahead_now() and not torch.cuda.is_current_stream_capturing():
         main = torch.cuda.current_stream(rows.device)
         aux = _side_streams(main)[2]
         fork = torch.cuda.Event()

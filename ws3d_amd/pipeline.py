@@ -135,14 +135,11 @@ class Stage1Pipeline:
             stream = slot["stream"]
             stream.wait_stream(torch.cuda.current_stream(self.device))
             from . import fastpath
-            ahead = fastpath.GEOMETRY_AHEAD      # the priming runs stay on the slot's stream: the eager path's side streams
-            fastpath.GEOMETRY_AHEAD = False      # would claim two more hardware queues that the graphs never use
-            try:
-                with torch.cuda.stream(stream):
-                    for _ in range(2):
-                        self.body(slot["inp"])
-            finally:
-                fastpath.GEOMETRY_AHEAD = ahead
+            # the priming runs stay on the slot's stream: the eager path's side streams would claim more hardware queues that
+            # the graphs never use (a context variable: forward passes of other threads keep their own stream topology)
+            with fastpath.geometry_ahead(False), torch.cuda.stream(stream):
+                for _ in range(2):
+                    self.body(slot["inp"])
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
