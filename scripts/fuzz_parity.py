@@ -107,6 +107,23 @@ def one_round(rng):
         mk = int(rng.integers(1, 60))
         kb, nb2 = c.nms_device_batched(dev(bev[None]), thr, normal, mk)
         assert int(nb2[0]) == min(mk, len(rk)) and np.array_equal(host(kb[0])[:min(mk, len(rk))], rk[:mk]), ("nms max_keep", n, thr, mk)
+    # clusters of near-identical boxes (centimetres / degrees apart, same or slightly different sizes): thousands of pairs right at the
+    # threshold -- the mask kernel's bound-based shortcut (iou3d.hip iou_surely_not_above) must never clear a bit the oracle sets
+    nc = int(rng.integers(2, 400)); thr2 = float(rng.choice([0.2, 0.5, 0.7, 0.8, 0.9, 0.97]))
+    cb = np.zeros((nc, 7), np.float32)
+    ncl = int(rng.integers(1, 6))
+    cc = rng.uniform(-10, 10, (ncl, 2)); ch = rng.uniform(-np.pi, np.pi, ncl); which = rng.integers(0, ncl, nc)
+    sp, asp = float(rng.choice([0.01, 0.05, 0.2, 0.6])), float(rng.choice([0.005, 0.05, 0.3]))
+    cb[:, 0] = cc[which, 0] + rng.normal(0, sp, nc); cb[:, 2] = 30 + cc[which, 1] + rng.normal(0, sp, nc)
+    cb[:, 1], cb[:, 3] = 1.0, 1.5
+    jit = 0.0 if rng.random() < 0.5 else float(rng.choice([0.02, 0.15]))
+    cb[:, 4] = 1.6 * (1 + rng.uniform(-jit, jit, nc)); cb[:, 5] = 3.9 * (1 + rng.uniform(-jit, jit, nc))
+    cb[:, 6] = ch[which] + rng.normal(0, asp, nc) + (np.pi / 2) * rng.integers(0, 4, nc) * (rng.random() < 0.3)
+    cbev = np.ascontiguousarray(synth.boxes3d_to_bev(cb))
+    assert np.array_equal(host(c.nms_mask(dev(cbev), thr2, False, full_grid=True)).view(np.uint64), oracle.nms_mask(cbev, thr2, False)), ("cluster mask", nc, thr2, sp, asp, jit)
+    rk2 = oracle.nms_sorted(cbev, thr2, False)
+    k2, num2 = c.nms_device(dev(cbev), thr2, False)
+    assert int(num2.item()) == len(rk2) and np.array_equal(host(k2)[:len(rk2)], rk2), ("cluster nms", nc, thr2)
     na = min(n, 60)
     ov = torch.zeros((na, n), device="cuda")
     c.boxes_overlap_bev_gpu(dev(bev[:na]), dev(bev), ov)
