@@ -437,6 +437,12 @@ WS3D_API int ws3d_radius_nms_batched(int batch, int n, const float *centers, flo
  * order, NaN first (torch.topk's convention).                                                       */
 WS3D_API int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx,
                               ws3d_stream_t stream);
+/* The same result with the sort of a scene spread over several workgroups (2048-key segments sorted side by side, then ranked
+ * against each other): workspace >= ws3d_topk_workspace_bytes(b, n) bytes of device memory, 16-byte aligned; with a NULL / short
+ * workspace, or n <= 2048 (ws3d_topk_workspace_bytes returns 0), it IS ws3d_topk_sorted.  At 16384 scores x 8 scenes: 107 -> ~25 us. */
+WS3D_API size_t ws3d_topk_workspace_bytes(int b, int n);
+WS3D_API int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
+                                 size_t workspace_bytes, ws3d_stream_t stream);
 
 /* Proposal decode (ws3d extension): xyz (b,n,3), rpn_reg (b,n,4*bins) -> boxes (b,n,7)
  * = [x + dx, y + h/2, z + dz, h, w, l, ry] with (dx, dz) = decode_center_target

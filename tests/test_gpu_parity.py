@@ -1291,14 +1291,21 @@ def test_nonfinite_coordinates_follow_the_reference_semantics(ops, oracle):
         np.testing.assert_array_equal(host(keep)[:len(ref_keep)], ref_keep)
 
 
-@pytest.mark.parametrize("B,n,k", [(3, 16384, 9000), (2, 5000, 5000), (1, 1, 1), (4, 700, 10), (2, 4096, 0)])
-def test_topk_sorted_kernel(ops, B, n, k):
+@pytest.mark.parametrize("B,n,k", [(3, 16384, 9000), (2, 5000, 5000), (1, 1, 1), (4, 700, 10), (2, 4096, 0), (8, 16384, 16384), (2, 2049, 2049),
+                                   (3, 9000, 100), (1, 12289, 9000), (5, 4097, 4000)])
+@pytest.mark.parametrize("segments", [True, False])
+def test_topk_sorted_kernel(ops, B, n, k, segments):
+    """segments: the sort of a scene spread over its CUs (2048-key segments + ranking, ws3d_topk_sorted_ws; n > 2048) against one
+    workgroup per scene (ws3d_topk_sorted) -- both are torch's stable descending sort"""
     g = torch.Generator().manual_seed(n)
     s = torch.randn((B, n), generator=g).cuda()
     if n > 300:
         s[0, 100:200] = s[0, 7]                      # ties: ascending index order
         s[-1, 5] = float("inf"); s[-1, 9] = float("-inf"); s[0, 3] = -0.0; s[0, 4] = 0.0
-    vals, idx = ops.c.topk_sorted(s, k)
+    if n > 4000:
+        s[0, 3000:3300] = s[0, 7]                    # the same value in another segment
+        s[-1, 2047] = s[-1, 2048] = s[-1, 4095]
+    vals, idx = ops.c.topk_sorted(s, k, spread=segments)
     ref_v, ref_i = torch.sort(s, dim=1, descending=True, stable=True)
     assert torch.equal(idx, ref_i[:, :k])
     assert torch.equal(vals, ref_v[:, :k])

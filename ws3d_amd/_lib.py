@@ -66,6 +66,8 @@ SIGNATURES = {
     "ws3d_mlp2_rows": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ws3d_decode_center_boxes": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ws3d_topk_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "ws3d_topk_sorted_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_three_nn_weights": (_i, [C.c_long, _vp, _vp, _vp]),
     "ws3d_three_nn_w": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),

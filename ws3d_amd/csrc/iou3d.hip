@@ -635,20 +635,10 @@ __device__ __forceinline__ uint64_t topk_key(float f, int i) {
     return ((uint64_t)u << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
 }
 
+// bitonic sort, descending, of the 1024 * E keys of a workgroup held E per thread (thread t owns positions t*E .. t*E+E-1)
 template <int E>
-__global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, const float *__restrict__ scores,
-                                                               float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
-    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
+__device__ __forceinline__ void topk_sort_regs(uint64_t (&v)[E], uint64_t *lds, const int t) {
     constexpr int POW2 = 1024 * E;
-    const int b = blockIdx.x, t = threadIdx.x;
-    const float *sc = scores + (size_t)b * n;
-    uint64_t v[E];
-#pragma unroll
-    for (int r = 0; r < E; ++r) {
-        const int i = t * E + r;
-        v[r] = i < n ? topk_key(sc[i], i) : 0ull;            // padding: below every real key
-    }
     // compare-exchange of a register pair; desc: the larger key goes to the lower position
     auto cx = [](uint64_t &lo, uint64_t &hi, bool desc) {
         const uint64_t a = lo, c = hi;
@@ -692,6 +682,22 @@ __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, con
             }
         }
     }
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, const float *__restrict__ scores,
+                                                               float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *sc = scores + (size_t)b * n;
+    uint64_t v[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const int i = t * E + r;
+        v[r] = i < n ? topk_key(sc[i], i) : 0ull;            // padding: below every real key
+    }
+    topk_sort_regs<E>(v, lds, t);
     // sorted descending; through LDS once more so that the output is written coalesced
     __syncthreads();
 #pragma unroll
@@ -702,6 +708,66 @@ __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, con
         const uint32_t id = 0xffffffffu - (uint32_t)(w & 0xffffffffu);
         out_idx[(size_t)b * k + i] = (int64_t)id;
         out_scores[(size_t)b * k + i] = sc[id];
+    }
+}
+
+// The sort of a scene spread over its CUs (4096 <= pow2 <= 16384, a workspace given): one workgroup sorts 16384 keys in 107 us --
+// on 8 of 256 CUs at batch 8, and the proposal stage waits for it.  (1) every 2048-key SEGMENT of a scene is sorted by its own
+// workgroup (E = 2: 66 passes instead of 105, a sixteenth of the compare-exchanges per thread) into the workspace; (2) one workgroup
+// per segment ranks its keys against the other segments -- own position + one binary search per other segment over LDS copies --
+// and writes the elements whose rank is below k.  Keys are distinct (index in the low word), so the ranks are a permutation:
+// the result is the full sort's, bit for bit.
+constexpr int TOPK_SEG = 2048;
+__global__ __launch_bounds__(1024) void topk_sort_segments_kernel(int n, const float *__restrict__ scores, uint64_t *__restrict__ ws, int nseg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+    uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
+    const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg, t = threadIdx.x;
+    const float *sc = scores + (size_t)b * n;
+    uint64_t v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = seg * TOPK_SEG + t * 2 + r;
+        v[r] = i < n ? topk_key(sc[i], i) : 0ull;
+    }
+    topk_sort_regs<2>(v, lds, t);
+    uint64_t *o = ws + ((size_t)b * nseg + seg) * TOPK_SEG;
+    *reinterpret_cast<ulonglong2 *>(o + 2 * t) = make_ulonglong2(v[0], v[1]);
+}
+
+__global__ __launch_bounds__(1024) void topk_merge_rank_kernel(int n, int k, const float *__restrict__ scores, const uint64_t *__restrict__ ws,
+                                                               int nseg, float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+    uint64_t *all = reinterpret_cast<uint64_t *>(smem_tk);             // nseg * 2048 keys: every segment of the scene, sorted descending
+    const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg, t = threadIdx.x;
+    const uint64_t *src = ws + (size_t)b * nseg * TOPK_SEG;
+    for (int i = t; i < nseg * TOPK_SEG / 2; i += 1024)
+        reinterpret_cast<ulonglong2 *>(all)[i] = reinterpret_cast<const ulonglong2 *>(src)[i];
+    __syncthreads();
+    const float *sc = scores + (size_t)b * n;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int p = t + r * 1024;                                     // position inside my segment
+        const uint64_t x = all[seg * TOPK_SEG + p];
+        if (x == 0ull) continue;                                        // padding
+        int rank = p;
+        for (int s2 = 0; s2 < nseg; ++s2) {
+            if (s2 == seg) continue;
+            const uint64_t *a = all + s2 * TOPK_SEG;
+            int lo = 0, hi = TOPK_SEG;                                  // number of keys of segment s2 above x: in [lo, hi]
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {                           // 2049 possible answers
+                const int mid = min((lo + hi) >> 1, TOPK_SEG - 1);
+                const bool above = lo < hi && a[mid] > x;
+                hi = (lo < hi && !above) ? mid : hi;
+                lo = above ? mid + 1 : lo;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            const uint32_t id = 0xffffffffu - (uint32_t)(x & 0xffffffffu);
+            out_idx[(size_t)b * k + rank] = (int64_t)id;
+            out_scores[(size_t)b * k + rank] = sc[id];
+        }
     }
 }
 
@@ -859,6 +925,38 @@ extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float 
     }
 #undef WS3D_TOPK_REG
     return check_launch("ws3d_topk_sorted");
+}
+
+extern "C" size_t ws3d_topk_workspace_bytes(int b, int n) {
+    if (b <= 0 || n <= 2048 || n > 16384) return 0;                      // small scenes: one workgroup, no workspace
+    int pow2 = 4096;
+    while (pow2 < n) pow2 <<= 1;
+    return (size_t)b * pow2 * sizeof(uint64_t);
+}
+
+extern "C" int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
+                                   size_t workspace_bytes, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const size_t need = ws3d_topk_workspace_bytes(b, n);
+    if (need == 0 || !workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return ws3d_topk_sorted(b, n, k, scores, out_scores, out_idx, stream);       // (it also reports the argument errors)
+    if (k < 0 || k > n || !scores || (k > 0 && (!out_scores || !out_idx)) || b > 65535) {
+        set_error("ws3d_topk_sorted_ws: invalid argument (b=%d n=%d k=%d)", b, n, k);
+        return WS3D_E_INVALID;
+    }
+    if (k == 0) return WS3D_OK;
+    const int nseg = (int)(need / ((size_t)b * TOPK_SEG * sizeof(uint64_t)));
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)topk_merge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr = true;
+    }
+    hipStream_t st = as_stream(stream);
+    uint64_t *ws = reinterpret_cast<uint64_t *>(workspace);
+    hipLaunchKernelGGL(topk_sort_segments_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)TOPK_SEG * sizeof(uint64_t), st, n, scores, ws, nseg);
+    hipLaunchKernelGGL(topk_merge_rank_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)nseg * TOPK_SEG * sizeof(uint64_t), st, n, k, scores, ws,
+                       nseg, out_scores, out_idx);
+    return check_launch("ws3d_topk_sorted_ws");
 }
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,
