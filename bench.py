@@ -793,7 +793,7 @@ def main():
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic ({getattr(wl, 'kind', args.kind)}, seed=1000*config+scene, random-init weights)",
+            "data": f"synthetic ({getattr(wl, 'kind', args.kind)}, seeded scenes: 1000*config + 100000*slot + scene, random-init weights)",
             "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS, "ranks_seen": comm["ranks_seen"],
                             "communicator": comm}, **wl.config()),  # (c5 overrides n_points)
         }

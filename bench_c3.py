@@ -128,6 +128,11 @@ class C3:
         self.kind = kind
         self.pc_host = np.stack([synth.cloud(kind, 16384, 1000 * 3 + rank * batch + s) for s in range(batch)])
         self.pts = torch.from_numpy(self.pc_host).cuda()
+        # every slot of the pipeline replays a batch of its OWN scenes (slot 0: the batch above, which the latency mode, the kernel
+        # table and the CPU baseline use as well): the timed region sees depth x batch different clouds, and the device-side
+        # choice between the SharedMLP forms is taken per batch
+        self.slot_pts = [self.pts] + [torch.from_numpy(np.stack([synth.cloud(kind, 16384, 1000 * 3 + 100000 * j + rank * batch + s) for s in range(batch)])).cuda()
+                                      for j in range(1, self.depth)]
         self._i = 0
         if model is None:
             model = Stage1Net(mode='TEST').eval()
@@ -164,7 +169,9 @@ class C3:
                 "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                 # data-dependent work: the SharedMLPs may run over the DISTINCT (centre, sample) pairs of the ball-query lists (bit-identical
                 # to all m * nsample rows); `list_fill` in the line says how full this data's lists are, `all_rows` what the other form costs
-                "sharedmlp_rows": self.rows_mode}
+                "sharedmlp_rows": self.rows_mode,
+                "scenes": "%d distinct scenes per GPU in the timed region (every pipeline slot replays a batch of its own; latency mode, "
+                          "kernels[] and the CPU baseline use slot 0's batch)" % (self.depth * self.B)}
 
     @torch.no_grad()
     def _body(self, pts=None):
@@ -185,6 +192,9 @@ class C3:
         for slot in self.pipe.slots:
             slot["inp"].copy_(self.pts)
         ok = self.pipe.capture_all()
+        for slot, pts in zip(self.pipe.slots, self.slot_pts):          # (capture_all primes every slot on slot 0's batch)
+            slot["inp"].copy_(pts)
+        torch.cuda.synchronize()
         self._graph = True if ok else None
         self._graph_err = self.pipe.graph_error
         self._launch_desc = ("hipGraph replay of the whole step, %d batches in flight on separate HIP streams" % self.depth) if ok \
@@ -192,11 +202,11 @@ class C3:
         return ok
 
     @torch.no_grad()
-    def step(self, timed=False, eager=False):
+    def step(self, timed=False, eager=False, pts=None):
         global _ACTIVE
         _ACTIVE = self
         if getattr(self, "_graph", None) is not None and not timed and not eager:
-            ticket = self.pipe.submit()                    # inputs already resident in the slot's buffer
+            ticket = self.pipe.submit(pts)                 # None: the slot's own batch, already resident in its input buffer
             slot = self.pipe.slots[ticket % self.depth]
             res = slot["out"]
             with torch.cuda.stream(slot["stream"]):
@@ -255,7 +265,7 @@ class C3:
     def dump(self, folder):
         """one more step, then this rank's own proposals and the gathered ones to <folder>/proposals_rank<r>.npz
         (tests/test_bench_contract.py compares them across ranks and with a single-process run)"""
-        self.step()
+        self.step(pts=self.pts)                            # (slot 0's batch, whichever slot is next)
         torch.cuda.synchronize()
         _, boxes, scores, count, _, _, gathered = self.last
         np.savez(os.path.join(folder, "proposals_rank%d.npz" % self.rank),
