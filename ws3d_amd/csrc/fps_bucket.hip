@@ -578,11 +578,6 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
     int wpos = 0, wtie = 0, wslot = 0;
     bool have = false;
     int j = 1;                          // samples selected so far; the last K of them are not applied yet
-    // the waves of the three SIMDs the certifying wave does NOT run on take the box tests of the round's CANDIDATES while it works
-    // (the candidates are parked in rank order half way through the certification; one mask per candidate, OR-ed once K is known)
-    const bool early_wave = (w & 3) != 0;
-    bool need_ready = false;
-    unsigned need_early = 0u;
 #ifdef FR_PROF      // scripts/ubench/fps_rounds_prof.sh: per-wave clocks per segment and the samples per round, returned through `temp`
     long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long pt = clock64();
@@ -610,18 +605,18 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #pragma unroll
             for (int i = 0; i < FR_Q; ++i)
                 if (i == K - 1) { qx[i] = qy[i] = qz[i] = FR_FAR; }
-            need_ready = false;
         }
         // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
         // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
-        unsigned need = need_early;
+        unsigned need = 0u;
 #define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
-        FR_REP(0) if (!need_ready) {
+        FR_REP(0) {
             float L = FR_BOX(qx[0], qy[0], qz[0]);                      // (independent chains: the samples' bounds overlap in the pipeline)
 #pragma unroll
             for (int i = 1; i < FR_Q; ++i) L = min_f32(FR_BOX(qx[i], qy[i], qz[i]), L);
             need = (unsigned)__ballot(L < bmax) & SLMASK;
         }
+#undef FR_BOX
         FRP(0)
         bool repick = !have;
         if (need) {
@@ -685,10 +680,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         FRP(3)
         FR_REP(4) lds_barrier();
         FRP(4)
-        float4 c_r = make_float4(0.f, 0.f, 0.f, 0.f);
-        int c_key = 0;
-        unsigned c_rk = 0u, c_tie = 0u;
-        if (tid < NW) {
+        FR_REP(5) if (tid < NW) {
             // ---- certification, by the first NW lanes of wave 0 (lane c = the candidate of wave c), on the vector unit and LDS only:
             // every hop vector -> scalar -> vector (ballot, readlane with a computed lane, a compare feeding a select) costs a lone
             // wave ~20 clk, and the sequential form of this block had ~40 of them (1,360 of a round's 4,600 clk).
@@ -725,26 +717,6 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             // accepted ones are never read as samples), all lanes read the leading ones back
             selq[rk] = r;
             auxs[rk] = a;
-            c_r = r; c_key = key; c_rk = rk; c_tie = (unsigned)__float_as_int(a.z) & 1u;
-        }
-        lds_barrier();                                                  // the candidates are parked: the early waves start on them
-        unsigned ne[FR_Q];
-        if (early_wave) {          // (straight into the sample registers: the previous round's samples are dead by now)
-            float4 cq[FR_Q];
-#pragma unroll
-            for (int i = 0; i < FR_Q; ++i) cq[i] = samples[j + i];
-#pragma unroll
-            for (int i = 0; i < FR_Q; ++i) {
-                qx[i] = cq[i].x; qy[i] = cq[i].y; qz[i] = cq[i].z;
-                ne[i] = (unsigned)__ballot(FR_BOX(qx[i], qy[i], qz[i]) < bmax) & SLMASK;
-            }
-        }
-        FR_REP(5) if (tid < NW) {
-            float4 *selq = samples + j;
-            float4 *auxs = reinterpret_cast<float4 *>(red);
-            const float4 r = c_r;
-            const int key = c_key;
-            const unsigned rk = c_rk, valid = ~(unsigned)(c_key >> 31);
             float dm = INFINITY;                                    // my candidate's smallest distance to the candidates of rank < i
             int bound = -1;                                         // the largest s_w of the waves of rank < i
             unsigned okw = 1u;                                      // bit i: my candidate would pass (b) and (c) AS rank i
@@ -758,7 +730,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
             }
             // per rank slot (a nibble): how many candidates hold it; 1 if its candidate passes, +2 if its wave flags a tie
             unsigned w1 = (valid & 1u) << (4u * rk);
-            unsigned w2 = (((okw >> rk) & 1u) | (c_tie << 1)) << (4u * rk);
+            unsigned w2 = (((okw >> rk) & 1u) | (((unsigned)__float_as_int(a.z) & 1u) << 1)) << (4u * rk);      // (the flag is 0 or 1)
 #define FR_ROWSUM(CTRL)                                                                                           \
     w1 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w1, CTRL, 0xF, 0xF, false);                             \
     w2 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w2, CTRL, 0xF, 0xF, false);
@@ -784,25 +756,12 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         FR_REP(6) lds_barrier();
         FRP(6)
         FR_REP(7) K = posr[0];
-        if (early_wave && K > 0) {
-            // the candidates of rank < K are the round's samples, the other slots the far point; the masks were taken beside the certification
-            need_early = 0u;
+        FR_REP(7) {   // (all five reads in flight before the first use)
+            float4 sq[FR_Q];
 #pragma unroll
-            for (int i = 0; i < FR_Q; ++i) {
-                const bool in = i < K;
-                qx[i] = in ? qx[i] : FR_FAR; qy[i] = in ? qy[i] : FR_FAR; qz[i] = in ? qz[i] : FR_FAR;
-                need_early |= in ? ne[i] : 0u;
-            }
-            need_ready = true;
-        } else {
-            FR_REP(7) {   // (all reads in flight before the first use)
-                float4 sq[FR_Q];
+            for (int i = 0; i < FR_Q; ++i) sq[i] = samples[j + i];
 #pragma unroll
-                for (int i = 0; i < FR_Q; ++i) sq[i] = samples[j + i];
-#pragma unroll
-                for (int i = 0; i < FR_Q; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
-            }
-            need_ready = false;
+            for (int i = 0; i < FR_Q; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
         }
         if (K <= 0) {
             // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
