@@ -717,7 +717,7 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     // kernel needs 6.4) and the cloud is large (8192 points: 0.78 vs 0.74).  WS3D_FPS_BUCKET=0 / 1 forces the choice (A/B runs).
     static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : -1;
     // round 3: with several certified samples per exchange (fps_rounds_kernel, m <= 6144) the pruned kernel wins at EVERY batch
-    // size -- 2.43 ms per 256 scenes, so 512 scenes take 4.96 ms in two waves of workgroups against 6.10 ms dense
+    // size -- 2.09 ms per 256 scenes, so 512 scenes take 4.05 ms in two waves of workgroups against 6.10 ms dense
     const bool bucket = use_bucket >= 0 ? use_bucket != 0 : (R > 8192 && (fps_rounds_covers(m) || !fps_pair_mode(b)));
     if (bucket && n > 4096 && n <= 16384 && m > 1)
         return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);

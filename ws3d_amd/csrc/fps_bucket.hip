@@ -1,12 +1,14 @@
 // fps_bucket.hip -- pruned furthest point sampling for 4096 < n <= 16384 (gfx950).
 //
-// STATUS: the DEFAULT kernel of furthest_point_sample for clouds of 8192 < n <= 16384 points whenever a scene gets a CU of its
-// own (batch <= 256; fps.hip fps_launch selects it -- WS3D_FPS_BUCKET=0 / 1 force the choice for A/B runs): level 1 of every
-// Stage-1 forward (16384 -> 4096, 8 scenes = 8 workgroups).  0.74 us per sampling step against 1.5 us of the dense sweep with one
-// scene per CU; batches above 256 scenes take the dense two-scenes-per-CU kernel of fps_v3.hip instead, which is VALU-bound and
-// fills the chip.  Bit-exact incl. the reference's tie order: tests/test_gpu_parity.py::test_fps_bit_exact (default dispatch, with
-// duplicated points), ::test_fps_ties, ::test_fps_bucket_kernel_subprocess (forced, every size class) and scripts/fuzz_parity.py.
-// The step is bound by its cross-lane chain (box test, bucket update, pick, record exchange: DESIGN.md 5.1 / 10.2), not by
+// STATUS: the DEFAULT kernels of furthest_point_sample for clouds of 8192 < n <= 16384 points at every batch size (fps.hip
+// fps_launch; WS3D_FPS_BUCKET=0 forces the dense sweep of fps_v3.hip, WS3D_FPS_ROUNDS=0 the one-sample-per-exchange kernel below, for
+// A/B runs): level 1 of every Stage-1 forward (16384 -> 4096, one workgroup = one CU per scene).  Two kernels live here:
+// fps_bucket_kernel (round 2: one sample per record exchange, 0.75 us per sample; still serves m > 6144) and fps_rounds_kernel
+// (round 3, further down: several CERTIFIED samples per exchange, 0.51 us per sample -- 2.09 ms per 256 scenes, 512 scenes 4.05 ms in
+// two waves of workgroups against 6.1 ms of the VALU-bound dense kernel).  Bit-exact incl. the reference's tie order:
+// tests/test_gpu_parity.py::test_fps_bit_exact (default dispatch, with duplicated points), ::test_fps_ties,
+// ::test_fps_kernel_variants_subprocess (every forced kernel, every size class), tests/test_golden.py and scripts/fuzz_parity.py.
+// A sampling step is bound by its cross-lane chain (box test, bucket update, pick, record exchange: DESIGN.md 5.1), not by
 // arithmetic: pruning removes ~95 % of the distance evaluations of a step.
 //
 // Same contract as fps.hip (bit-exact indices incl. the reference's tie order), different
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
 
 // does the multi-sample kernel take this launch?  (fps.hip: it then serves every batch size -- 512 scenes in two waves of
-// workgroups take 4.96 ms against 6.10 ms of the dense two-scenes-per-CU kernel)
+// workgroups take 4.05 ms against 6.10 ms of the dense two-scenes-per-CU kernel)
 bool fps_rounds_covers(int m) {
 #if FB_NW == 16 && !defined(FB_PROF)
     static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
