@@ -47,9 +47,9 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (2: launch gates of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists;
- * 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
-#define WS3D_ABI_VERSION 2
+/* bumped whenever an entry point is added or a signature changes (3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+ * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
+#define WS3D_ABI_VERSION 3
 WS3D_API int ws3d_abi_version(void);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
  * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
