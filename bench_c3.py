@@ -77,6 +77,13 @@ FAMILIES = {
     "decode_center_boxes": "proposals: decode + top-k + gather + select", "topk_sorted": "proposals: decode + top-k + gather + select",
     "gather_boxes_bev": "proposals: decode + top-k + gather + select", "select_proposals": "proposals: decode + top-k + gather + select",
     "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d", "roipool3d_forward_fill": "roipool3d"}
+# rows whose alg_bytes are the REFERENCE operator's byte model while the own kernels that replace it move far less:
+# bench.py reports them as effective GB/s without a fraction of the HBM roof
+EFFECTIVE_ROWS = {
+    "fps levels 2-4 (verified prefix)": "A_model of three more sampling passes; fps_nested verifies the picks as a prefix of level 1's order and reads "
+                                        "each level once",
+    "FP first layer (interpolate + add, own kernels)": "three_interpolate's (C, m) in / (C, n) out; the own kernels interpolate the per-known-point "
+                                                       "products Q of the first layer instead (fewer channels, no (C, n) intermediate)"}
 IN_FORWARD = lambda fam: not fam.startswith(("proposals", "nms", "roipool"))   # families inside rpn_forward (the rest follow it)
 _ACTIVE = None
 _HOOKED = False
@@ -284,7 +291,17 @@ class C3:
         steps = max(len(self.ev), 1)
         cfg, B = self.cfg, self.B
         nn_b, interp_b = _interp_bytes(cfg)
-        roi_b = cfg.rpn_post_nms_top_n * cfg.roi_sampled_pts * (3 + 128) * 4 + cfg.num_points * (3 + 128) * 4
+        # roipool3d: bytes this batch needs moved, measured on the device like bench.py's c5 row -- rows of the NON-EMPTY RoIs written
+        # once, xyz scanned once, the feature rows of the distinct pooled points read once (the proposals of a random-weight net
+        # land where they land; rows of empty RoIs stay untouched by contract)
+        roi_total = None
+        if self.last is not None:
+            pooled, empty = self.last[4], self.last[5]
+            nonempty = int((empty == 0).sum().item())
+            distinct = sum(int(torch.unique(pooled[b, :, :, :3].reshape(-1, 3), dim=0).size(0)) for b in range(B))
+            roi_total = nonempty * cfg.roi_sampled_pts * (3 + 128) * 4 + B * cfg.num_points * 12 + distinct * (3 + 128) * 4
+            self.roi_stats = {"non_empty_rois": nonempty, "rois": B * cfg.rpn_post_nms_top_n, "distinct_pooled_points": distinct}
+        roi_b = (cfg.rpn_post_nms_top_n * cfg.roi_sampled_pts * (3 + 128) * 4 + cfg.num_points * (3 + 128) * 4) if roi_total is None else roi_total / B
         n1, m1 = cfg.num_points, cfg.npoints[0]
         fps1_b = (m1 - 1) * n1 * 12 + m1 * 4
         alg = {"fps level 1 (16384 -> 4096)": fps1_b * B, "fps levels 2-4 (verified prefix)": (_fps_model_bytes(cfg) - fps1_b) * B,
@@ -295,7 +312,11 @@ class C3:
         for key, evs in self.op_ev.items():
             ms = float(sum(a.elapsed_time(b) for a, b in evs)) / steps
             row = {"name": key, "ms_per_step": ms, "launches_per_step": len(evs) / steps,
-                   "alg_bytes_per_step": alg.get(key, 0), "traffic_key": None, "bound": "hbm"}
+                   "alg_bytes_per_step": alg.get(key, 0), "traffic_key": "c3:" + key, "bound": "hbm"}
+            if key in EFFECTIVE_ROWS:
+                row["bytes_model"] = "reference op (effective): " + EFFECTIVE_ROWS[key]
+            if key == "roipool3d" and getattr(self, "roi_stats", None):
+                row.update(self.roi_stats)
             if key.startswith("fps level 1"):
                 from bench import fps_lane_instr
                 from bench import fps_valu_pmc
@@ -318,7 +339,7 @@ class C3:
         custom_in_fwd = sum(r["ms_per_step"] for r in rows if IN_FORWARD(r["name"]))
         rows.append({"name": "library residual of rpn_forward: Tensile GEMMs (per-point products P / Q, skip products, second FP layers) + at::native "
                              "glue (fills, cat, copies)", "ms_per_step": max(fwd - custom_in_fwd, 0.0), "launches_per_step": 0, "alg_bytes_per_step": 0,
-                     "traffic_key": None, "bound": "library"})
+                     "traffic_key": "c3:library residual of rpn_forward: Tensile GEMMs + at::native glue", "bound": "library"})
         self.breakdown = {"rpn_forward_ms": fwd,
                           "proposals_nms_ms": float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev])),
                           "roipool_ms": float(np.mean([a[2].elapsed_time(a[3]) for a in self.ev])),

@@ -30,8 +30,11 @@ done
 done
 python - $OUT <<'PY'
 import json, sys
+sys.path.insert(0, ".")
+import bench
 out = sys.argv[1]
-res = {"_note": "rocprofv3 --pmc, one counter per pass, bench.py --workload c2 --kind K --batch B -> key bB_K; values per launch (average over the traced launches); "
+res = {"_source_blobs": {f: bench.git_blob_sha1(f) for f in bench.FPS_KERNEL_SOURCES},     # bench.py refuses the counts on other sources
+       "_note": "rocprofv3 --pmc, one counter per pass, bench.py --workload c2 --kind K --batch B -> key bB_K; values per launch (average over the traced launches); "
                 "sq_insts_valu = wave64 VALU instructions; physical VALU share = sq_insts_valu * 64 / duration / (1024 * 32 * 2.4e9)"}
 for ln in open(out + "/fps_valu_rows.txt"):
     p = ln.rstrip("\n").split("\t")

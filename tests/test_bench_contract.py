@@ -40,7 +40,11 @@ def test_default_line_is_the_baseline_headline():
     assert c2["workload"].startswith("c2") and c2["batch_per_gpu"] == 64 and c2["scenes_per_s_per_gpu"] > 0
     assert {"a_model", "a_min", "a_model_bytes_per_scene", "a_min_bytes_per_scene"} <= set(c2["path_gbps_per_gpu"])
     roof = out["roofline"]
-    assert roof["bound"] == "valu" and 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["bound"] == "valu"
+    if roof["frac"] is None:      # no committed --pmc pass of the kernel sources on disk for this batch: bench.py refuses a stale count
+        assert roof["frac_is"].startswith("null") and 0 < roof["dense_equivalent_frac"] <= 1 and roof["achieved"] is None
+    else:
+        assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["effective_frac"] > 0 and "fps" in roof["kernel"]
     hbm = [k for k in c2["kernels"] if k["bound"] == "hbm"]
     assert hbm and all(0 < k["frac_of_8TBps"] <= 1 for k in hbm)
@@ -58,20 +62,23 @@ def test_bench_line_follows_the_contract(flags):
     roof = out["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
     assert roof["bound"] in ("hbm", "valu") and roof["unit"] in ("GB/s", "Tlane-instr/s")
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] <= 1
+    if roof["frac"] is None:
+        assert roof["bound"] == "valu" and roof["frac_is"].startswith("null") and 0 < roof["dense_equivalent_frac"] <= 1
+    else:
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0 < roof["frac"] <= 1
     if "--no-cpu-baseline" not in flags:
         cpu = out["cpu_baseline"]
         assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu), cpu
         assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu.get("gpu_matches_oracle_on_sample", True)
 
 
-def _two_rank_bench(tmp_path, workload_flags, port):
-    """2 ranks of bench.py on ONE GPU (gloo for the exchange, both ranks on cuda:0): the N>1 path with the real kernels"""
+def _two_rank_bench(tmp_path, workload_flags, port, ranks=2):
+    """`ranks` ranks of bench.py on ONE GPU (gloo for the exchange, every rank on cuda:0): the N>1 path with the real kernels"""
     env = dict(os.environ, WS3D_DIST_BACKEND="gloo", WS3D_BENCH_DUMP=str(tmp_path), WS3D_TUNE_GEMMS="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % ranks, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", *workload_flags]
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -107,10 +114,42 @@ def test_two_ranks_c3_gather_equals_the_single_process_result(tmp_path):
         json.dump(out, f)
 
 
+def test_eight_ranks_batch_64_gather_equals_the_single_process_result(tmp_path):
+    """BASELINE configs[3]'s SHAPE without its hardware: 8 ranks x 8 scenes (global batch 64), the launcher's default depth for
+    world > 1 (16 batches in flight per rank), all eight ranks sharing the box's one GPU with gloo for the exchange.  Every rank ends
+    with the same (64, 100, 8) tensor in scene order, and it equals what one process computes for the same 64 scenes.  (No 1 -> 8
+    scaling curve exists for this build: no multi-GPU node was available to it.)"""
+    import numpy as np
+    import torch
+    out = _two_rank_bench(tmp_path, ("--workload", "c3", "--batch", "8", "--c2-batch", "0"), 29634, ranks=8)
+    assert out["n_gpus"] == 8 and out["config"]["ranks_seen"] == 8 and out["config"]["communicator"]["size"] == 8
+    assert out["config"]["batch_per_gpu"] == 8 and out["throughput_mode"]["batches_in_flight"] == 16 and "all_gather" in out["config"]["exchange"]
+    d = [np.load(os.path.join(tmp_path, "proposals_rank%d.npz" % r)) for r in range(8)]
+    assert d[0]["gathered"].shape == (64, 100, 8) and d[0]["gathered_count"].shape == (64,)
+    for r in range(8):
+        assert np.array_equal(d[r]["gathered"], d[0]["gathered"]) and np.array_equal(d[r]["gathered_count"], d[0]["gathered_count"])
+        assert np.array_equal(d[0]["gathered"][8 * r:8 * r + 8], d[r]["local"]) and np.array_equal(d[0]["gathered_count"][8 * r:8 * r + 8], d[r]["local_count"])
+    os.environ.setdefault("WS3D_TUNE_GEMMS", "0")
+    sys.path.insert(0, ROOT)
+    from bench_c3 import C3
+    from ws3d_amd import dist as wdist
+    model = None
+    for r in range(8):
+        wl = C3(8, r, 1, "hdl64", depth=1, model=model)
+        model = wl.model
+        wl.step()
+        torch.cuda.synchronize()
+        _, boxes, scores, count, _, _, _ = wl.last
+        assert np.array_equal(count.cpu().numpy(), d[0]["gathered_count"][8 * r:8 * r + 8])
+        np.testing.assert_allclose(wdist.pack_proposals(boxes, scores).cpu().numpy(), d[0]["gathered"][8 * r:8 * r + 8], rtol=0, atol=1e-4)
+    with open(os.path.join(ROOT, "gpurun_out", "eight_rank_c3.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.devnull, "w") as f:
+        json.dump(out, f)
+
+
 def test_two_ranks_c2_shards_without_a_collective(tmp_path):
     out = _two_rank_bench(tmp_path, ("--workload", "c2", "--batch", "64"), 29632)
     assert out["n_gpus"] == 2 and out["config"]["workload"].startswith("c2") and out["config"]["batch_per_gpu"] == 64
-    assert out["value"] > 0 and 0 < out["roofline"]["frac"] <= 1
+    assert out["value"] > 0 and (out["roofline"]["frac"] is None or 0 < out["roofline"]["frac"] <= 1)
     with open(os.path.join(ROOT, "gpurun_out", "two_rank_c2.json") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.devnull, "w") as f:
         json.dump(out, f)
 

@@ -594,6 +594,10 @@ def rpn_forward(model, pts_input: torch.Tensor, defer_reg_join: bool = False) ->
             rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
             reg_ready = torch.cuda.Event()
             reg_ready.record(aux)
+        # rpn_reg's block belongs to the aux stream's pool but is read on the caller's stream (and whichever stream consumes the
+        # dict): without this the caching allocator may hand the block to another pass's aux-stream allocation as soon as the
+        # tensor is dropped, while a kernel of the caller's stream still reads it (several caller streams share the pooled aux)
+        rpn_reg.record_stream(main)
         rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
         if not defer_reg_join:
             main.wait_event(reg_ready)

@@ -253,6 +253,26 @@ def proposal_boxes(batch: int, m: int, config_id: int, near_cars: bool = True) -
     return out
 
 
+def proposal_boxes_on_scene(pc: np.ndarray, cars: np.ndarray, m: int, seed: int, min_points: int = 16) -> np.ndarray:
+    """(m, 7) proposals for roipool/NMS benches on a scene whose objects are only partly visible (hdl64: frustum crop + occlusion
+    leave many of the 15 cars without a single return): centres near the cars that DO hold points -- at least `min_points` of
+    `pc` (n, >=3) within 2 m of the car centre in the ground plane -- sizes CLS_MEAN_SIZE * U(0.9, 1.1) like `proposal_boxes`.
+    SURVEY 8d: 'seeded random centres near the car clusters'; here after the crop, so that (almost) every RoI is non-empty."""
+    r = _rng(seed * 31 + 11)
+    bx = random_boxes3d(m, seed * 17 + 3)
+    d2 = (pc[None, :, 0] - cars[:, None, 0]) ** 2 + (pc[None, :, 2] - cars[:, None, 2]) ** 2
+    seen = np.nonzero((d2 < 4.0).sum(1) >= min_points)[0]
+    if seen.size == 0:                       # no visible object: centre the proposals on points of the scene
+        pick = r.integers(0, pc.shape[0], m)
+        bx[:, 0], bx[:, 2] = pc[pick, 0], pc[pick, 2]
+        return bx
+    pick = seen[r.integers(0, seen.size, m)]
+    bx[:, 0] = cars[pick, 0] + r.normal(0, 0.5, m)
+    bx[:, 2] = cars[pick, 2] + r.normal(0, 0.5, m)
+    bx[:, 6] = cars[pick, 6] + r.normal(0, 0.2, m)
+    return bx.astype(np.float32)
+
+
 def distinct_scores(n: int, seed: int) -> np.ndarray:
     """n DISTINCT float32 scores in (0,1) (torch.sort is unstable, iou3d_utils.py:67)."""
     r = _rng(seed)
