@@ -46,7 +46,12 @@ constexpr int FB_NT = FB_NW * 64;
 constexpr int FB_MAXN = FB_NW * FB_SL * 64;  // 16384
 constexpr unsigned FB_SLMASK = FB_SL == 32 ? 0xFFFFFFFFu : (1u << (FB_SL & 31)) - 1u;
 constexpr unsigned FB_WMASK = (1u << FB_NW) - 1u;
-constexpr int FB_CELLS = 1024;  // 32 x 32 Z-order cells
+#ifndef FB_GRID_BITS
+#define FB_GRID_BITS 6    // Z-order cells per axis = 1 << FB_GRID_BITS.  64 x 64 (round 4) instead of 32 x 32: the 64-point buckets are tighter and a
+                          // sample's box test leaves 4.5 instead of 5.5 buckets to update on the hdl64 scenes (simulated: scripts/sim_fps_prune.py)
+#endif
+constexpr int FB_GRID = 1 << FB_GRID_BITS;
+constexpr int FB_CELLS = FB_GRID * FB_GRID;
 
 
 typedef float f32x32 __attribute__((ext_vector_type(32)));
@@ -56,12 +61,13 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 __device__ __forceinline__ int zcell(float x, float z, float xmin, float zmin, float ix, float iz) {
     const float fx = (x - xmin) * ix, fz = (z - zmin) * iz;
-    const unsigned cx = fx > 0.f ? (fx < 31.f ? (unsigned)fx : 31u) : 0u;  // NaN -> 0
-    const unsigned cz = fz > 0.f ? (fz < 31.f ? (unsigned)fz : 31u) : 0u;
-    // 5+5 bit Morton code by table-free bit tricks
+    constexpr float top = (float)(FB_GRID - 1);
+    const unsigned cx = fx > 0.f ? (fx < top ? (unsigned)fx : (unsigned)(FB_GRID - 1)) : 0u;  // NaN -> 0
+    const unsigned cz = fz > 0.f ? (fz < top ? (unsigned)fz : (unsigned)(FB_GRID - 1)) : 0u;
+    // Morton code of the cell by table-free bit tricks
     unsigned a = cx, b = cz, code = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) code |= ((a >> i) & 1u) << (2 * i) | ((b >> i) & 1u) << (2 * i + 1);
+    for (int i = 0; i < FB_GRID_BITS; ++i) code |= ((a >> i) & 1u) << (2 * i) | ((b >> i) & 1u) << (2 * i + 1);
     return (int)code;
 }
 
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
         zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
     }
     const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
-    const float ix = (xmn < xmx) ? 32.0f / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? 32.0f / (zmx - zmn) : 0.f;
+    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
     for (int k = tid; k < n; k += FB_NT)
         atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
     __syncthreads();
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
         zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
     }
     const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
-    const float ix = (xmn < xmx) ? 32.0f / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? 32.0f / (zmx - zmn) : 0.f;
+    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
     for (int k = tid; k < n; k += NT)
         atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
     __syncthreads();
@@ -844,6 +850,441 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 #endif
 }
 
+// ================================================================================================================================
+// fps_rounds2_kernel (round 4): TWO published candidates per wave and up to FR2_KQ = 8 certified samples per round.
+//
+// What limited fps_rounds_kernel to ~3.1 samples per round was not the certification conditions but the supply of candidates: every
+// wave offers ONE point, and once it is used the bound on "everything else the wave holds" is the wave's runner-up -- usually
+// above the next wave's best.  Here a wave publishes the best point of its best bucket AND the best point of its second-best
+// bucket, plus ONE bound s_w on every point it did not publish (the third-best bucket maximum, the runners-up inside the two
+// candidate buckets).  With B = max_w s_w, the candidates taken in decreasing value are the next samples of the sequential sweep
+// for as long as each one
+//   (a) is the only candidate with its value (equal values: the reference's tie order decides -- stop, resolution round if first),
+//   (b) exceeds B (no unpublished point can beat it; running distances only fall), and
+//   (c) is not touched by the samples accepted before it in this round: fl|c - q_i|^2 >= v_c, the update's own fp32 expression.
+// scripts/sim_fps_topk.py (CPU, the bench's clouds, this bucket -> wave ownership): 5.7 (hdl64) / 6.4 (lidar) samples per round at
+// up to 8 per round against 3.15 / 3.28 of the one-candidate rounds; the sequence is the plain sweep's (also checked there).
+// The round itself is re-cut so that the extra sample slots cost nothing where the old one paid for them:
+//   * box tests on all 64 lanes: lane (g = lane >> 4, s = lane & 15) tests bucket s against the samples 2g, 2g + 1 of the round
+//     only -- two tests per lane instead of four, and the 64-bit ballot says which PAIR of samples reaches which bucket;
+//   * a bucket update applies only the pairs that reach it (their coordinates fetched into scalars from the lanes that hold them);
+//   * every lane reads just its own pair from LDS after the exchange (two 16-byte reads per wave instead of four broadcasts).
+// The certification (32 lanes of wave 0, lane c = candidate c) stays on the vector unit + LDS: ranks = number of candidates with a
+// larger key (15 row rotations + 16 against the other row, fetched by one ds_swizzle), candidates scattered by rank into the sample
+// array, a per-rank counter (ds_add) that says whether a rank is held by exactly one candidate (ties share a rank), then lane i
+// checks conditions (a)-(c) for the candidate of rank i.  No tie flags: a duplicate inside a bucket shows as s_w == v (b fails), a
+// duplicate across buckets or waves as two candidates of one rank (a fails).
+#ifndef FR2_KQ
+#define FR2_KQ 8
+#endif
+constexpr int FR2_PER = FR2_KQ / 4;           // samples tested per lane
+static_assert(FR2_KQ == 8 || FR2_KQ == 16, "2 or 4 samples per lane group");
+constexpr size_t FR2_FIXED = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * 256 * 6 + sizeof(float4) * 32 + sizeof(int) * 32 +
+                             sizeof(float) * 16 + sizeof(int) * 48 + sizeof(int) * 48 + sizeof(int) * 4 + sizeof(unsigned) * 16 + sizeof(float4) + sizeof(float) * 64 +
+                             sizeof(int) * 16;
+constexpr size_t FR2_SAMPLES_OFF = (FR2_FIXED + 15) & ~(size_t)15;
+constexpr size_t FR2_SAMPLES_MAX_M = 6144;
+static size_t fps_rounds2_smem(int m) { return FR2_SAMPLES_OFF + sizeof(float4) * (size_t)(m + FR2_KQ + 8); }
+
+__global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
+                                                           float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
+    constexpr int NW = 16, SL = 16, NT = 1024, KQ = FR2_KQ, PER = FR2_PER;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
+    int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
+    float *bbox = reinterpret_cast<float *>(hist + FB_CELLS);        // 256 * 6
+    float4 *rec = reinterpret_cast<float4 *>(bbox + 256 * 6);        // 32 candidates {x, y, z, sorted position}: [0, 16) the waves' first, [16, 32) their second
+    int *keys = reinterpret_cast<int *>(rec + 32);                   // 32: the candidates' running distances (bit patterns; negative: no candidate)
+    float *sbnd = reinterpret_cast<float *>(keys + 32);              // 16: s_w
+    int *selk = reinterpret_cast<int *>(sbnd + 16);                  // 48: keys in rank order
+    int *rcnt = selk + 48;                                           // 48: candidates per rank (zero between rounds)
+    int *posr = rcnt + 48;                                           // [0] = samples of this round (-1: tie at its head), [1] = the largest key
+    unsigned *tiekey = reinterpret_cast<unsigned *>(posr + 4);       // 16
+    float4 *tiept = reinterpret_cast<float4 *>(tiekey + 16);         // 1
+    float *red = reinterpret_cast<float *>(tiept + 1);               // 64: stage A
+    int *wsum = reinterpret_cast<int *>(red + 64);                   // 16
+    float4 *samples = reinterpret_cast<float4 *>(smem + FR2_SAMPLES_OFF);   // m + KQ + 8: every sample {x, y, z, sorted position}, in order
+
+    const int b = blockIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    if (temp) temp += (size_t)b * n;
+    if (new_xyz) new_xyz += (size_t)b * m * 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, grp = lane >> 4;      // (w as a scalar: the candidates' positions ((S NW + w) << 6) + lane stay scalar arithmetic)
+
+    // ---------------- stage A: Z-order counting sort of the scene into `order` (as in the kernels above)
+    float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
+    for (int k = tid; k < n; k += NT) {
+        const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
+        if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
+        if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
+    }
+    xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
+    if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
+    for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
+    for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
+    if (tid < 48) rcnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
+        zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
+    }
+    const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
+    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
+    for (int k = tid; k < n; k += NT)
+        atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FB_CELLS / NT;
+        int a[CPT], v = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
+        const int mine = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        int excl = off + v - mine;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += NT) {
+        const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+        order[pos] = (uint16_t)k;
+    }
+    __syncthreads();
+
+    // ---------------- registers: slot s of this lane = sorted position ((s*NW + w)*64 + lane)
+    float px[SL], py[SL], pz[SL], t[SL];
+    float bmax = -2.0f;                 // lane (g, s): the largest running distance of bucket s of this wave (-1: no point); the same in all four rows
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int pos = ((s * NW + w) << 6) + lane;
+        const int k = (int)order[pos];
+        const bool valid = k != 0xFFFF;
+        px[s] = valid ? xyz[(size_t)k * 3 + 0] : 0.f;
+        py[s] = valid ? xyz[(size_t)k * 3 + 1] : 0.f;
+        pz[s] = valid ? xyz[(size_t)k * 3 + 2] : 0.f;
+        t[s] = valid ? (temp ? temp[k] : 1e10f) : -1.0f;
+        const float lx = wave_min(valid ? px[s] : INFINITY), hx = wave_max(valid ? px[s] : -INFINITY);
+        const float ly = wave_min(valid ? py[s] : INFINITY), hy = wave_max(valid ? py[s] : -INFINITY);
+        const float lz = wave_min(valid ? pz[s] : INFINITY), hz = wave_max(valid ? pz[s] : -INFINITY);
+        if (lane == 0) {
+            float *bb = bbox + (w * SL + s) * 6;
+            bb[0] = lx; bb[1] = hx; bb[2] = ly; bb[3] = hy; bb[4] = lz; bb[5] = hz;
+        }
+        const float bm0 = wave_max(t[s]);
+        bmax = l15 == s ? bm0 : bmax;
+    }
+    __syncthreads();
+    float blx, bhx, bly, bhy, blz, bhz;
+    {
+        const float *bb = bbox + (w * SL + l15) * 6;
+        blx = bb[0]; bhx = bb[1]; bly = bb[2]; bhy = bb[3]; blz = bb[4]; bhz = bb[5];
+    }
+    FbT32 tt;
+    { tt.v0 = t[0]; tt.v1 = t[1]; tt.v2 = t[2]; tt.v3 = t[3]; tt.v4 = t[4]; tt.v5 = t[5]; tt.v6 = t[6]; tt.v7 = t[7]; tt.v8 = t[8]; tt.v9 = t[9]; tt.v10 = t[10]; tt.v11 = t[11]; tt.v12 = t[12]; tt.v13 = t[13]; tt.v14 = t[14]; tt.v15 = t[15];
+      tt.v16 = tt.v17 = tt.v18 = tt.v19 = tt.v20 = tt.v21 = tt.v22 = tt.v23 = tt.v24 = tt.v25 = tt.v26 = tt.v27 = tt.v28 = tt.v29 = tt.v30 = tt.v31 = -1.f; }
+    __syncthreads();
+
+    // the samples about to be applied: lane group g holds samples PER g .. PER g + PER - 1 of the round; unused slots hold a far point
+    // (its distance to anything is ~3e36: min() ignores it and the box test never fires).  The sweep starts from point 0.
+    constexpr float FR_FAR = 1e18f;
+    float qx[PER], qy[PER], qz[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const bool first = grp == 0 && i == 0;
+        qx[i] = first ? xyz[0] : FR_FAR; qy[i] = first ? xyz[1] : FR_FAR; qz[i] = first ? xyz[2] : FR_FAR;
+    }
+    int K = 1;
+    int slot1 = 0, slot2 = 0;
+    bool have = false;
+    int j = 1;                          // samples selected so far; the last K of them are not applied yet
+#ifdef FR2_PROF     // scripts/ubench/fps_rounds2_prof.sh: clocks per segment of three waves, bucket updates, samples per round -- returned through `temp`
+    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kh[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long pt = clock64();
+    const bool prof_wave = w == 0 || w == 5 || w == 15;
+    long long cc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ct = 0;          // inside the certification (wave 0 only)
+#define FR2P(k) if (prof_wave) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
+#define FR2C0 ct = clock64();
+#define FR2C(k) { const long long now = clock64(); cc[k] += now - ct; ct = now; }
+#else
+#define FR2P(k)
+#define FR2C0
+#define FR2C(k)
+#endif
+    for (;;) {
+        // (per-round copies of the lane coordinates the optimiser cannot see through: it would hoist the sixteen `row lane == S` masks
+        // of the bucket updates and the certification's addresses out of the loop and spill them)
+        int l15v = l15, lanev = lane;
+        asm volatile("" : "+v"(l15v), "+v"(lanev));
+#ifdef FR2_PROF
+        if (j >= m) break;
+#endif
+        if (j >= m && !temp) break;
+        if (j >= m) {                   // `temp` leaves the kernel as the reference leaves it: every sample applied but the last one picked
+            const int gl = (K - 1) / PER, il = (K - 1) % PER;
+#pragma unroll
+            for (int i = 0; i < PER; ++i)
+                if (i == il && grp == gl) { qx[i] = qy[i] = qz[i] = FR_FAR; }
+        }
+        // ---- which buckets can change?  bit (16 g + s): bucket s is within reach of a sample of pair g (exact lower bound, see above)
+#define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
+        float L = FR_BOX(qx[0], qy[0], qz[0]);
+#pragma unroll
+        for (int i = 1; i < PER; ++i) L = min_f32(FR_BOX(qx[i], qy[i], qz[i]), L);
+#undef FR_BOX
+        const uint64_t need64 = __ballot(L < bmax);
+        FR2P(0)
+        bool repick = !have;
+        if (need64) {
+            const unsigned need_lo = (unsigned)need64, need_hi = (unsigned)(need64 >> 32);      // pairs 0, 1 / pairs 2, 3
+            const unsigned need16 = (need_lo | (need_lo >> 16) | need_hi | (need_hi >> 16)) & 0xFFFFu;
+            // the pairs that reach something, as scalars (from the first lane of the group that holds them)
+            float sx[4][PER], sy[4][PER], sz[4][PER];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) { sx[g][i] = 0.f; sy[g][i] = 0.f; sz[g][i] = 0.f; }
+                if ((g < 2 ? need_lo : need_hi) & (0xFFFFu << (16 * (g & 1)))) {
+#pragma unroll
+                    for (int i = 0; i < PER; ++i) { sx[g][i] = readlane_f(qx[i], 16 * g); sy[g][i] = readlane_f(qy[i], 16 * g); sz[g][i] = readlane_f(qz[i], 16 * g); }
+                }
+            }
+#define FR2_GRP(S, G)                                                                                  \
+    if (((G) < 2 ? need_lo : need_hi) & (1u << (16 * ((G) & 1) + (S)))) {                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) d = min_f32(sqdist3(px[S] - sx[G][i_], py[S] - sy[G][i_], pz[S] - sz[G][i_]), d); \
+    }
+#define FR2_UPD(S)                                                                                     \
+    if (need16 & (1u << (S))) {                                                                        \
+        float d = INFINITY;                                                                            \
+        FR2_GRP(S, 0) FR2_GRP(S, 1) FR2_GRP(S, 2) FR2_GRP(S, 3)                                        \
+        fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
+        const float bm = wave_max(fb_t<S>(tt));                                                        \
+        bmax = l15v == (S) ? bm : bmax;                                                                \
+    }
+#define FR2_UPD8(G8) if (need16 & (0xFFu << (G8))) { FR2_UPD(G8) FR2_UPD(G8 + 1) FR2_UPD(G8 + 2) FR2_UPD(G8 + 3) FR2_UPD(G8 + 4) FR2_UPD(G8 + 5) FR2_UPD(G8 + 6) FR2_UPD(G8 + 7) }
+            FR2_UPD8(0) FR2_UPD8(8)
+#undef FR2_UPD8
+#undef FR2_UPD
+#undef FR2_GRP
+            // running distances only fall: the published candidates stay the wave's two best buckets unless one of THEM changed (the
+            // published bound may go stale; it stays an upper bound)
+            repick = repick || (((need16 >> slot1) | (need16 >> slot2)) & 1u);
+#ifdef FR2_PROF
+            pc[7] += __builtin_popcount(need16);
+#endif
+        }
+        FR2P(1)
+        if (j >= m) break;
+        if (repick) {
+            // the two best buckets (their cached maxima live in lanes 0 .. 15 of every row), the best of the rest
+            const float m1 = readlane_f(row16_max(bmax), 0);
+            slot1 = (int)__builtin_ctz((unsigned)__ballot(bmax == m1) & 0xFFFFu);
+            const float bm2 = l15v == slot1 ? -3.0f : bmax;
+            const float m2 = readlane_f(row16_max(bm2), 0);
+            slot2 = (int)__builtin_ctz((unsigned)__ballot(bm2 == m2) & 0xFFFFu);
+            const float bm3 = l15v == slot2 ? -3.0f : bm2;
+            const float m3 = readlane_f(row16_max(bm3), 0);
+            float c1x = 0.f, c1y = 0.f, c1z = 0.f, c2x = 0.f, c2y = 0.f, c2z = 0.f, t21 = -3.0f, t22 = -3.0f;
+            int c1p = 0, c2p = 0;
+            // the best point of bucket S (value V) and the largest OTHER value of that bucket
+#define FR2_PICK(S, V, CX, CY, CZ, CP, T2)                                                             \
+    case S: {                                                                                          \
+        const uint64_t eql = __ballot(fb_t<S>(tt) == (V));                                             \
+        const int wl = (int)__builtin_ctzll(eql);                                                      \
+        CX = readlane_f(px[S], wl); CY = readlane_f(py[S], wl); CZ = readlane_f(pz[S], wl);            \
+        CP = ((S * NW + w) << 6) + wl;                                                                 \
+        T2 = wave_max(lanev == wl ? -3.0f : fb_t<S>(tt));                                               \
+    } break;
+#define FR2_PICK16(V, CX, CY, CZ, CP, T2, SLOT)                                                        \
+    switch (SLOT) {                                                                                    \
+        FR2_PICK(0, V, CX, CY, CZ, CP, T2) FR2_PICK(1, V, CX, CY, CZ, CP, T2) FR2_PICK(2, V, CX, CY, CZ, CP, T2) FR2_PICK(3, V, CX, CY, CZ, CP, T2) \
+        FR2_PICK(4, V, CX, CY, CZ, CP, T2) FR2_PICK(5, V, CX, CY, CZ, CP, T2) FR2_PICK(6, V, CX, CY, CZ, CP, T2) FR2_PICK(7, V, CX, CY, CZ, CP, T2) \
+        FR2_PICK(8, V, CX, CY, CZ, CP, T2) FR2_PICK(9, V, CX, CY, CZ, CP, T2) FR2_PICK(10, V, CX, CY, CZ, CP, T2) FR2_PICK(11, V, CX, CY, CZ, CP, T2) \
+        FR2_PICK(12, V, CX, CY, CZ, CP, T2) FR2_PICK(13, V, CX, CY, CZ, CP, T2) FR2_PICK(14, V, CX, CY, CZ, CP, T2) FR2_PICK(15, V, CX, CY, CZ, CP, T2) \
+    }
+            FR2_PICK16(m1, c1x, c1y, c1z, c1p, t21, slot1)
+            if (m2 >= 0.f) { FR2_PICK16(m2, c2x, c2y, c2z, c2p, t22, slot2) }
+#undef FR2_PICK16
+#undef FR2_PICK
+            const float bound = max_f32(max_f32(m3, t21), t22);
+            if (lane == 0) {
+                rec[w] = make_float4(c1x, c1y, c1z, __int_as_float(c1p));
+                rec[16 + w] = make_float4(c2x, c2y, c2z, __int_as_float(c2p));
+                keys[w] = __float_as_int(m1);
+                keys[16 + w] = __float_as_int(m2);
+                sbnd[w] = bound;
+            }
+            have = true;
+        }
+        FR2P(2)
+        lds_barrier();
+        FR2P(3)
+        if (w == 0) {
+            // ---- certification by wave 0 (see the header).  Every value compared is >= 0 or a negative "nothing" mark: non-negative
+            // floats order like their bit patterns, so the comparisons are sign bits of integer differences (marks clamped to -1).
+            // Ranks on all four rows at once: row q compares candidate set q >> 1 (0 = the waves' first candidates, 1 = their second)
+            // with set q & 1 -- 16 rotations -- and rows 0 / 2 add the count of rows 1 / 3 (one ds_swizzle).
+            FR2C0
+            float4 *selq = samples + j;
+            const int row = lanev >> 4;
+            const int aidx = ((row >> 1) << 4) + l15v, bidx = ((row & 1) << 4) + l15v;
+            const int key = keys[aidx];
+            const int keyb = keys[bidx];
+            const float4 r = rec[aidx];
+            const float sb = sbnd[l15v];
+            __builtin_amdgcn_sched_barrier(0);
+            FR2C(0)
+            const int nA = ~max(key, -1), nB = ~max(keyb, -1);       // ~a - ~b = b - a
+            unsigned above = __builtin_amdgcn_alignbit(0u, (unsigned)nB - (unsigned)nA, 31u);
+            // v_sub_u32_dpp d, a, b row_ror:N  =  a[lane rotated] - b[own]  (checked on the device, see the kernel above)
+#define FR2_RANK(N, NOP)                                                                                                          \
+    {                                                                                                                             \
+        unsigned d_;                                                                                                              \
+        asm(NOP "v_sub_u32_dpp %0, %1, %2 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(d_) : "v"(nB), "v"(nA));              \
+        above = __builtin_amdgcn_alignbit(above, d_, 31u);                                                                        \
+    }
+            FR2_RANK(1, "s_nop 1\n\t") FR2_RANK(2, "") FR2_RANK(3, "") FR2_RANK(4, "") FR2_RANK(5, "") FR2_RANK(6, "") FR2_RANK(7, "") FR2_RANK(8, "")
+            FR2_RANK(9, "") FR2_RANK(10, "") FR2_RANK(11, "") FR2_RANK(12, "") FR2_RANK(13, "") FR2_RANK(14, "") FR2_RANK(15, "")
+#undef FR2_RANK
+            const int part = (int)__builtin_popcount(above);
+            const int other = __builtin_amdgcn_ds_swizzle(part, (0x10 << 10) | 0x1F);      // lane ^ 16 (bit mode: and 0x1F, xor 0x10)
+            const int rk = key < 0 ? KQ + 1 : min(part + other, KQ + 1);     // marks and ranks > KQ share a slot nothing reads
+            FR2C(1)
+            // the candidates in rank order (rows 0 and 2 hold the totals); how many hold each rank
+            if ((row & 1) == 0) {
+                selq[rk] = r;
+                selk[rk] = key;
+                atomicAdd(&rcnt[rk], 1);
+            }
+            // B = the largest bound of all waves (every row computes it)
+            const int Bk = max(__float_as_int(row16_max(sb)), -1);
+            // (one wave, and a wave's LDS operations execute in order: the reads below see the scatter)
+            // the checks, lane 8 i + jj: the candidate of rank i against the one of rank jj < i -- all 28 pairs at once
+            const int pi = lanev >> 3, pj = lanev & 7;
+            static_assert(KQ == 8, "the pair layout is 8 x 8 lanes");
+            const float4 ci = selq[pi], cj = selq[pj];
+            const int ki = selk[pi];
+            const int cnt = rcnt[pi];
+            const int top = selk[0];
+            __builtin_amdgcn_sched_barrier(0);
+            FR2C(2)
+            float dm = sqdist3(ci.x - cj.x, ci.y - cj.y, ci.z - cj.z);
+            dm = pj < pi ? dm : INFINITY;
+            dm = min_f32(dm, dpp_f<DPP_QUAD_XOR1>(dm));              // smallest distance to the candidates of smaller rank: min over the 8 lanes
+            dm = min_f32(dm, dpp_f<DPP_QUAD_XOR2>(dm));
+            dm = min_f32(dm, dpp_f<DPP_ROW_HALF_MIRROR>(dm));
+            FR2C(3)
+            if (lanev < KQ + 2) rcnt[lanev] = 0;                     // (zero for the next round)
+            const int cap = min(KQ, m - j);
+            // (a) alone at its rank, (b) above every unpublished point, (c) untouched by the samples before it
+            const bool pass = pi < cap && cnt == 1 && ki > Bk && __float_as_int(dm) >= ki;
+            const uint64_t pm = __ballot(pass);                      // (the 8 lanes of a rank agree)
+            int nk = pm == ~0ull ? KQ : (int)(__builtin_ctzll(~pm) >> 3);        // leading passes (ranks >= cap never pass)
+            if (nk == 0) nk = -1;                                    // the head of the round is tied: resolution round
+            // the slots past the accepted samples become the far point (in-order LDS: after the candidates parked there)
+            if (pj == 0 && pi >= max(nk, 1)) selq[pi] = make_float4(FR_FAR, FR_FAR, FR_FAR, 0.f);
+            if (lanev == 0) { posr[0] = nk; posr[1] = top; }
+            FR2C(4)
+        }
+        FR2P(4)
+        lds_barrier();
+        FR2P(5)
+        {   // this lane's pair of samples and the count in flight together (unused slots hold the far point; a tie round overwrites them)
+            float4 sq[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) sq[i] = samples[j + PER * grp + i];
+            K = posr[0];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
+        }
+        if (K > 0) {
+        } else {
+            // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
+            const float gmax = __int_as_float(posr[1]);
+            unsigned key = 0xFFFFFFFFu;
+            const float ta[32] = FB_T32_LIST(tt);
+#pragma unroll
+            for (int s = 0; s < SL; ++s) {
+                if (ta[s] == gmax) {
+                    const int pos = ((s * NW + w) << 6) + lane;
+                    const int k = (int)order[pos];
+                    const unsigned rank = (unsigned)(fb_bitrev(k & (bs - 1), log2bs) * S + (k >> log2bs));
+                    key = min(key, (rank << 14) | (unsigned)pos);
+                }
+            }
+            const unsigned wkey = wave_min_u32(key);
+            if (lane == 0) tiekey[w] = wkey;
+            lds_barrier();
+            unsigned gk = tiekey[lane & (NW - 1)];
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR1, 0xF, 0xF, false));
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR2, 0xF, 0xF, false));
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
+            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_MIRROR, 0xF, 0xF, false));
+            const int ipos = (int)(__builtin_amdgcn_readfirstlane(gk) & 0x3FFFu);
+            const int ob = ipos >> 6, ol = ipos & 63;           // owning bucket / lane
+            if ((ob & (NW - 1)) == w) {
+                const int os = ob / NW;                       // wave-uniform slot
+                float ox = 0.f, oy = 0.f, oz = 0.f;
+#define FR_OWN(S) case S: ox = readlane_f(px[S], ol); oy = readlane_f(py[S], ol); oz = readlane_f(pz[S], ol); break;
+                switch (os) {
+                    FR_OWN(0) FR_OWN(1) FR_OWN(2) FR_OWN(3) FR_OWN(4) FR_OWN(5) FR_OWN(6) FR_OWN(7)
+                    FR_OWN(8) FR_OWN(9) FR_OWN(10) FR_OWN(11) FR_OWN(12) FR_OWN(13) FR_OWN(14) FR_OWN(15)
+                }
+#undef FR_OWN
+                if (lane == 0) *tiept = make_float4(ox, oy, oz, 0.f);
+            }
+            lds_barrier();
+            const float4 c = *tiept;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const bool first = grp == 0 && i == 0;
+                qx[i] = first ? c.x : FR_FAR; qy[i] = first ? c.y : FR_FAR; qz[i] = first ? c.z : FR_FAR;
+            }
+            K = 1;
+            if (tid == NT - 64) samples[j] = make_float4(c.x, c.y, c.z, __int_as_float(ipos));
+        }
+        j += K;
+#ifdef FR2_PROF
+        kh[K < 11 ? K : 11] += 1;
+#endif
+        FR2P(6)
+    }
+
+    // the samples leave the chip: sorted positions -> point indices, coordinates as stored (pure copies of xyz)
+    __syncthreads();
+    for (int jj = tid; jj < m; jj += NT) {
+        if (jj == 0) {
+            idx[0] = 0;
+            if (new_xyz) { new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
+        } else {
+            const float4 sm = samples[jj];
+            idx[jj] = (int)order[__float_as_int(sm.w)];
+            if (new_xyz) { new_xyz[jj * 3 + 0] = sm.x; new_xyz[jj * 3 + 1] = sm.y; new_xyz[jj * 3 + 2] = sm.z; }
+        }
+    }
+    if (temp) {
+        const float ta[32] = FB_T32_LIST(tt);
+#pragma unroll
+        for (int s = 0; s < SL; ++s) {
+            const int k = (int)order[((s * NW + w) << 6) + lane];
+            if (k != 0xFFFF) temp[k] = ta[s];
+        }
+    }
+#ifdef FR2_PROF
+    __syncthreads();
+    if (temp && lane == 0) {
+        for (int k = 0; k < 8; ++k) temp[w * 8 + k] = (float)pc[k];
+        for (int k = 0; k < 12; ++k) temp[128 + w * 12 + k] = (float)kh[k];
+        if (w == 0) for (int k = 0; k < 8; ++k) temp[512 + k] = (float)cc[k];
+    }
+#endif
+}
+
 size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
 
 // does the multi-sample kernel take this launch?  (fps.hip: it then serves every batch size -- 512 scenes in two waves of
@@ -866,8 +1307,18 @@ int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_
         attr_set = true;
     }
 #if FB_NW == 16 && !defined(FB_PROF)
-    // several certified samples per record exchange (fps_rounds_kernel); WS3D_FPS_ROUNDS=0: one sample per exchange (A/B runs)
-    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
+    // WS3D_FPS_ROUNDS: 2 (default) = two candidates per wave, up to 8 certified samples per round (fps_rounds2_kernel, round 4);
+    // 1 = one candidate per wave, up to 4 (fps_rounds_kernel, round 3); 0 = one sample per exchange (A/B runs)
+    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 2;
+    if (rounds >= 2 && (size_t)m <= FR2_SAMPLES_MAX_M) {
+        static bool attr3 = false;
+        if (!attr3) {
+            (void)hipFuncSetAttribute((const void *)fps_rounds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds2_smem((int)FR2_SAMPLES_MAX_M));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(fps_rounds2_kernel, dim3(b), dim3(1024), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
+        return check_launch("furthest_point_sampling(rounds2)");
+    }
     if (rounds && (size_t)m <= FR_SAMPLES_MAX_M) {
         static bool attr2 = false;
         if (!attr2) {
