@@ -257,16 +257,16 @@ class C2:
     def kernel_table(self):
         fps = float(np.mean([a[0].elapsed_time(a[1]) for a in self.ev]))
         qg = float(np.mean([a[1].elapsed_time(a[2]) for a in self.ev]))
-        # round 3: fps_rounds_kernel (fps_bucket.hip) at every batch size -- one scene per CU, ceil(B / 256) waves of workgroups; 4.96 ms
-        # per 512 scenes against 6.10 ms of the dense two-scenes-per-CU kernel (profiles/r03_fps_rounds_ab.txt)
+        # round 4: fps_rounds2_kernel (fps_bucket.hip) at every batch size -- one scene per CU, ceil(B / 256) waves of workgroups; 3.3 ms
+        # per 512 scenes (round 3's fps_rounds_kernel 4.07, the dense two-scenes-per-CU kernel 6.10)
         pmc = fps_valu_pmc(self.B, self.kind)
-        fps_row = {"name": "fps_rounds_kernel<16> (exact pruned sampling, several certified samples per record exchange; one scene per CU, "
+        fps_row = {"name": "fps_rounds2_kernel (exact pruned sampling, two candidates per wave, up to 8 certified samples per record exchange; one scene per CU, "
                            "%d wave(s) of workgroups) (furthest_point_sample + gather)" % -(-self.B // 256), "ms_per_step": fps,
                    "launches_per_step": 1, "bound": "valu", "lane_instr_per_step": fps_lane_instr(N_PTS, M_PTS) * self.B,
                    "physical_lane_instr_per_step": None if pmc is None else pmc["sq_insts_valu_per_launch"] * 64.0,
                    "us_per_sample": fps * 1e3 / (M_PTS - 1) / -(-self.B // 256),
                    "alg_bytes_per_step": a_model_fps() * self.B,
-                   "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_rounds_kernel",
+                   "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_rounds2_kernel",
                    "comment": "chain-bound, not VALU-bound: a round of the kernel is box tests, bucket updates, a re-pick, a record exchange and the "
                               "certification of up to 4 samples (fps_bucket.hip); pruning leaves ~1/4 of the dense sweep's instructions.  valu_frac = "
                               "ISSUED wave64 VALU instructions x 64 lanes (SQ_INSTS_VALU of the committed --pmc pass of this batch and generator, "
@@ -868,7 +868,7 @@ def main():
                 e8 = fps_valu_pmc(wl.scenes(), args.kind)
                 pmc = None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0 / (c3fps["ms_per_step"] * 1e-3) / (VALU_PEAK * wl.scenes() / 256.0)
                 out["roofline"]["same_kernel_family_in_the_timed_c3_step"] = {
-                    "kernel": "fps_rounds_kernel<16> (exact pruned sampling, several certified samples per exchange; level 1: 16384 -> 4096)",
+                    "kernel": "fps_rounds2_kernel (exact pruned sampling, two candidates per wave, up to 8 certified samples per exchange; level 1: 16384 -> 4096)",
                     "ms_per_step_eager": c3fps["ms_per_step"],
                     "workgroups": wl.scenes(), "us_per_sample": us, "clk_per_sample_at_2.4GHz": None if us is None else us * 2400.0,
                     "valu_share_of_occupied_CUs_pmc": pmc,

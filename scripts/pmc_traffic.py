@@ -20,7 +20,7 @@ def short(name):
         return "fps_v3_pair_kernel" if ", true, " in name else "fps_v3_kernel"
     if "roipool3d_pipe_kernel" in name or "roipool3d_kernel" in name:      # the large-scene variant reports under the same key
         return "roipool3d_kernel"
-    for k in ("fps_rounds_kernel", "ball_query_grid_coop_kernel", "fps_bucket_kernel", "fps_zlds_kernel", "fps_reg_kernel", "fps_big_kernel", "ball_query_grid_kernel", "bin_points_grid_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_rot_mask_kernel", "nms_sweep_kernel", "bev_frames_kernel", "roipool3d_kernel",
+    for k in ("fps_rounds2_kernel", "fps_rounds_kernel", "ball_query_grid_coop_kernel", "fps_bucket_kernel", "fps_zlds_kernel", "fps_reg_kernel", "fps_big_kernel", "ball_query_grid_kernel", "bin_points_grid_kernel", "ball_query_sorted_kernel", "bin_points_x_kernel", "ball_query_kernel", "nms_rot_mask_kernel", "nms_sweep_kernel", "bev_frames_kernel", "roipool3d_kernel",
               "three_nn_kernel", "three_interpolate_kernel", "group_points_kernel"):
         if k in name:
             return k

@@ -14,7 +14,7 @@ import sys
 
 # kernel-name fragment -> family name of bench_c3.FAMILIES (first match wins)
 FAMILY_OF = [
-    ("fps_rounds_kernel", "fps level 1 (16384 -> 4096)"), ("fps_bucket_kernel", "fps level 1 (16384 -> 4096)"), ("fps_v3_kernel", "fps level 1 (16384 -> 4096)"),
+    ("fps_rounds2_kernel", "fps level 1 (16384 -> 4096)"), ("fps_rounds_kernel", "fps level 1 (16384 -> 4096)"), ("fps_bucket_kernel", "fps level 1 (16384 -> 4096)"), ("fps_v3_kernel", "fps level 1 (16384 -> 4096)"),
     ("fps_nested_", "fps levels 2-4 (verified prefix)"),
     ("bin_points_", "binning (grid / x slabs / xz grid)"),
     ("ball_query_", "ball_query"),
@@ -53,8 +53,8 @@ def per_dispatch(db_path, counter):
 
 def main(fetch_db, write_db, out, kind, batch):
     f, w = per_dispatch(fetch_db, "FETCH_SIZE"), per_dispatch(write_db, "WRITE_SIZE")
-    steps_f = sum(n for k, (_, n) in f.items() if "fps_rounds_kernel" in k or "fps_bucket_kernel" in k) or 1
-    steps_w = sum(n for k, (_, n) in w.items() if "fps_rounds_kernel" in k or "fps_bucket_kernel" in k) or 1
+    steps_f = sum(n for k, (_, n) in f.items() if "fps_rounds2_kernel" in k or "fps_rounds_kernel" in k or "fps_bucket_kernel" in k) or 1
+    steps_w = sum(n for k, (_, n) in w.items() if "fps_rounds2_kernel" in k or "fps_rounds_kernel" in k or "fps_bucket_kernel" in k) or 1
     res = {"_note": "c3 eager step, batch %s, generator %s: HBM bytes PER STEP per launch family (sum over the family's dispatches / steps "
                     "traced), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; fetch raw (gfx950: wide streams under-reported 2x)" % (batch, kind),
            "_scenes_per_launch": int(batch), "_kind": kind, "_steps_traced": [steps_f, steps_w]}

@@ -18,9 +18,11 @@ for kind in ("hdl64", "lidar"):
     compat.furthest_point_sampling_gather(B, N, M, xyz, temp, idx, nx)
     torch.cuda.synchronize()
     t = temp[0, :128].cpu().numpy().reshape(16, 8)
-    kh = temp[0, 128:128 + 192].cpu().numpy().reshape(16, 12)[0]
+    khall = temp[0, 128:128 + 192].cpu().numpy().reshape(16, 12)
+    kh = khall[0].copy(); repicks = khall[:, 11].copy(); kh[11] = 0
     rounds = kh.sum()
     print("%s: %d rounds for %d samples = %.2f samples per round; rounds by number of samples (tie-round, 1, 2, ...): %s" % (kind, rounds, M - 1, (M - 1) / rounds, [int(v) for v in kh]))
+    print("  re-picks per round: %.1f of 16 waves (busiest wave %.2f)" % (repicks.sum() / rounds, repicks.max() / rounds))
     print("  bucket updates per round: %.1f in all 16 waves, busiest wave %.2f, average wave %.2f" % (t[:, 7].sum() / rounds, t[:, 7].max() / rounds, t[:, 7].mean() / rounds))
     names = ["box tests", "updates", "re-pick + publish", "wait A", "certify / idle", "wait B", "read samples"]
     cc = temp[0, 512:520].cpu().numpy()

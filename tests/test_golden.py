@@ -398,7 +398,7 @@ def test_gpu_fps_follows_the_references_getGreedyPerm():
             np.testing.assert_array_equal(got[:min(k, m)], perm[:min(k, m)], err_msg="%s m=%d" % (key, m))
 
 
-# --- the same at FULL size: 16384 points -> 4096 samples, the shape of the headline's level-1 launch (csrc/fps_bucket.hip fps_rounds_kernel)
+# --- the same at FULL size: 16384 points -> 4096 samples, the shape of the headline's level-1 launch (csrc/fps_bucket.hip fps_rounds2_kernel)
 def _greedyperm_full_cases():
     """tests/golden/fps_greedyperm_16k.npz: getGreedyPerm over the 16384 x 16384 float64 matrix of four full scenes (hdl64 x 2, lidar,
     uniform), first 4096 steps kept (make_golden_greedyperm.py FULL_CASES)"""
@@ -448,8 +448,8 @@ print("RESULT " + json.dumps(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"WS3D_FPS_ROUNDS": "0"}, {"WS3D_FPS_BUCKET": "0"}],
-                         ids=["default_fps_rounds_kernel", "one_sample_per_exchange", "dense_sweep"])
+@pytest.mark.parametrize("env", [{}, {"WS3D_FPS_ROUNDS": "1"}, {"WS3D_FPS_ROUNDS": "0"}, {"WS3D_FPS_BUCKET": "0"}],
+                         ids=["default_fps_rounds2_kernel", "one_candidate_per_wave_rounds", "one_sample_per_exchange", "dense_sweep"])
 def test_gpu_fps_follows_getGreedyPerm_at_full_size(env):
     """the reference-held permutation on the kernel that carries the headline (default dispatch above 8192 points) and on the two
     kernels behind it, each in its own process (the switches are read once per process)"""

@@ -154,6 +154,8 @@ FPS_ENV_VARIANTS = [
     {"WS3D_FPS_STREAM": "1"},                            # the round-1 streaming kernel above 16384 points
     {"WS3D_FPS_BUCKET": "0"},                            # dense sweep also where the pruned kernel is the default
     {"WS3D_FPS_BUCKET": "1"},                            # pruned kernel for every cloud of 4097..16384 points
+    {"WS3D_FPS_BUCKET": "1", "WS3D_FPS_ROUNDS": "1"},    # round 3's rounds (one candidate per wave, up to 4 samples per exchange)
+    {"WS3D_FPS_BUCKET": "1", "WS3D_FPS_ROUNDS": "0"},    # round 2's kernel (one sample per exchange)
 ]
 
 

@@ -1120,6 +1120,9 @@ __global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restri
                 sbnd[w] = bound;
             }
             have = true;
+#ifdef FR2_PROF
+            kh[11] += 1;                 // (re-picks of this wave; rounds with more than 10 samples do not exist at KQ = 8)
+#endif
         }
         FR2P(2)
         lds_barrier();
