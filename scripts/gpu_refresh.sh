@@ -55,7 +55,6 @@ $T bash scripts/pmc_fps_valu.sh $OUT/pmc_fps > $OUT/pmc_fps_valu.txt 2>&1
 $T bash scripts/ubench/fps_rounds_prof.sh > $OUT/fps_rounds_segments.txt 2>&1
 $T python scripts/graph_fork_debug.py > $OUT/graph_fork_join_stress.txt 2>&1
 $T python scripts/ubench/compact_vs_dense.py > $OUT/compact_vs_dense_dispatch.txt 2>&1
-for coop in 1 0; do WS3D_BQ_GRID_COOP=$coop $T python bench.py --no-cpu-baseline --no-side-runs --c2-batch 512 2>/dev/null | tail -1 > $OUT/bench_ab_ball_query_coop$coop.json; done
 rm -rf /tmp/tl; (cd /tmp && $T rocprofv3 --kernel-trace -d /tmp/tl -o t -- python $OLDPWD/scripts/host_issue_time.py > $OLDPWD/$OUT/host_issue_time.txt 2>&1)
 python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_rounds2_kernel $OUT/c3_eager_timeline.txt > /dev/null 2>>$OUT/host_issue_time.txt
 python scripts/host_issue_time.py > $OUT/host_issue_time_untraced.txt 2>&1

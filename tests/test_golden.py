@@ -448,8 +448,8 @@ print("RESULT " + json.dumps(out))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"WS3D_FPS_ROUNDS": "1"}, {"WS3D_FPS_ROUNDS": "0"}, {"WS3D_FPS_BUCKET": "0"}],
-                         ids=["default_fps_rounds2_kernel", "one_candidate_per_wave_rounds", "one_sample_per_exchange", "dense_sweep"])
+@pytest.mark.parametrize("env", [{}, {"WS3D_FPS_ROUNDS": "0"}, {"WS3D_FPS_BUCKET": "0"}],
+                         ids=["default_fps_rounds2_kernel", "one_sample_per_exchange", "dense_sweep"])
 def test_gpu_fps_follows_getGreedyPerm_at_full_size(env):
     """the reference-held permutation on the kernel that carries the headline (default dispatch above 8192 points) and on the two
     kernels behind it, each in its own process (the switches are read once per process)"""

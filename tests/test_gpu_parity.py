@@ -144,18 +144,10 @@ def test_fps_two_scenes_per_cu_kernel_subprocess(ops, oracle, tmp_path):
 
 
 FPS_ENV_VARIANTS = [
-    {"WS3D_FPS_IMPL": "2"},                              # the round-1 kernels (fps.hip) for every shape
-    {"WS3D_FPS_SMALL3": "1"},                            # fps_v3 kernels also for the one-to-four-wave shapes
-    {"WS3D_FPS_ONEX": "1"},                              # one-exchange variant of the 16384-point kernel
-    {"WS3D_FPS_ONEX": "1", "WS3D_FPS_GEOM3": "1024"},
-    {"WS3D_FPS_GEOM3": "512"}, {"WS3D_FPS_GEOM3": "256"}, {"WS3D_FPS_GEOM3": "1024"},
-    {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "0"}, {"WS3D_FPS_PAIR": "1", "WS3D_FPS_PRIO": "2"},
-    {"WS3D_FPS_PAIR": "1", "WS3D_FPS_DUO": "1"},          # two scenes per workgroup, half a step out of phase (even batches)
-    {"WS3D_FPS_STREAM": "1"},                            # the round-1 streaming kernel above 16384 points
-    {"WS3D_FPS_BUCKET": "0"},                            # dense sweep also where the pruned kernel is the default
-    {"WS3D_FPS_BUCKET": "1"},                            # pruned kernel for every cloud of 4097..16384 points
-    {"WS3D_FPS_BUCKET": "1", "WS3D_FPS_ROUNDS": "1"},    # round 3's rounds (one candidate per wave, up to 4 samples per exchange)
-    {"WS3D_FPS_BUCKET": "1", "WS3D_FPS_ROUNDS": "0"},    # round 2's kernel (one sample per exchange)
+    {"WS3D_FPS_PAIR": "1"},                              # two scenes per CU (the dense kernel's form for more scenes than CUs)
+    {"WS3D_FPS_BUCKET": "0"},                            # dense sweep also where the pruned kernels are the default
+    {"WS3D_FPS_BUCKET": "1"},                            # pruned kernels for every cloud of 4097..16384 points
+    {"WS3D_FPS_BUCKET": "1", "WS3D_FPS_ROUNDS": "0"},    # ... one sample per record exchange (round 2's kernel; serves m > 6144 by default)
 ]
 
 
@@ -1916,10 +1908,9 @@ def test_mlp2_rows_matches_two_layers(rows, o2, relu2, bias):
     assert C.mlp2_rows(x[:31], w1t, b1, True, w2t, b2, relu2) is None
 
 
-@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
-def test_gemm_pool_tile_variants_subprocess(tile):
-    """every selectable output tile of ws3d_gemm_pool (WS3D_GP_TILE = row blocks, column blocks of 64 per workgroup) against the
-    float64 product + group max; shapes on and off the tile multiples (those fall back to the 64 x 64 kernel)"""
+def test_gemm_pool_both_output_tiles():
+    """ws3d_gemm_pool against the float64 product + group max on shapes that take the 64 x 64 kernel and on one that takes the
+    128 x 128 one (rows % 128 == 0, O % 128 == 0, >= 512 tiles: the last shape); in a child process like the other library-level checks"""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent(f"""
@@ -1940,15 +1931,13 @@ def test_gemm_pool_tile_variants_subprocess(tile):
             assert err <= 2e-5 * max(1.0, float(ref.abs().max())), (rows, ns, k, o, err)
         print("ok")
     """)
-    env = dict(os.environ, WS3D_GP_TILE=tile)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("tile", ["11", "21", "12", "22"])
-def test_interp_gemm_tile_variants_subprocess(tile):
-    """every selectable output tile of ws3d_interp_gemm (WS3D_IG_TILE) against three_interpolate + concat + float64 product,
-    including the c1 = 1 ragged skip block of FP1 and shapes off the tile multiples (which run the 64 x 64 kernel)"""
+def test_interp_gemm_both_output_tiles():
+    """ws3d_interp_gemm against three_interpolate + concat + float64 product, including the c1 = 1 ragged skip block of FP1: shapes
+    that take the 64 x 64 kernel and one that takes the 64 x 128 one (O % 128 == 0, >= 512 tiles: the last shape)"""
     import subprocess, sys, os, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent(f"""
@@ -1973,8 +1962,7 @@ def test_interp_gemm_tile_variants_subprocess(tile):
             assert err <= 4e-6 * max(want.abs().max().item(), 1.0) * np.sqrt((C2 + C1) / 96), (B, N, M, C2, C1, O, err)
         print("ok")
     """)
-    env = dict(os.environ, WS3D_IG_TILE=tile)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 

@@ -46,7 +46,7 @@ def hipcc() -> str:
 
 def _deps(src: str):
     return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "binning.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
-            os.path.abspath(__file__)]
+            os.path.join(CSRC, "exports.map"), os.path.abspath(__file__)]
 
 
 def _compile(src: str, force: bool, verbose: bool, dist_mode: int = 0) -> str:
@@ -75,7 +75,7 @@ def build(force: bool = False, verbose: bool = False, dist_mode: int = 0) -> str
         objs = list(ex.map(lambda s: _compile(s, force, verbose, dist_mode), SOURCES))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         # export only the extern "C" ws3d_* symbols (-fvisibility=hidden + default below)
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

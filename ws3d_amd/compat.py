@@ -146,7 +146,7 @@ SORTED_MIN_N = 2048  # below this the LDS-tiled brute-force scan is already chea
 
 
 BQ_FINE_GRID = True   # sort_points_x builds the fine (x, z) grid (ws3d_sort_points_grid); False: x slabs (A/B runs)
-TOPK_SEGMENTS = os.environ.get("WS3D_TOPK_SEGMENTS", "1") != "0"   # topk_sorted: a scene's sort spread over its CUs (ws3d_topk_sorted_ws); 0: one workgroup per scene (A/B runs)
+TOPK_SEGMENTS = True   # topk_sorted: a scene's sort spread over its CUs (ws3d_topk_sorted_ws); False: one workgroup per scene (tests flip it)
 
 
 def sort_points_x(xyz, min_n=None, grid=None):

@@ -1129,9 +1129,8 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         while (gz < 64 && tiles * gz < 1024 && (64L * nsample) / (gz * 2) >= 64) gz *= 2;
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
-        static const int coop_env = getenv("WS3D_BQ_GRID_COOP") ? atoi(getenv("WS3D_BQ_GRID_COOP")) : 1;     // 0: one lane per centre (A/B runs)
         const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP + 4 * 16 * 64);
-        if (coop_env && nsample <= 64 && smem_c <= 64 * 1024) {
+        if (nsample <= 64 && smem_c <= 64 * 1024) {      // one wave per centre; longer lists: one lane per centre (below)
             hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
                                radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
             return check_launch(what);

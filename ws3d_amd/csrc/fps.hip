@@ -721,9 +721,9 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     const bool bucket = use_bucket >= 0 ? use_bucket != 0 : (R > 8192 && (fps_rounds_covers(m) || !fps_pair_mode(b)));
     if (bucket && n > 4096 && n <= 16384 && m > 1)
         return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-    // round-2 kernels (fps_v3.hip: hand-scheduled sweep, winner-only lookup); WS3D_FPS_IMPL=2 keeps the round-1 ones
-    static const int impl = getenv("WS3D_FPS_IMPL") ? atoi(getenv("WS3D_FPS_IMPL")) : 3;
-    if (impl == 3 && R <= 1024L * 16 && fps_v3_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, R, fps_pair_mode(b), st))
+    // round-2 kernels (fps_v3.hip: hand-scheduled sweep, winner-only lookup) for 2048 < R <= 16384; the kernels of this file serve the
+    // small clouds, the large ones, and every size of the un-contracted distance convention (WS3D_DIST_MODE == 1: fps_v3 declines)
+    if (R <= 1024L * 16 && fps_v3_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, R, fps_pair_mode(b), st))
         return check_launch("furthest_point_sampling");
     if (R <= 64L * 16) {
         const int ppt = (int)((R + 63) / 64);
@@ -750,14 +750,10 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
         // Fewer, fatter waves win: the cross-lane reduction chain (DPP/readlane/ballot) does not
         // overlap between waves of one SIMD, so 8 waves x 32 points/lane (2 waves/SIMD, 231
         // VGPRs) beat 16 waves x 16 points/lane by 18 % per step (measured 1.17 vs 1.38 us).
-        // WS3D_FPS_GEOM=0 selects the 1024-thread geometry for A/B runs.
-        static const int geom = getenv("WS3D_FPS_GEOM") ? atoi(getenv("WS3D_FPS_GEOM")) : 1;
-        if (ppt <= 8 && geom != 0) launch_reg<16, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-        else if (ppt <= 8) launch_reg<8, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-        else if (geom != 0) launch_reg<32, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-        else launch_reg<16, 1024>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-    } else if (n <= 65536 && bs == 1024 && !(getenv("WS3D_FPS_STREAM") && atoi(getenv("WS3D_FPS_STREAM")))) {
-        // min-distance in registers, xyz streamed from L2 (WS3D_FPS_STREAM=1 keeps the round-1 streaming kernel: A/B runs)
+        if (ppt <= 8) launch_reg<16, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+        else launch_reg<32, 512>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
+    } else if (n <= 65536 && bs == 1024) {
+        // min-distance in registers, xyz streamed from L2
         if (n <= 32768) hipLaunchKernelGGL(fps_big_kernel<64>, dim3(b), dim3(512), 0, st, xyz, temp, idx, new_xyz, n, m);
         else hipLaunchKernelGGL(fps_big_kernel<128>, dim3(b), dim3(512), 0, st, xyz, temp, idx, new_xyz, n, m);
     } else {

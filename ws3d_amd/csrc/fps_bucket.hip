@@ -1,13 +1,16 @@
 // fps_bucket.hip -- pruned furthest point sampling for 4096 < n <= 16384 (gfx950).
 //
 // STATUS: the DEFAULT kernels of furthest_point_sample for clouds of 8192 < n <= 16384 points at every batch size (fps.hip
-// fps_launch; WS3D_FPS_BUCKET=0 forces the dense sweep of fps_v3.hip, WS3D_FPS_ROUNDS=0 the one-sample-per-exchange kernel below, for
-// A/B runs): level 1 of every Stage-1 forward (16384 -> 4096, one workgroup = one CU per scene).  Two kernels live here:
-// fps_bucket_kernel (round 2: one sample per record exchange, 0.75 us per sample; still serves m > 6144) and fps_rounds_kernel
-// (round 3, further down: several CERTIFIED samples per exchange, 0.51 us per sample -- 2.09 ms per 256 scenes, 512 scenes 4.05 ms in
-// two waves of workgroups against 6.1 ms of the VALU-bound dense kernel).  Bit-exact incl. the reference's tie order:
-// tests/test_gpu_parity.py::test_fps_bit_exact (default dispatch, with duplicated points), ::test_fps_ties,
-// ::test_fps_kernel_variants_subprocess (every forced kernel, every size class), tests/test_golden.py and scripts/fuzz_parity.py.
+// fps_dispatch; WS3D_FPS_BUCKET=0 forces the dense sweep of fps_v3.hip, WS3D_FPS_ROUNDS=0 the one-sample-per-exchange kernel, for
+// A/B runs and tests): level 1 of every Stage-1 forward (16384 -> 4096, one workgroup = one CU per scene).  Two kernels live here:
+//   fps_bucket_kernel   (round 2) one sample per record exchange, 0.75 us per sample; serves m > 6144 (the samples of the
+//                       rounds kernel would not fit in LDS beside the sort tables);
+//   fps_rounds2_kernel  (round 4, further down) two published candidates per wave, up to 8 CERTIFIED samples per exchange:
+//                       0.375-0.39 us per sample -- 1.53-1.60 ms per 8 .. 256 scenes, 512 scenes 3.2-3.3 ms in two waves of
+//                       workgroups (round 3's one-candidate rounds: 2.08 / 4.07 ms; the VALU-bound dense kernel 6.1 ms).
+// Bit-exact incl. the reference's tie order: tests/test_gpu_parity.py::test_fps_bit_exact (default dispatch, with duplicated
+// points), ::test_fps_ties, ::test_fps_kernel_variants_subprocess (every forced kernel, every size class), tests/test_golden.py
+// (the reference's own getGreedyPerm at 16384 points through every one of these kernels) and scripts/fuzz_parity.py.
 // A sampling step is bound by its cross-lane chain (box test, bucket update, pick, record exchange: DESIGN.md 5.1), not by
 // arithmetic: pruning removes ~95 % of the distance evaluations of a step.
 //
@@ -430,432 +433,20 @@ __global__ __launch_bounds__(FB_NT) void fps_bucket_kernel(const float *__restri
 #endif
 }
 
-// ================================================================================================================================
-// fps_rounds_kernel (round 3): SEVERAL samples per record exchange, each CERTIFIED before it is applied.
-//
-// The step of the kernel above is a chain -- box test, bucket update, pick, record exchange -- of ~1,800 clk of which the arithmetic
-// is a small part; what it buys is ONE sample.  But late in the sweep consecutive samples are far apart (that is what furthest
-// point sampling does) and touch disjoint buckets: the records of one exchange already name the next few samples.  With every
-// wave publishing, next to its best point (value v_w), an upper bound s_w on ALL its other points, the candidate c of wave w is
-// the (k+1)-th sample of this round, with certainty, iff
-//   (a) v_c is the strict maximum of the v_w of the waves not yet used (an equal value, or a wave that flags a tie: stop);
-//   (b) v_c > s_a for every wave a already used this round (their remaining points cannot beat it, whatever the updates did);
-//   (c) fl|c - q_i|^2 >= v_c for every sample q_i accepted before it this round (the update with q_i leaves c's running minimum
-//       untouched: min(d, t) = t) -- the SAME fp32 expression, operands in the same order, as the update itself.
-// Running distances only fall, so under (a)-(c) c is the unique maximum of the state the sequential algorithm would have reached:
-// the accepted samples are exactly its next picks, in order (scripts/sim_fps_rounds.py: 3.1-3.3 samples per round at up to 4 per
-// round on the 16384 -> 4096 level, the sequence identical to the plain sweep).  Then ALL accepted samples are applied in one pass:
-// the box test of a bucket takes the minimum over the samples' bounds, an affected bucket one fused update min(t, d_1, .., d_K)
-// and ONE wave reduction, the wave one re-pick.  ONE wave certifies (16 waves doing it side by side would share four SIMDs)
-// and hands the samples out through LDS: two LDS-only barriers per round.  The certification runs on 16 lanes (lane c = the
-// candidate of wave c) and never leaves the vector unit: the candidates' order from 15 row rotations (lane c counts the
-// candidates above its own), the candidates in rank order through LDS, conditions (b) and (c) of ALL ranks at once as sign
-// bits of integer differences, "exactly one candidate per rank and it passes" from two row sums of nibble counters.  The
-// sequential form (max, ballot, ctz, readlane per sample) cost 1,360 of the round's 4,600 clk: every vector -> scalar ->
-// vector hop stalls a lone wave ~20 clk; this form costs ~830.  The unused sample slots of a round hold a far point
-// (distance ~3e36 to everything: min() ignores it, its box bound never fires), so the round has no branch on K.
-// Ties at the head of a round take the resolution round of the kernel above (one sample).  Bit-exact incl. the tie order.
-// Anatomy without clock hooks: scripts/ubench/fps_rounds_dup.sh (one segment of the round executed twice per build).
-#ifndef FR_KMAX
-#define FR_KMAX 4
-#endif
-#define FR_Q (FR_KMAX < 4 ? 4 : FR_KMAX)      // sample slots every wave reads and applies per round
 constexpr size_t FB_SMEM_BYTES = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_CELLS + sizeof(float) * FB_NW * FB_SL * 6 +
                                  sizeof(float4) * 2 * FB_NW + sizeof(unsigned) * (3 * FB_NW + 4) + sizeof(float4) + sizeof(float) * 4 * FB_NW +
-                                 sizeof(int) * FB_NW + 64;                   // the LDS layout both kernels share
-constexpr size_t FR_SAMPLES_OFF = (FB_SMEM_BYTES + 15) & ~(size_t)15;
-constexpr size_t FR_SAMPLES_MAX_M = 6144;      // m above this: the samples do not fit beside the sort tables (one sample per exchange then)
-static size_t fps_rounds_smem(int m) { return FR_SAMPLES_OFF + sizeof(float4) * (size_t)(m + 8); }   // (the certification parks candidates up to 7 slots ahead)
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
-                                                           float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
-    static_assert(NW == 16 || NW == 8, "16 waves x 16 buckets or 8 waves x 32 buckets");
-    constexpr int SL = 256 / NW, NT = NW * 64;                     // buckets per wave, threads
-    constexpr unsigned SLMASK = SL == 32 ? 0xFFFFFFFFu : (1u << (SL & 31)) - 1u, WMASK = (1u << NW) - 1u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
-    int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
-    float *bbox = reinterpret_cast<float *>(hist + FB_CELLS);        // 256 * 6
-    float4 *rec = reinterpret_cast<float4 *>(bbox + 256 * 6);        // 16 records {x, y, z, sorted position}, then 16 {v, s, tie, -} (NW used)
-    float4 *aux = rec + 16;
-    unsigned *tiem = reinterpret_cast<unsigned *>(rec + 2 * 16);    // (layout of the kernel above: the launch shares its LDS size)
-    int *posr = reinterpret_cast<int *>(tiem + 4);                     // [0] = number of samples of this round (-1: tie at its head)
-    unsigned *tiekey = reinterpret_cast<unsigned *>(posr + 2 * 16);  // 16
-    float4 *tiept = reinterpret_cast<float4 *>(tiekey + 16);      // 1
-    float *red = reinterpret_cast<float *>(tiept + 1);               // 4 * NW: stage A; afterwards the round's samples (FR_KMAX float4)
-    int *wsum = reinterpret_cast<int *>(red + 4 * 16);            // 16
-    // every sample {x, y, z, sorted position}, in order: the certifying wave appends a round's samples, all waves read them from
-    // here, and idx / new_xyz leave the chip ONCE, after the loop (a global store per round kept its wave ~1,000 clk behind the others)
-    float4 *samples = reinterpret_cast<float4 *>(smem + FR_SAMPLES_OFF);   // m + FR_KMAX
-
-    const int b = blockIdx.x;
-    xyz += (size_t)b * n * 3;
-    idx += (size_t)b * m;
-    if (temp) temp += (size_t)b * n;
-    if (new_xyz) new_xyz += (size_t)b * m * 3;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-
-    // ---------------- stage A: Z-order counting sort of the scene into `order` (as above)
-    float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
-    for (int k = tid; k < n; k += NT) {
-        const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
-        if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
-        if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
-    }
-    xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
-    if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
-    for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
-    for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
-        zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
-    }
-    const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
-    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
-    for (int k = tid; k < n; k += NT)
-        atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-    __syncthreads();
-    {
-        constexpr int CPT = FB_CELLS / NT;
-        int a[CPT], v = 0;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
-        const int mine = v;
-        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
-        if (lane == 63) wsum[w] = v;
-        __syncthreads();
-        int off = 0;
-        for (int i = 0; i < w; ++i) off += wsum[i];
-        int excl = off + v - mine;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
-    }
-    __syncthreads();
-    for (int k = tid; k < n; k += NT) {
-        const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-        order[pos] = (uint16_t)k;
-    }
-    __syncthreads();
-
-    // ---------------- registers: slot s of this lane = sorted position ((s*NW + w)*64 + lane)
-    float px[SL], py[SL], pz[SL], t[SL];
-    float bmax = -2.0f;                 // lane s < SL: the largest running distance of bucket s of this wave (-1: no point)
-#pragma unroll
-    for (int s = 0; s < SL; ++s) {
-        const int pos = ((s * NW + w) << 6) + lane;
-        const int k = (int)order[pos];
-        const bool valid = k != 0xFFFF;
-        px[s] = valid ? xyz[(size_t)k * 3 + 0] : 0.f;
-        py[s] = valid ? xyz[(size_t)k * 3 + 1] : 0.f;
-        pz[s] = valid ? xyz[(size_t)k * 3 + 2] : 0.f;
-        t[s] = valid ? (temp ? temp[k] : 1e10f) : -1.0f;
-        const float lx = wave_min(valid ? px[s] : INFINITY), hx = wave_max(valid ? px[s] : -INFINITY);
-        const float ly = wave_min(valid ? py[s] : INFINITY), hy = wave_max(valid ? py[s] : -INFINITY);
-        const float lz = wave_min(valid ? pz[s] : INFINITY), hz = wave_max(valid ? pz[s] : -INFINITY);
-        if (lane == 0) {
-            float *bb = bbox + (w * SL + s) * 6;
-            bb[0] = lx; bb[1] = hx; bb[2] = ly; bb[3] = hy; bb[4] = lz; bb[5] = hz;
-        }
-        const float bm0 = wave_max(t[s]);
-        bmax = lane == s ? bm0 : bmax;
-    }
-    __syncthreads();
-    float blx = INFINITY, bhx = -INFINITY, bly = INFINITY, bhy = -INFINITY, blz = INFINITY, bhz = -INFINITY;
-    if (lane < SL) {
-        const float *bb = bbox + (w * SL + lane) * 6;
-        blx = bb[0]; bhx = bb[1]; bly = bb[2]; bhy = bb[3]; blz = bb[4]; bhz = bb[5];
-    }
-    FbT32 tt;
-    { tt.v0 = t[0 % SL]; tt.v1 = t[1 % SL]; tt.v2 = t[2 % SL]; tt.v3 = t[3 % SL]; tt.v4 = t[4 % SL]; tt.v5 = t[5 % SL]; tt.v6 = t[6 % SL]; tt.v7 = t[7 % SL]; tt.v8 = t[8 % SL]; tt.v9 = t[9 % SL]; tt.v10 = t[10 % SL]; tt.v11 = t[11 % SL]; tt.v12 = t[12 % SL]; tt.v13 = t[13 % SL]; tt.v14 = t[14 % SL]; tt.v15 = t[15 % SL];
-      tt.v16 = SL > 16 ? t[16 % SL] : -1.f; tt.v17 = SL > 16 ? t[17 % SL] : -1.f; tt.v18 = SL > 16 ? t[18 % SL] : -1.f; tt.v19 = SL > 16 ? t[19 % SL] : -1.f; tt.v20 = SL > 16 ? t[20 % SL] : -1.f; tt.v21 = SL > 16 ? t[21 % SL] : -1.f; tt.v22 = SL > 16 ? t[22 % SL] : -1.f; tt.v23 = SL > 16 ? t[23 % SL] : -1.f;
-      tt.v24 = SL > 16 ? t[24 % SL] : -1.f; tt.v25 = SL > 16 ? t[25 % SL] : -1.f; tt.v26 = SL > 16 ? t[26 % SL] : -1.f; tt.v27 = SL > 16 ? t[27 % SL] : -1.f; tt.v28 = SL > 16 ? t[28 % SL] : -1.f; tt.v29 = SL > 16 ? t[29 % SL] : -1.f; tt.v30 = SL > 16 ? t[30 % SL] : -1.f; tt.v31 = SL > 16 ? t[31 % SL] : -1.f; }
-    if (tid < 4) tiem[tid] = 0u;
-    __syncthreads();
-
-    // the samples about to be applied (wave-uniform): the sweep starts from point 0 (sampling_gpu.cu:119)
-    int K = 1;
-    // (always FR_KMAX of them: the slots past the round's K hold a point FR_FAR away on every axis -- its distance to anything is ~3e36,
-    // finite and above every running distance, so min() ignores it and the box test never fires: no branch on K in the round)
-    constexpr float FR_FAR = 1e18f;
-    float qx[FR_Q], qy[FR_Q], qz[FR_Q];
-#pragma unroll
-    for (int i = 0; i < FR_Q; ++i) { qx[i] = i ? FR_FAR : xyz[0]; qy[i] = i ? FR_FAR : xyz[1]; qz[i] = i ? FR_FAR : xyz[2]; }
-    float wv = -1.0f, wx = 0.f, wy = 0.f, wz = 0.f, ws2 = -1.0f;       // this wave's candidate and the bound on everything else it holds
-    int wpos = 0, wtie = 0, wslot = 0;
-    bool have = false;
-    int j = 1;                          // samples selected so far; the last K of them are not applied yet
-#ifdef FR_PROF      // scripts/ubench/fps_rounds_prof.sh: per-wave clocks per segment and the samples per round, returned through `temp`
-    long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, kh[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long pt = clock64();
-    // (only three waves carry the hooks: sixteen waves executing s_memtime at the same moment queue on the scalar memory path and
-    // the last one reads ~900 clk more than the first -- an artefact that would look like SIMD contention)
-    const bool prof_wave = w == 0 || w == 5 || w == 15;
-#define FRP(k) if (prof_wave) { const long long now = clock64(); pc[k] += now - pt; pt = now; }
-#else
-#define FRP(k)
-#endif
-#ifdef FR_DUP       // scripts/ubench/fps_rounds_dup.sh: segment FR_DUP of every round is executed TWICE (each is idempotent: same results); the
-    // rise of the launch time over the plain build / the number of rounds = what that segment contributes to the round's critical path.
-    // (compile-time constant: the loop unrolls into a second copy of the segment, the asm keeps the copies from being merged)
-#define FR_REP(k) _Pragma("unroll") for (int rep_ = 0; rep_ < (FR_DUP == (k) ? 2 : 1); ++rep_, ({ asm volatile("" : "+v"(qx[0]), "+v"(qx[1]), "+v"(qx[2]), "+v"(qx[3]), "+v"(bmax) :: "memory"); }))
-#else
-#define FR_REP(k)
-#endif
-    for (;;) {
-#ifdef FR_PROF
-        if (j >= m) break;
-#endif
-        if (j >= m && !temp) break;                                    // nothing reads the running distances any more
-        // `temp` leaves the kernel as the reference leaves it: every sample applied but the last one picked (sampling_gpu.cu:118-208)
-        if (j >= m) {
-#pragma unroll
-            for (int i = 0; i < FR_Q; ++i)
-                if (i == K - 1) { qx[i] = qy[i] = qz[i] = FR_FAR; }
-        }
-        // ---- which of my buckets can change?  L = the kernel's own distance expression on the per-axis gaps between a sample and
-        // the box (0 inside): a lower bound of d for every point of the bucket (exact pruning, see the kernel above)
-        unsigned need = 0u;
-#define FR_BOX(QX, QY, QZ) sqdist3(max3_f32(blx - QX, QX - bhx, 0.f), max3_f32(bly - QY, QY - bhy, 0.f), max3_f32(blz - QZ, QZ - bhz, 0.f))
-        FR_REP(0) {
-            float L = FR_BOX(qx[0], qy[0], qz[0]);                      // (independent chains: the samples' bounds overlap in the pipeline)
-#pragma unroll
-            for (int i = 1; i < FR_Q; ++i) L = min_f32(FR_BOX(qx[i], qy[i], qz[i]), L);
-            need = (unsigned)__ballot(L < bmax) & SLMASK;
-        }
-#undef FR_BOX
-        FRP(0)
-        bool repick = !have;
-        if (need) {
-#define FR_UPD(S)                                                                                      \
-    if (need & (1u << (S))) {                                                                          \
-        float d = sqdist3(px[S] - qx[0], py[S] - qy[0], pz[S] - qz[0]);                                \
-        _Pragma("unroll") for (int i_ = 1; i_ < FR_Q; ++i_) d = min_f32(sqdist3(px[S] - qx[i_], py[S] - qy[i_], pz[S] - qz[i_]), d); \
-        fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
-        const float bm = wave_max(fb_t<S>(tt));                                                        \
-        bmax = lane == (S) ? bm : bmax;                 /* (v_writelane instead: same time) */         \
-    }
-#define FR_UPD8(G) if (need & (0xFFu << (G))) { FR_UPD(G) FR_UPD(G + 1) FR_UPD(G + 2) FR_UPD(G + 3) FR_UPD(G + 4) FR_UPD(G + 5) FR_UPD(G + 6) FR_UPD(G + 7) }
-            FR_REP(1) { FR_UPD8(0) }
-            FR_REP(3) { FR_UPD8(8) }
-            if constexpr (SL == 32) { FR_UPD8(16 % SL) FR_UPD8(24 % SL) }
-#undef FR_UPD8
-#undef FR_UPD
-            repick = repick || ((need >> wslot) & 1u);
-        }
-        FRP(1)
-        if (j >= m) break;
-        FR_REP(2) if (repick) {
-            // the wave's candidate (the bucket holding the largest cached maximum, then the lane inside it) and the bound on the
-            // rest of the wave: the largest maximum of the OTHER buckets, the largest OTHER value of the candidate's bucket
-            const float wmax = SL <= 16 ? readlane_f(row16_max(bmax), 0) : wave_max(bmax);   // the cached maxima live in lanes 0 .. SL-1
-            const unsigned eqb = (unsigned)__ballot(bmax == wmax) & SLMASK;
-            wslot = (int)__builtin_ctz(eqb);
-            const float b2m = lane == wslot ? -2.0f : bmax;
-            const float b2 = SL <= 16 ? readlane_f(row16_max(b2m), 0) : wave_max(b2m);
-            uint64_t eql = 0;
-            float t2 = -2.0f;
-#define FR_PICK_BODY(S)                                                                                \
-    {                                                                                                  \
-        eql = __ballot(fb_t<S>(tt) == wmax);                                                           \
-        const int wl = (int)__builtin_ctzll(eql);                                                      \
-        wx = readlane_f(px[S], wl); wy = readlane_f(py[S], wl); wz = readlane_f(pz[S], wl);            \
-        wpos = ((S * NW + w) << 6) + wl;                                                               \
-        t2 = wave_max(lane == wl ? -2.0f : fb_t<S>(tt));                                               \
-    }
-#define FR_PICK(S) case S: FR_PICK_BODY(S) break;
-#define FR_PICK2(S) case S: if constexpr (SL == 32) { FR_PICK_BODY(S % SL) } break;
-            switch (wslot) {
-                FR_PICK(0) FR_PICK(1) FR_PICK(2) FR_PICK(3) FR_PICK(4) FR_PICK(5) FR_PICK(6) FR_PICK(7)
-                FR_PICK(8) FR_PICK(9) FR_PICK(10) FR_PICK(11) FR_PICK(12) FR_PICK(13) FR_PICK(14) FR_PICK(15)
-                FR_PICK2(16) FR_PICK2(17) FR_PICK2(18) FR_PICK2(19) FR_PICK2(20) FR_PICK2(21) FR_PICK2(22) FR_PICK2(23)
-                FR_PICK2(24) FR_PICK2(25) FR_PICK2(26) FR_PICK2(27) FR_PICK2(28) FR_PICK2(29) FR_PICK2(30) FR_PICK2(31)
-            }
-#undef FR_PICK2
-#undef FR_PICK
-            wtie = (__builtin_popcount(eqb) > 1 || __builtin_popcountll(eql) > 1) ? 1 : 0;
-            wv = wmax;
-            ws2 = max_f32(b2, t2);
-            have = true;
-        }
-        FRP(2)
-        // ---- publish (only a wave whose candidate changed: the records persist), then ONE wave certifies the samples of the round
-        if (repick && lane == 0) {
-            rec[w] = make_float4(wx, wy, wz, __int_as_float(wpos));
-            aux[w] = make_float4(wv, ws2, __int_as_float(wtie), 0.f);
-        }
-        FRP(3)
-        FR_REP(4) lds_barrier();
-        FRP(4)
-        FR_REP(5) if (tid < NW) {
-            // ---- certification, by the first NW lanes of wave 0 (lane c = the candidate of wave c), on the vector unit and LDS only:
-            // every hop vector -> scalar -> vector (ballot, readlane with a computed lane, a compare feeding a select) costs a lone
-            // wave ~20 clk, and the sequential form of this block had ~40 of them (1,360 of a round's 4,600 clk).
-            float4 *selq = samples + j;
-            float4 *auxs = reinterpret_cast<float4 *>(red);        // the {v, s, tie} of the candidates in rank order
-            const float4 r = rec[lane];                            // {x, y, z, sorted position} (both reads in flight before the first use)
-            const float4 a = aux[lane];                            // {v, s, tie, -}
-            __builtin_amdgcn_sched_barrier(0);
-            // every value compared below is >= 0 or a negative "nothing" mark (-1 no point, -2 / -3 unused): non-negative floats
-            // order like their bit patterns, so all comparisons are integer comparisons -- done as sign bits of differences (marks
-            // clamped to -1: no overflow).
-            const int key = __float_as_int(a.x);
-            const int keyc = max(key, -1);
-            // rank of my candidate = the number of candidates above it: 15 row rotations, one sign bit each (equal values share a rank:
-            // a tie, the round stops there)
-            // (explicit v_sub_u32_dpp = rotated - own, checked on the device: the compiler folds `own - update_dpp(..)` into
-            // v_subrev_u32_dpp, which on this chip ALSO returns rotated - own -- the ranks came out upside down.  The order is
-            // reversed by complementing the keys instead: ~a < ~b <=> a > b.)
-            const int nkey = ~keyc;
-            unsigned above = 0u;
-#define FR_RANK(N, NOP)                                                                                                           \
-    {                                                                                                                             \
-        unsigned d_;                                                                                                              \
-        asm(NOP "v_sub_u32_dpp %0, %1, %1 row_ror:" #N " row_mask:0xf bank_mask:0xf" : "=v"(d_) : "v"(nkey));                     \
-        above = __builtin_amdgcn_alignbit(above, d_, 31u);                                                                        \
-    }
-            FR_RANK(1, "s_nop 1\n\t") FR_RANK(2, "") FR_RANK(3, "") FR_RANK(4, "") FR_RANK(5, "") FR_RANK(6, "") FR_RANK(7, "") FR_RANK(8, "")
-            FR_RANK(9, "") FR_RANK(10, "") FR_RANK(11, "") FR_RANK(12, "") FR_RANK(13, "") FR_RANK(14, "") FR_RANK(15, "")
-#undef FR_RANK
-            const unsigned valid = ~(unsigned)(key >> 31);         // all ones for a candidate, 0 for a mark
-            const unsigned rk = min((unsigned)__builtin_popcount(above) | (~valid & 7u), 7u);   // marks and ranks >= 7 share slot 7, which nothing reads
-            static_assert(FR_KMAX <= 7, "rank slots");
-            // the candidates in rank order through LDS: the first FR_KMAX are the round's samples if they pass (slots past the
-            // accepted ones are never read as samples), all lanes read the leading ones back
-            selq[rk] = r;
-            auxs[rk] = a;
-            float dm = INFINITY;                                    // my candidate's smallest distance to the candidates of rank < i
-            int bound = -1;                                         // the largest s_w of the waves of rank < i
-            unsigned okw = 1u;                                      // bit i: my candidate would pass (b) and (c) AS rank i
-#pragma unroll
-            for (int i = 0; i + 1 < FR_KMAX; ++i) {
-                const float4 c = selq[i];
-                dm = min_f32(sqdist3(r.x - c.x, r.y - c.y, r.z - c.z), dm);
-                bound = max(bound, __float_as_int(auxs[i].y));
-                // (b) beats everything the waves of smaller rank still hold: key > bound; (c) untouched by the samples before it: dm >= key
-                okw |= ((((unsigned)bound - (unsigned)key) >> 31) & ~(((unsigned)__float_as_int(dm) - (unsigned)key) >> 31)) << (i + 1);   // (unsigned: wraps, stays arithmetic)
-            }
-            // per rank slot (a nibble): how many candidates hold it; 1 if its candidate passes, +2 if its wave flags a tie
-            unsigned w1 = (valid & 1u) << (4u * rk);
-            unsigned w2 = (((okw >> rk) & 1u) | (((unsigned)__float_as_int(a.z) & 1u) << 1)) << (4u * rk);      // (the flag is 0 or 1)
-#define FR_ROWSUM(CTRL)                                                                                           \
-    w1 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w1, CTRL, 0xF, 0xF, false);                             \
-    w2 += (unsigned)__builtin_amdgcn_update_dpp(0, (int)w2, CTRL, 0xF, 0xF, false);
-            FR_ROWSUM(DPP_QUAD_XOR1) FR_ROWSUM(DPP_QUAD_XOR2) FR_ROWSUM(DPP_ROW_HALF_MIRROR) FR_ROWSUM(DPP_ROW_MIRROR)
-#undef FR_ROWSUM
-            // a slot is good iff exactly one candidate holds it (a), it passes and its wave flags no tie: both nibbles == 1
-            unsigned bad = (w1 ^ 0x11111111u) | (w2 ^ 0x11111111u);
-            bad = (bad | (bad >> 1) | (bad >> 2) | (bad >> 3)) & 0x11111111u;
-            const int cap = min(FR_KMAX, m - j);
-            int nk = (int)__builtin_ctz(bad | (1u << (4 * cap))) >> 2;     // leading good slots
-            if (nk == 0 && w1 != 0u) {                              // (w1 != 0: there is a candidate, and the best one holds slot 0)
-                nk = -1;                                            // a tie at the head of the round: the tied maximum goes into the first slot
-                if (lane == 0) reinterpret_cast<int *>(selq)[0] = __float_as_int(auxs[0].x);
-            }
-            {   // the slots past the accepted samples become the far point (in-order LDS: after the candidates parked there)
-                const int first = max(nk, 1);
-                const int park = ((first - 1 - lane) >> 31) & ((lane - FR_Q) >> 31);         // all ones: first <= lane < FR_Q (the slots every wave reads)
-                selq[(lane & park) | (7 & ~park)] = make_float4(FR_FAR, FR_FAR, FR_FAR, 0.f);
-            }
-            if (lane == 0) posr[0] = nk;
-        }
-        FRP(5)
-        FR_REP(6) lds_barrier();
-        FRP(6)
-        FR_REP(7) K = posr[0];
-        FR_REP(7) {   // (all five reads in flight before the first use)
-            float4 sq[FR_Q];
-#pragma unroll
-            for (int i = 0; i < FR_Q; ++i) sq[i] = samples[j + i];
-#pragma unroll
-            for (int i = 0; i < FR_Q; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
-        }
-        if (K <= 0) {
-            // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
-            const float gmax = qx[0];                              // (the certifying wave left the tied maximum in the first slot)
-            unsigned key = 0xFFFFFFFFu;
-            const float ta[32] = FB_T32_LIST(tt);
-#pragma unroll
-            for (int s = 0; s < SL; ++s) {
-                if (ta[s] == gmax) {
-                    const int pos = ((s * NW + w) << 6) + lane;
-                    const int k = (int)order[pos];
-                    const unsigned rank = (unsigned)(fb_bitrev(k & (bs - 1), log2bs) * S + (k >> log2bs));
-                    key = min(key, (rank << 14) | (unsigned)pos);
-                }
-            }
-            const unsigned wkey = wave_min_u32(key);
-            if (lane == 0) tiekey[w] = wkey;
-            lds_barrier();
-            unsigned gk = tiekey[lane & (NW - 1)];
-            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR1, 0xF, 0xF, false));
-            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR2, 0xF, 0xF, false));
-            gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
-            if constexpr (NW == 16) gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_MIRROR, 0xF, 0xF, false));
-            const int ipos = (int)(__builtin_amdgcn_readfirstlane(gk) & 0x3FFFu);
-            const int ob = ipos >> 6, ol = ipos & 63;           // owning bucket / lane
-            if ((ob & (NW - 1)) == w) {
-                const int os = ob / NW;                       // wave-uniform slot
-                float ox = 0.f, oy = 0.f, oz = 0.f;
-#define FR_OWN(S) case S: ox = readlane_f(px[S], ol); oy = readlane_f(py[S], ol); oz = readlane_f(pz[S], ol); break;
-#define FR_OWN2(S) case S: if constexpr (SL == 32) { ox = readlane_f(px[S % SL], ol); oy = readlane_f(py[S % SL], ol); oz = readlane_f(pz[S % SL], ol); } break;
-                switch (os) {
-                    FR_OWN(0) FR_OWN(1) FR_OWN(2) FR_OWN(3) FR_OWN(4) FR_OWN(5) FR_OWN(6) FR_OWN(7)
-                    FR_OWN(8) FR_OWN(9) FR_OWN(10) FR_OWN(11) FR_OWN(12) FR_OWN(13) FR_OWN(14) FR_OWN(15)
-                    FR_OWN2(16) FR_OWN2(17) FR_OWN2(18) FR_OWN2(19) FR_OWN2(20) FR_OWN2(21) FR_OWN2(22) FR_OWN2(23)
-                    FR_OWN2(24) FR_OWN2(25) FR_OWN2(26) FR_OWN2(27) FR_OWN2(28) FR_OWN2(29) FR_OWN2(30) FR_OWN2(31)
-                }
-#undef FR_OWN2
-#undef FR_OWN
-                if (lane == 0) *tiept = make_float4(ox, oy, oz, 0.f);
-            }
-            lds_barrier();
-            const float4 c = *tiept;
-            qx[0] = c.x; qy[0] = c.y; qz[0] = c.z;
-            K = 1;
-            if (tid == NT - 64) samples[j] = make_float4(qx[0], qy[0], qz[0], __int_as_float(ipos));
-        }
-        j += K;
-#ifdef FR_PROF
-        kh[K & 7] += 1;
-#endif
-        FRP(7)
-    }
-
-    // the samples leave the chip: sorted positions -> point indices, coordinates as stored (pure copies of xyz)
-    __syncthreads();
-    for (int jj = tid; jj < m; jj += NT) {
-        if (jj == 0) {
-            idx[0] = 0;
-            if (new_xyz) { new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
-        } else {
-            const float4 sm = samples[jj];
-            idx[jj] = (int)order[__float_as_int(sm.w)];
-            if (new_xyz) { new_xyz[jj * 3 + 0] = sm.x; new_xyz[jj * 3 + 1] = sm.y; new_xyz[jj * 3 + 2] = sm.z; }
-        }
-    }
-    if (temp) {
-        const float ta[32] = FB_T32_LIST(tt);
-#pragma unroll
-        for (int s = 0; s < SL; ++s) {
-            const int k = (int)order[((s * NW + w) << 6) + lane];
-            if (k != 0xFFFF) temp[k] = ta[s];
-        }
-    }
-#ifdef FR_PROF
-    __syncthreads();
-    if (temp && lane == 0)
-        for (int k = 0; k < 8; ++k) { temp[w * 8 + k] = (float)pc[k]; temp[128 + w * 8 + k] = (float)kh[k]; }
-#endif
-}
+                                 sizeof(int) * FB_NW + 64;                   // the LDS layout of fps_bucket_kernel
 
 // ================================================================================================================================
 // fps_rounds2_kernel (round 4): TWO published candidates per wave and up to FR2_KQ = 8 certified samples per round.
 //
-// What limited fps_rounds_kernel to ~3.1 samples per round was not the certification conditions but the supply of candidates: every
-// wave offers ONE point, and once it is used the bound on "everything else the wave holds" is the wave's runner-up -- usually
-// above the next wave's best.  Here a wave publishes the best point of its best bucket AND the best point of its second-best
+// The step of fps_bucket_kernel is a chain -- box test, bucket update, pick, record exchange -- of ~1,800 clk of which the arithmetic
+// is a small part; what it buys is ONE sample.  But late in the sweep consecutive samples are far apart (that is what furthest
+// point sampling does) and touch disjoint buckets: the records of one exchange already name the next few samples, if each can be
+// CERTIFIED before it is applied.  Round 3's kernel (fps_rounds_kernel, git history) did that with ONE candidate per wave and got
+// ~3.1 samples per exchange: what limited it was not the certification conditions but the supply of candidates -- once a wave's
+// point is used, the bound on "everything else the wave holds" is the wave's runner-up, usually above the next wave's best.
+// Here a wave publishes the best point of its best bucket AND the best point of its second-best
 // bucket, plus ONE bound s_w on every point it did not publish (the third-best bucket maximum, the runners-up inside the two
 // candidate buckets).  With B = max_w s_w, the candidates taken in decreasing value are the next samples of the sequential sweep
 // for as long as each one
@@ -869,11 +460,17 @@ __global__ __launch_bounds__(NW * 64) void fps_rounds_kernel(const float *__rest
 //     only -- two tests per lane instead of four, and the 64-bit ballot says which PAIR of samples reaches which bucket;
 //   * a bucket update applies only the pairs that reach it (their coordinates fetched into scalars from the lanes that hold them);
 //   * every lane reads just its own pair from LDS after the exchange (two 16-byte reads per wave instead of four broadcasts).
-// The certification (32 lanes of wave 0, lane c = candidate c) stays on the vector unit + LDS: ranks = number of candidates with a
-// larger key (15 row rotations + 16 against the other row, fetched by one ds_swizzle), candidates scattered by rank into the sample
-// array, a per-rank counter (ds_add) that says whether a rank is held by exactly one candidate (ties share a rank), then lane i
-// checks conditions (a)-(c) for the candidate of rank i.  No tie flags: a duplicate inside a bucket shows as s_w == v (b fails), a
-// duplicate across buckets or waves as two candidates of one rank (a fails).
+// The certification (wave 0) stays on the vector unit + LDS (every vector -> scalar -> vector hop stalls a lone wave ~20 clk):
+//   * ranks on all four DPP rows at once -- row q compares candidate set q >> 1 (the waves' first / second candidates) with set
+//     q & 1 by 16 row rotations, one sign bit each; rows 0 / 2 add the counts of rows 1 / 3 through one ds_swizzle;
+//   * the candidates are scattered by rank into the sample array, a per-rank counter (ds_add) says whether a rank is held by
+//     exactly one candidate (equal values share a rank);
+//   * lane 8 i + jj checks the candidate of rank i against the one of rank jj < i: all 28 pairs of condition (c) in ONE distance
+//     evaluation + three DPP minima, conditions (a) and (b) beside it; the number of leading ranks that pass is one ballot.
+// No tie flags: a duplicate inside a bucket shows as s_w == v (b fails), a duplicate across buckets or waves as two candidates
+// of one rank (a fails).  Ties at the head of a round take the resolution round of fps_bucket_kernel (one sample): the smallest
+// reference rank among ALL points holding the maximum.  Bit-exact incl. the tie order.
+// Anatomy: scripts/ubench/fps_rounds2_prof.sh (-DFR2_PROF: clocks per segment, bucket updates, re-picks, samples per round).
 #ifndef FR2_KQ
 #define FR2_KQ 8
 #endif
@@ -912,7 +509,7 @@ __global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restri
     if (new_xyz) new_xyz += (size_t)b * m * 3;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, grp = lane >> 4;      // (w as a scalar: the candidates' positions ((S NW + w) << 6) + lane stay scalar arithmetic)
 
-    // ---------------- stage A: Z-order counting sort of the scene into `order` (as in the kernels above)
+    // ---------------- stage A: Z-order counting sort of the scene into `order` (as in fps_bucket_kernel)
     float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
     for (int k = tid; k < n; k += NT) {
         const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
@@ -1144,7 +741,7 @@ __global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restri
             FR2C(0)
             const int nA = ~max(key, -1), nB = ~max(keyb, -1);       // ~a - ~b = b - a
             unsigned above = __builtin_amdgcn_alignbit(0u, (unsigned)nB - (unsigned)nA, 31u);
-            // v_sub_u32_dpp d, a, b row_ror:N  =  a[lane rotated] - b[own]  (checked on the device, see the kernel above)
+            // v_sub_u32_dpp d, a, b row_ror:N  =  a[lane rotated] - b[own]  (checked on the device: the compiler folds `own - update_dpp(..)` into v_subrev_u32_dpp, which on this chip ALSO returns rotated - own, so the subtraction is spelled in asm and the order reversed by complementing the keys)
 #define FR2_RANK(N, NOP)                                                                                                          \
     {                                                                                                                             \
         unsigned d_;                                                                                                              \
@@ -1295,7 +892,7 @@ size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
 bool fps_rounds_covers(int m) {
 #if FB_NW == 16 && !defined(FB_PROF)
     static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
-    return rounds != 0 && (size_t)m <= FR_SAMPLES_MAX_M;
+    return rounds != 0 && (size_t)m <= FR2_SAMPLES_MAX_M;
 #else
     return false;
 #endif
@@ -1310,10 +907,9 @@ int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_
         attr_set = true;
     }
 #if FB_NW == 16 && !defined(FB_PROF)
-    // WS3D_FPS_ROUNDS: 2 (default) = two candidates per wave, up to 8 certified samples per round (fps_rounds2_kernel, round 4);
-    // 1 = one candidate per wave, up to 4 (fps_rounds_kernel, round 3); 0 = one sample per exchange (A/B runs)
-    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 2;
-    if (rounds >= 2 && (size_t)m <= FR2_SAMPLES_MAX_M) {
+    // WS3D_FPS_ROUNDS=0: one sample per record exchange (fps_bucket_kernel) also where the rounds kernel is the default (A/B runs, tests)
+    static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
+    if (rounds && (size_t)m <= FR2_SAMPLES_MAX_M) {
         static bool attr3 = false;
         if (!attr3) {
             (void)hipFuncSetAttribute((const void *)fps_rounds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds2_smem((int)FR2_SAMPLES_MAX_M));
@@ -1321,16 +917,6 @@ int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_
         }
         hipLaunchKernelGGL(fps_rounds2_kernel, dim3(b), dim3(1024), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
         return check_launch("furthest_point_sampling(rounds2)");
-    }
-    if (rounds && (size_t)m <= FR_SAMPLES_MAX_M) {
-        static bool attr2 = false;
-        if (!attr2) {
-            (void)hipFuncSetAttribute((const void *)fps_rounds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds_smem((int)FR_SAMPLES_MAX_M));
-            attr2 = true;
-        }
-        // (an 8-wave x 32-bucket build of the same kernel -- half the contention, twice the updates per wave -- was measured: 2.86 vs 2.45 ms)
-        hipLaunchKernelGGL(fps_rounds_kernel<16>, dim3(b), dim3(1024), fps_rounds_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
-        return check_launch("furthest_point_sampling(rounds)");
     }
 #endif
     hipLaunchKernelGGL(fps_bucket_kernel, dim3(b), dim3(FB_NT), fps_bucket_smem(), st, xyz, temp, idx, new_xyz, n,

@@ -639,7 +639,7 @@ static void launch_v3(int b, int n, int m, const float *xyz, float *temp, int32_
             attr = true;
         }
     }
-    static const int prio_mode = getenv("WS3D_FPS_PRIO") ? atoi(getenv("WS3D_FPS_PRIO")) : 1;   // 0: no priorities (A/B runs)
+    constexpr int prio_mode = 1;       // chain priority + sweep priority of the first scene (0 / 2 / start-up offsets were A/B runs: round 2)
     hipLaunchKernelGGL((fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>), dim3(DUO ? b / 2 : b), dim3(DUO ? 2 * NT : NT), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S,
                        prio_mode);
 }
@@ -648,38 +648,20 @@ static void launch_v3(int b, int n, int m, const float *xyz, float *temp, int32_
 // returns false when the shape is not covered (caller falls through to the streaming kernel)
 bool fps_v3_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz, int bs, int log2bs, int S,
                    long R, bool pair, hipStream_t st) {
-    // WS3D_FPS_GEOM3: "<threads>" overrides the workgroup size of the large shapes (A/B runs)
-    static const int geom = getenv("WS3D_FPS_GEOM3") ? atoi(getenv("WS3D_FPS_GEOM3")) : 0;
 #if WS3D_DIST_MODE == 1
     return false;     // the hand-scheduled sweep spells the two contracted forms only; the un-contracted build uses fps.hip
 #endif
 #define V3(P, T, Z) launch_v3<P, T, Z>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st)
     // small clouds (<= 2048 positions: one to four waves) stay on fps.hip's kernels: with so few waves a step is a serial
     // instruction stream at ~4.2 clk per instruction, and their packed-math sweep issues fewer instructions (measured:
-    // 0.42 vs 0.53 us/step at 1024 points).  WS3D_FPS_SMALL3=1 routes them here (A/B runs).
-    static const int small3 = getenv("WS3D_FPS_SMALL3") ? atoi(getenv("WS3D_FPS_SMALL3")) : 0;
-    if (R <= 2048 && !small3) return false;
-    if (R <= 64) V3(1, 64, false);
-    else if (R <= 128) V3(2, 64, false);
-    else if (R <= 256) V3(4, 64, false);
-    else if (R <= 512) V3(8, 64, false);
-    else if (R <= 1024) V3(16, 64, false);
-    else if (R <= 2048) V3(8, 256, false);
-    else if (R <= 4096) { if (geom == 256) V3(16, 256, false); else V3(8, 512, false); }
-    else if (R <= 8192) { if (geom == 256) V3(32, 256, false); else if (geom == 1024) V3(8, 1024, false); else V3(16, 512, false); }
+    // 0.42 vs 0.53 us/step at 1024 points)
+    if (R <= 2048) return false;
+    if (R <= 4096) V3(8, 512, false);
+    else if (R <= 8192) V3(16, 512, false);
     else if (R <= 16384) {
-        static const int onex = getenv("WS3D_FPS_ONEX") ? atoi(getenv("WS3D_FPS_ONEX")) : 0;
-        // WS3D_FPS_DUO=1: two scenes per workgroup, half a step out of phase (A/B runs: measured SLOWER than two independent
-        // workgroups per CU with chain priority, 6.55-6.85 vs 6.14 ms for 512 scenes -- a slot lasts ~2000 clk, not the ~1500
-        // of a sweep: the reduction stage of one scene does not hide under the sweep of the other as modelled)
-        static const int duo_mode = getenv("WS3D_FPS_DUO") ? atoi(getenv("WS3D_FPS_DUO")) : 0;
-        if (onex && !pair) {
-            if (geom == 1024) launch_v3<16, 1024, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-            else launch_v3<32, 512, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-        } else if (pair && duo_mode && (b & 1) == 0) {
-            launch_v3<32, 512, true, false, true>(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
-        } else if (pair) V3(32, 512, true);
-        else if (geom == 512) V3(32, 512, false);
+        // (measured and removed in round 4's clean-up, see profiles/r02_fps_ab_old_vs_v3.txt: a one-exchange variant, 256 / 512 /
+        // 1024-thread geometries, two scenes per WORKGROUP half a step out of phase -- 6.55-6.85 vs 6.14 ms for 512 scenes)
+        if (pair) V3(32, 512, true);
         else V3(16, 1024, false);
     } else return false;
 #undef V3

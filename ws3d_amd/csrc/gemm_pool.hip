@@ -117,14 +117,8 @@ __global__ __launch_bounds__(256) void gemm_pool_kernel(int k_dim, int o_dim, co
 // tile (64 x 64: 16 flop per byte, 128 x 128: 32).  Measured on the six last-layer shapes (scripts/ubench/gemm_pool_tiles.sh,
 // profiles/r02_gemm_pool_tiles.txt): L2 requests and LDS cycles halve at 128 x 128, the kernel time does not move (0.288 vs
 // 0.293 ms in total): SQ_VALU_MFMA_BUSY_CYCLES = 64 clk x the instruction count at every tile, i.e. the matrix pipe is busy
-// 77 % of the kernel at the 2.0 GHz the chip sustains under this kernel (s_memtime / s_memrealtime, gemm_pool_prof.sh; a
+// 77 % of the kernel at the 2.0 GHz the chip sustains under this kernel (s_memtime / s_memrealtime hooks, profiles/r02_gemm_pool_wave_timeline.txt; a
 // register-only loop of the same instruction holds 2.35 GHz and 154 TFLOP/s, scripts/ubench/mfma_f32_peak.hip).
-#ifdef GP_PROF       // scripts/ubench/gemm_pool_prof.sh: per-wave time stamps of the tile loop (s_memtime)
-__device__ long long gp_prof[8 * 65536];
-#define GP_STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#else
-#define GP_STAMP(var) do { } while (0)
-#endif
 template <int NS, int MB, int NB>
 __global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim, const float *__restrict__ x,
                                                             const float *__restrict__ wt, const float *__restrict__ bias,
@@ -184,21 +178,13 @@ __global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim
         for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    long long ts0 = 0, ts1 = 0, ta = 0, tb = 0, tc = 0, s_mma = 0, s_stage = 0, s_bar = 0;
-    (void)ts0; (void)ts1; (void)ta; (void)tb; (void)tc; (void)s_mma; (void)s_stage; (void)s_bar;
-#ifdef GP_PROF
-    const long long rt0 = __builtin_amdgcn_s_memrealtime();       // constant 100 MHz
-#endif
-    GP_STAMP(ts0);
     load(0);
     stage(0);
     __syncthreads();
-    GP_STAMP(ts1);
     const int ntiles = (k_dim + GP_KT - 1) / GP_KT;
     const int ar = wm * 32 * MB + (lane & 31), bc = wn * 32 * NB + (lane & 31), kh = lane >> 5;
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1;
-        GP_STAMP(ta);
         if (t + 1 < ntiles) load((t + 1) * GP_KT);
 #pragma unroll
         for (int k = 0; k < GP_KT; k += 2) {
@@ -212,26 +198,9 @@ __global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim
 #pragma unroll
                 for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
         }
-        GP_STAMP(tb);
         if (t + 1 < ntiles) stage(cur ^ 1);
-        GP_STAMP(tc);
         __syncthreads();
-#ifdef GP_PROF
-        { long long td; GP_STAMP(td); s_mma += tb - ta; s_stage += tc - tb; s_bar += td - tc; }
-#endif
     }
-#ifdef GP_PROF
-    {
-        long long te; GP_STAMP(te);
-        const long wv = (long)blockIdx.x * 4 + w;
-        if (lane == 0 && wv < 65536) {
-            long long *q = gp_prof + wv * 8;
-            q[0] = ts0; q[1] = ts1; q[2] = s_mma; q[3] = s_stage; q[4] = s_bar; q[5] = te;
-            q[6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       // HW_ID
-            q[7] = __builtin_amdgcn_s_memrealtime() - rt0;
-        }
-    }
-#endif
 #pragma unroll
     for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -1189,15 +1158,14 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    constexpr int xcd_env = 1;        // XCD-aware tile order (the plain order was an A/B switch until round 4)
     // tile: 128 x 128 when that still gives two workgroups per CU (same kernel time as 64 x 64 -- the matrix pipe is the bound at
-    // either size -- at half the L2 and LDS traffic: +1.3 % in the 20-deep pipeline), else 64 x 64.  WS3D_GP_TILE = MB NB: A/B runs
-    static const int tile_forced = getenv("WS3D_GP_TILE") ? atoi(getenv("WS3D_GP_TILE")) : 0;
-    const int tile_env = tile_forced ? tile_forced : ((rows % 128 == 0 && o_dim % 128 == 0 && (rows / 128) * (o_dim / 128) >= 512) ? 22 : 11);
+    // either size -- at half the L2 and LDS traffic: +1.3 % in the 20-deep pipeline), else 64 x 64 (128 x 64 and 64 x 128 were
+    // measured too: profiles/r02_gemm_pool_tiles.txt)
+    const int tile_env = (rows % 128 == 0 && o_dim % 128 == 0 && (rows / 128) * (o_dim / 128) >= 512) ? 22 : 11;
     {
         const int mb = tile_env / 10, nb = tile_env % 10;
-        static const bool force_big = getenv("WS3D_GP_FORCE_BIG") != nullptr;
-        if ((tile_env != 11 || force_big) && rows % (64 * mb) == 0 && o_dim % (64 * nb) == 0) {
+        if (tile_env != 11) {
             const long rt = rows / (64 * mb);
             const int xc = (xcd_env && rt % 8 == 0) ? 1 : 0;
             const dim3 grid((unsigned)((o_dim / (64 * nb)) * rt)), block(256);
@@ -1209,7 +1177,7 @@ extern "C" int ws3d_gemm_pool(long rows, int nsample, int k_dim, int o_dim, cons
             hipLaunchKernelGGL((gemm_pool_big_kernel<32, M_, N_>), grid, block, 0, as_stream(stream), k_dim, o_dim, x_rows, wt, bias, relu, out, out_stride, xc, gate, gate_limit); \
         return check_launch("ws3d_gemm_pool");                                                                                      \
     }
-            GP_BIG(1, 1) GP_BIG(2, 1) GP_BIG(1, 2) GP_BIG(2, 2)
+            GP_BIG(2, 2)
 #undef GP_BIG
         }
     }
@@ -1235,7 +1203,7 @@ extern "C" int ws3d_gather_gemm(int b, int n, int m, int nsample, int c_feat, in
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    constexpr int xcd_env = 1;
     const long per_scene = (long)m * nsample;
     const int tps = (xcd_env && (b & 7) == 0 && per_scene % 64 == 0) ? (int)(per_scene / 64) : 0;
     hipLaunchKernelGGL(gather_gemm_kernel, dim3((unsigned)((o_dim / 64) * (rows / 64))), dim3(256), 0, as_stream(stream), c_feat, o_dim, n, m,
@@ -1256,12 +1224,11 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
         return WS3D_E_UNSUPPORTED;
     }
     if (rows == 0) return WS3D_OK;
-    static const int xcd_env = getenv("WS3D_GEMM_XCD") ? atoi(getenv("WS3D_GEMM_XCD")) : 1;      // 0: plain tile order (A/B runs)
+    constexpr int xcd_env = 1;
     // 64 x 128 output tiles where they leave two workgroups per CU (FP1..FP3 of the c3 network): the interpolated A tile is built
     // half as often; measured 120 / 119 / 81 us against 128 / 131 / 82 at 64 x 64 and 119 / 123 / 90 at 128 x 128
-    // (profiles/r02_interp_gemm_tiles.txt).  WS3D_IG_TILE = MB NB: A/B runs
-    static const int tile_forced = getenv("WS3D_IG_TILE") ? atoi(getenv("WS3D_IG_TILE")) : 0;
-    const int tile = tile_forced ? tile_forced : ((o_dim % 128 == 0 && (rows / 64) * (o_dim / 128) >= 512) ? 12 : 11);
+    // (profiles/r02_interp_gemm_tiles.txt)
+    const int tile = (o_dim % 128 == 0 && (rows / 64) * (o_dim / 128) >= 512) ? 12 : 11;
     const int mb = tile / 10, nb = tile % 10;
     if (tile != 11 && rows % (64 * mb) == 0 && o_dim % (64 * nb) == 0) {
         const int tpsb = (xcd_env && (b & 7) == 0 && n % (64 * mb) == 0) ? n / (64 * mb) : 0;
@@ -1272,7 +1239,7 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
                            unknown_feats, idx, weight, wt, bias, relu, out, tpsb);                                                      \
         return check_launch("ws3d_interp_gemm");                                                                                        \
     }
-        IG_BIG(2, 1) IG_BIG(1, 2) IG_BIG(2, 2)
+        IG_BIG(1, 2)
 #undef IG_BIG
     }
     const int tps = (xcd_env && (b & 7) == 0 && n % 64 == 0) ? n / 64 : 0;
@@ -1435,8 +1402,3 @@ extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const
     return check_launch("ws3d_gemm_pool_compact");
 }
 
-#ifdef GP_PROF
-extern "C" __attribute__((visibility("default"))) int ws3d_gp_prof_read(long long *host, long n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ws3d::gp_prof), sizeof(long long) * (size_t)n, 0, hipMemcpyDeviceToHost);
-}
-#endif

@@ -492,9 +492,8 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
     const long blocks = (rows + 255) / 256;
     if (blocks > 0x7fffffffL) { set_error("ws3d_sa_mlp3_pool: too many rows"); return WS3D_E_UNSUPPORTED; }
     hipStream_t st = as_stream(stream);
-    // the wide scale on the matrix cores (WS3D_SA_MFMA=0: the VALU kernel, A/B runs)
-    static const int mfma_env = getenv("WS3D_SA_MFMA") ? atoi(getenv("WS3D_SA_MFMA")) : 1;
-    if (mfma_env && rows % 32 == 0) {
+    // on the matrix cores when the rows fill whole 32-row tiles (the VALU kernel below serves the ragged shapes)
+    if (rows % 32 == 0) {
         const long tiles = rows / 32;
         const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);          // 3 workgroups per CU, waves walk over tiles
 #define WS3D_SA_MFMA_CASE(A, B, C, N)                                                                                     \

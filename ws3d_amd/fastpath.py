@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import contextlib
 import contextvars
-import os
 
 import torch
 import torch.nn as nn
@@ -29,13 +28,15 @@ import torch.nn as nn
 from . import compat as _C
 from . import nn_blocks, pn2_ops
 
-
+# The switches below are module attributes, not environment variables (round 4): every one of them selects between two exact
+# forms of the same function; tests/test_gpu_parity.py::test_fast_path_switches_agree flips them, bench.py flips COMPACT_PAIRS
+# for its all-rows block.  The defaults are what every measurement in profiles/ ran.
 FUSED_SA_MLP = True   # ws3d_sa_mlp3_pool for the 4-channel SA level (clear to A/B against the GEMM chain)
-SA1_FROM_LISTS = os.environ.get("WS3D_SA1_FROM_LISTS", "1") != "0"  # first level: rows built from the neighbour lists inside the MLP kernel (0: grouped tensor)
+SA1_FROM_LISTS = True  # first level: rows built from the neighbour lists inside the MLP kernel (0: grouped tensor)
 FUSED_GEMM_POOL = True   # ws3d_gemm_pool: last layer of the other SA levels + pool on the matrix cores
-FUSED_INTERP_GEMM = os.environ.get("WS3D_FUSED_INTERP_GEMM", "1") != "0"  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
-NESTED_FPS = os.environ.get("WS3D_NESTED_FPS", "1") != "0"  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
-GEOMETRY_AHEAD = os.environ.get("WS3D_GEOMETRY_AHEAD", "1") != "0"  # sampling chain + searches on side streams beside the GEMMs
+FUSED_INTERP_GEMM = True  # ws3d_interp_gemm: three_interpolate + skip concat fused into the first FP layer's A operand
+NESTED_FPS = True  # levels 2-4: verified-prefix sampling (pn2_ops.furthest_point_sample_gather_nested)
+GEOMETRY_AHEAD = True  # sampling chain + searches on side streams beside the GEMMs
 _AHEAD_OVERRIDE = contextvars.ContextVar("ws3d_geometry_ahead", default=None)
 
 
@@ -53,26 +54,26 @@ def geometry_ahead(on: bool):
 def _geometry_ahead_now() -> bool:
     v = _AHEAD_OVERRIDE.get()
     return GEOMETRY_AHEAD if v is None else v
-GEOMETRY_IN_CAPTURE = os.environ.get("WS3D_GEOMETRY_IN_CAPTURE", "0") != "0"  # ... also while a hipGraph is captured (fork / join inside the graph)
-PER_POINT_L1 = os.environ.get("WS3D_PER_POINT_L1", "1") != "0"  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
-COMPACT_MAX_FILL = float(os.environ.get("WS3D_COMPACT_MAX_FILL", "0.55"))  # lists fuller than this (distinct rows / all rows) take the dense kernels
-COMPACT_PAIRS = os.environ.get("WS3D_COMPACT_PAIRS", "1") != "0"  # the SharedMLPs over the distinct (centre, sample) pairs only (0: all m * nsample rows)
+GEOMETRY_IN_CAPTURE = False  # ... also while a hipGraph is captured (fork / join inside the graph)
+PER_POINT_L1 = True  # SA2..SA4: layer 1 as feats @ W_f per point + gather (ws3d_pgather_*)
+COMPACT_MAX_FILL = 0.55  # lists fuller than this (distinct rows / all rows) take the dense kernels
+COMPACT_PAIRS = True  # the SharedMLPs over the distinct (centre, sample) pairs only (0: all m * nsample rows)
 # How a scale chooses between the compact and the dense form of its SharedMLP (both exact):
 #   device  (default) both forms are launched, every kernel reads the pair total of THIS batch in its prologue and the form on the
 #           wrong side of COMPACT_MAX_FILL returns at once (include/ws3d_ops.h "launch gates") -- no host synchronisation, nothing
 #           latched per process, a captured hipGraph adapts per batch;
 #   compact always the compact kernels (A/B runs).
-# WS3D_COMPACT_PAIRS=0 is "always dense".
-PAIR_DISPATCH = os.environ.get("WS3D_PAIR_DISPATCH", "device")
-PER_POINT_FP = os.environ.get("WS3D_PER_POINT_FP", "1") != "0"  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
-FUSED_MLP2_ROWS = os.environ.get("WS3D_FUSED_MLP2_ROWS", "1") != "0"  # ws3d_mlp2_rows: the two layers of a head in one kernel
-FUSED_GATHER_GEMM2 = os.environ.get("WS3D_FUSED_GATHER_GEMM2", "1") != "0"  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
+# COMPACT_PAIRS = False is "always dense".
+PAIR_DISPATCH = "device"
+PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
+FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
+FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
 # the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
-GRID_MIN_N = int(os.environ.get("WS3D_GRID_MIN_N", "256"))
-PARALLEL_SCALES = os.environ.get("WS3D_PARALLEL_SCALES", "1") != "0"  # eager side-stream mode: the second scale of a level beside the first
-PARALLEL_HEADS = os.environ.get("WS3D_PARALLEL_HEADS", "1") != "0"  # ... and the regression head beside the classification head + top-k
+GRID_MIN_N = 256
+PARALLEL_SCALES = True  # eager side-stream mode: the second scale of a level beside the first
+PARALLEL_HEADS = True  # ... and the regression head beside the classification head + top-k
 
 
 def _row_weights(block):
@@ -279,15 +280,10 @@ def _side_streams(main: torch.cuda.Stream):
     stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has descriptors
     gets time-sliced (measured: a pair per Stage1Pipeline slot, 60 streams, ran every kernel of the process ~1.6x slower; the
     limit sits at 24 queues: 20 pipeline slots + the null stream + a pair of its own = 23 was fine, a third one was not).
-    Sharing the pool costs nothing: a pass that runs eagerly beside a pipeline in flight merely queues behind its slots."""
-    from .streams import pooled_stream
-    picked, j = [], 0
-    while len(picked) < 3:
-        st = pooled_stream(main.device, j)
-        j += 1
-        if st.cuda_stream != main.cuda_stream:
-            picked.append(st)
-    return tuple(picked)
+    Sharing the pool costs nothing: a pass that runs eagerly beside a pipeline in flight merely queues behind its slots -- the side
+    streams are taken from the far end of the pool and never one that is capturing a hipGraph (streams.side_streams)."""
+    from .streams import side_streams
+    return side_streams(main, 3)
 
 
 class _Geometry:
@@ -415,7 +411,12 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                             gate = (pairs[2], limit)
                             yd = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2, out=yc, gate=gate)
                             if yd is None or not _C.gemm_pool(yd, wt3, b3, r3, ns, out, col, gate=gate):
-                                raise RuntimeError("the gated dense kernels declined a shape _pair_limit accepted")
+                                # the dense side declined a call dense_ok let through (an alignment or stride check the C side makes and
+                                # this restatement does not): the compact kernels once more, ungated -- both are idempotent (plain row
+                                # stores; an atomic max into the zeroed pool), so the batch is complete whichever side of the limit it is on
+                                yc = _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, limit=-1)
+                                if yc is None or not _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col, limit=-1):
+                                    raise RuntimeError("neither the gated dense nor the ungated compact kernels took the shape")
                         return
                 if o1 <= 128:
                     wt2, b2, r2 = _row_weights(blocks[1])
@@ -465,7 +466,8 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
                 if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
                     if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
-                        raise RuntimeError("ws3d_sa_mlp3_pool_lists declined a shape ws3d_sa_mlp3_pool_compact accepted")
+                        if not _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=-1):      # (ungated, idempotent: see above)
+                            raise RuntimeError("neither ws3d_sa_mlp3_pool_lists nor the ungated compact kernel took the shape")
                     return
         g = _C.query_and_group_nlc(grouper.radius, grouper.nsample, xyz, new_xyz, feats, grouper.use_xyz, sorted_xyz)
         rows = g.view(-1, g.size(3))
