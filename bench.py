@@ -268,11 +268,12 @@ class C2:
                    "alg_bytes_per_step": a_model_fps() * self.B,
                    "alg_bytes_min_per_step": a_min_fps() * self.B, "traffic_key": "fps_rounds2_kernel",
                    "comment": "chain-bound, not VALU-bound: a round of the kernel is box tests, bucket updates, a re-pick, a record exchange and the "
-                              "certification of up to 4 samples (fps_bucket.hip); pruning leaves ~1/4 of the dense sweep's instructions.  valu_frac = "
+                              "certification of up to 8 samples (fps_bucket.hip); pruning leaves ~1/7 of the dense sweep's instructions.  valu_frac = "
                               "ISSUED wave64 VALU instructions x 64 lanes (SQ_INSTS_VALU of the committed --pmc pass of this batch and generator, "
                               "profiles/traffic_fps_valu.json) / the duration measured here / the VALU issue roof; dense_equivalent_valu_frac counts "
                               "the dense sweep's %d lane-instructions per point and step instead (what the VALU-bound dense kernel issues: 0.55-0.57 "
-                              "of the roof at 6.1 ms per 512 scenes, 1.23 x slower than this kernel)" % FPS_VALU_PER_POINT}
+                              "of the roof at 6.1-6.2 ms per 512 scenes, 1.9 x slower than this kernel; above 1: faster than a VALU-bound "
+                              "dense sweep could be)" % FPS_VALU_PER_POINT}
         return [
             fps_row,
             {"name": "bin_points_grid + ball_query_grid_coop_kernel<fused> (ball_query, one wave per centre, + group + centre + cat)", "ms_per_step": qg,
@@ -662,7 +663,7 @@ def roofline_of(k, where):
                   "hbm_frac_physical": (traffic / (sec / launches) / HBM_PEAK) if traffic else None,
                   "note": "FPS never re-reads the scene, so HBM does not bound it; the roof that applies is VALU issue (MI355X_MICROARCH.md: a wave64 "
                           "instruction = 2 clk on a SIMD-32).  frac = VALU lane-instructions ISSUED (hardware counter) / duration / that roof: the "
-                          "physical utilisation of a kernel that is deliberately NOT VALU-bound -- the sampling kernel of round 3 prunes ~3/4 of the "
+                          "physical utilisation of a kernel that is deliberately NOT VALU-bound -- the sampling kernel prunes ~6/7 of the "
                           "dense sweep's instructions and is bound by its cross-lane chain; its figure of merit is us_per_sample.  dense_equivalent_frac "
                           "= the dense sweep's instruction count (8 per point and step) / duration / roof: what a VALU-bound kernel would need to reach "
                           "for the same speed.  effective_frac = SURVEY 8d's A_model bytes / duration / 8 TB/s (the north-star's accounting; exceeds 1 "
@@ -874,7 +875,7 @@ def main():
                     "valu_share_of_occupied_CUs_pmc": pmc,
                     "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs (throughput mode overlaps 20 batches).  This kernel is "
                             "chain-bound, not VALU-bound: its figure is the time per sample (a round = box tests, bucket updates, re-pick, record "
-                            "exchange, certification of up to 4 samples; ~3.1 samples per round), in us and clk; valu_share_of_occupied_CUs_pmc = "
+                            "exchange, certification of up to 8 samples; 5.6 / 6.4 samples per round on hdl64 / lidar), in us and clk; valu_share_of_occupied_CUs_pmc = "
                             "SQ_INSTS_VALU x 64 lanes / duration / the VALU roof of the 8 CUs it runs on, from the committed --pmc pass of this batch "
                             "and generator (profiles/traffic_fps_valu.json) or null"}
             out["c2"] = c2blk

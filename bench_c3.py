@@ -323,7 +323,7 @@ class C3:
                 e8 = fps_valu_pmc(B, self.kind)
                 row.update({"bound": "valu", "lane_instr_per_step": fps_lane_instr(n1, m1) * B, "us_per_fps_step": ms * 1e3 / (m1 - 1),
                             "physical_lane_instr_per_step": None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0,
-                            "comment": "one workgroup per scene (8 of 256 CUs): fps_rounds_kernel (fps_bucket.hip), exact pruned sampling with several "
+                            "comment": "one workgroup per scene (8 of 256 CUs): fps_rounds2_kernel (fps_bucket.hip), exact pruned sampling with two candidates per wave and up to 8 "
                                        "certified samples per record exchange.  Chain-bound: us_per_fps_step (time per sample) is the figure to "
                                        "watch; valu_frac = issued VALU lane-instructions (committed --pmc pass) / duration / the WHOLE chip's roof, "
                                        "lane_instr_per_step the dense sweep's count (8 per point and step)"})

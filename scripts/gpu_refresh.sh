@@ -51,14 +51,20 @@ for wl in c5:8; do
 done
 # round-2 extras: FPS kernels side by side, the eager step's kernel timeline (side streams), roipool3d ablation, ubenches
 { python scripts/ab_fps.py default; WS3D_FPS_BUCKET=0 python scripts/ab_fps.py dense 8x16384x4096 256x16384x4096 512x16384x4096 8x12345x3000; WS3D_FPS_ROUNDS=0 python scripts/ab_fps.py one-sample-per-exchange 8x16384x4096 256x16384x4096 512x16384x4096; } > $OUT/fps_ab.txt 2>/dev/null
+# HBM traffic of the eager c3 step per launch family (separate --pmc passes) -> traffic_c3.json
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_c3_$c
+  $T rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_c3_$c -o pmc -- python bench.py --workload c3 --pipeline-depth 1 --no-graph --c2-batch 0 --steps 4 --warmup 2 --no-cpu-baseline --no-side-runs > $OUT/pmc_c3_$c.log 2>&1
+done
+python scripts/pmc_traffic_c3.py "$(find /tmp/pmc_c3_FETCH_SIZE -name '*.db' | head -1)" "$(find /tmp/pmc_c3_WRITE_SIZE -name '*.db' | head -1)" \
+  $OUT/traffic_c3.json hdl64 8 > $OUT/traffic_c3_summary.txt 2>>$OUT/pmc_c3_WRITE_SIZE.log
 $T bash scripts/pmc_fps_valu.sh $OUT/pmc_fps > $OUT/pmc_fps_valu.txt 2>&1
-$T bash scripts/ubench/fps_rounds_prof.sh > $OUT/fps_rounds_segments.txt 2>&1
+$T bash scripts/ubench/fps_rounds2_prof.sh > $OUT/fps_rounds2_segments.txt 2>&1
 $T python scripts/graph_fork_debug.py > $OUT/graph_fork_join_stress.txt 2>&1
 $T python scripts/ubench/compact_vs_dense.py > $OUT/compact_vs_dense_dispatch.txt 2>&1
 rm -rf /tmp/tl; (cd /tmp && $T rocprofv3 --kernel-trace -d /tmp/tl -o t -- python $OLDPWD/scripts/host_issue_time.py > $OLDPWD/$OUT/host_issue_time.txt 2>&1)
 python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_rounds2_kernel $OUT/c3_eager_timeline.txt > /dev/null 2>>$OUT/host_issue_time.txt
 python scripts/host_issue_time.py > $OUT/host_issue_time_untraced.txt 2>&1
 $T bash scripts/ablate_roi.sh > $OUT/roipool3d_ablation.txt 2>&1
-$T bash scripts/ubench/fps_bucket_prof.sh > $OUT/fps_bucket_segments.txt 2>&1
 (cd scripts/ubench && hipcc -O3 --offload-arch=gfx950 row_copy.hip -o /tmp/row_copy 2>/dev/null && timeout 120 /tmp/row_copy) > $OUT/ubench_row_copy.txt 2>&1
 ls -la $OUT

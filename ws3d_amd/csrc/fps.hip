@@ -712,14 +712,18 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     while ((1 << log2bs) < bs) ++log2bs;
     const int S = (n + bs - 1) / bs;
     const long R = (long)bs * S;  // number of tie-order positions
-    // pruned (bucket) kernel, fps_bucket.hip: one scene per CU, 0.77 us per step at 16384 points against 1.02 of the dense sweep
-    // -- the choice when the scenes do not outnumber the CUs (two dense scenes per CU sample 512 scenes in 6.1 ms, the pruned
-    // kernel needs 6.4) and the cloud is large (8192 points: 0.78 vs 0.74).  WS3D_FPS_BUCKET=0 / 1 forces the choice (A/B runs).
+    // pruned kernels, fps_bucket.hip (one scene per CU).  With several certified samples per exchange (fps_rounds2_kernel, m <= 6144)
+    // they beat the dense sweep from 2049 points up (scripts/ab_fps.py, profiles/r04_fps_ab_small_clouds.txt; us per sample, rounds /
+    // dense): 16384 points 0.38 / 1.02 at every batch size (512 scenes: 3.2 vs 6.2 ms), 8192: 0.40 / 0.73 (512 scenes 1.65 vs 2.19 ms),
+    // 4096: 0.45 / 0.58 while the scenes do not outnumber the CUs (512 scenes: 0.96 vs 0.79 ms -- several dense workgroups share a CU),
+    // 2049: 0.55 / 0.59; at 1025 the dense kernel wins (0.66 / 0.57).  m > 6144 (the samples do not fit in LDS beside the sort
+    // tables): the one-sample-per-exchange kernel above 8192 points while the scenes do not outnumber the CUs, else the dense sweep.
+    // WS3D_FPS_BUCKET=0 / 1 forces the choice for 2049 .. 16384 points (A/B runs, tests).
     static const int use_bucket = getenv("WS3D_FPS_BUCKET") ? atoi(getenv("WS3D_FPS_BUCKET")) : -1;
-    // round 3: with several certified samples per exchange (fps_rounds_kernel, m <= 6144) the pruned kernel wins at EVERY batch
-    // size -- 2.09 ms per 256 scenes, so 512 scenes take 4.05 ms in two waves of workgroups against 6.10 ms dense
-    const bool bucket = use_bucket >= 0 ? use_bucket != 0 : (R > 8192 && (fps_rounds_covers(m) || !fps_pair_mode(b)));
-    if (bucket && n > 4096 && n <= 16384 && m > 1)
+    const bool many = fps_pair_mode(b), rounds = fps_rounds_covers(m);
+    const bool bucket = use_bucket >= 0 ? use_bucket != 0
+                                        : (R > 8192 ? (rounds || !many) : (rounds && (R > 4096 || (R > 2048 && !many))));
+    if (bucket && n > 2048 && n <= 16384 && m > 1)
         return fps_bucket_launch(b, n, m, xyz, temp, idx, new_xyz, bs, log2bs, S, st);
     // round-2 kernels (fps_v3.hip: hand-scheduled sweep, winner-only lookup) for 2048 < R <= 16384; the kernels of this file serve the
     // small clouds, the large ones, and every size of the un-contracted distance convention (WS3D_DIST_MODE == 1: fps_v3 declines)
