@@ -11,8 +11,6 @@ for f in bench_default.json bench_default_lidar.json bench_c3_b8_steps160.json b
   [ -s $S/$f ] && cp $S/$f $D/${R}_$f
 done
 [ -s $S/host_issue_time_untraced.txt ] && cp $S/host_issue_time_untraced.txt $D/${R}_host_issue_time.txt
-[ -s $S/bench_ab_ball_query_coop0.json ] && cp $S/bench_ab_ball_query_coop0.json $D/${R}_ab_ball_query_one_lane_per_centre_hdl64.json
-[ -s $S/bench_ab_ball_query_coop1.json ] && cp $S/bench_ab_ball_query_coop1.json $D/${R}_ab_ball_query_one_wave_per_centre_hdl64.json
 for f in traffic.json traffic_c5.json traffic_c3.json; do [ -s $S/$f ] && cp $S/$f $D/$f; done
 [ -s $S/pmc_fps/traffic_fps_valu.json ] && cp $S/pmc_fps/traffic_fps_valu.json $D/traffic_fps_valu.json
 [ -s $S/pmc_fps_valu.txt ] && cp $S/pmc_fps_valu.txt $D/${R}_fps_valu_counters.txt
