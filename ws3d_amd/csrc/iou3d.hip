@@ -255,6 +255,10 @@ struct LeadArgs {
     const int *done;   // per-scene flag written by the previous level's sweep (nullptr: first level)
     int prev_lead;     // tiles with row < prev_lead && col < prev_lead were built by that level
     int internal;      // 1: mask lives in the NMS workspace, lower-triangle zero fill is skipped
+    int walk;          // > 0 (rotated kernel only): the launch is (workgroups, 1, scenes) and every workgroup WALKS the walk x walk tiles of
+                       // its scene in strides of gridDim.x -- the later levels, which usually find their scene done: 2,048 workgroups that
+                       // return at once instead of one per tile (141 x 141 x 8 = 159 k at 9000 boxes: 48 of the NMS's 140 us went into
+                       // launching workgroups that exit)
     __device__ __forceinline__ bool skip_tile(int row, int col, int scene) const {
         if (done && done[scene]) return true;
         if (row < prev_lead && col < prev_lead) return true;
@@ -374,15 +378,18 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
     }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     MaskTileLds &s = *reinterpret_cast<MaskTileLds *>(smem_raw);
-    const int row_start = blockIdx.y, col_start = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int col_blocks = (boxes_num + 63) / 64;
+    if (la.walk > 0 && la.done && la.done[blockIdx.z]) return;
+    // the workgroup's tile: (blockIdx.y, blockIdx.x), or in walk mode every gridDim.x-th tile of the scene (all conditions workgroup-uniform)
+    for (int tile = la.walk > 0 ? (int)blockIdx.x : 0, ntile = la.walk > 0 ? la.walk * la.walk : 1; tile < ntile; tile += la.walk > 0 ? (int)gridDim.x : 1) {
+    const int row_start = la.walk > 0 ? tile / la.walk : (int)blockIdx.y, col_start = la.walk > 0 ? tile % la.walk : (int)blockIdx.x;
     const int row_size = min(boxes_num - row_start * 64, 64);
     const int col_size = min(boxes_num - col_start * 64, 64);
-    if (la.skip_tile(row_start, col_start, blockIdx.z)) return;
+    if (la.skip_tile(row_start, col_start, blockIdx.z)) continue;
     if (col_start < row_start && !full_grid) {  // never read by the sweep (iou3d.cpp:108)
         if (tid < row_size) mask[(size_t)(row_start * 64 + tid) * col_blocks + col_start] = 0;
-        return;
+        continue;
     }
     if (tid < 128) {
         const int which = tid >> 6;  // 0: row frames, 1: column frames
@@ -433,6 +440,8 @@ __global__ __launch_bounds__(256) void nms_rot_mask_kernel(int boxes_num, float 
     if (tid < row_size)
         mask[(size_t)(row_start * 64 + tid) * col_blocks + col_start] =
             ((uint64_t)s.words[tid][1] << 32) | (uint64_t)s.words[tid][0];
+    __syncthreads();      // (walk mode: the next tile reuses the LDS)
+    }
 }
 
 // iou3d.cpp:100-116 greedy sweep, on the device.  One 256-lane workgroup.  Per 64-row chunk:
@@ -811,6 +820,10 @@ static int mask_launch(int batch, int boxes_num, const float *boxes, float thres
             const long total = (long)batch * boxes_num;
             hipLaunchKernelGGL(bev_frames_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
                                boxes, frames);
+        }
+        if (la.done) {      // a later level of the ladder: few workgroups that walk the tiles (LeadArgs::walk) -- most scenes are done
+            la.walk = gc;
+            grid = dim3((unsigned)std::min((long)gc * gc, 256L), 1, batch);
         }
         hipLaunchKernelGGL(nms_rot_mask_kernel, grid, dim3(256), sizeof(MaskTileLds), st, boxes_num, thresh,
                            full_grid, boxes, frames, mask, la);
