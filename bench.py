@@ -882,6 +882,20 @@ def main():
         else:
             out["roofline"] = roofline_of(dom, "the timed region (HIP events on the launch stream)")
         out.update(side)
+        if "list_fill" in out and "throughput_mode" in out and hasattr(wl, "cfg"):
+            import bench_c3
+            # the second roof of the step: the matrix work its GEMM-shaped kernels execute (own fp32-MFMA kernels + the library's
+            # GEMMs) against the dense fp32 MFMA peak -- with 20 batches in flight the step is closer to this roof than to HBM's
+            mw = bench_c3.matrix_work(wl.cfg, out["list_fill"]["scales"], wl.scenes())
+            tf = mw["gflop_per_batch"] / ms_per_step
+            mw.update({"bound": "mfma", "achieved": tf, "peak": bench_c3.FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / bench_c3.FP32_MFMA_PEAK_TFLOPS,
+                       "note": "useful multiply-adds executed per batch (counted from the layer widths and the distinct pairs measured on the batch, "
+                               "bench_c3.matrix_work; tile padding not counted) / ms_per_step of the timed region; f32 in, f32 accumulate "
+                               "(v_mfma_f32_32x32x2_f32: the rate of the f32 vector unit, 1/16 of bf16)"})
+            if "all_rows" in out:
+                ar = bench_c3.matrix_work(wl.cfg, out["list_fill"]["scales"], wl.scenes(), compact=False)["gflop_per_batch"]
+                mw["all_rows"] = {"gflop_per_batch": ar, "achieved": ar / out["all_rows"]["ms_per_batch"], "frac": ar / out["all_rows"]["ms_per_batch"] / bench_c3.FP32_MFMA_PEAK_TFLOPS}
+            out["throughput_mode"]["matrix_roofline"] = mw
         out.update({"kernels": kernels, "step_ms_percentiles": step_percentiles(wl), "path_gbps_per_gpu": wl.path_gbps(per_gpu)})
         if not args.no_cpu_baseline and world == 1:
             try:

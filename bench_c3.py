@@ -90,6 +90,52 @@ _HOOKED = False
 _DOUBLE = os.environ.get("WS3D_BENCH_DOUBLE", "")
 
 
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32 (no xf32 / TF32 on gfx950)
+
+
+def matrix_work(cfg, fill_rows, batch, compact=True):
+    """Multiply-adds the matrix cores EXECUTE for one batch of the c3 forward pass as ws3d_amd/fastpath.py runs it, counted from the
+    layer widths of the configuration and the distinct (centre, sample) pairs measured on the batch (`fill_rows` = fastpath.list_fill):
+      * SA level 1: three layers over the rows of each scale (distinct pairs when the scale's fill <= COMPACT_MAX_FILL, else all m * nsample);
+      * SA levels 2-4: the first layer is linear in the gathered features, so its feature part is ONE product over the n source points
+        (P = X W, per point) and only the 3 xyz columns are per row; layers 2 and 3 over the rows;
+      * FP modules: the interpolated half of the first layer is a product over the KNOWN points (Q), the skip half and the second layer
+        over the unknown points;  * heads: two layers each over every point.
+    Padding of K / N to tile multiples is NOT counted (useful work only).  Returns per-batch GFLOP by family (2 flops per multiply-add)."""
+    from ws3d_amd import fastpath
+    n_in = cfg.num_points
+    cin = int(cfg.use_intensity)
+    mac = {"SA1 (three layers over rows)": 0.0, "SA2-4 first layer per point (P)": 0.0, "SA2-4 layers 2+3 over rows": 0.0,
+           "FP known-point products (Q)": 0.0, "FP skip half + second layer": 0.0, "heads": 0.0}
+    sa_out = [cin]
+    it = iter(fill_rows)
+    n = n_in
+    for lvl, (npnt, specs, nsamples) in enumerate(zip(cfg.npoints, cfg.mlps, cfg.nsample)):
+        c_prev = sa_out[-1]
+        for spec, ns in zip(specs, nsamples):
+            f = next(it)
+            rows = npnt * (f["distinct_per_list"] if (compact and f["fill"] <= fastpath.COMPACT_MAX_FILL) else ns)
+            c1, c2, c3 = spec
+            if lvl == 0:
+                mac["SA1 (three layers over rows)"] += rows * ((c_prev + 3) * c1 + c1 * c2 + c2 * c3)
+            else:
+                mac["SA2-4 first layer per point (P)"] += n * c_prev * c1
+                mac["SA2-4 layers 2+3 over rows"] += rows * (3 * c1 + c1 * c2 + c2 * c3)
+        sa_out.append(sum(s[-1] for s in specs))
+        n = npnt
+    counts = [n_in] + list(cfg.npoints)
+    pre = sa_out[-1]
+    for k in range(len(cfg.fp_mlps) - 1, -1, -1):           # FP module k: unknown = level k, known = level k + 1
+        c1, c2 = cfg.fp_mlps[k]
+        mac["FP known-point products (Q)"] += counts[k + 1] * pre * c1
+        mac["FP skip half + second layer"] += counts[k] * (sa_out[k] * c1 + c1 * c2)
+        pre = c2
+    per_loc_bin_num = int(cfg.loc_scope / cfg.loc_bin_size) * 2
+    mac["heads"] += n_in * (pre * cfg.cls_fc[0] + cfg.cls_fc[0] * 1 + pre * cfg.reg_fc[0] + cfg.reg_fc[0] * per_loc_bin_num * 4)
+    g = {k: 2.0 * v * batch / 1e9 for k, v in mac.items()}
+    return {"gflop_per_batch": sum(g.values()), "by_family_gflop": {k: round(v, 3) for k, v in g.items()}}
+
+
 def _install_hooks():
     global _HOOKED
     if _HOOKED:

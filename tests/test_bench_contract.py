@@ -36,6 +36,9 @@ def test_default_line_is_the_baseline_headline():
     assert out["metric"] == base["metric"] and out["config"]["workload"].startswith("c3") and out["config"]["batch_per_gpu"] == 8
     assert out["throughput_mode"]["value"] == out["value"] and out["throughput_mode"]["batches_in_flight"] == 3
     assert out["latency_mode"]["batches_in_flight"] == 1 and 0 < out["latency_mode"]["value"] <= out["value"] * 1.05
+    mr = out["throughput_mode"]["matrix_roofline"]     # the step's GEMM-shaped work against the dense fp32 MFMA peak
+    assert mr["bound"] == "mfma" and mr["peak"] == 157.3 and 0 < mr["frac"] < 1 and abs(mr["frac"] - mr["achieved"] / mr["peak"]) < 1e-9
+    assert abs(mr["achieved"] - mr["gflop_per_batch"] / out["ms_per_step"]) < 1e-6 and mr["all_rows"]["gflop_per_batch"] > mr["gflop_per_batch"]
     c2 = out["c2"]
     assert c2["workload"].startswith("c2") and c2["batch_per_gpu"] == 64 and c2["scenes_per_s_per_gpu"] > 0
     assert {"a_model", "a_min", "a_model_bytes_per_scene", "a_min_bytes_per_scene"} <= set(c2["path_gbps_per_gpu"])

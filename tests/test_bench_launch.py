@@ -28,3 +28,42 @@ def test_under_a_launcher_nothing_is_started_and_a_world_mismatch_is_rc_nonzero(
     p = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], dict(NO_LAUNCHER, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", WS3D_BENCH_LAUNCH_DRYRUN="1"))
     assert p.returncode != 0 and "self_launch" not in p.stdout
     assert "WORLD_SIZE=1" in p.stderr and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_matrix_work_counts_the_multiply_adds_of_the_network_as_built():
+    """bench_c3.matrix_work (the numerator of throughput_mode.matrix_roofline) against the weights of the Stage-1 network itself: with every
+    list full, its count = the conv weights' sizes x the rows each is applied to in fastpath.py's formulation (first SA layers of
+    levels 2-4 split into a per-point product + 3 xyz columns per row, first FP layers split into known-point / skip halves)"""
+    sys.path.insert(0, ROOT)
+    import bench_c3
+    from ws3d_amd import stage1
+    cfg = stage1.DEFAULT_CFG
+    net = stage1.Stage1Net(mode="TEST", cfg=cfg)
+    bb = net.rpn.backbone_net
+    fill = [{"distinct_per_list": float(ns), "fill": 1.0} for nss in cfg.nsample for ns in nss]
+    convs = lambda mod: [m.weight for m in mod.modules() if hasattr(m, "weight") and m.weight.dim() >= 3]     # (bn weights are 1-D)
+    want, n = 0, cfg.num_points
+    counts = [cfg.num_points] + list(cfg.npoints)
+    for lvl, sa in enumerate(bb.SA_modules):
+        for mlp, ns in zip(sa.mlps, cfg.nsample[lvl]):
+            ws = convs(mlp)
+            rows = sa.npoint * ns
+            first = ws[0]
+            if lvl == 0:
+                want += rows * first.numel()
+            else:
+                want += n * first.size(0) * (first.size(1) - 3) + rows * 3 * first.size(0)
+            want += rows * sum(w.numel() for w in ws[1:])
+        n = sa.npoint
+    for k, fp in enumerate(bb.FP_modules):
+        ws = convs(fp.mlp)
+        first = ws[0]
+        skip = first.size(1) - (cfg.fp_mlps[k + 1][-1] if k + 1 < len(cfg.fp_mlps) else sum(m[-1] for m in cfg.mlps[-1]))
+        want += counts[k + 1] * first.size(0) * (first.size(1) - skip) + counts[k] * first.size(0) * skip + counts[k] * sum(w.numel() for w in ws[1:])
+    for head in (net.rpn.rpn_cls_layer, net.rpn.rpn_reg_layer):
+        want += cfg.num_points * sum(w.numel() for w in convs(head))
+    got = bench_c3.matrix_work(cfg, fill, batch=8, compact=False)
+    assert abs(got["gflop_per_batch"] - 2.0 * want * 8 / 1e9) < 1e-6 * got["gflop_per_batch"], (got, 2.0 * want * 8 / 1e9)
+    half = [dict(f, distinct_per_list=f["distinct_per_list"] / 4, fill=0.25) for f in fill]
+    assert bench_c3.matrix_work(cfg, half, batch=8)["gflop_per_batch"] < got["gflop_per_batch"]
+    assert bench_c3.matrix_work(cfg, half, batch=8, compact=False)["gflop_per_batch"] == got["gflop_per_batch"]
