@@ -230,7 +230,7 @@ WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const
  * which one is faster depends on how full the ball-query lists are (break-even ~55 % distinct rows), a number that only exists
  * on the device and changes per batch -- a captured hipGraph cannot branch on the host.  So the caller launches BOTH forms and
  * every kernel of a form reads the pair total in its prologue:
- *   compact kernels (ws3d_pgather_gemm2_compact, ws3d_gemm_pool_compact, ws3d_sa_mlp3_pool_compact): `limit` -- run iff *total <= limit
+ *   compact kernels (ws3d_pgather_gemm2_compact, ws3d_gemm_pool_compact, ws3d_pgather_gemm3_compact, ws3d_sa_mlp3_pool_compact): `limit` -- run iff *total <= limit
  *                  (limit < 0: always);
  *   dense kernels   (ws3d_pgather_gemm2, ws3d_gemm_pool, ws3d_sa_mlp3_pool_lists): `gate`, `gate_limit` -- run iff *gate > gate_limit
  *                  (gate == NULL: always), gate = the `total` word of ws3d_compact_pairs.
@@ -247,6 +247,8 @@ WS3D_API int ws3d_qinterp_rows(int b, int n, int m, int o, const float *q, const
  *                             workgroups beyond *total return at once
  *   ws3d_gemm_pool_compact:   last layer + ReLU + max over each centre's rows by integer atomic max into out[centre, 0:o_dim]
  *                             (row stride out_stride), which the caller ZEROES first; the layer must end in a ReLU
+ *   ws3d_pgather_gemm3_compact: the two above in ONE kernel (o1 in {64, 128}, o3 % 128 == 0, layer 2's tile kept in LDS: WS3D_E_UNSUPPORTED
+ *                             beyond 159 KB): out[centre, 0:o3] by integer atomic max, bit-identical to the two-kernel form
  * ws3d extensions, used by ws3d_amd/fastpath.py.                                                                          */
  /* ws3d_compact_pairs: count + placement in ONE launch (*total must be ZERO on entry; the order of the compact rows is then arrival
  *  order of the 256-centre workgroups -- undefined, and irrelevant to every consumer above) */
@@ -257,6 +259,10 @@ WS3D_API int ws3d_compact_pairs_rows(long centres, int nsample, const int32_t *n
 WS3D_API int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, int o1, int o2, const float *pmat, int p_stride, const float *xyz,
                                const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
                                const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out, long limit, ws3d_stream_t stream);
+WS3D_API int ws3d_pgather_gemm3_compact(int b, int n, int m, long max_rows, int o1, int o2, int o3, const float *pmat, int p_stride, const float *xyz,
+                               const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
+                               const float *b1, int relu1, const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3,
+                               float *out, int out_stride, long limit, ws3d_stream_t stream);
 WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
                            const float *wt, const float *bias, float *out, int out_stride, long limit, ws3d_stream_t stream);
 

@@ -2133,6 +2133,18 @@ def test_compact_pairs_path_is_bit_identical_to_the_dense_one(ops, B, N, M, ns, 
     yc = ops.c.pgather_gemm2_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True)
     assert yc is not None and ops.c.gemm_pool_compact(yc, (rowc, rowsrc, total), w3, b3, out, 64)
     assert bool((out[:, :64] == 0).all())
+    # the same chain in ONE kernel (ws3d_pgather_gemm3_compact: layer 2's tile stays in LDS): bit-identical to the two-kernel form
+    # wherever it takes the shape (o1 in {64, 128}, O3 % 128, the tiles within the LDS), gated by the same limit
+    out3 = torch.zeros((B * M, O3 + 64), device="cuda")
+    took = ops.c.pgather_gemm3_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True, w3, b3, out3, 64)
+    assert took == (O1 in (64, 128) and O3 % 128 == 0)
+    if took:
+        assert torch.equal(out3, out)
+        assert not ops.c.pgather_gemm3_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True, w3, b3, out3, 64, max_lds=16 * 1024)
+        for limit, runs in ((T - 1, False), (T, True)):
+            o3_ = torch.zeros((B * M, O3), device="cuda")
+            assert ops.c.pgather_gemm3_compact(pmat, 0, O1, xyz, new_xyz, (rowc, rowsrc, total), w1x, b1, True, w2, b2, True, w3, b3, o3_, 0, limit=limit)
+            assert torch.equal(o3_, out[:, 64:]) if runs else bool((o3_ == 0).all()), "the fused compact kernel ignored its limit"
     if dense is not None:
         assert torch.equal(out[:, 64:], dense)
         # device-side dispatch (launch gates): both forms launched into the same buffers, the pair total decides in the kernels'

@@ -88,6 +88,7 @@ SIGNATURES = {
     "ws3d_compact_pairs_count": (_i, [C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_compact_pairs_rows": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_pgather_gemm2_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_long, _vp]),
+    "ws3d_pgather_gemm3_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_gemm_pool_compact": (_i, [C.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_sa_mlp3_pool_lists": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),

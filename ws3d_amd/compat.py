@@ -564,6 +564,30 @@ def pgather_gemm2_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w
     return out
 
 
+def pgather_gemm3_compact(pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out2d, col_offset, limit=-1, max_lds=160 * 1024):
+    """pgather_gemm2_compact + gemm_pool_compact in ONE kernel (layer 2's tile stays in LDS): the whole SharedMLP of a scale over the
+    compact rows, reduced by atomic max into out2d[:, col_offset : col_offset + O3] -- ZERO on entry; the last layer ends in a ReLU.
+    True, or False when the shape is not covered (o1 in {64, 128}, O2 % 4, O3 % 128, the two tiles within `max_lds` bytes of LDS).
+    Bit-identical to the two-kernel form.  ws3d extension."""
+    rowc, rowsrc, total = pairs
+    dev = _dev(pmat, xyz, new_xyz, rowc, w1x, w2t, w3t, out2d)
+    _f32(pmat, "pmat"); _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz"); _f32(w1x, "w1x"); _f32(w2t, "w2t"); _f32(w3t, "w3t"); _f32(out2d, "out2d")
+    B, N = xyz.size(0), xyz.size(1)
+    M = new_xyz.size(1)
+    O2, O3 = w2t.size(1), w3t.size(1)
+    rows = rowc.numel()
+    lds = 4 * ((o1 + (O2 + 15) // 16 * 16) * 65 + 2 * 16 * 64)
+    if (o1 not in (64, 128) or O2 % 4 or O3 % 128 or lds > min(max_lds, 160 * 1024 - 1024) or pmat.dim() != 2 or pmat.size(0) != B * N or pmat.stride(1) != 1 or
+            col0 < 0 or col0 + o1 > pmat.size(1) or tuple(w1x.shape) != (3, o1) or w2t.size(0) != o1 or w3t.size(0) != O2 or not w1x.is_contiguous() or
+            not w2t.is_contiguous() or not w3t.is_contiguous() or out2d.dim() != 2 or out2d.stride(1) != 1 or col_offset < 0 or col_offset + O3 > out2d.size(1)):
+        return False
+    with _on(dev):
+        check(_lib.load().ws3d_pgather_gemm3_compact(B, N, M, rows, o1, O2, O3, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc),
+                                                     _p(rowsrc), _p(total), _p(w1x), _p(b1), int(bool(relu1)), _p(w2t), _p(b2), int(bool(relu2)), _p(w3t), _p(b3),
+                                                     out2d.data_ptr() + 4 * col_offset, out2d.stride(0), int(limit), _stream()), "pgather_gemm3_compact")
+    return True
+
+
 def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset, limit=-1):
     """last SharedMLP layer (+ bias + ReLU) over the compact rows + max over each centre's rows, by atomic max into
     out2d[:, col_offset : col_offset + O] -- which must be ZERO on entry.  True, or False when the shape is not covered

@@ -903,6 +903,173 @@ __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o
     if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + prev_c * out_stride + col), __float_as_int(run));
 }
 
+// ---- the WHOLE SharedMLP of a set-abstraction scale over compact rows in one kernel (round 4): pgather_gemm2_compact_kernel's
+// layer 1 (gathered P row + xyz term) and layer 2, layer 2's 64 x O2 tile kept in LDS next to layer 1's (as gather_gemm2_kernel<.., POOL>
+// does for dense rows) and gemm_pool_compact_kernel's last layer + atomic max multiplied straight out of it, 128 output columns per
+// pass.  Against the two-kernel form: the (rows, O2) activation never reaches HBM (98 MB per batch of 8 at SA2, written and read
+// back), the rows of a tile are gathered once instead of once per 64-column pass of layer 2, one launch per scale instead of two.
+// The k order of every dot product is the two kernels' (ascending k, two per matrix instruction, zero padding behind o2): the
+// pooled rows are bit-identical to theirs.  LDS: (O1 + O2 rounded up to 16) x 65 + 2 x 16 x 64 floats -- 41 / 50 KB at SA2.
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int o3, int n, int m, const float *__restrict__ pmat, int p_stride,
+                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                                    const float *__restrict__ b2, int relu2, const float *__restrict__ w3t,
+                                                                    const float *__restrict__ b3, float *__restrict__ out, int out_stride, long limit) {
+    constexpr int O1 = NB1 * 64;
+    const long T = *total;
+    const long row0 = (long)blockIdx.x * 64;
+    if (row0 >= T || (limit >= 0 && T > limit)) return;      // workgroup-uniform; beyond the limit the dense kernels run instead
+    extern __shared__ __attribute__((aligned(16))) float smem2[];
+    const int o2p = (o2 + GP_KT - 1) / GP_KT * GP_KT;
+    float *act = smem2, *act2 = smem2 + O1 * GP_XS, *w2s = smem2 + (O1 + o2p) * GP_XS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1;
+    const int ar = wm * 32 + (lane & 31), bc = wn * 32 + (lane & 31), kh = lane >> 5;
+    float a0, a1;
+    {
+        const long t = min(row0 + ar, T - 1);                // rows behind the end repeat the last one (never reduced)
+        const long cm = rowc[t];
+        const long scene = cm / m;
+        const int src = rowsrc[t];
+        const float *pr = xyz + ((size_t)scene * n + (size_t)src) * 3, *cr = new_xyz + (size_t)cm * 3;
+        const float dx = pr[0] - cr[0], dy = pr[1] - cr[1], dz = pr[2] - cr[2];
+        a0 = kh ? dy : dx;
+        a1 = kh ? 0.f : dz;
+    }
+    int cidx[16];                                            // the centre of each of this lane's 16 accumulator rows (-1: behind the end)
+    floatx16 acc1[NB1];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const long tr = row0 + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4);
+        const long t = min(tr, T - 1);
+        const int cm = rowc[t];
+        cidx[v] = tr < T ? cm : -1;
+        const long scene = cm / m;
+        const float *prow = pmat + ((size_t)scene * n + (size_t)rowsrc[t]) * p_stride + bc;
+#pragma unroll
+        for (int j = 0; j < NB1; ++j) acc1[j][v] = prow[j * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NB1; ++j) {
+        const int col = j * 64 + bc;
+        const float wb0 = w1x[kh * O1 + col];
+        const float wb1 = kh ? 0.f : w1x[2 * O1 + col];
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, wb0, acc1[j], 0, 0, 0);
+        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, wb1, acc1[j], 0, 0, 0);
+        const float bv = b1 ? b1[col] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float y = acc1[j][v] + bv;
+            if (relu1) y = y < 0.f ? 0.f : y;
+            act[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4)] = y;
+        }
+    }
+    // layer 2 into act2, 64 output columns per pass
+    const int wk = tid >> 4, wc = (tid & 15) * 4;
+    const int nchunk = (o2 + 63) / 64;
+    constexpr int nt2 = O1 / GP_KT;
+    for (int c = 0; c < nchunk; ++c) {
+        const int col0 = c * 64;
+        auto load_w2 = [&](int t) {
+            const int col = col0 + wc;
+            return col < o2 ? *reinterpret_cast<const float4 *>(w2t + (long)(t * GP_KT + wk) * o2 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        floatx16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+        float4 w2v = load_w2(0);
+        __syncthreads();                    // the activation tile is complete / the previous pass has left w2s
+        *reinterpret_cast<float4 *>(w2s + wk * 64 + wc) = w2v;
+        __syncthreads();
+        for (int t = 0; t < nt2; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt2) w2v = load_w2(t + 1);
+            const float *wl = w2s + cur * GP_KT * 64;
+#pragma unroll
+            for (int k = 0; k < GP_KT; k += 2)
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(act[(t * GP_KT + k + kh) * GP_XS + ar], wl[(k + kh) * 64 + bc], acc2, 0, 0, 0);
+            if (t + 1 < nt2) *reinterpret_cast<float4 *>(w2s + (cur ^ 1) * GP_KT * 64 + wk * 64 + wc) = w2v;
+            __syncthreads();
+        }
+        const int col = col0 + bc;
+        if (col < o2p) {                    // columns o2 .. o2p - 1: the zero padding of layer 3's k dimension
+            const float bv = (col < o2 && b2) ? b2[col] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float y = acc2[v] + bv;
+                if (relu2) y = y < 0.f ? 0.f : y;
+                act2[col * GP_XS + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4)] = col < o2 ? y : 0.f;
+            }
+        }
+    }
+    // layer 3 out of act2, 128 output columns per pass (o3 % 128 == 0), W3 tiles ([2][GP_KT][128]) in layer 1's tile, which is dead by now
+    const int nt3 = o2p / GP_KT;
+    const int wk3 = tid >> 5, wc3 = (tid & 31) * 4;
+    float *w3s = smem2;
+    for (int c = 0; c < o3 / 128; ++c) {
+        const int col0 = c * 128;
+        float4 w3v[2];
+        auto load_w3 = [&](int t) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = t * GP_KT + wk3 + 8 * q;
+                w3v[q] = k < o2 ? *reinterpret_cast<const float4 *>(w3t + (long)k * o3 + col0 + wc3) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto stage_w3 = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(w3s + buf * GP_KT * 128 + (wk3 + 8 * q) * 128 + wc3) = w3v[q];
+        };
+        floatx16 acc3[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc3[q][i] = 0.f;
+        load_w3(0);
+        __syncthreads();                    // act2 is complete, act is dead / the previous pass has left w3s
+        stage_w3(0);
+        __syncthreads();
+        for (int t = 0; t < nt3; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < nt3) load_w3(t + 1);
+            const float *wl = w3s + cur * GP_KT * 128;
+#pragma unroll
+            for (int k = 0; k < GP_KT; k += 2) {
+                const float a = act2[(t * GP_KT + k + kh) * GP_XS + ar];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc3[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wl[(k + kh) * 128 + q * 64 + bc], acc3[q], 0, 0, 0);
+            }
+            if (t + 1 < nt3) stage_w3(cur ^ 1);
+            __syncthreads();
+        }
+        // bias + ReLU, runs of one centre combined inside the lane's 16 rows, then the integer atomic max (gemm_pool_compact_kernel)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = col0 + q * 64 + bc;
+            const float bv = b3 ? b3[col] : 0.f;
+            int prev_c = -1;
+            float run = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int cm = cidx[v];
+                if (cm < 0) continue;
+                float y = acc3[q][v] + bv;
+                y = y < 0.f ? 0.f : y;
+                if (cm != prev_c) {
+                    if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev_c * out_stride + col), __float_as_int(run));
+                    prev_c = cm; run = y;
+                } else {
+                    run = y > run ? y : run;
+                }
+            }
+            if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev_c * out_stride + col), __float_as_int(run));
+        }
+    }
+}
+
 // ---- first layer of a feature-propagation module WITHOUT its per-point product over the interpolated channels.  Interpolation
 // is linear, so  W_a (w0 f[i0] + w1 f[i1] + w2 f[i2]) = w0 (W_a f)[i0] + w1 (W_a f)[i1] + w2 (W_a f)[i2]:  Q = known_feats @ W_a
 // is one product over the m KNOWN points (a quarter of the unknown ones), and the layer is
@@ -1386,6 +1553,34 @@ extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, in
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     }
     return check_launch("ws3d_pgather_gemm2_compact");
+}
+
+extern "C" int ws3d_pgather_gemm3_compact(int b, int n, int m, long max_rows, int o1, int o2, int o3, const float *pmat, int p_stride, const float *xyz,
+                                          const float *new_xyz, const int32_t *rowc, const int32_t *rowsrc, const int32_t *total, const float *w1x,
+                                          const float *b1, int relu1, const float *w2t, const float *b2, int relu2, const float *w3t, const float *b3,
+                                          float *out, int out_stride, long limit, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const size_t o2p = ((size_t)o2 + GP_KT - 1) / GP_KT * GP_KT;
+    const size_t lds = sizeof(float) * (((size_t)o1 + o2p) * GP_XS + (size_t)2 * GP_KT * 64);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(w2t) | reinterpret_cast<uintptr_t>(w3t);
+    if (b <= 0 || n <= 0 || m <= 0 || max_rows <= 0 || (o1 != 64 && o1 != 128) || o2 <= 0 || (o2 & 3) || o3 <= 0 || (o3 & 127) || p_stride < o1 || !pmat || !xyz ||
+        !new_xyz || !rowc || !rowsrc || !total || !w1x || !w2t || !w3t || !out || out_stride < o3 || (al & 15) || lds > 160 * 1024 - 1024) {
+        set_error("ws3d_pgather_gemm3_compact: unsupported shape (b=%d n=%d m=%d rows<=%ld o1=%d o2=%d o3=%d; o1 in {64,128}, o2 %% 4, o3 %% 128, %zu B of LDS)",
+                  b, n, m, max_rows, o1, o2, o3, lds);
+        return WS3D_E_UNSUPPORTED;
+    }
+    const dim3 grid((unsigned)((max_rows + 63) / 64));
+    static size_t attr[2] = {0, 0};        // LDS above the default limit: raise the kernel's cap once per size
+    if (o1 == 64) {
+        if (lds > 64 * 1024 && attr[0] < lds) { (void)hipFuncSetAttribute((const void *)pgather_gemm3_compact_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        hipLaunchKernelGGL((pgather_gemm3_compact_kernel<1>), grid, dim3(256), lds, as_stream(stream), o2, o3, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out, out_stride, limit);
+    } else {
+        if (lds > 64 * 1024 && attr[1] < lds) { (void)hipFuncSetAttribute((const void *)pgather_gemm3_compact_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        hipLaunchKernelGGL((pgather_gemm3_compact_kernel<2>), grid, dim3(256), lds, as_stream(stream), o2, o3, n, m, pmat, p_stride, xyz, new_xyz, rowc,
+                           rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out, out_stride, limit);
+    }
+    return check_launch("ws3d_pgather_gemm3_compact");
 }
 
 extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,

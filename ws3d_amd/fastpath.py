@@ -68,6 +68,7 @@ PAIR_DISPATCH = "device"
 PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
+FUSED_COMPACT3_MAX_LDS = 64 * 1024   # ws3d_pgather_gemm3_compact (the whole SharedMLP of a scale over compact rows in one kernel) where its two LDS tiles fit in this many bytes (SA2: 41 / 50 KB); 0: the two-kernel form everywhere
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
 # the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
@@ -405,8 +406,10 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     dense_ok = (o1 in (64, 128) and (sa.npoint * ns) % 64 == 0 and rows // 64 <= 65535 and o3 % 64 == 0 and
                                 wt2.size(1) % 4 == 0 and ns in (16, 32))
                     limit = _pair_limit(rows, dense_ok)
-                    yc = _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, limit=limit)
-                    if yc is not None and _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col, limit=limit):
+                    fused = _C.pgather_gemm3_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, wt3, b3, out, col,
+                                                     limit=limit, max_lds=FUSED_COMPACT3_MAX_LDS)
+                    yc = None if fused else _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, limit=limit)
+                    if fused or (yc is not None and _C.gemm_pool_compact(yc, pairs, wt3, b3, out, col, limit=limit)):
                         if limit >= 0:
                             gate = (pairs[2], limit)
                             yd = _C.pgather_gemm2(pmat, offs[si], o1, xyz, new_xyz, nbr, w1xs[si], b1, r1, wt2, b2, r2, out=yc, gate=gate)
