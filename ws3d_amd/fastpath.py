@@ -68,6 +68,7 @@ PAIR_DISPATCH = "device"
 PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
+BIN_INPUT_AHEAD = True     # eager pass with geometry ahead: bin the input cloud on the search stream beside the first level's sampling kernel
 FUSED_COMPACT3_MAX_LDS = 64 * 1024   # ws3d_pgather_gemm3_compact (the whole SharedMLP of a scale over compact rows in one kernel) where its two LDS tiles fit in this many bytes (SA2: 41 / 50 KB); 0: the two-kernel form everywhere
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
@@ -302,9 +303,20 @@ class _Geometry:
         s_fps, s_search, s_aux = _side_streams(main)
         self.aux = s_aux
         self.xyz = [xyz]
-        # (binning the input cloud on the side stream BESIDE this kernel instead of behind it was measured: 5.22-5.26 vs 5.19-5.20 ms
-        # per batch -- anything that shares the memory path slows the sampling chain by more than the 30 us it hides)
+        # the binned copy of the input cloud needs the coordinates only: on the search stream BESIDE the first level's sampling kernel
+        # (round 2 measured this as a loss -- 5.22-5.26 vs 5.19-5.20 ms per batch -- when the sampling kernel re-read the scene every
+        # step and anything on the memory path slowed it; the round-4 kernel keeps the scene in registers)
+        srt0 = ev0 = None
+        if BIN_INPUT_AHEAD:
+            pre = torch.cuda.Event()
+            pre.record(main)
         _, nx = pn2_ops.furthest_point_sample_gather(xyz, sas[0].npoint)            # everything waits for this one: caller's stream
+        if BIN_INPUT_AHEAD:                  # (issued BEHIND the sampling launch: the host's time in front of it is on the critical path)
+            s_search.wait_event(pre)
+            with torch.cuda.stream(s_search):
+                srt0 = pn2_ops.sort_points_x(xyz)
+                ev0 = torch.cuda.Event()
+                ev0.record(s_search)
         self.xyz.append(nx)
         start = torch.cuda.Event()
         start.record(main)
@@ -318,7 +330,7 @@ class _Geometry:
                 ev = torch.cuda.Event()
                 ev.record(s_fps)
                 fps_done.append(ev)
-        self.sorted, self.nbr, self.sa_ready = [None], [None], [None]
+        self.sorted, self.nbr, self.sa_ready = [srt0], [None], [ev0]
         self.nn, self.nn_ready = [], []
         c_feat = [c0] + [sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) for sa in sas]
         with torch.cuda.stream(s_search):
@@ -362,7 +374,10 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             geo.main.wait_event(geo.sa_ready[level])
             sorted_xyz, nbrs = geo.sorted[level], geo.nbr[level]
         else:
-            sorted_xyz, nbrs = pn2_ops.sort_points_x(xyz), _neighbour_lists(sa, xyz, new_xyz, None, c_feat, zeros)
+            if geo.sa_ready[0] is not None:
+                geo.main.wait_event(geo.sa_ready[0])
+            sorted_xyz = geo.sorted[0] if geo.sa_ready[0] is not None else pn2_ops.sort_points_x(xyz)
+            nbrs = _neighbour_lists(sa, xyz, new_xyz, None, c_feat, zeros)
     else:
         _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
         sorted_xyz = pn2_ops.sort_points_x(xyz, GRID_MIN_N)
