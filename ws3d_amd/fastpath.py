@@ -260,7 +260,10 @@ def _lists_and_pairs(radius, nsample, xyz, new_xyz, sorted_xyz, zeros=None):
 
 
 def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
-    """per grouper: the (B, npoint, nsample) neighbour list when its first layer gathers its own rows, else None"""
+    """per grouper: the (B, npoint, nsample) neighbour list when its first layer gathers its own rows, else None.
+    (The two scales' searches of a level on two streams -- a FOURTH side stream -- was measured in round 4: the whole eager pass
+    ran 0.9 ms slower, every segment of it, profiles/r04_latency_segments.txt: three side streams + the caller's is what this runtime
+    drives without loss.)"""
     B = xyz.size(0)
     lists = []
     for grouper, mlp in zip(sa.groupers, sa.mlps):
@@ -276,7 +279,7 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
     return lists
 
 
-def _side_streams(main: torch.cuda.Stream):
+def _side_streams(main: torch.cuda.Stream, count: int = 3):
     """the three side streams of a forward pass: the sampling chain, the searches, and one for the second scale of a level / the
     second head.  Taken from the per-device pool that Stage1Pipeline's slots use (ws3d_amd/streams.py) -- never the caller's own
     stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has descriptors
@@ -285,7 +288,7 @@ def _side_streams(main: torch.cuda.Stream):
     Sharing the pool costs nothing: a pass that runs eagerly beside a pipeline in flight merely queues behind its slots -- the side
     streams are taken from the far end of the pool and never one that is capturing a hipGraph (streams.side_streams)."""
     from .streams import side_streams
-    return side_streams(main, 3)
+    return side_streams(main, count)
 
 
 class _Geometry:
@@ -338,9 +341,10 @@ class _Geometry:
             # first as they run: with the SharedMLPs over the compact pairs the caller's stream reaches level 2 some 0.1 ms
             # after level 1's sampling, and the 3-NN of FP1 (131072 queries) in front of level 2's lists was on its path
             for i in range(1, len(sas)):
-                s_search.wait_event(fps_done[i])                                     # level i + 1 exists
+                s_search.wait_event(fps_done[i - 1])                                 # level i exists: its binned copy does not need level i + 1
                 srt = pn2_ops.sort_points_x(self.xyz[i], GRID_MIN_N)
                 self.sorted.append(srt)
+                s_search.wait_event(fps_done[i])                                     # level i + 1 exists
                 self.nbr.append(_neighbour_lists(sas[i], self.xyz[i], self.xyz[i + 1], srt, c_feat[i], zeros))
                 ev = torch.cuda.Event()
                 ev.record(s_search)
