@@ -66,6 +66,7 @@ FAMILIES = {
     "sa_mlp3_pool": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)", "sa_mlp3_pool_compact": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
     "sa_mlp3_pool_lists": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
     "pgather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "pgather_gemm2_compact": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
+    "pgather_gemm3_compact": "SharedMLP SA2 whole scale over compact rows (one own MFMA kernel)",
     "pgather_rows": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)", "gather_gemm": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
     "gather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
     "gemm_pool": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)", "gemm_pool_compact": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",

@@ -20,6 +20,7 @@ FAMILY_OF = [
     ("ball_query_", "ball_query"),
     ("pair_", "pair compaction"),
     ("sa_mlp3_", "SharedMLP SA1 (3 layers + pool, own MFMA kernels)"),
+    ("pgather_gemm3_", "SharedMLP SA2 whole scale over compact rows (one own MFMA kernel)"),
     ("pgather_", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"), ("gather_gemm", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"),
     ("gemm_pool_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"), ("rowmax_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"),
     ("three_nn", "three_nn (+ weights)"), ("nn_weights_kernel", "three_nn (+ weights)"),

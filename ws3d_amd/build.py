@@ -45,7 +45,7 @@ def hipcc() -> str:
 
 
 def _deps(src: str):
-    return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "binning.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
+    return [src, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "binning.h"), os.path.join(CSRC, "compact_pool.h"), os.path.join(HERE, "..", "include", "ws3d_ops.h"),
             os.path.join(CSRC, "exports.map"), os.path.abspath(__file__)]
 
 

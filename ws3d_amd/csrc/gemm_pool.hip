@@ -9,6 +9,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "compact_pool.h"
 
 namespace ws3d {
 
@@ -882,25 +883,10 @@ __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o
     }
     const int col = col0 + bc;
     const float bv = bias ? bias[col] : 0.f;
-    const long rb = row0 + wm * 32 + 4 * kh;
-    // consecutive rows mostly belong to one centre: combine runs inside the lane's 16 rows before touching memory
-    long prev_c = -1;
-    float run = 0.f;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const long t = rb + 8 * (v / 4) + (v % 4);
-        if (t >= T) continue;
-        const long c = rowc[t];
-        float y = acc[v] + bv;
-        y = y < 0.f ? 0.f : y;
-        if (c != prev_c) {
-            if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + prev_c * out_stride + col), __float_as_int(run));
-            prev_c = c; run = y;
-        } else {
-            run = y > run ? y : run;
-        }
-    }
-    if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + prev_c * out_stride + col), __float_as_int(run));
+    // consecutive rows mostly belong to one centre: each half pools 16 consecutive rows in registers, one atomic per centre (compact_pool.h)
+    int cen[16];
+    compact_centres16(rowc, row0 + wm * 32 + 16 * kh, T, cen);
+    compact_pool_atomic(acc, bv, cen, out + col, out_stride);
 }
 
 // ---- the WHOLE SharedMLP of a set-abstraction scale over compact rows in one kernel (round 4): pgather_gemm2_compact_kernel's
@@ -939,14 +925,14 @@ __global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int 
         a0 = kh ? dy : dx;
         a1 = kh ? 0.f : dz;
     }
-    int cidx[16];                                            // the centre of each of this lane's 16 accumulator rows (-1: behind the end)
+    int cidx[16];                                            // the centres of the 16 consecutive rows this half pools (compact_pool.h)
+    compact_centres16(rowc, row0 + wm * 32 + 16 * kh, T, cidx);
     floatx16 acc1[NB1];
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const long tr = row0 + wm * 32 + 8 * (v / 4) + 4 * kh + (v % 4);
         const long t = min(tr, T - 1);
         const int cm = rowc[t];
-        cidx[v] = tr < T ? cm : -1;
         const long scene = cm / m;
         const float *prow = pmat + ((size_t)scene * n + (size_t)rowsrc[t]) * p_stride + bc;
 #pragma unroll
@@ -1045,27 +1031,11 @@ __global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int 
             if (t + 1 < nt3) stage_w3(cur ^ 1);
             __syncthreads();
         }
-        // bias + ReLU, runs of one centre combined inside the lane's 16 rows, then the integer atomic max (gemm_pool_compact_kernel)
+        // bias + ReLU, each half pools its 16 consecutive rows, one integer atomic max per centre (compact_pool.h)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int col = col0 + q * 64 + bc;
-            const float bv = b3 ? b3[col] : 0.f;
-            int prev_c = -1;
-            float run = 0.f;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int cm = cidx[v];
-                if (cm < 0) continue;
-                float y = acc3[q][v] + bv;
-                y = y < 0.f ? 0.f : y;
-                if (cm != prev_c) {
-                    if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev_c * out_stride + col), __float_as_int(run));
-                    prev_c = cm; run = y;
-                } else {
-                    run = y > run ? y : run;
-                }
-            }
-            if (prev_c >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev_c * out_stride + col), __float_as_int(run));
+            compact_pool_atomic(acc3[q], b3 ? b3[col] : 0.f, cidx, out + col, out_stride);
         }
     }
 }

@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "compact_pool.h"
 
 namespace ws3d {
 
@@ -193,6 +194,9 @@ __global__ __launch_bounds__(256) void sa_mlp3_pool_mfma_kernel(long tiles, cons
 // input row [dx dy dz f] is built here from xyz / new_xyz / the one feature channel -- no grouped tensor -- and the pool is an
 // integer atomic max of the ReLU'd values (>= 0) into the centre's row, which the caller zeroes.  *total rows; the grid is
 // sized for the worst case and waves walk the tiles that exist.
+#ifndef SA1_ABL
+#define SA1_ABL 0
+#endif
 template <int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                                    const float *__restrict__ feat, const int32_t *__restrict__ rowc,
@@ -225,16 +229,32 @@ __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m,
     }
 #pragma unroll
     for (int blk = 0; blk < NB3; ++blk) b3v[blk] = b3[blk * 32 + c];
+    // the row of a tile is two dependent round trips away (compact row -> (centre, source point) -> coordinates): the indices are
+    // fetched two tiles ahead and the coordinates one tile ahead, under the matrix chain of the tile in hand
+    auto row_index = [&](long tile, int &cm, int &src) {
+        const long t = min(tile * 32 + c, T - 1);                   // (tiles behind the end repeat the last row; never pooled)
+        cm = rowc[t];
+        src = rowsrc[t];
+    };
+    auto row_fetch = [&](int cm, int src) {
+        const size_t p = (size_t)(cm / m) * n + (size_t)src;
+        const float *pr = xyz + p * 3, *cr = new_xyz + (size_t)cm * 3;
+        return make_float4(pr[0] - cr[0], pr[1] - cr[1], pr[2] - cr[2], feat[p]);
+    };
+    int cm_n, src_n;
+    row_index(wave, cm_n, src_n);
+    float4 xr_n = row_fetch(cm_n, src_n);
+    row_index(wave + nwaves, cm_n, src_n);
     for (long tile = wave; tile < tiles; tile += nwaves) {
-        float4 xr;
-        {
-            const long t = min(tile * 32 + c, T - 1);
-            const long cm = rowc[t];
-            const int src = rowsrc[t];
-            const size_t p = (size_t)(cm / m) * n + (size_t)src;
-            const float *pr = xyz + p * 3, *cr = new_xyz + (size_t)cm * 3;
-            xr = make_float4(pr[0] - cr[0], pr[1] - cr[1], pr[2] - cr[2], feat[p]);
+        float4 xr = xr_n;
+#if SA1_ABL & 2     // (scripts/ubench/sa1_compact_ablation.sh: what the gather costs -- NOT the operator)
+        xr = make_float4((float)c, (float)(tile & 255), 1.f, 0.5f);
+#else
+        if (tile + nwaves < tiles) {
+            xr_n = row_fetch(cm_n, src_n);
+            row_index(tile + 2 * nwaves, cm_n, src_n);
         }
+#endif
         sa_f16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -249,13 +269,14 @@ __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m,
         for (int v = 0; v < V1; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[v], act[v], acc, 0, 0, 0);
 #pragma unroll
         for (int v = 0; v < V2; ++v) act[v] = fmaxf(acc[v] + bb2[v], 0.f);
-        // the centres of this lane's 16 rows (rows kp(v)), once for all channel blocks
+        // the centres of the 16 consecutive rows this half pools (compact_pool.h), once for all channel blocks
         int cen[16];
+#if SA1_ABL & 2
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const long t = tile * 32 + kp(v);
-            cen[v] = t < T ? rowc[t] : -1;
-        }
+        for (int r = 0; r < 16; ++r) { const long t = tile * 32 + 16 * h + r; cen[r] = t < T ? (int)(t >> 4) : -1; }
+#else
+        compact_centres16(rowc, tile * 32 + 16 * h, T, cen);
+#endif
 #pragma unroll
         for (int blk = 0; blk < NB3; ++blk) {
 #pragma unroll
@@ -263,20 +284,14 @@ __global__ __launch_bounds__(256) void sa_mlp3_compact_mfma_kernel(int n, int m,
 #pragma unroll
             for (int v = 0; v < V2; ++v) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(act[v], a3[blk][v], acc, 0, 0, 0);
             const float bias = b3v[blk];
-            int prev = -1;
-            float run = 0.f;
+#if SA1_ABL & 1     // (what the atomic epilogue costs: one plain store per tile and block instead)
+            float mx = 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                if (cen[v] < 0) continue;
-                const float y = fmaxf(acc[v] + bias, 0.f);
-                if (cen[v] != prev) {
-                    if (prev >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev * out_stride + blk * 32 + c), __float_as_int(run));
-                    prev = cen[v]; run = y;
-                } else {
-                    run = fmaxf(run, y);
-                }
-            }
-            if (prev >= 0) atomicMax(reinterpret_cast<int *>(out + (long)prev * out_stride + blk * 32 + c), __float_as_int(run));
+            for (int v = 0; v < 16; ++v) mx = fmaxf(mx, cen[v] < 0 ? 0.f : fmaxf(acc[v] + bias, 0.f));
+            out[(long)(tile & 1023) * out_stride + blk * 32 + c] = mx;
+#else
+            compact_pool_atomic(acc, bias, cen, out + blk * 32 + c, out_stride);
+#endif
         }
     }
 }
