@@ -7,7 +7,8 @@ for f in bench_default.json bench_default_lidar.json bench_c3_b8_steps160.json b
          bench_c5_b8.json bench_s2_b800.json bench_t1_b8.json \
          c2_kernel_stats.csv c3_kernel_stats.csv c5_kernel_stats.csv s2_kernel_stats.csv default_kernel_stats.csv \
          fps_ab.txt fps_rounds2_segments.txt graph_fork_join_stress.txt compact_vs_dense_dispatch.txt \
-         c3_eager_timeline.txt roipool3d_ablation.txt pytest_gpu.log; do
+         c3_eager_timeline.txt roipool3d_ablation.txt pytest_gpu.log bench_default_steps20_warmup5.json \
+         throughput_marginal_cost.txt sa1_compact_ablation.txt; do
   [ -s $S/$f ] && cp $S/$f $D/${R}_$f
 done
 [ -s $S/host_issue_time_untraced.txt ] && cp $S/host_issue_time_untraced.txt $D/${R}_host_issue_time.txt

@@ -1,7 +1,7 @@
 """EXPERIMENT: the library GEMMs of the c3 step (14 per batch: per-point products P / Q, FP skip halves + second layers; the largest
-family by marginal cost in throughput mode) with PyTorch's TunableOp choosing among the rocBLAS / hipBLASLt solutions per shape instead
-of the library's heuristic.  Tuning happens in an eager forward pass (not capturable), then tuning is switched off, the pipeline is
-re-captured and timed.    python scripts/exp_tunable_gemm.py [steps] [results.csv]"""
+family by marginal cost in throughput mode) after a SECOND, longer TunableOp pass.  Stage1Pipeline already tunes during its priming runs
+(pipeline._tunable), so the "plain" rows replay tuned solutions; here every shape is tuned again in an eager pass with a larger budget,
+tuning is switched off, the pipeline is re-captured and timed.    python scripts/exp_tunable_gemm.py [steps] [results.csv]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

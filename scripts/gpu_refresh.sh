@@ -10,8 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 T="timeout 900"
 $T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
-$T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-$T python bench.py --kind lidar                               2>$OUT/bench_default_lidar.err | tail -1 > $OUT/bench_default_lidar.json
+# (the default lines are taken LAST, after this run's counter passes have been copied into profiles/: they quote them)
 $T python bench.py --steps 160 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
 $T python bench.py --pipeline-depth 1 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
 GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
@@ -67,4 +66,13 @@ python scripts/rocpd_timeline.py "$(find /tmp/tl -name '*.db' | head -1)" fps_ro
 python scripts/host_issue_time.py > $OUT/host_issue_time_untraced.txt 2>&1
 $T bash scripts/ablate_roi.sh > $OUT/roipool3d_ablation.txt 2>&1
 (cd scripts/ubench && hipcc -O3 --offload-arch=gfx950 row_copy.hip -o /tmp/row_copy 2>/dev/null && timeout 120 /tmp/row_copy) > $OUT/ubench_row_copy.txt 2>&1
+$T python scripts/exp_latency_segments.py 30 > $OUT/latency_segments.txt 2>&1
+$T bash scripts/ubench/sa1_compact_ablation.sh > $OUT/sa1_compact_ablation.txt 2>&1
+timeout 1500 bash scripts/throughput_marginal.sh hdl64 > $OUT/throughput_marginal_cost.txt 2>&1
+# the default lines, quoting THIS run's counter passes (profiles/ of the box's scratch copy)
+cp $OUT/traffic.json $OUT/traffic_c5.json $OUT/traffic_c3.json profiles/ 2>/dev/null
+[ -s $OUT/pmc_fps/traffic_fps_valu.json ] && cp $OUT/pmc_fps/traffic_fps_valu.json profiles/
+$T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+$T python bench.py --kind lidar                               2>$OUT/bench_default_lidar.err | tail -1 > $OUT/bench_default_lidar.json
+$T python bench.py --steps 20 --warmup 5                      2>>$OUT/bench_default.err | tail -1 > $OUT/bench_default_steps20_warmup5.json
 ls -la $OUT

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B 
     _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
 E_INVALID, E_LAUNCH, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4      # WS3D_E_* of include/ws3d_ops.h
-ABI_VERSION = 3     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
+ABI_VERSION = 4     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -63,6 +63,7 @@ SIGNATURES = {
     "ws3d_three_interpolate_nlc": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ws3d_rowmax_rows": (_i, [C.c_long, _i, _i, _vp, _vp, _i, _vp]),
     "ws3d_sa_mlp3_pool": (_i, [C.c_long, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ws3d_qinterp_gemm128": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ws3d_mlp2_rows": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ws3d_decode_center_boxes": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ws3d_topk_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
