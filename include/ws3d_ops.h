@@ -47,7 +47,7 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm128; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (4: ws3d_pgather_gemm3_compact; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 4
 WS3D_API int ws3d_abi_version(void);
@@ -389,16 +389,6 @@ WS3D_API int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, c
  * compute units.  ws3d extension, used by ws3d_amd/fastpath.py.                                                        */
 WS3D_API int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x_rows, const float *w1t, const float *b1, int relu1,
                    const float *w2t, const float *b2, int relu2, float *out, int *ticket, ws3d_stream_t stream);
-
-/* A feature-propagation module with two 128-wide layers (the last one, at the input resolution) in one kernel (round 4):
- *   x = relu1?( w0 Q[i0] + w1 Q[i1] + w2 Q[i2] + skip (b*n, c1 <= 4) @ wb (c1, 128) + b1 )   -- ws3d_qinterp_rows' expression, to the bit
- *   out (b*n, 128) = relu2?( x @ w2t (128, 128) + b2 )
- * q (b, m, 128) = known_feats @ W_a, idx / weight (b, n, 3) from ws3d_three_nn_w.  x stays in registers (fp32 matrix cores).
- * b*n % 32 == 0, c1 <= 4; otherwise WS3D_E_UNSUPPORTED (the caller runs ws3d_qinterp_rows + a GEMM).  ticket as in ws3d_mlp2_rows.
- * ws3d extension, used by ws3d_amd/fastpath.py.                                                                                */
-WS3D_API int ws3d_qinterp_gemm128(int b, int n, int m, const float *q, const int32_t *idx, const float *weight, const float *skip, int c1,
-                         const float *wb, const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out,
-                         int *ticket, ws3d_stream_t stream);
 
 /* -------------------------------------------------------------------- iou3d_cuda */
 

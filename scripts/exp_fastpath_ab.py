@@ -1,6 +1,6 @@
 """A/B of one module attribute of ws3d_amd.fastpath (two exact forms of the same function) on the c3 step: throughput mode (20 in
 flight) and latency mode, ABAB on one box, both generators; outputs compared to the first run.
-    python scripts/exp_fastpath_ab.py FUSED_QINTERP_GEMM False True [steps]"""
+    python scripts/exp_fastpath_ab.py FUSED_COMPACT3_MAX_LDS 0 65536 [steps]"""
 import ast, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2082,41 +2082,6 @@ def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
         assert ops.c.qinterp_rows(q[:, :, :O - 1].contiguous(), idx, weight, relu=True) is None if (O - 1) % 4 else True
 
 
-@pytest.mark.parametrize("B,N,M,C2,C1,relu1,bias1", [(1, 16384, 4096, 256, 1, True, True), (2, 4096, 1024, 64, 0, True, False), (2, 2048, 512, 128, 4, False, True),
-                                                       (1, 4100, 1024, 128, 1, True, True)])
-def test_qinterp_gemm128_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M, C2, C1, relu1, bias1):
-    """ws3d_qinterp_gemm128 (both 128-wide layers of the last FP module in one kernel; the first layer's rows stay in registers):
-    with an identity second layer it returns ws3d_qinterp_rows' rows to the bit (same fmaf expression); with a real one it follows the
-    float64 product of those rows; row counts that are no multiple of 32 are declined (the caller runs the two-launch form)"""
-    rng = np.random.default_rng(23)
-    pc = synth.make_batch("hdl64", B, 16384, 71)[:, :N, :3].copy()
-    unknown = dev(pc)
-    known = unknown[:, ::max(N // M, 1)][:, :M].contiguous()
-    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
-    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
-    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
-    wa = dev((rng.standard_normal((C2, 128)) / np.sqrt(C2)).astype(np.float32))
-    wb = dev(rng.standard_normal((C1, 128)).astype(np.float32)) if C1 else None
-    b1 = dev(rng.standard_normal(128).astype(np.float32)) if bias1 else None
-    q = (kf.view(B * M, C2) @ wa).view(B, M, 128)
-    rows = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wb, bias=b1, relu=relu1)
-    eye = torch.eye(128, device="cuda")
-    got = ops.c.qinterp_gemm128(q, idx, weight, uf, wb, b1, relu1, eye, None, False)
-    if (B * N) % 32:
-        assert got is None
-        return
-    assert got is not None and tuple(got.shape) == (B * N, 128) and torch.equal(got, rows)
-    w2 = dev((rng.standard_normal((128, 128)) / np.sqrt(128)).astype(np.float32))
-    b2 = dev(rng.standard_normal(128).astype(np.float32))
-    want = torch.relu(rows.double() @ w2.double() + b2.double())
-    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
-    for tk in (None, ticket):
-        got = ops.c.qinterp_gemm128(q, idx, weight, uf, wb, b1, relu1, w2, b2, True, tk)
-        assert (got.double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0)
-    assert int(ticket.item()) >= -(-(B * N // 32) // 8)         # every chunk of 8 tiles was handed out through the counter
-    assert torch.equal(got, ops.c.qinterp_gemm128(q, idx, weight, uf, wb, b1, relu1, w2, b2, True))       # the hand-out order does not reach the result
-
-
 @pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),
                                                   (1, 1024, 256, 32, 256, 128, 196, 256, 2.0), (2, 4096, 1024, 32, 96, 64, 96, 128, 6.0),
                                                   (2, 256, 64, 32, 512, 256, 384, 512, 4.0), (1, 512, 37, 16, 8, 64, 20, 64, 0.01)])

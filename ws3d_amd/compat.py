@@ -510,27 +510,6 @@ def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=T
     return out
 
 
-def qinterp_gemm128(q, idx, weight, skip, wb, b1, relu1, w2t, b2, relu2, ticket=None):
-    """qinterp_rows (lin None form: <= 4 skip channels) + the next 128 -> 128 layer in ONE kernel: q (B, M, 128), idx / weight (B, N, 3),
-    skip (B, N, C1 <= 4) or None, wb (C1, 128), w2t (128, 128) -> (B*N, 128), or None when the shape is not covered (the first layer's
-    rows stay in registers; its values are qinterp_rows' to the bit).  ticket as in mlp2_rows.  ws3d extension."""
-    dev = _dev(q, idx, weight, w2t)
-    _f32(q, "q"); _i32(idx, "idx"); _f32(weight, "weight"); _f32(w2t, "w2t")
-    B, M, O = q.shape
-    N = idx.size(1)
-    c1 = 0 if skip is None else skip.size(2)
-    if (O != 128 or tuple(w2t.shape) != (128, 128) or (B * N) % 32 or c1 > 4 or not q.is_contiguous() or not w2t.is_contiguous() or not idx.is_contiguous() or
-            not weight.is_contiguous() or (c1 > 0 and (wb is None or tuple(wb.shape) != (c1, 128) or not wb.is_contiguous() or not skip.is_contiguous()))):
-        return None
-    out = torch.empty((B * N, 128), dtype=torch.float32, device=dev)
-    if ticket is None:
-        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-    with _on(dev):
-        check(_lib.load().ws3d_qinterp_gemm128(B, N, M, _p(q), _p(idx), _p(weight), _p(skip), c1, _p(wb), _p(b1), int(bool(relu1)), _p(w2t), _p(b2),
-                                               int(bool(relu2)), _p(out), _p(ticket), _stream()), "qinterp_gemm128")
-    return out
-
-
 def compact_pairs(nbr, ordered=False):
     """(B, M, ns) ball-query lists -> (rowc, rowsrc, total): the DISTINCT (centre, source point) pairs as compact rows (int32
     tensors of B*M*ns entries, the first `total` -- a 1-element device tensor -- valid); a list's padding repeats its first hit

@@ -490,113 +490,6 @@ __global__ __launch_bounds__(512) void mlp2_rows_kernel(long tiles, int o2, cons
     }
 }
 
-// ---- a feature-propagation module whose layers are 128 wide (the last one, at the input resolution) in ONE kernel (round 4):
-//   x[r, :] = relu?( w0 Q[i0, :] + w1 Q[i1, :] + w2 Q[i2, :] + skip[r, 0:c1] Wb + b1 )      -- qinterp_rows_kernel's expression, to the bit
-//   out[r, :] = relu?( x[r, :] W2 + b2 )
-// with x built in REGISTERS -- lane (row, half h) of a 32-row tile gathers the 64 channels 64 h .. 64 h + 63 of its row's three Q rows --
-// and multiplied straight out of them (A = those registers: step s pairs channels s and 64 + s; B = W2 from LDS, lane = output
-// column), so the result comes out row-major.  The (rows, 128) activation between the two layers (67 MB per batch of 8, written by
-// qinterp_rows and read back by a library GEMM) never exists, and the second layer runs on this kernel's 256 matrix instructions
-// per tile instead of a library launch.  W2's rows k >= 64 are stored with their columns XOR 32 (the halves of a wave read rows 64
-// apart: disjoint banks), as in mlp2_rows_kernel; tiles are handed out by the same ticket counter.
-__global__ __launch_bounds__(512) void qinterp_gemm128_kernel(long tiles, int n, int m, const float *__restrict__ q, const int32_t *__restrict__ idx3,
-                                                              const float *__restrict__ w3, const float *__restrict__ skip, int c1,
-                                                              const float *__restrict__ wb, const float *__restrict__ b1, int relu1,
-                                                              const float *__restrict__ w2t, const float *__restrict__ b2, int relu2,
-                                                              float *__restrict__ out, int *__restrict__ ticket) {
-    extern __shared__ __attribute__((aligned(16))) float smem_qg[];
-    float *w2s = smem_qg;                       // [128][128], rows >= 64 with columns XOR 32
-    float *wbs = w2s + 128 * 128;               // [4][128]  (zero beyond c1)
-    float *b1s = wbs + 4 * 128;                 // [128]
-    __shared__ int first_chunk[2];
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    if (ticket && tid == 0) first_chunk[0] = atomicAdd(ticket, 1);
-    for (int i = tid; i < 128 * 128 / 4; i += 512) {
-        const int k = i >> 5, o4 = i & 31;
-        reinterpret_cast<float4 *>(w2s)[k * 32 + (k >= 64 ? o4 ^ 8 : o4)] = reinterpret_cast<const float4 *>(w2t)[i];
-    }
-    if (tid < 128) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wbs[k * 128 + tid] = k < c1 ? wb[k * 128 + tid] : 0.f;
-        b1s[tid] = b1 ? b1[tid] : 0.f;
-    }
-    __syncthreads();
-    long chunk = ticket ? first_chunk[0] : blockIdx.x;
-    for (int par = 0; chunk * 8 < tiles; par ^= 1) {
-        int ahead = 0;
-        if (ticket && tid == 0) ahead = atomicAdd(ticket, 1);        // consumed after this chunk's work
-        const long tile = chunk * 8 + (tid >> 6);
-        if (tile < tiles) {
-            const long r = tile * 32 + c;
-            const long scene = r / n;
-            const int i0 = idx3[r * 3 + 0], i1 = idx3[r * 3 + 1], i2 = idx3[r * 3 + 2];
-            const float w0 = w3[r * 3 + 0], w1 = w3[r * 3 + 1], w2 = w3[r * 3 + 2];
-            const float *qb = q + (size_t)scene * m * 128 + 64 * h;
-            const float4 *p0 = reinterpret_cast<const float4 *>(qb + (size_t)i0 * 128), *p1 = reinterpret_cast<const float4 *>(qb + (size_t)i1 * 128),
-                         *p2 = reinterpret_cast<const float4 *>(qb + (size_t)i2 * 128);
-            float sv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (k < c1) sv[k] = skip[r * (long)c1 + k];
-            float xv[64];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float4 a = p0[j], b = p1[j], d = p2[j];
-                float4 y = make_float4(__builtin_fmaf(w2, d.x, __builtin_fmaf(w0, a.x, w1 * b.x)), __builtin_fmaf(w2, d.y, __builtin_fmaf(w0, a.y, w1 * b.y)),
-                                       __builtin_fmaf(w2, d.z, __builtin_fmaf(w0, a.z, w1 * b.z)), __builtin_fmaf(w2, d.w, __builtin_fmaf(w0, a.w, w1 * b.w)));
-                const int ch = 64 * h + 4 * j;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < c1) {
-                        const float4 wv = *reinterpret_cast<const float4 *>(wbs + k * 128 + ch);
-                        y.x = __builtin_fmaf(sv[k], wv.x, y.x); y.y = __builtin_fmaf(sv[k], wv.y, y.y);
-                        y.z = __builtin_fmaf(sv[k], wv.z, y.z); y.w = __builtin_fmaf(sv[k], wv.w, y.w);
-                    }
-                if (b1) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(b1s + ch);
-                    y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
-                }
-                if (relu1) { y.x = y.x < 0.f ? 0.f : y.x; y.y = y.y < 0.f ? 0.f : y.y; y.z = y.z < 0.f ? 0.f : y.z; y.w = y.w < 0.f ? 0.f : y.w; }
-                xv[4 * j + 0] = y.x; xv[4 * j + 1] = y.y; xv[4 * j + 2] = y.z; xv[4 * j + 3] = y.w;
-                if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // twelve 16-byte loads in flight, not forty-eight (registers)
-            }
-            sa_f16 acc[4];
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[blk][i] = 0.f;
-            // physical column of logical column blk * 32 + c in this half's rows (k = 64 h + s): XOR 32 for h = 1
-            const float *wbase = w2s + 64 * h * 128 + c;
-#pragma unroll
-            for (int s2 = 0; s2 < 64; ++s2) {
-                const float *wrow = wbase + s2 * 128;
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk)
-                    acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[s2], wrow[((blk * 32) ^ (32 * h))], acc[blk], 0, 0, 0);
-                if ((s2 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk) {
-                const int col = blk * 32 + c;
-                const float bv = b2 ? b2[col] : 0.f;
-                float *o = out + (tile * 32 + 4 * h) * 128 + col;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    float y = acc[blk][v] + bv;
-                    if (relu2) y = fmaxf(y, 0.f);
-                    o[(long)(8 * (v / 4) + (v % 4)) * 128] = y;
-                }
-            }
-        }
-        if (ticket) {
-            if (tid == 0) first_chunk[par ^ 1] = ahead;
-            __syncthreads();
-            chunk = first_chunk[par ^ 1];
-        } else {
-            chunk += gridDim.x;
-        }
-    }
-}
-
 }  // namespace ws3d
 
 extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, const float *x_rows4,
@@ -717,25 +610,4 @@ extern "C" int ws3d_sa_mlp3_pool_lists(int b, int n, int m, int nsample, int c1,
 #undef WS3D_SA_LISTS
     set_error("ws3d_sa_mlp3_pool_lists: no kernel for widths (%d, %d, %d) x nsample %d", c1, c2, c3, nsample);
     return WS3D_E_UNSUPPORTED;
-}
-
-extern "C" int ws3d_qinterp_gemm128(int b, int n, int m, const float *q, const int32_t *idx, const float *weight, const float *skip, int c1,
-                                    const float *wb, const float *b1, int relu1, const float *w2t, const float *b2, int relu2, float *out,
-                                    int *ticket, ws3d_stream_t stream) {
-    using namespace ws3d;
-    const long rows = (long)b * n;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(w2t) | reinterpret_cast<uintptr_t>(out);
-    if (b < 0 || n <= 0 || m <= 0 || (rows & 31) || c1 < 0 || c1 > 4 || (c1 > 0 && (!skip || !wb)) || !q || !idx || !weight || !w2t || !out || (al & 15)) {
-        set_error("ws3d_qinterp_gemm128: unsupported shape (b=%d n=%d m=%d c1=%d; rows %% 32, c1 <= 4, 128 -> 128)", b, n, m, c1);
-        return WS3D_E_UNSUPPORTED;
-    }
-    if (rows == 0) return WS3D_OK;
-    const long tiles = rows / 32;
-    const unsigned grid = (unsigned)(tiles / 8 < 256 ? (tiles + 7) / 8 : 256);        // one 8-wave workgroup per CU, waves walk over tiles
-    const size_t lds = sizeof(float) * (128 * 128 + 4 * 128 + 128);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void *)qinterp_gemm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL(qinterp_gemm128_kernel, dim3(grid), dim3(512), lds, as_stream(stream), tiles, n, m, q, idx, weight, skip, c1, wb, b1, relu1, w2t, b2,
-                       relu2, out, ticket);
-    return check_launch("ws3d_qinterp_gemm128");
 }

@@ -69,7 +69,6 @@ PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolat
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 BIN_INPUT_AHEAD = True     # eager pass with geometry ahead: bin the input cloud on the search stream beside the first level's sampling kernel
-FUSED_QINTERP_GEMM = True   # ws3d_qinterp_gemm128: both layers of the last FP module (128 -> 128 at the input resolution) in one kernel
 FUSED_COMPACT3_MAX_LDS = 64 * 1024   # ws3d_pgather_gemm3_compact (the whole SharedMLP of a scale over compact rows in one kernel) where its two LDS tiles fit in this many bytes (SA2: 41 / 50 KB); 0: the two-kernel form everywhere
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
@@ -528,7 +527,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
     return new_xyz, out.view(B, sa.npoint, -1)
 
 
-def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None, ticket=None):
+def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
     B, n = unknown.size(0), unknown.size(1)
     idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
@@ -548,12 +547,6 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
             lin = torch.mm(unknown_feats.reshape(B * n, c1), wb) if b1 is None else torch.addmm(b1, unknown_feats.reshape(B * n, c1), wb)
             y = _C.qinterp_rows(q, idx, weight, lin=lin, relu=r1)
         else:
-            if FUSED_QINTERP_GEMM and len(blocks) == 2 and q.size(2) == 128:
-                # both layers in one kernel: the first layer's rows stay in registers (the last module, at the input resolution)
-                wt2, b2, r2 = _row_weights(blocks[1])
-                y = _C.qinterp_gemm128(q, idx, weight, None if c1 == 0 else unknown_feats.contiguous(), wb if c1 else None, b1, r1, wt2, b2, r2, ticket)
-                if y is not None:
-                    return y.view(B, n, -1)
             y = _C.qinterp_rows(q, idx, weight, skip=None if c1 == 0 else unknown_feats.contiguous(), wb=wb if c1 else None, bias=b1, relu=r1)
         if y is not None:
             for blk in blocks[1:]:
@@ -596,8 +589,7 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
                 lvl = len(l_xyz) + i - 1                                   # unknown level of this module
                 geo.main.wait_event(geo.nn_ready[lvl])
                 nn3 = geo.nn[lvl]
-            tick = zeros.take((1,), torch.int32) if (zeros is not None and FUSED_QINTERP_GEMM and i == -len(net.FP_modules)) else None
-            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3, ticket=tick)
+            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3)
     finally:
         if geo is not None:       # also when a layer raised: the side streams' tensors go back to their pools behind the caller's stream
             geo.release()
