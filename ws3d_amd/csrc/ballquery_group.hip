@@ -852,8 +852,11 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 constexpr int BQC_HCAP = 1024;        // hits kept per centre (uint16 in LDS, per wave)
 constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the ordered scan takes over
 
-template <bool FUSED>
-__global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
+// NW waves per workgroup share a tile of 64 centres, CPW = 64 / NW each: 4 x 16 when the launch fills the chip by itself (the c2 block: 32768
+// workgroups), 16 x 4 when it does not (a batch of 8 at level 1: 512 tiles -- sixteen centres in turn per wave left 2 waves per SIMD and a
+// kernel as long as one wave's sixteen searches).
+template <bool FUSED, int NW>
+__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
                                                                    const float *__restrict__ xyz, const char *__restrict__ ws,
                                                                    const float *__restrict__ new_xyz, const float *__restrict__ features,
                                                                    int32_t *__restrict__ idx_out, float *__restrict__ out,
@@ -864,8 +867,9 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
     uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
     const int rstride = nsample + 1;
-    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // 4 waves x BQC_HCAP
-    uint16_t *stage_all = hits_all + 4 * BQC_HCAP;                     // 4 waves x 16 centres x 64: the hits of each centre's first 64 candidates
+    constexpr int CPW = 64 / NW;                                      // centres per wave
+    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // NW waves x BQC_HCAP
+    uint16_t *stage_all = hits_all + NW * BQC_HCAP;                    // NW waves x CPW centres x 64: the hits of each centre's first 64 candidates
     const int tiles = (m + 63) / 64;
     int b, tile;
     if ((nb & 7) == 0) {
@@ -886,7 +890,7 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     const int *params = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
     new_xyz += (size_t)b * m * 3;
     uint16_t *hits = hits_all + w * BQC_HCAP;
-    uint16_t *stage = stage_all + w * (16 * 64);
+    uint16_t *stage = stage_all + w * (CPW * 64);
     const float radius2 = radius * radius;
     const float rabs = fabsf(radius);
     // the host picks this kernel from what the sort entry points noted per buffer ADDRESS; a buffer of another flavour that
@@ -897,12 +901,12 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
     const int id_bits = 32 - __builtin_clz(max(n - 1, 1));            // ids < n
 
-    // ---- 1. this lane's (centre, row) of the wave's 16 centres x first 4 grid rows
+    // ---- 1. this lane's (centre, row) of the wave's CPW centres x first 4 grid rows (lanes 4 CPW .. 63 idle when CPW < 16)
     const int ci_l = lane >> 2, q_l = lane & 3;
-    const int mi_l = m0 + 16 * w + ci_l;
+    const int mi_l = ci_l < CPW ? m0 + CPW * w + ci_l : m;
     float lcx = 0.f, lcy = 0.f, lcz = 0.f;
     if (mi_l < m) { lcx = new_xyz[mi_l * 3 + 0]; lcy = new_xyz[mi_l * 3 + 1]; lcz = new_xyz[mi_l * 3 + 2]; }
-    if (q_l == 0) cen[16 * w + ci_l] = make_float4(lcx, lcy, lcz, 0.f);
+    if (q_l == 0 && ci_l < CPW) cen[CPW * w + ci_l] = make_float4(lcx, lcy, lcz, 0.f);
     int l_ix0 = 0, l_ix1 = 0, l_iz0 = 0, l_nrows = 0, l_k0 = 0, l_ke = 0;
     if (mi_l < m && lcx == lcx) {
         // see ball_query_sorted_kernel for the bounds argument (hits lie within r (1 + 2^-23) of the centre on each axis)
@@ -922,13 +926,13 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
     auto locate = [&](const int j, const int (&k0)[4], const int p1, const int p2, const int p3) {
         return j < p1 ? k0[0] + j : (j < p2 ? k0[1] + (j - p1) : (j < p3 ? k0[2] + (j - p2) : k0[3] + (j - p3)));
     };
-    // ---- 2a. the first 64 candidates of all 16 centres: 16 independent loads in flight, then the tests; the hits of centre i go
+    // ---- 2a. the first 64 candidates of all CPW centres: CPW independent loads in flight, then the tests; the hits of centre i go
     //          to stage[i][..] (this is the whole search of a centre in a sparse neighbourhood -- no memory round trip per centre)
     int l_h0 = 0;                                                       // lane i (< 16): hits among centre i's first 64 candidates
     {
-        float4 pre[16];
+        float4 pre[CPW];
 #pragma unroll
-        for (int ci = 0; ci < 16; ++ci) {
+        for (int ci = 0; ci < CPW; ++ci) {
             int k0[4], len[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -940,7 +944,7 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
             if (lane < L) pre[ci] = sorted[locate(lane, k0, p1, p2, p3)];
         }
 #pragma unroll
-        for (int ci = 0; ci < 16; ++ci) {
+        for (int ci = 0; ci < CPW; ++ci) {
             const int L4 = (__builtin_amdgcn_readlane(l_ke, 4 * ci) - __builtin_amdgcn_readlane(l_k0, 4 * ci)) +
                            (__builtin_amdgcn_readlane(l_ke, 4 * ci + 1) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 1)) +
                            (__builtin_amdgcn_readlane(l_ke, 4 * ci + 2) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 2)) +
@@ -953,8 +957,8 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
             if (lane == ci) l_h0 = __popcll(mask);
         }
     }
-    for (int ci = 0; ci < 16; ++ci) {
-        const int c = 16 * w + ci;                                     // centre slot of the workgroup
+    for (int ci = 0; ci < CPW; ++ci) {
+        const int c = CPW * w + ci;                                    // centre slot of the workgroup
         uint16_t *row = rows + (size_t)c * rstride;
         const int src = 4 * ci;
         const int nrows = __builtin_amdgcn_readlane(l_nrows, src);
@@ -1085,15 +1089,17 @@ __global__ __launch_bounds__(256) void ball_query_grid_coop_kernel(int nb, int n
             if (lane == 63) pfx[64] = base_row + v;
         }
         __syncthreads();
-        const int c = tid >> 2;
-        const int first = pfx[c], k = pfx[c + 1] - first;
-        const int32_t cm = (int32_t)((size_t)b * m + m0 + c);
-        for (int s2 = tid & 3; s2 < k; s2 += 4) {
-            rowc[first + s2] = cm;
-            rowsrc[first + s2] = (int32_t)rows[(size_t)c * rstride + s2];
+        if (tid < 256) {
+            const int c = tid >> 2;
+            const int first = pfx[c], k = pfx[c + 1] - first;
+            const int32_t cm = (int32_t)((size_t)b * m + m0 + c);
+            for (int s2 = tid & 3; s2 < k; s2 += 4) {
+                rowc[first + s2] = cm;
+                rowsrc[first + s2] = (int32_t)rows[(size_t)c * rstride + s2];
+            }
         }
     }
-    bq_emit<uint16_t, FUSED, 256, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
+    bq_emit<uint16_t, FUSED, 64 * NW, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
 }
 
 static size_t bq_smem(int nsample, size_t idx_bytes) {
@@ -1129,10 +1135,17 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         while (gz < 64 && tiles * gz < 1024 && (64L * nsample) / (gz * 2) >= 64) gz *= 2;
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
-        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + 4 * BQC_HCAP + 4 * 16 * 64);
-        if (nsample <= 64 && smem_c <= 64 * 1024) {      // one wave per centre; longer lists: one lane per centre (below)
-            hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
-                               radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
+        // one wave per centre; 16 waves x 4 centres per tile when the tiles alone do not fill the chip, else 4 x 16
+        const bool wide = (long)b * ((m + 63) / 64) * gz < 2048;
+        const int nw = wide ? 16 : 4;
+        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
+        if (nsample <= 64 && smem_c <= 64 * 1024) {      // longer lists: one lane per centre (below)
+            if (wide)
+                hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 16>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(1024), smem_c, st, b, n, m, c,
+                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
+            else
+                hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 4>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
+                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
             return check_launch(what);
         }
         if (rowc) { set_error("%s: nsample %d is not covered by the kernel that emits the pairs", what, nsample); return WS3D_E_UNSUPPORTED; }
