@@ -1383,10 +1383,12 @@ def test_sampling_plan_equals_sampling_inside_the_modules(ops):
         _, cur = ops.pn.furthest_point_sample_gather(cur, lvl.size(1))
         assert torch.equal(cur, lvl)
     # NO warm-up pass (round 3 added one after a single unexplained failure in a full run): the two passes below are the first two
-    # forward passes of this network.  Every leaf module's output is recorded, so a mismatch names the first layer that differs.
+    # forward passes of this network.  The output of EVERY module that returns a tensor is recorded (in training mode a Conv block runs
+    # conv1x1_train + bn_relu_train as functions: its conv / bn / activation children are never called, the block itself is), so a
+    # mismatch names the first block that differs.
     rec, names = [], {m: n for n, m in net.named_modules()}
     hooks = [m.register_forward_hook(lambda m, i, o: rec[-1].append((names[m], o.detach().clone())) if isinstance(o, torch.Tensor) else None)
-             for m in net.modules() if not list(m.children())]
+             for m in net.modules()]
     rec.append([])
     torch.manual_seed(1)                                     # the heads' Dropout draws from the global generator
     a = net({"pts_input": pts})
@@ -1396,8 +1398,22 @@ def test_sampling_plan_equals_sampling_inside_the_modules(ops):
     for h in hooks:
         h.remove()
     first = next(((n, float((x - y).abs().max())) for (n, x), (_, y) in zip(rec[0], rec[1]) if not torch.equal(x, y)), None)
-    assert first is None, "first leaf module whose output differs between the two passes (name, max abs difference): %s" % (first,)
-    assert torch.equal(a["rpn_cls"], b["rpn_cls"]) and torch.equal(a["rpn_reg"], b["rpn_reg"])
+    assert [n for n, _ in rec[0]] == [n for n, _ in rec[1]] and len(rec[0]) > 40, "the hooks did not see the same modules in both passes"
+    assert first is None, "first module whose output differs between the two passes (name, max abs difference): %s" % (first,)
+    # (rpn_cls is a VIEW of its head's output -- (B, 1, N) transposed is contiguous as it stands -- so it can be compared with the
+    # clone the hook took of that very buffer: a difference says the buffer changed AFTER the head had produced it)
+    def diagnose(key, head):
+        last = {p: [o for n_, o in rec[p] if n_ == "rpn." + head][-1].transpose(1, 2) for p in (0, 1)}
+        out = []
+        for p, t in ((0, a[key]), (1, b[key])):
+            bad = (t != last[p]).flatten().nonzero().flatten()
+            if bad.numel():
+                out.append("pass %d: %s differs from the clone taken at its head's exit in %d of %d elements, flat positions %s .. %s, first values now / then %s / %s"
+                           % (p, key, bad.numel(), t.numel(), bad[:4].tolist(), bad[-4:].tolist(), t.flatten()[bad[:4]].tolist(), last[p].flatten()[bad[:4]].tolist()))
+        return out or ["%s: both passes still equal their head-exit clones; the passes differ in %d elements"
+                       % (key, int((a[key] != b[key]).sum()))]
+    same = torch.equal(a["rpn_cls"], b["rpn_cls"]) and torch.equal(a["rpn_reg"], b["rpn_reg"])
+    assert same, "; ".join(diagnose("rpn_cls", "rpn_cls_layer") + diagnose("rpn_reg", "rpn_reg_layer"))
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])
