@@ -849,6 +849,9 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 // More than BQC_HCAP hits or BQC_MAX_CAND candidates (pathological density): the wave scans the scene in INDEX order, 64 points
 // per step, and stops at nsample hits -- the reference's own loop (ball_query_gpu.cu:29-44), 64 wide.
 // Same candidate bounds, same distance expression and operand order as above: bit-identical lists.
+#ifndef BQC_WIDE_BELOW
+#define BQC_WIDE_BELOW 2048   // tiles of 64 centres below which a launch uses 16 waves x 4 centres per tile (scripts/ubench/bq_wide_threshold.sh)
+#endif
 constexpr int BQC_HCAP = 1024;        // hits kept per centre (uint16 in LDS, per wave)
 constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the ordered scan takes over
 
@@ -1136,7 +1139,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     }
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
         // one wave per centre; 16 waves x 4 centres per tile when the tiles alone do not fill the chip, else 4 x 16
-        const bool wide = (long)b * ((m + 63) / 64) * gz < 2048;
+        const bool wide = (long)b * ((m + 63) / 64) * gz < BQC_WIDE_BELOW;
         const int nw = wide ? 16 : 4;
         const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
         if (nsample <= 64 && smem_c <= 64 * 1024) {      // longer lists: one lane per centre (below)
