@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."
 OBJ=ws3d_amd/csrc/build
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Iinclude -Iws3d_amd/csrc"
-hipcc $FLAGS -DBQC_WIDE_BELOW=2000000000 -c ws3d_amd/csrc/ballquery_group.hip -o /tmp/bq_wide.o 2>/dev/null || { echo "compile failed"; exit 1; }
+hipcc $FLAGS ${BQ_DEFS:--DBQC_WIDE_BELOW=2000000000} -c ws3d_amd/csrc/ballquery_group.hip -o /tmp/bq_wide.o 2>/dev/null || { echo "compile failed"; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libws3d_bqwide.so $(ls $OBJ/*.o | grep -v "/ballquery_group") /tmp/bq_wide.o
 for rep in 1 2; do
 for lib in default wide; do

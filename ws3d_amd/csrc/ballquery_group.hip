@@ -852,6 +852,9 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 #ifndef BQC_WIDE_BELOW
 #define BQC_WIDE_BELOW 2048   // tiles of 64 centres below which a launch uses 16 waves x 4 centres per tile (scripts/ubench/bq_wide_threshold.sh)
 #endif
+#ifndef BQC_LARGE_NW
+#define BQC_LARGE_NW 4      // waves per tile of the launches that fill the chip by themselves
+#endif
 constexpr int BQC_HCAP = 1024;        // hits kept per centre (uint16 in LDS, per wave)
 constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the ordered scan takes over
 
@@ -1140,14 +1143,14 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     if (sorted && n <= SORT_MAX_N && b <= 65535 && grid_flavour(sorted)) {
         // one wave per centre; 16 waves x 4 centres per tile when the tiles alone do not fill the chip, else 4 x 16
         const bool wide = (long)b * ((m + 63) / 64) * gz < BQC_WIDE_BELOW;
-        const int nw = wide ? 16 : 4;
+        const int nw = wide ? 16 : BQC_LARGE_NW;
         const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
         if (nsample <= 64 && smem_c <= 64 * 1024) {      // longer lists: one lane per centre (below)
             if (wide)
                 hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 16>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(1024), smem_c, st, b, n, m, c,
                                    radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
             else
-                hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 4>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(256), smem_c, st, b, n, m, c,
+                hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, BQC_LARGE_NW>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(64 * BQC_LARGE_NW), smem_c, st, b, n, m, c,
                                    radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
             return check_launch(what);
         }
