@@ -72,8 +72,9 @@ FAMILIES = {
     "gemm_pool": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)", "gemm_pool_compact": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
     "rowmax_rows": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
     "three_nn_wrapper": "three_nn (+ weights)", "three_nn_with_weights": "three_nn (+ weights)",
-    "qinterp_rows": "FP first layer (interpolate + add, own kernels)", "interp_gemm": "FP first layer (interpolate + add, own kernels)",
-    "three_interpolate_nlc": "FP first layer (interpolate + add, own kernels)", "three_interpolate_wrapper": "FP first layer (interpolate + add, own kernels)",
+    "qinterp_gemm": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
+    "qinterp_rows": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)", "interp_gemm": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
+    "three_interpolate_nlc": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)", "three_interpolate_wrapper": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
     "mlp2_rows": "heads (2 layers, own MFMA kernel)",
     "decode_center_boxes": "proposals: decode + top-k + gather + select", "topk_sorted": "proposals: decode + top-k + gather + select",
     "gather_boxes_bev": "proposals: decode + top-k + gather + select", "select_proposals": "proposals: decode + top-k + gather + select",
@@ -83,7 +84,7 @@ FAMILIES = {
 EFFECTIVE_ROWS = {
     "fps levels 2-4 (verified prefix)": "A_model of three more sampling passes; fps_nested verifies the picks as a prefix of level 1's order and reads "
                                         "each level once",
-    "FP first layer (interpolate + add, own kernels)": "three_interpolate's (C, m) in / (C, n) out; the own kernels interpolate the per-known-point "
+    "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)": "three_interpolate's (C, m) in / (C, n) out; the own kernels interpolate the per-known-point "
                                                        "products Q of the first layer instead (fewer channels, no (C, n) intermediate)"}
 IN_FORWARD = lambda fam: not fam.startswith(("proposals", "nms", "roipool"))   # families inside rpn_forward (the rest follow it)
 _ACTIVE = None
@@ -353,7 +354,7 @@ class C3:
         fps1_b = (m1 - 1) * n1 * 12 + m1 * 4
         alg = {"fps level 1 (16384 -> 4096)": fps1_b * B, "fps levels 2-4 (verified prefix)": (_fps_model_bytes(cfg) - fps1_b) * B,
                "ball_query": _bq_bytes(cfg) * B, "ball_query+group": _qg_bytes(cfg) * B, "three_nn (+ weights)": nn_b * B,
-               "FP first layer (interpolate + add, own kernels)": interp_b * B, "roipool3d": roi_b * B,
+               "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)": interp_b * B, "roipool3d": roi_b * B,
                "nms(mask+sweep)": (cfg.rpn_pre_nms_top_n * 20 + cfg.rpn_pre_nms_top_n * 141 * 8) * B}
         rows = []
         for key, evs in self.op_ev.items():

@@ -47,7 +47,7 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (4: ws3d_pgather_gemm3_compact; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 4
 WS3D_API int ws3d_abi_version(void);
@@ -389,6 +389,15 @@ WS3D_API int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3, c
  * compute units.  ws3d extension, used by ws3d_amd/fastpath.py.                                                        */
 WS3D_API int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x_rows, const float *w1t, const float *b1, int relu1,
                    const float *w2t, const float *b2, int relu2, float *out, int *ticket, ws3d_stream_t stream);
+
+/* Both layers of a two-layer feature-propagation module in one kernel (round 4): the first layer's rows are built in the A operand of the
+ * second layer's product exactly as ws3d_qinterp_rows builds them,
+ *   x = relu1?( w0 Q[i0] + w1 Q[i1] + w2 Q[i2] + (lin (b*n, c)  |  skip (b*n, c1 <= 4) @ wb (c1, c) + b1) ),   out (b*n, o) = relu2?( x @ w2t (c, o) + b2 )
+ * q (b, m, c) = known_feats @ W_a; idx / weight (b, n, 3).  b*n % 64, c % 16, o % 128; otherwise WS3D_E_UNSUPPORTED (the caller runs
+ * ws3d_qinterp_rows + a GEMM).  ws3d extension, used by ws3d_amd/fastpath.py.                                                          */
+WS3D_API int ws3d_qinterp_gemm(int b, int n, int m, int c, int o_dim, const float *q, const int32_t *idx, const float *weight, const float *lin,
+                      const float *skip, int c1, const float *wb, const float *b1, int relu1, const float *w2t, const float *b2, int relu2,
+                      float *out, ws3d_stream_t stream);
 
 /* -------------------------------------------------------------------- iou3d_cuda */
 

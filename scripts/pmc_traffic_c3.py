@@ -24,8 +24,8 @@ FAMILY_OF = [
     ("pgather_", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"), ("gather_gemm", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"),
     ("gemm_pool_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"), ("rowmax_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"),
     ("three_nn", "three_nn (+ weights)"), ("nn_weights_kernel", "three_nn (+ weights)"),
-    ("qinterp_rows_kernel", "FP first layer (interpolate + add, own kernels)"), ("interp_gemm", "FP first layer (interpolate + add, own kernels)"),
-    ("three_interpolate", "FP first layer (interpolate + add, own kernels)"),
+    ("qinterp_rows_kernel", "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)"), ("interp_gemm", "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)"),
+    ("three_interpolate", "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)"),
     ("fp_fused", "FP module fused (interpolate + skip + 2 layers, own MFMA kernel)"),
     ("mlp2_rows_kernel", "heads (2 layers, own MFMA kernel)"),
     ("decode_center_boxes_kernel", "proposals: decode + top-k + gather + select"), ("topk_", "proposals: decode + top-k + gather + select"),

@@ -1993,7 +1993,8 @@ def test_fast_path_switches_agree(ops):
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 6))
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
-    names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS")
+    names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2004,12 +2005,15 @@ def test_fast_path_switches_agree(ops):
         return out["rpn_cls"].clone(), out["rpn_reg"].clone()
     try:
         off = {"FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False,
-               "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False}
+               "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False, "FUSED_COMPACT3_MAX_LDS": 0, "FUSED_QINTERP_GEMM_MIN_ROWS": 1 << 60,
+               "BIN_INPUT_AHEAD": False}
         base = run(**off)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
                    {"SA1_FROM_LISTS": True}, {"SA1_FROM_LISTS": True, "COMPACT_PAIRS": True, "PER_POINT_L1": True}, {"PARALLEL_SCALES": True, "PARALLEL_HEADS": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True},
-                   {"FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True}):
+                   {"FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True},
+                   {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 64 * 1024}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 160 * 1024},
+                   {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 30000}, {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 1}, {"BIN_INPUT_AHEAD": True, "PARALLEL_SCALES": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
             got = run(**dict(off, **kw))
@@ -2096,6 +2100,42 @@ def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
         nb = ops.c.qinterp_rows(q, idx, weight, skip=uf, wb=wt[C2:].contiguous() if C1 else None, bias=None, relu=False)
         assert (nb.double() - x.view(-1, C2 + C1).double() @ wt.double()).abs().max().item() <= tol
         assert ops.c.qinterp_rows(q[:, :, :O - 1].contiguous(), idx, weight, relu=True) is None if (O - 1) % 4 else True
+
+
+@pytest.mark.parametrize("B,N,M,C2,C1,C,O,relu1", [(1, 16384, 4096, 256, 1, 128, 128, True), (2, 4096, 1024, 512, 96, 256, 256, True), (2, 1024, 256, 512, 256, 512, 512, True),
+                                                     (2, 256, 64, 64, 0, 64, 128, False), (1, 1000, 256, 64, 3, 64, 128, True), (2, 1024, 256, 64, 2, 48, 64, True)])
+def test_qinterp_gemm_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M, C2, C1, C, O, relu1):
+    """ws3d_qinterp_gemm (both layers of a two-layer FP module in one kernel: the first layer's rows are built in the A operand of the
+    second layer's product): with an identity second layer it returns ws3d_qinterp_rows' rows to the bit -- both skip forms -- and with a
+    real one the float64 product of those rows; shapes outside its tiles are declined (the caller runs the two-launch form)"""
+    rng = np.random.default_rng(29)
+    pc = synth.make_batch("hdl64", B, 16384, 72)[:, :N, :3].copy()
+    unknown = dev(pc)
+    known = unknown[:, ::max(N // M, 1)][:, :M].contiguous()
+    kf = dev(rng.standard_normal((B, M, C2)).astype(np.float32))
+    uf = dev(rng.standard_normal((B, N, C1)).astype(np.float32)) if C1 else None
+    idx, weight = ops.c.three_nn_with_weights(unknown, known, None)
+    wa = dev((rng.standard_normal((C2, C)) / np.sqrt(C2)).astype(np.float32))
+    wb = dev((rng.standard_normal((C1, C)) / np.sqrt(max(C1, 1))).astype(np.float32)) if C1 else None
+    b1 = dev(rng.standard_normal(C).astype(np.float32))
+    q = (kf.view(B * M, C2) @ wa).view(B, M, C)
+    if C1 > 4:
+        kw = dict(lin=torch.addmm(b1, uf.view(B * N, C1), wb))
+    else:
+        kw = dict(skip=uf, wb=wb, bias=b1)
+    rows = ops.c.qinterp_rows(q, idx, weight, relu=relu1, **kw)
+    w2 = dev((rng.standard_normal((C, O)) / np.sqrt(C)).astype(np.float32))
+    b2 = dev(rng.standard_normal(O).astype(np.float32))
+    got = ops.c.qinterp_gemm(q, idx, weight, w2, b2, True, relu=relu1, **kw)
+    if (B * N) % 64 or C % 16 or O % 128:
+        assert got is None
+        return
+    want = torch.relu(rows.double() @ w2.double() + b2.double())
+    assert got is not None and tuple(got.shape) == (B * N, O)
+    assert (got.double() - want).abs().max().item() <= 2e-5 * max(want.abs().max().item(), 1.0) * np.sqrt(max(C, 128) / 128)
+    if C == O:
+        eye = torch.eye(C, device="cuda")
+        assert torch.equal(ops.c.qinterp_gemm(q, idx, weight, eye, None, False, relu=relu1, **kw), rows)
 
 
 @pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ws3d_three_interpolate_nlc": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "ws3d_rowmax_rows": (_i, [C.c_long, _i, _i, _vp, _vp, _i, _vp]),
     "ws3d_sa_mlp3_pool": (_i, [C.c_long, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "ws3d_qinterp_gemm": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     "ws3d_mlp2_rows": (_i, [C.c_long, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "ws3d_decode_center_boxes": (_i, [_i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ws3d_topk_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -510,6 +510,27 @@ def qinterp_rows(q, idx, weight, lin=None, skip=None, wb=None, bias=None, relu=T
     return out
 
 
+def qinterp_gemm(q, idx, weight, w2t, b2, relu2, lin=None, skip=None, wb=None, bias=None, relu=True):
+    """qinterp_rows + the module's second layer in ONE kernel (the first layer's rows are built in the product's A operand, to the bit as
+    qinterp_rows builds them): q (B, M, C), idx / weight (B, N, 3), lin (B*N, C) or skip (B, N, C1 <= 4) + wb (C1, C) + bias, w2t (C, O)
+    -> (B*N, O), or None when the shape is not covered (B*N % 64, C % 16, O % 128).  ws3d extension."""
+    dev = _dev(q, idx, weight, w2t)
+    _f32(q, "q"); _i32(idx, "idx"); _f32(weight, "weight"); _f32(w2t, "w2t")
+    B, M, C = q.shape
+    N = idx.size(1)
+    O = w2t.size(1)
+    c1 = 0 if skip is None else skip.size(2)
+    if ((B * N) % 64 or C % 16 or O % 128 or w2t.size(0) != C or not q.is_contiguous() or not w2t.is_contiguous() or not idx.is_contiguous() or
+            not weight.is_contiguous() or (lin is None and c1 > 4) or (lin is not None and (tuple(lin.shape) != (B * N, C) or not lin.is_contiguous())) or
+            (lin is None and c1 > 0 and (wb is None or tuple(wb.shape) != (c1, C) or not wb.is_contiguous() or not skip.is_contiguous()))):
+        return None
+    out = torch.empty((B * N, O), dtype=torch.float32, device=dev)
+    with _on(dev):
+        check(_lib.load().ws3d_qinterp_gemm(B, N, M, C, O, _p(q), _p(idx), _p(weight), _p(lin), _p(skip), c1, _p(wb), _p(bias), int(bool(relu)), _p(w2t),
+                                            _p(b2), int(bool(relu2)), _p(out), _stream()), "qinterp_gemm")
+    return out
+
+
 def compact_pairs(nbr, ordered=False):
     """(B, M, ns) ball-query lists -> (rowc, rowsrc, total): the DISTINCT (centre, source point) pairs as compact rows (int32
     tensors of B*M*ns entries, the first `total` -- a 1-element device tensor -- valid); a list's padding repeats its first hit

@@ -1166,11 +1166,17 @@ __global__ __launch_bounds__(256) void interp_gemm_kernel(int c2, int c1, int o_
 // interp_gemm_kernel with a (64 MB) x (64 NB) output tile (see gemm_pool_big_kernel): besides the lighter L2 / LDS traffic the
 // interpolated A tile -- three gathered rows and three fmaf per element -- is built once per 64 NB output columns instead of
 // once per 64 (at FP1, 128 output channels: exactly once).
-template <int MB, int NB>
+template <int MB, int NB, bool PRE = false>
 __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, int o_dim, int n, int m, const float *__restrict__ known_feats,
                                                               const float *__restrict__ unknown_feats, const int32_t *__restrict__ idx3,
                                                               const float *__restrict__ w3, const float *__restrict__ wt,
-                                                              const float *__restrict__ bias, int relu, float *__restrict__ out, int tps) {
+                                                              const float *__restrict__ bias, int relu, float *__restrict__ out, int tps,
+                                                              const float *__restrict__ lin = nullptr, const float *__restrict__ wb = nullptr,
+                                                              const float *__restrict__ b1 = nullptr, int relu_a = 0) {
+    // PRE (ws3d_qinterp_gemm): the A operand is the FIRST layer of the module, built on the fly as ws3d_qinterp_rows builds it --
+    //   x[r, k] = relu_a?( w0 Q[i0, k] + w1 Q[i1, k] + w2 Q[i2, k] + (lin[r, k]  |  sum_j skip[r, j] wb[j, k] + b1[k]) )
+    // with known_feats = Q (c2 = the layer's width), unknown_feats = the c1 <= 4 skip channels of the second form -- and this kernel's
+    // product is the SECOND layer: K = c2, no concatenated columns.
     constexpr int TM = 64 * MB, TN = 64 * NB, XS = TM + 1;
     __shared__ float xs[2][GP_KT][XS];        // [k][row]
     __shared__ float ws[2][GP_KT][TN];        // [k][col]
@@ -1181,9 +1187,10 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
     gg_tile(o_dim / TN, tps, row_tile, col_tile);
     const long row0 = row_tile * TM;
     const int col0 = col_tile * TN;
-    const int k_dim = c2 + c1;
+    const int k_dim = PRE ? c2 : c2 + c1;
     const int xk = (tid & 3) * 4;
     const float *f0[MB], *f1[MB], *f2[MB], *urow[MB];
+    const float *lrow[MB];
     float w0[MB], w1[MB], w2[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
@@ -1193,6 +1200,7 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
         f0[i] = base + (size_t)idx3[r * 3 + 0] * c2; f1[i] = base + (size_t)idx3[r * 3 + 1] * c2; f2[i] = base + (size_t)idx3[r * 3 + 2] * c2;
         w0[i] = w3[r * 3 + 0]; w1[i] = w3[r * 3 + 1]; w2[i] = w3[r * 3 + 2];
         urow[i] = unknown_feats ? unknown_feats + (size_t)r * c1 : nullptr;
+        lrow[i] = (PRE && lin) ? lin + (size_t)r * c2 : nullptr;
     }
     float4 xv[MB], wv[NB];
     auto load = [&](int k0) {
@@ -1206,6 +1214,27 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
                                     __builtin_fmaf(w2[i], p2.y, __builtin_fmaf(w0[i], p0.y, w1[i] * p1.y)),
                                     __builtin_fmaf(w2[i], p2.z, __builtin_fmaf(w0[i], p0.z, w1[i] * p1.z)),
                                     __builtin_fmaf(w2[i], p2.w, __builtin_fmaf(w0[i], p0.w, w1[i] * p1.w)));
+                if (PRE) {
+                    float4 y = xv[i];
+                    if (lrow[i]) {
+                        const float4 l4 = *reinterpret_cast<const float4 *>(lrow[i] + k);
+                        y.x += l4.x; y.y += l4.y; y.z += l4.z; y.w += l4.w;
+                    } else {
+                        for (int j = 0; j < c1; ++j) {
+                            const float sv = urow[i][j];
+                            const float4 wv4 = *reinterpret_cast<const float4 *>(wb + (long)j * c2 + k);
+                            y.x = __builtin_fmaf(sv, wv4.x, y.x); y.y = __builtin_fmaf(sv, wv4.y, y.y); y.z = __builtin_fmaf(sv, wv4.z, y.z); y.w = __builtin_fmaf(sv, wv4.w, y.w);
+                        }
+                        if (b1) {
+                            const float4 bv = *reinterpret_cast<const float4 *>(b1 + k);
+                            y.x += bv.x; y.y += bv.y; y.z += bv.z; y.w += bv.w;
+                        }
+                    }
+                    if (relu_a) { y.x = y.x < 0.f ? 0.f : y.x; y.y = y.y < 0.f ? 0.f : y.y; y.z = y.z < 0.f ? 0.f : y.z; y.w = y.w < 0.f ? 0.f : y.w; }
+                    xv[i] = y;
+                }
+            } else if (PRE) {
+                xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 const int ku = k - c2;
                 if (ku + 3 < c1) {
@@ -1383,6 +1412,26 @@ extern "C" int ws3d_interp_gemm(int b, int n, int m, int c2, int c1, int o_dim, 
     hipLaunchKernelGGL(interp_gemm_kernel, dim3((unsigned)((o_dim / 64) * (rows / 64))), dim3(256), 0, as_stream(stream), c2, c1, o_dim, n, m,
                        known_feats, unknown_feats, idx, weight, wt, bias, relu, out, tps);
     return check_launch("ws3d_interp_gemm");
+}
+
+extern "C" int ws3d_qinterp_gemm(int b, int n, int m, int c, int o_dim, const float *q, const int32_t *idx, const float *weight, const float *lin,
+                                const float *skip, int c1, const float *wb, const float *b1, int relu1, const float *w2t, const float *b2, int relu2,
+                                float *out, ws3d_stream_t stream) {
+    using namespace ws3d;
+    const long rows = (long)b * n;
+    const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(w2t) | reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(wb) |
+                         reinterpret_cast<uintptr_t>(b1);
+    if (b < 0 || n <= 0 || m <= 0 || c <= 0 || (c & 15) || o_dim <= 0 || (o_dim & 127) || (rows & 63) || !q || !idx || !weight || !w2t || !out || (al & 15) ||
+        (!lin && (c1 < 0 || c1 > 4 || (c1 > 0 && (!skip || !wb))))) {
+        set_error("ws3d_qinterp_gemm: unsupported shape (b=%d n=%d m=%d c=%d o=%d c1=%d; rows %% 64, c %% 16, o %% 128, lin or c1 <= 4)", b, n, m, c, o_dim, c1);
+        return WS3D_E_UNSUPPORTED;
+    }
+    if (rows == 0) return WS3D_OK;
+    const int tpsb = ((b & 7) == 0 && n % 64 == 0) ? n / 64 : 0;
+    const dim3 grid((unsigned)((o_dim / 128) * (rows / 64)));
+    hipLaunchKernelGGL((interp_gemm_big_kernel<1, 2, true>), grid, dim3(256), 0, as_stream(stream), c, lin ? 0 : c1, o_dim, n, m, q, lin ? nullptr : skip, idx,
+                       weight, w2t, b2, relu2, out, tpsb, lin, wb, b1, relu1);
+    return check_launch("ws3d_qinterp_gemm");
 }
 
 extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, int o1, int o2, const float *feats, const float *xyz,

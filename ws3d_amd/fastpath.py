@@ -69,6 +69,7 @@ PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolat
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
 BIN_INPUT_AHEAD = True     # eager pass with geometry ahead: bin the input cloud on the search stream beside the first level's sampling kernel
+FUSED_QINTERP_GEMM_MIN_ROWS = 30000    # ws3d_qinterp_gemm (both layers of an FP module in one kernel) from this many rows on (batch 8: FP1, FP2; smaller modules lose, profiles/r04_qinterp_gemm_ab.txt); 1 << 60: never
 FUSED_COMPACT3_MAX_LDS = 64 * 1024   # ws3d_pgather_gemm3_compact (the whole SharedMLP of a scale over compact rows in one kernel) where its two LDS tiles fit in this many bytes (SA2: 41 / 50 KB); 0: the two-kernel form everywhere
 FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first layer's A operand (no grouped tensor in HBM)
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
@@ -543,11 +544,21 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
         wa, wb = _split_rows(blocks[0], wt1, c2)
         m = known_feats.size(1)
         q = torch.mm(known_feats.reshape(B * m, c2), wa).view(B, m, -1)
+        fuse2 = len(blocks) == 2 and B * n >= FUSED_QINTERP_GEMM_MIN_ROWS
+        if fuse2:
+            wt2, b2, r2 = _row_weights(blocks[1])
         if c1 > 4:
             lin = torch.mm(unknown_feats.reshape(B * n, c1), wb) if b1 is None else torch.addmm(b1, unknown_feats.reshape(B * n, c1), wb)
+            y = _C.qinterp_gemm(q, idx, weight, wt2, b2, r2, lin=lin, relu=r1) if fuse2 else None
+            if y is not None:
+                return y.view(B, n, -1)
             y = _C.qinterp_rows(q, idx, weight, lin=lin, relu=r1)
         else:
-            y = _C.qinterp_rows(q, idx, weight, skip=None if c1 == 0 else unknown_feats.contiguous(), wb=wb if c1 else None, bias=b1, relu=r1)
+            sk = None if c1 == 0 else unknown_feats.contiguous()
+            y = _C.qinterp_gemm(q, idx, weight, wt2, b2, r2, skip=sk, wb=wb if c1 else None, bias=b1, relu=r1) if fuse2 else None
+            if y is not None:
+                return y.view(B, n, -1)
+            y = _C.qinterp_rows(q, idx, weight, skip=sk, wb=wb if c1 else None, bias=b1, relu=r1)
         if y is not None:
             for blk in blocks[1:]:
                 y = _layer(y, blk)
