@@ -676,6 +676,125 @@ def roofline_of(k, where):
     return r
 
 
+LINE_BUDGET = 4096          # bytes of the ONE stdout line (the driver parses the tail of stdout: round 4's 24.8 KB line was not parsed)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _short(s, n=200):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def _num(x, nd=6):
+    """floats to `nd` significant digits: the line is read by a parser and by people, not diffed"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    if isinstance(x, dict):
+        return {k: _num(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, nd) for v in x]
+    return x
+
+
+def c3_step_roofline(out, kernels, wl, kind):
+    """The tier contract's `roofline` for the c3 line: it describes the TIMED REGION of this line (one Stage-1 step over one batch,
+    throughput mode), not another launch.  The step is nearer its matrix roof than its HBM roof, so the top-level
+    bound is "mfma": useful f32 multiply-adds of the step (counted from the layer widths and the distinct pairs measured on the batch,
+    bench_c3.matrix_work) / ms_per_step / the dense f32 MFMA peak.  `traffic` = HBM bytes per step from the committed rocprofv3 --pmc
+    passes of the same step (profiles/traffic_c3.json: FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections) when they were
+    taken at this batch and generator, else null; `hbm` = that traffic against 8 TB/s; `dominant_kernel` = the level-1 sampling
+    kernel AT THIS LINE'S BATCH, duration from HIP events around its launches in the eager steps after the timed region."""
+    import bench_c3
+    mw = out.get("throughput_mode", {}).get("matrix_roofline")
+    tot = load_traffic("c3:_total_hbm_bytes_per_step")
+    same = wl.scenes() == traffic_batch("c3:x") and traffic_kind("c3:x") == kind
+    traffic = float(tot) if (tot and same) else None
+    sec = out["ms_per_step"] * 1e-3
+    a_min = 88550656 * wl.scenes()                 # SURVEY 8d: compulsory bytes of the custom ops of one scene's Stage-1 forward
+    r = {"measured_in": "the timed region of this line (%s, batch %d per GPU, %s)" % (wl.name, wl.scenes(), kind),
+         "bound": "mfma", "unit": "TFLOP/s", "peak": bench_c3.FP32_MFMA_PEAK_TFLOPS,
+         "achieved": mw["achieved"] if mw else None, "frac": mw["frac"] if mw else None,
+         "gflop_per_step": mw["gflop_per_batch"] if mw else None, "traffic": traffic,
+         "hbm": {"peak_GBps": HBM_PEAK / 1e9, "traffic_GBps": traffic / sec / 1e9 if traffic else None,
+                 "frac": traffic / sec / HBM_PEAK if traffic else None,
+                 "a_min_bytes_per_step": a_min, "a_min_frac": a_min / sec / HBM_PEAK,
+                 "traffic_source": "profiles/traffic_c3.json (rocprofv3 --pmc, eager step)" if traffic else
+                                   "null: the committed --pmc pass is for batch %s / %s" % (traffic_batch("c3:x"), traffic_kind("c3:x"))}}
+    fps = next((k for k in kernels if k.get("bound") == "valu"), None)
+    if fps is not None:
+        us = fps.get("us_per_fps_step")
+        e8 = fps_valu_pmc(wl.scenes(), kind)
+        share = None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0 / (fps["ms_per_step"] * 1e-3) / (VALU_PEAK * wl.scenes() / 256.0)
+        r["dominant_kernel"] = {"name": "fps_rounds2_kernel (level-1 furthest_point_sample 16384 -> 4096 + gather)", "measured_in": "this line's batch, eager steps, HIP events",
+                                "ms_per_launch": fps["ms_per_step"] / max(fps["launches_per_step"], 1), "workgroups": wl.scenes(),
+                                "us_per_sample": us, "clk_per_sample": None if us is None else us * 2400.0,
+                                "bound": "cross-lane chain (neither HBM nor VALU issue)", "valu_frac_of_occupied_CUs": share,
+                                "valu_frac_of_chip": fps.get("valu_frac"), "hbm_bytes_per_launch": (fps.get("traffic_bytes_per_launch") or {}).get("hbm_bytes")}
+    return r
+
+
+def compact_line(out, detail_path):
+    """The ONE line the driver parses: the contract keys, `roofline`, `cpu_baseline` and a dozen scalars -- everything else
+    (kernels[], the c2 block, list_fill, the other generator, notes) lives in `detail_path` and on stderr."""
+    cfg = out["config"]
+    comm = cfg.get("communicator") or {}
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype")}
+    line["data"] = _short(out["data"], 160)
+    line["config"] = {"workload": cfg["workload"], "batch_per_gpu": cfg["batch_per_gpu"], "n_points": cfg["n_points"],
+                      "ranks_seen": cfg["ranks_seen"], "generator": out.get("generator"), "backend": comm.get("backend"),
+                      "communicator_size": comm.get("size", 1),
+                      "launcher": _short(comm.get("launcher", ""), 60)}
+    for k in ("launch", "exchange", "hw_queues", "pipeline_depth", "m_points", "nsample", "radius", "proposals", "channels", "sampled"):
+        if k in cfg and not isinstance(cfg[k], (dict, list)):
+            line["config"][k] = _short(cfg[k], 120) if isinstance(cfg[k], str) else cfg[k]
+    roof = dict(out["roofline"])
+    for k in ("note", "frac_is"):
+        if k in roof:
+            roof[k] = _short(roof[k], 120)
+    roof.pop("note", None)
+    roof["kernel"] = _short(roof.get("kernel", roof.get("measured_in", "")), 160) if "kernel" in roof else None
+    if roof["kernel"] is None:
+        roof.pop("kernel")
+    line["roofline"] = roof
+    if "cpu_baseline" in out:
+        cb = out["cpu_baseline"]
+        line["cpu_baseline"] = {k: (_short(v, 280) if isinstance(v, str) else v) for k, v in cb.items() if k != "host"}
+        if isinstance(cb.get("host"), dict):
+            line["cpu_baseline"]["host_cpu"] = _short(cb["host"].get("cpu", ""), 60)
+    lat, c2 = out.get("latency_mode"), out.get("c2")
+    if lat:
+        line["latency_ms"], line["latency_scenes_per_s"] = lat["ms_per_batch"], lat["value"]
+    if out.get("generator"):
+        line["value_" + out["generator"]] = out["value"]
+    og = out.get("other_generator")
+    if og:
+        line["value_" + og["generator"]] = og["value"]
+        line["latency_ms_" + og["generator"]] = og.get("latency_ms_per_batch")
+    if "value_all_rows" in out:
+        line["value_all_rows"] = out["value_all_rows"]
+    if c2:
+        line["c2_batch"], line["c2_scenes_per_s"] = c2["batch_per_gpu"], c2["scenes_per_s_per_gpu"]
+        for k in c2["kernels"]:
+            if k.get("bound") == "valu":
+                line["c2_fps_ms"], line["c2_fps_us_per_sample"] = k["ms_per_step"], k.get("us_per_sample")
+            elif k.get("bound") == "hbm":
+                line["c2_query_group_ms"], line["c2_query_group_hbm_frac"] = k["ms_per_step"], k.get("frac_of_8TBps")
+        pg = c2.get("path_gbps_per_gpu") or {}
+        line["c2_a_min_hbm_frac"] = pg["a_min"] * 1e9 / HBM_PEAK if pg.get("a_min") else None
+        line["c2_a_model_effective_GBps"] = pg.get("a_model")
+        if isinstance(c2.get("cpu_baseline"), dict) and "value" in c2["cpu_baseline"]:
+            line["c2_cpu_scenes_per_s"] = c2["cpu_baseline"]["value"]
+    line["detail"] = os.path.basename(detail_path) if detail_path else None
+    line = _num(line)
+    text = json.dumps(line)
+    if len(text) > LINE_BUDGET:                     # never lose the line to its own size again: drop the optional scalars first
+        for k in [k for k in line if k.startswith(("c2_", "latency_ms_", "value_all"))]:
+            line.pop(k)
+        line["roofline"].pop("dominant_kernel", None)
+    return line
+
+
 def c2_block(batch, rank, kind, steps=10, warmup=2):
     """BASELINE configs[1] measured outside the timed region of the headline run: the 'FPS+group HBM GB/s'
     half of the metric, and the chip-filling launch of the path's dominant kernel (FPS)"""
@@ -768,6 +887,9 @@ def main():
     ap.add_argument("--no-side-runs", action="store_true",
                     help="c3: skip the blocks measured after the timed region (all_rows = SharedMLPs over all m*nsample rows; the other generator)")
     ap.add_argument("--no-graph", action="store_true", help="c3: time eager launches instead of hipGraph replay")
+    ap.add_argument("--detail", default=None, help="where the full record goes (kernels[], the c2 block, list_fill, the other generator, notes); "
+                                                   "default bench_detail.json beside bench.py; '' = do not write it")
+    ap.add_argument("--full-line", action="store_true", help="print the full record on stdout instead of the compact line (scripts/ that read kernels[])")
     ap.add_argument("--no-prefetch", action="store_true", help="t1: sample inside the step instead of one step ahead")
     ap.add_argument("--pipeline-depth", type=int, default=None,
                     help="c3: batches in flight (one HIP stream + graph each); default 20 on one GPU, 16 with --gpus > 1 (headroom for the "
@@ -831,8 +953,11 @@ def main():
         wl.dump(os.environ["WS3D_BENCH_DUMP"])
     kernels = finish_kernel_rows(wl.kernel_table(), wl.scenes(), getattr(wl, 'kind', args.kind)) if rank == 0 else None
     side = {}
+    if args.workload == "c3" and rank == 0:
+        # distinct pairs per ball-query scale on the timed batch: what the matrix roofline of the step is counted from
+        side["list_fill"] = {"generator": wl.kind, "scales": wl.list_fill()}
     if args.workload == "c3" and world == 1 and not args.no_side_runs and use_graph:
-        side = c3_side_runs(wl, args, value, latency)
+        side.update(c3_side_runs(wl, args, value, latency))
     c2wl = c2blk = None
     if args.workload == "c3" and args.c2_batch > 0:
         c2wl, c2blk = c2_block(args.c2_batch, rank, args.kind)
@@ -845,10 +970,10 @@ def main():
             "metric": getattr(wl, "metric", HEADLINE_METRIC), "value": value, "unit": getattr(wl, "unit", "scenes/s"),
             "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
+            "vs_baseline": None, "dtype": "f32", "generator": getattr(wl, 'kind', args.kind),
             "data": f"synthetic ({getattr(wl, 'kind', args.kind)}, seeded scenes: 1000*config + 100000*slot + scene, random-init weights)",
             "config": dict({"workload": wl.name, "batch_per_gpu": wl.scenes(), "n_points": N_PTS, "ranks_seen": comm["ranks_seen"],
-                            "communicator": comm,
+                            "communicator": comm, "pipeline_depth": getattr(wl, "depth", None),
                             "multi_gpu_evidence": "no 1 -> 8 GPU scaling curve has been measured for this build (no multi-GPU node was available to it): "
                                                   "the N > 1 path is covered by 2- and 8-rank runs of this file with every rank on ONE GPU (gloo "
                                                   "exchange, tests/test_bench_contract.py) and by RCCL at world size 1"},
@@ -859,28 +984,13 @@ def main():
                                       "unit": out["unit"]}
             out["latency_mode"] = latency
         if c2blk is not None:
-            # the dominant kernel family of the Stage-1 forward is furthest_point_sample (kernels[] below); its
-            # roofline is quoted on the chip-filling launch of the c2 block, with the c3 launch (8 workgroups) beside it
+            # BASELINE configs[1] beside the headline: its own block with its own roofline (the chip-filling launch of the sampling
+            # kernel); the LINE's roofline below describes the line's timed region
             c2dom = max(c2blk["kernels"], key=lambda k: k["ms_per_step"])
-            out["roofline"] = roofline_of(c2dom, "c2 block of this run (batch %d per launch)" % c2blk["batch_per_gpu"])
-            c3fps = next((k for k in kernels if k.get("bound") == "valu"), None)
-            if c3fps is not None:
-                us = c3fps.get("us_per_fps_step")
-                e8 = fps_valu_pmc(wl.scenes(), args.kind)
-                pmc = None if e8 is None else e8["sq_insts_valu_per_launch"] * 64.0 / (c3fps["ms_per_step"] * 1e-3) / (VALU_PEAK * wl.scenes() / 256.0)
-                out["roofline"]["same_kernel_family_in_the_timed_c3_step"] = {
-                    "kernel": "fps_rounds2_kernel (exact pruned sampling, two candidates per wave, up to 8 certified samples per exchange; level 1: 16384 -> 4096)",
-                    "ms_per_step_eager": c3fps["ms_per_step"],
-                    "workgroups": wl.scenes(), "us_per_sample": us, "clk_per_sample_at_2.4GHz": None if us is None else us * 2400.0,
-                    "valu_share_of_occupied_CUs_pmc": pmc,
-                    "note": "one workgroup per scene: a batch of 8 occupies 8 of 256 CUs (throughput mode overlaps 20 batches).  This kernel is "
-                            "chain-bound, not VALU-bound: its figure is the time per sample (a round = box tests, bucket updates, re-pick, record "
-                            "exchange, certification of up to 8 samples; 5.6 / 6.4 samples per round on hdl64 / lidar), in us and clk; valu_share_of_occupied_CUs_pmc = "
-                            "SQ_INSTS_VALU x 64 lanes / duration / the VALU roof of the 8 CUs it runs on, from the committed --pmc pass of this batch "
-                            "and generator (profiles/traffic_fps_valu.json) or null"}
+            c2blk["roofline"] = roofline_of(c2dom, "c2 block of this run (batch %d per launch)" % c2blk["batch_per_gpu"])
             out["c2"] = c2blk
-        else:
-            out["roofline"] = roofline_of(dom, "the timed region (HIP events on the launch stream)")
+        if args.workload != "c3":
+            out["roofline"] = roofline_of(dom, "the timed region of this line (HIP events on the launch stream)")
         out.update(side)
         if "list_fill" in out and "throughput_mode" in out and hasattr(wl, "cfg"):
             import bench_c3
@@ -896,6 +1006,8 @@ def main():
                 ar = bench_c3.matrix_work(wl.cfg, out["list_fill"]["scales"], wl.scenes(), compact=False)["gflop_per_batch"]
                 mw["all_rows"] = {"gflop_per_batch": ar, "achieved": ar / out["all_rows"]["ms_per_batch"], "frac": ar / out["all_rows"]["ms_per_batch"] / bench_c3.FP32_MFMA_PEAK_TFLOPS}
             out["throughput_mode"]["matrix_roofline"] = mw
+        if args.workload == "c3":
+            out["roofline"] = c3_step_roofline(out, kernels, wl, getattr(wl, "kind", args.kind))
         out.update({"kernels": kernels, "step_ms_percentiles": step_percentiles(wl), "path_gbps_per_gpu": wl.path_gbps(per_gpu)})
         if not args.no_cpu_baseline and world == 1:
             try:
@@ -904,7 +1016,19 @@ def main():
                     out["c2"]["cpu_baseline"] = c2wl.cpu_baseline(min_seconds=args.cpu_baseline_seconds)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
                 out.setdefault("cpu_baseline", {"error": repr(e)})
-        print(json.dumps(out), flush=True)
+        detail_path = os.path.join(ROOT, DETAIL_FILE) if args.detail is None else args.detail
+        if detail_path:
+            try:
+                with open(detail_path, "w") as f:
+                    json.dump(out, f, indent=1)
+            except OSError as e:
+                print("bench.py: could not write %s: %r" % (detail_path, e), file=sys.stderr)
+                detail_path = ""
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            print("[bench detail] " + json.dumps(out), file=sys.stderr, flush=True)        # the full record, for the log
+            print(json.dumps(compact_line(out, detail_path)), flush=True)                   # THE line (<= 4 KB)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -11,7 +11,7 @@ done
 for v in FULL NO_SCAN NO_COPY; do
   for st in 16; do for pp in 0 2; do
     lib=""; [ $v != FULL ] && lib=/tmp/libws3d_$v.so
-    line=$(WS3D_HIP_LIB=$lib WS3D_ROI_PIPE=$pp WS3D_ROI_STAGE=$st timeout 200 python bench.py --workload c5 --no-cpu-baseline 2>/dev/null | tail -1)
+    line=$(WS3D_HIP_LIB=$lib WS3D_ROI_PIPE=$pp WS3D_ROI_STAGE=$st timeout 200 python bench.py --full-line --workload c5 --no-cpu-baseline 2>/dev/null | tail -1)
     echo "$v stage=$st pipe=$pp $(echo "$line" | python -c "import json,sys; d=json.loads(sys.stdin.read()); k=[x for x in d['kernels'] if 'roipool' in x['name']][0]; print('kernel ms', round(k['ms_per_step'],4), 'step ms', round(d['ms_per_step'],4))")"
   done; done
 done

@@ -1,4 +1,4 @@
-python bench.py --no-side-runs --no-cpu-baseline --c2-batch 0 "$@" 2>/dev/null | python -c "
+python bench.py --full-line --no-side-runs --no-cpu-baseline --c2-batch 0 "$@" 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1])
 print('value %.0f  ms/batch %.4f  latency %.3f ms' % (d['value'], d['ms_per_step'], d['latency_mode']['ms_per_batch']))

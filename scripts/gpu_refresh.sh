@@ -11,16 +11,16 @@ export TMPDIR=/tmp
 T="timeout 900"
 $T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 # (the default lines are taken LAST, after this run's counter passes have been copied into profiles/: they quote them)
-$T python bench.py --steps 160 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
-$T python bench.py --pipeline-depth 1 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
-GPU_MAX_HW_QUEUES=4 $T python bench.py --pipeline-depth 3 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
-$T python bench.py --workload c2                              2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b512.json
+$T python bench.py --full-line --steps 160 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_steps160.json
+$T python bench.py --full-line --pipeline-depth 1 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth1.json
+GPU_MAX_HW_QUEUES=4 $T python bench.py --full-line --pipeline-depth 3 --no-cpu-baseline --no-side-runs --c2-batch 0 2>>$OUT/bench_default.err | tail -1 > $OUT/bench_c3_b8_depth3_queues4.json
+$T python bench.py --full-line --workload c2                              2>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b512.json
 for b in 1 8 64 256 1024; do
-  $T python bench.py --workload c2 --batch $b --no-cpu-baseline 2>>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b$b.json
+  $T python bench.py --full-line --workload c2 --batch $b --no-cpu-baseline 2>>$OUT/bench_c2.err | tail -1 > $OUT/bench_c2_b$b.json
 done
-$T python bench.py --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
-$T python bench.py --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
-$T python bench.py --workload t1 --no-cpu-baseline 2>$OUT/bench_t1_b8.err | tail -1 > $OUT/bench_t1_b8.json
+$T python bench.py --full-line --workload c5               2>$OUT/bench_c5_b8.err   | tail -1 > $OUT/bench_c5_b8.json
+$T python bench.py --full-line --workload s2               2>$OUT/bench_s2_b800.err | tail -1 > $OUT/bench_s2_b800.json
+$T python bench.py --full-line --workload t1 --no-cpu-baseline 2>$OUT/bench_t1_b8.err | tail -1 > $OUT/bench_t1_b8.json
 for w in c2 c3 c5 s2; do
   extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph --c2-batch 0"
   rm -rf /tmp/prof_$w
@@ -72,7 +72,7 @@ timeout 1500 bash scripts/throughput_marginal.sh hdl64 > $OUT/throughput_margina
 # the default lines, quoting THIS run's counter passes (profiles/ of the box's scratch copy)
 cp $OUT/traffic.json $OUT/traffic_c5.json $OUT/traffic_c3.json profiles/ 2>/dev/null
 [ -s $OUT/pmc_fps/traffic_fps_valu.json ] && cp $OUT/pmc_fps/traffic_fps_valu.json profiles/
-$T python bench.py                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-$T python bench.py --kind lidar                               2>$OUT/bench_default_lidar.err | tail -1 > $OUT/bench_default_lidar.json
-$T python bench.py --steps 20 --warmup 5                      2>>$OUT/bench_default.err | tail -1 > $OUT/bench_default_steps20_warmup5.json
+$T python bench.py --full-line                                            2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+$T python bench.py --full-line --kind lidar                               2>$OUT/bench_default_lidar.err | tail -1 > $OUT/bench_default_lidar.json
+$T python bench.py --full-line --steps 20 --warmup 5                      2>>$OUT/bench_default.err | tail -1 > $OUT/bench_default_steps20_warmup5.json
 ls -la $OUT

@@ -4,7 +4,7 @@
 # else of 19 other batches runs beside it.  Families whose rise is ~0 hide behind other work; the rest bound the headline.
 cd "$(dirname "$0")/.."
 KIND=${1:-hdl64}
-run() { WS3D_BENCH_DOUBLE="$1" python bench.py --kind $KIND --steps 60 --warmup 3 --no-side-runs --no-cpu-baseline --c2-batch 0 2>/dev/null | python -c "
+run() { WS3D_BENCH_DOUBLE="$1" python bench.py --full-line --kind $KIND --steps 60 --warmup 3 --no-side-runs --no-cpu-baseline --c2-batch 0 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.readlines()[-1])
 print('%-58s %8.4f ms/batch  latency %6.3f ms' % (sys.argv[1] or '(plain)', d['ms_per_step'], d['latency_mode']['ms_per_batch']))" "$1"; }

@@ -67,3 +67,53 @@ def test_matrix_work_counts_the_multiply_adds_of_the_network_as_built():
     half = [dict(f, distinct_per_list=f["distinct_per_list"] / 4, fill=0.25) for f in fill]
     assert bench_c3.matrix_work(cfg, half, batch=8)["gflop_per_batch"] < got["gflop_per_batch"]
     assert bench_c3.matrix_work(cfg, half, batch=8, compact=False)["gflop_per_batch"] == got["gflop_per_batch"]
+
+
+def test_self_launch_command_gives_every_rank_a_device_of_its_own():
+    """``python bench.py --gpus 8``: the command it builds is ONE node, 8 processes -- torch.distributed.run then numbers LOCAL_RANK
+    0..7, one per device -- and nothing in it pins or shares a device (no CUDA/HIP_VISIBLE_DEVICES edits, no --gpus rewrite)"""
+    p = _run(["--gpus", "8", "--steps", "2", "--warmup", "1"], dict(NO_LAUNCHER, WS3D_BENCH_LAUNCH_DRYRUN="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["self_launch"]
+    assert cmd.count("--nproc-per-node") == 1 and cmd[cmd.index("--nproc-per-node") + 1] == "8" and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--gpus") + 1] == "8" and not any("VISIBLE_DEVICES" in c for c in cmd)
+    # LOCAL_RANK -> device is the identity in bench.dist_setup / ws3d_amd.dist.init over RCCL (more ranks than devices: an error)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'if backend == "nccl" and world > ndev:' in src and "sys.exit(3)" in src
+
+
+def test_compact_line_fits_the_drivers_parser():
+    """bench.compact_line on a full record of round 4 (profiles/r04_bench_default_steps20_warmup5.json, 24.8 KB -- the line the
+    driver could not parse): the extract is < 4 KB, holds the contract keys, and no string longer than 300 characters"""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_default_steps20_warmup5.json")).read().strip().splitlines()[-1])
+    full.setdefault("generator", "hdl64")
+
+    class W:
+        name = full["config"]["workload"]
+
+        def scenes(self):
+            return 8
+    full["roofline"] = bench.c3_step_roofline(full, full["kernels"], W(), "hdl64")
+    line = bench.compact_line(full, "bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET < len(json.dumps(full))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert {"workload", "batch_per_gpu", "n_points", "ranks_seen", "generator", "backend"} <= set(line["config"])
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and abs(r["frac"] - 0.302) < 0.01 and abs(r["hbm"]["frac"] - 0.122) < 0.01      # the verdict's own recomputation
+    assert "c3_stage1" in r["measured_in"] and r["dominant_kernel"]["workgroups"] == 8
+
+    def strings(x):
+        if isinstance(x, dict):
+            for v in x.values():
+                yield from strings(v)
+        elif isinstance(x, list):
+            for v in x:
+                yield from strings(v)
+        elif isinstance(x, str):
+            yield x
+    assert max(len(t) for t in strings(line)) <= 300

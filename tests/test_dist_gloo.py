@@ -58,3 +58,29 @@ def test_two_process_gloo_all_gather(tmp_path, gb):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+def test_more_rccl_ranks_than_devices_raises_instead_of_wrapping(monkeypatch):
+    """dist.init over RCCL never puts two ranks on one device: the device pick raises; only the
+    explicit gloo test mode wraps LOCAL_RANK onto the devices there are"""
+    import pytest
+    import torch
+    from ws3d_amd import dist as wdist
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    for world, local in ((4, 3), (4, 1), (3, 2)):
+        with pytest.raises(RuntimeError, match="one device per rank"):
+            wdist._local_device(local, world, "nccl")
+    assert [wdist._local_device(l, 2, "nccl") for l in (0, 1)] == [0, 1]
+    assert [wdist._local_device(l, 4, "gloo") for l in range(4)] == [0, 1, 0, 1]
+
+
+def test_rccl_without_a_device_is_an_error(monkeypatch):
+    import pytest
+    import torch
+    from ws3d_amd import dist as wdist
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    for k, v in (("WORLD_SIZE", "2"), ("RANK", "0"), ("LOCAL_RANK", "0")):
+        monkeypatch.setenv(k, v)
+    with pytest.raises(RuntimeError, match="without a HIP device"):
+        wdist.init("nccl")

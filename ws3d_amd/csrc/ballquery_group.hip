@@ -1167,9 +1167,7 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         const size_t smem_s = sizeof(float4) * 64 + sizeof(int) * 256 +
                               sizeof(uint16_t) * (size_t)5 * 64 * (nsample + 1);
         if (smem_s <= 150 * 1024) {
-            if (smem_s > 64 * 1024)
-                (void)hipFuncSetAttribute((const void *)ball_query_sorted_kernel<FUSED>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_s);
+            if (int rc = raise_lds_cap((const void *)ball_query_sorted_kernel<FUSED>, smem_s, what)) return rc;
             hipLaunchKernelGGL((ball_query_sorted_kernel<FUSED>), dim3((m + 63) / 64, b, gz), dim3(256), smem_s, st, n,
                                m, c, radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted),
                                new_xyz, features, idx, out);
@@ -1184,15 +1182,11 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
     }
     dim3 grid((m + 63) / 64, b, gz);
     if (small_idx) {
-        if (smem > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)ball_query_kernel<uint16_t, FUSED>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (int rc = raise_lds_cap((const void *)ball_query_kernel<uint16_t, FUSED>, smem, what)) return rc;
         hipLaunchKernelGGL((ball_query_kernel<uint16_t, FUSED>), grid, dim3(64 * BQ_NW), smem, st, n, m, c,
                            radius, nsample, use_xyz, xyz, new_xyz, features, idx, out);
     } else {
-        if (smem > 64 * 1024)
-            (void)hipFuncSetAttribute((const void *)ball_query_kernel<int32_t, FUSED>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (int rc = raise_lds_cap((const void *)ball_query_kernel<int32_t, FUSED>, smem, what)) return rc;
         hipLaunchKernelGGL((ball_query_kernel<int32_t, FUSED>), grid, dim3(64 * BQ_NW), smem, st, n, m, c,
                            radius, nsample, use_xyz, xyz, new_xyz, features, idx, out);
     }

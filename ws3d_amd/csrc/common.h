@@ -15,6 +15,10 @@ namespace ws3d {
 
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
+// Raise a kernel's dynamic-LDS cap to at least `bytes` ON THE CURRENT DEVICE (hipFuncSetAttribute acts on the function's code object
+// of the current device: a process that drives several devices must raise it on each).  Remembered per (function, device) under a
+// mutex; a failure is reported through set_error / WS3D_E_LAUNCH.  No-op for bytes <= 64 KiB (the default cap).
+int raise_lds_cap(const void *fn, size_t bytes, const char *what);
 
 static inline hipStream_t as_stream(ws3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

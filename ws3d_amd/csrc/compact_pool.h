@@ -36,13 +36,12 @@ __device__ __forceinline__ void compact_pool_atomic(const ACC &acc, float bias, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (cen[r] < 0) continue;
-        float v = y[r] + bias;
-        v = v < 0.f ? 0.f : v;
+        const float v = fmaxf(y[r] + bias, 0.f);          // NaN -> 0, like the dense / list forms' fmaxf: the integer atomicMax below never sees a NaN pattern
         if (cen[r] != prev) {
             if (prev >= 0) atomicMax(reinterpret_cast<int *>(out_col + (long)prev * out_stride), __float_as_int(run));
             prev = cen[r]; run = v;
         } else {
-            run = v > run ? v : run;
+            run = fmaxf(run, v);
         }
     }
     if (prev >= 0) atomicMax(reinterpret_cast<int *>(out_col + (long)prev * out_stride), __float_as_int(run));

@@ -2,6 +2,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "common.h"
 
@@ -22,6 +25,25 @@ int check_launch(const char *what) {
         set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
         return WS3D_E_LAUNCH;
     }
+    return WS3D_OK;
+}
+
+int raise_lds_cap(const void *fn, size_t bytes, const char *what) {
+    if (bytes <= 64 * 1024) return WS3D_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> caps;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &cur = caps[std::make_pair(fn, dev)];
+    if (cur >= bytes) return WS3D_OK;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: raising the dynamic LDS cap to %zu B on device %d failed: %s", what, bytes, dev, hipGetErrorString(e));
+        (void)hipGetLastError();
+        return WS3D_E_LAUNCH;
+    }
+    cur = bytes;
     return WS3D_OK;
 }
 

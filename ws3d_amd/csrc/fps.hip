@@ -743,11 +743,7 @@ static int fps_dispatch(int b, int n, int m, const float *xyz, float *temp, int3
     } else if (R <= 1024L * 16 && R > 512L * 16 && fps_pair_mode(b)) {
         // two scenes per CU: only pays when there are more scenes than CUs
         constexpr size_t lds = (size_t)32 * 512 * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)fps_zlds_kernel<32, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        if (int rc = raise_lds_cap((const void *)fps_zlds_kernel<32, 512>, lds, "furthest_point_sampling")) return rc;
         hipLaunchKernelGGL((fps_zlds_kernel<32, 512>), dim3(b), dim3(512), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
     } else if (R <= 1024L * 16) {
         const int ppt = (int)((R + 1023) / 1024);

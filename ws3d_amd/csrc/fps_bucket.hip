@@ -900,21 +900,12 @@ bool fps_rounds_covers(int m) {
 
 int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_t *idx, float *new_xyz,
                       int bs, int log2bs, int S, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)fps_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)fps_bucket_smem());
-        attr_set = true;
-    }
+    if (int rc = raise_lds_cap((const void *)fps_bucket_kernel, fps_bucket_smem(), "furthest_point_sampling(bucket)")) return rc;
 #if FB_NW == 16 && !defined(FB_PROF)
     // WS3D_FPS_ROUNDS=0: one sample per record exchange (fps_bucket_kernel) also where the rounds kernel is the default (A/B runs, tests)
     static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
     if (rounds && (size_t)m <= FR2_SAMPLES_MAX_M) {
-        static bool attr3 = false;
-        if (!attr3) {
-            (void)hipFuncSetAttribute((const void *)fps_rounds2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fps_rounds2_smem((int)FR2_SAMPLES_MAX_M));
-            attr3 = true;
-        }
+        if (int rc = raise_lds_cap((const void *)fps_rounds2_kernel, fps_rounds2_smem((int)FR2_SAMPLES_MAX_M), "furthest_point_sampling(rounds2)")) return rc;
         hipLaunchKernelGGL(fps_rounds2_kernel, dim3(b), dim3(1024), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
         return check_launch("furthest_point_sampling(rounds2)");
     }

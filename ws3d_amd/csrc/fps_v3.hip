@@ -633,11 +633,7 @@ static void launch_v3(int b, int n, int m, const float *xyz, float *temp, int32_
                       hipStream_t st) {
     constexpr size_t lds = ZLDS ? (size_t)(DUO ? 2 : 1) * (PPT + (PPT == 32 ? 4 : 0)) * NT * sizeof(float) : 0;   // z (+ the last y quad)
     if constexpr (ZLDS) {
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void *)fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
+        (void)raise_lds_cap((const void *)fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>, lds, "furthest_point_sampling(v3)");   // (a failure surfaces at the launch check)
     }
     constexpr int prio_mode = 1;       // chain priority + sweep priority of the first scene (0 / 2 / start-up offsets were A/B runs: round 2)
     hipLaunchKernelGGL((fps_v3_kernel<PPT, NT, ZLDS, ONEX, DUO>), dim3(DUO ? b / 2 : b), dim3(DUO ? 2 * NT : NT), lds, st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S,

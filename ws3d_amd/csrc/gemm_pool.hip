@@ -1451,8 +1451,7 @@ extern "C" int ws3d_gather_gemm2(int b, int n, int m, int nsample, int c_feat, i
     const size_t lds = sizeof(float) * (p1 > p2 ? p1 : p2);
 #define WS3D_GG2(NB)                                                                                                                   \
     {                                                                                                                                  \
-        if (lds > 64 * 1024)                                                                                                           \
-            (void)hipFuncSetAttribute((const void *)gather_gemm2_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        if (int rc = raise_lds_cap((const void *)gather_gemm2_kernel<NB>, lds, "ws3d_gather_gemm2")) return rc;                         \
         hipLaunchKernelGGL((gather_gemm2_kernel<NB>), dim3((unsigned)(rows / 64)), dim3(256), lds, as_stream(stream), c_feat, o2, n, m, nsample, \
                            feats, xyz, new_xyz, nbr, w1t, b1, relu1, w2t, b2, relu2, out);                                             \
     }
@@ -1566,8 +1565,7 @@ extern "C" int ws3d_pgather_gemm2_compact(int b, int n, int m, long max_rows, in
         hipLaunchKernelGGL((pgather_gemm2_compact_kernel<2>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     else {
-        static bool attr = false;          // 74 KB of LDS: above the default limit
-        if (!attr) { (void)hipFuncSetAttribute((const void *)pgather_gemm2_compact_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+        if (int rc = raise_lds_cap((const void *)pgather_gemm2_compact_kernel<4>, lds, "ws3d_pgather_gemm2_compact")) return rc;          // 74 KB of LDS: above the default limit
         hipLaunchKernelGGL((pgather_gemm2_compact_kernel<4>), grid, dim3(256), lds, as_stream(stream), o2, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, out, limit);
     }
@@ -1589,13 +1587,12 @@ extern "C" int ws3d_pgather_gemm3_compact(int b, int n, int m, long max_rows, in
         return WS3D_E_UNSUPPORTED;
     }
     const dim3 grid((unsigned)((max_rows + 63) / 64));
-    static size_t attr[2] = {0, 0};        // LDS above the default limit: raise the kernel's cap once per size
     if (o1 == 64) {
-        if (lds > 64 * 1024 && attr[0] < lds) { (void)hipFuncSetAttribute((const void *)pgather_gemm3_compact_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[0] = lds; }
+        if (int rc = raise_lds_cap((const void *)pgather_gemm3_compact_kernel<1>, lds, "ws3d_pgather_gemm3_compact")) return rc;
         hipLaunchKernelGGL((pgather_gemm3_compact_kernel<1>), grid, dim3(256), lds, as_stream(stream), o2, o3, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out, out_stride, limit);
     } else {
-        if (lds > 64 * 1024 && attr[1] < lds) { (void)hipFuncSetAttribute((const void *)pgather_gemm3_compact_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[1] = lds; }
+        if (int rc = raise_lds_cap((const void *)pgather_gemm3_compact_kernel<2>, lds, "ws3d_pgather_gemm3_compact")) return rc;
         hipLaunchKernelGGL((pgather_gemm3_compact_kernel<2>), grid, dim3(256), lds, as_stream(stream), o2, o3, n, m, pmat, p_stride, xyz, new_xyz, rowc,
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out, out_stride, limit);
     }

@@ -831,12 +831,7 @@ static int three_nn_launch(int b, int n, int m, const float *unknown, const floa
     if (sorted_known && m >= 3 && m <= SORT_MAX_N) {
         const size_t lds = (size_t)m * sizeof(float4) + (size_t)(BQS_CELLS + 4) * sizeof(int);
         if ((size_t)m * sizeof(float4) <= 64 * 1024) {
-            static bool attr = false;
-            if (!attr) {
-                (void)hipFuncSetAttribute((const void *)three_nn_sorted_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          80 * 1024);
-                attr = true;
-            }
+            if (int rc = raise_lds_cap((const void *)three_nn_sorted_kernel<true>, 80 * 1024, "ws3d_three_nn")) return rc;
             hipLaunchKernelGGL(three_nn_sorted_kernel<true>, dim3((n + 511) / 512, b), dim3(512), lds, as_stream(stream),
                                n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight);
         }

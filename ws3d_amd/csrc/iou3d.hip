@@ -810,12 +810,7 @@ static int mask_launch(int batch, int boxes_num, const float *boxes, float thres
     if (normal) {
         hipLaunchKernelGGL(nms_normal_mask_kernel, grid, dim3(64), 0, st, boxes_num, thresh, full_grid, boxes, mask, la);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)nms_rot_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)sizeof(MaskTileLds));
-            attr_set = true;
-        }
+        if (int rc = raise_lds_cap((const void *)nms_rot_mask_kernel, sizeof(MaskTileLds), what)) return rc;
         if (frames && build_frames) {
             const long total = (long)batch * boxes_num;
             hipLaunchKernelGGL(bev_frames_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total,
@@ -864,8 +859,7 @@ static int sweep_launch(int batch, int n, int max_keep, const uint64_t *mask, in
                         int chunk_limit, const int *done_in, int *done_out, hipStream_t st, const char *what) {
     const size_t smem = sizeof(uint64_t) * (size_t)((n + 63) / 64);
     if (smem > 150 * 1024) { set_error("%s: boxes_num too large for the LDS removed-set", what); return WS3D_E_UNSUPPORTED; }
-    if (smem > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)nms_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (int rc = raise_lds_cap((const void *)nms_sweep_kernel, smem, what)) return rc;
     hipLaunchKernelGGL(nms_sweep_kernel, dim3(batch), dim3(256), smem, st, n, max_keep, mask, keep, num_keep,
                        chunk_limit, done_in, done_out);
     return check_launch(what);
@@ -912,20 +906,11 @@ extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float 
     int pow2 = 2;
     while (pow2 < n) pow2 <<= 1;
     const size_t smem = (size_t)pow2 * sizeof(uint64_t);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)topk_sorted_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr = true;
-    }
+    if (int rc = raise_lds_cap((const void *)topk_sorted_kernel, 128 * 1024, "ws3d_topk_sorted")) return rc;
     hipStream_t st = as_stream(stream);
 #define WS3D_TOPK_REG(E)                                                                                                  \
     do {                                                                                                                  \
-        static bool attr_reg = false;                                                                                     \
-        if (!attr_reg) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void *)topk_sorted_reg_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      128 * 1024);                                                                        \
-            attr_reg = true;                                                                                              \
-        }                                                                                                                 \
+        if (int rc = raise_lds_cap((const void *)topk_sorted_reg_kernel<E>, 128 * 1024, "ws3d_topk_sorted")) return rc;   \
         hipLaunchKernelGGL(topk_sorted_reg_kernel<E>, dim3(b), dim3(1024), smem, st, n, k, scores, out_scores, out_idx);   \
     } while (0)
     switch (pow2) {
@@ -959,11 +944,7 @@ extern "C" int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, flo
     }
     if (k == 0) return WS3D_OK;
     const int nseg = (int)(need / ((size_t)b * TOPK_SEG * sizeof(uint64_t)));
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void *)topk_merge_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr = true;
-    }
+    if (int rc = raise_lds_cap((const void *)topk_merge_rank_kernel, 128 * 1024, "ws3d_topk_sorted")) return rc;
     hipStream_t st = as_stream(stream);
     uint64_t *ws = reinterpret_cast<uint64_t *>(workspace);
     hipLaunchKernelGGL(topk_sort_segments_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)TOPK_SEG * sizeof(uint64_t), st, n, scores, ws, nseg);

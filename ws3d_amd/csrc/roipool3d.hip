@@ -595,8 +595,7 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
                           sizeof(uint16_t) * (size_t)sg * 4 * sampled_pts_num;
 #define WS3D_ROI_PIPE_LAUNCH(SGV, CRV)                                                                                            \
         {                                                                                                                         \
-            if (pm > 64 * 1024)                                                                                                   \
-                (void)hipFuncSetAttribute((const void *)roipool3d_pipe_kernel<SGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pm); \
+            if (int rc = raise_lds_cap((const void *)roipool3d_pipe_kernel<SGV, CRV>, pm, "ws3d_roipool3d")) return rc;            \
             hipLaunchKernelGGL((roipool3d_pipe_kernel<SGV, CRV>), dim3((unsigned)(((boxes_num + 3) / 4) * batch_size)), dim3(256), pm, as_stream(stream), \
                                pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features,   \
                                pooled_empty_flag, pts_idx, fill, batch_size);                                                                 \
@@ -608,9 +607,7 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
     }
 #define WS3D_ROI_LAUNCH(BGV, CRV)                                                                                  \
     {                                                                                                              \
-        if (smem > 64 * 1024)                                                                                      \
-            (void)hipFuncSetAttribute((const void *)roipool3d_kernel<BGV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem);                                                                  \
+        if (int rc = raise_lds_cap((const void *)roipool3d_kernel<BGV, CRV>, smem, "ws3d_roipool3d")) return rc;   \
         hipLaunchKernelGGL((roipool3d_kernel<BGV, CRV>), dim3((unsigned)(((boxes_num + BGV - 1) / BGV) * batch_size)), dim3(256), smem, \
                            as_stream(stream), pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d,   \
                            pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill, batch_size);                        \

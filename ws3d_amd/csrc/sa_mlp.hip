@@ -551,11 +551,12 @@ extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float 
     const unsigned grid = (unsigned)(tiles / 8 < 256 ? (tiles + 7) / 8 : 256);        // one 8-wave workgroup per CU, waves walk over tiles
     const int o2b = o2 <= 32 ? 1 : 2;
     const size_t lds = sizeof(float) * (128 * 128 + 128 * (size_t)(o2b == 1 ? 40 : 72) + 128);
-    auto go = [&](auto kern) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    auto go = [&](auto kern) -> int {
+        if (int rc = raise_lds_cap((const void *)kern, lds, "ws3d_mlp2_rows")) return rc;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, as_stream(stream), tiles, o2, x_rows, w1t, b1, relu1, w2t, b2, relu2, out, ticket);
+        return WS3D_OK;
     };
-    if (o2b == 1) go(mlp2_rows_kernel<1>); else go(mlp2_rows_kernel<2>);
+    if (int rc = o2b == 1 ? go(mlp2_rows_kernel<1>) : go(mlp2_rows_kernel<2>)) return rc;
     return check_launch("ws3d_mlp2_rows");
 }
 

@@ -18,6 +18,18 @@ import torch
 import torch.distributed as dist
 
 
+def _local_device(local: int, world: int, backend: str) -> int:
+    """The device of local rank `local`.  Over RCCL every rank needs a device of its own: more ranks than devices raises instead of
+    wrapping (two ranks on one device hang or fail late inside the collective library).  Only the explicit test mode
+    (backend "gloo": control-flow runs of the multi-rank paths with the ranks sharing a device) wraps."""
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and (world > ndev or local >= ndev):
+        raise RuntimeError("ws3d_amd.dist.init: backend 'nccl' (RCCL) needs one device per rank, but WORLD_SIZE=%d / LOCAL_RANK=%d and "
+                           "this node shows %d device(s); WS3D_DIST_BACKEND=gloo is the test mode that lets ranks share a device"
+                           % (world, local, ndev))
+    return local % max(ndev, 1)
+
+
 def init(backend: str = None) -> Tuple[int, int, int]:
     """Initialise torch.distributed from the torchrun environment.  Returns (world, rank, local)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -31,13 +43,15 @@ def init(backend: str = None) -> Tuple[int, int, int]:
         backend = backend or os.environ.get("WS3D_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if torch.cuda.is_available():
-            local = local % max(torch.cuda.device_count(), 1)
+            local = _local_device(local, world, backend)
             torch.cuda.set_device(local)
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", local)
+        elif backend == "nccl":
+            raise RuntimeError("ws3d_amd.dist.init: backend 'nccl' (RCCL) without a HIP device")
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
-        local = local % max(torch.cuda.device_count(), 1)
+        local = _local_device(local, world, dist.get_backend() if dist.is_initialized() else (backend or "nccl") if world > 1 else "single")
     return world, rank, local
 
 
