@@ -759,7 +759,9 @@ def compact_line(out, detail_path):
     line["roofline"] = roof
     if "cpu_baseline" in out:
         cb = out["cpu_baseline"]
-        line["cpu_baseline"] = {k: (_short(v, 280) if isinstance(v, str) else v) for k, v in cb.items() if k != "host"}
+        line["cpu_baseline"] = {k: (_short(v, 280) if isinstance(v, str) else v) for k, v in cb.items() if k not in ("host", "ms_per_scene_by_part", "search_only")}
+        if isinstance(cb.get("search_only"), dict):
+            line["cpu_baseline"]["search_only_value"] = cb["search_only"].get("value")
         if isinstance(cb.get("host"), dict):
             line["cpu_baseline"]["host_cpu"] = _short(cb["host"].get("cpu", ""), 60)
     lat, c2 = out.get("latency_mode"), out.get("c2")

@@ -404,6 +404,17 @@ class C3:
         return self.B
 
     def cpu_baseline(self, min_seconds=6.0):
+        """Two figures on this box's host cores (the reference has no CPU path for these operators, the oracle port stands in):
+        `value` = the WHOLE step like for like (bench_cpu.whole_step_baseline: search + grouping + SharedMLPs on torch-CPU + proposal
+        stage + NMS + roipool3d, the pooling also through the reference's own compiled `roipool3d_cpu`), and `search_only` = the custom
+        search operators alone (4x FPS, 8x ball_query, 4x three_nn: the figure of rounds 1-4)."""
+        import bench_cpu
+        search = self.cpu_search_only(min_seconds)
+        whole = bench_cpu.whole_step_baseline(self.model, self.cfg, self.pc_host, search, min_seconds)
+        whole["search_only"] = search
+        return whole
+
+    def cpu_search_only(self, min_seconds=6.0):
         """The custom ops of ONE scene's Stage-1 forward on the CPU oracle port (the MLPs are
         torch/BLAS on both sides and are excluded): 4x FPS, 8x ball_query+group, 4x three_nn."""
         import oracle
@@ -426,7 +437,7 @@ class C3:
                 oracle.three_nn_dist2(levels[k - 1], levels[k])
         _, dt, reps = repeat_for(one_pass, min_seconds)
         oracle.set_threads(1)
-        return {"value": ns * reps / dt, "unit": "scenes/s", "cores": threads, "kind": "port", "host": host_info(threads),
+        return {"value": ns * reps / dt, "unit": "scenes/s", "cores": threads, "kind": "port",
                 "sample": f"{ns} scenes (the batch tiled {reps_of_batch}x) x {reps} pass(es): the search ops of the Stage-1 forward "
                           f"only (4 FPS, 8 ball queries, 4 three_nn) "
                           f"on oracle/ws3d_oracle.c with OpenMP, wall {dt:.2f} s; grouping copies and MLPs excluded"}

@@ -1,0 +1,180 @@
+"""(part of bench.py) The WHOLE c3 step on the host, for `cpu_baseline` (like for like).
+
+What the GPU line times -- Stage-1 forward (4 SA-MSG + 4 FP + heads), proposal stage (top 9000, rotated NMS 0.8, top 100) and
+roipool3d -- restated on the CPU: every custom operator on the oracle library (oracle/ws3d_oracle.c, OpenMP; the literal restatement of
+the reference kernels), the SharedMLPs / heads on torch-CPU (the network's own modules moved to the host: the reference runs them on
+the library too), and roipool3d additionally through the REFERENCE's own compiled CPU fallback (`roipool3d_cpu`,
+lib/utils/roipool3d/src/roipool3d.cpp:127-195, built into oracle/_ref by oracle/build_ref.py; one thread, as the reference runs it)
+when that build is present.  Only bench.py's cpu_baseline leg imports this file; nothing of it is on the product path."""
+from __future__ import annotations
+
+import copy
+import os
+import time
+
+import numpy as np
+import torch
+
+
+class Clock:
+    def __init__(self):
+        self.t = {}
+
+    def add(self, key, t0):
+        self.t[key] = self.t.get(key, 0.0) + time.perf_counter() - t0
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _chunked(mod, x, chunk=8):
+    """mod(x) in chunks of `chunk` scenes: bounds the host memory of the (S, C, m, nsample) activations when the batch is tiled"""
+    if x.size(0) <= chunk:
+        return mod(x)
+    return torch.cat([mod(x[i:i + chunk]) for i in range(0, x.size(0), chunk)], dim=0)
+
+
+@torch.no_grad()
+def forward_cpu(model_cpu, cfg, pc, clk: Clock):
+    """(S, N, 4) float32 scenes -> dict of numpy outputs; the dataflow of pointnet2_msg.py:56-70 / pointnet2_modules.py:19-55,116-156"""
+    import oracle
+    bb = model_cpu.rpn.backbone_net
+    xyz = np.ascontiguousarray(pc[:, :, :3])
+    feats = np.ascontiguousarray(pc[:, :, 3:].transpose(0, 2, 1))
+    l_xyz, l_feat = [xyz], [feats]
+    S = xyz.shape[0]
+    for k, sa in enumerate(bb.SA_modules):
+        cur, cf = l_xyz[-1], l_feat[-1]
+        t0 = time.perf_counter()
+        idx = oracle.furthest_point_sample(cur, sa.npoint)
+        new = np.stack([cur[b][idx[b]] for b in range(S)])
+        clk.add("fps", t0)
+        cur_t = np.ascontiguousarray(cur.transpose(0, 2, 1))
+        pooled = []
+        for grouper, mlp in zip(sa.groupers, sa.mlps):
+            t0 = time.perf_counter()
+            nbr = oracle.ball_query(grouper.radius, grouper.nsample, cur, new)
+            clk.add("ball_query", t0)
+            t0 = time.perf_counter()
+            gx = oracle.grouping_operation(cur_t, nbr)
+            gx -= new.transpose(0, 2, 1)[..., None]
+            g = np.concatenate([gx, oracle.grouping_operation(cf, nbr)], axis=1)          # (S, 3 + C, m, ns): xyz first (QueryAndGroup)
+            clk.add("group", t0)
+            t0 = time.perf_counter()
+            pooled.append(_chunked(lambda t: torch.max(mlp(t), dim=3)[0], _t(g)).numpy())
+            clk.add("shared_mlp", t0)
+        l_xyz.append(new)
+        l_feat.append(np.concatenate(pooled, axis=1))
+    for i in range(-1, -(len(bb.FP_modules) + 1), -1):
+        t0 = time.perf_counter()
+        d2, idx = oracle.three_nn_dist2(l_xyz[i - 1], l_xyz[i])
+        dist = np.sqrt(d2)                                                                  # pointnet2_utils.py:122 (three_nn returns sqrt)
+        inv = 1.0 / (dist + np.float32(1e-8))
+        w = (inv / inv.sum(axis=2, keepdims=True)).astype(np.float32)
+        clk.add("three_nn", t0)
+        t0 = time.perf_counter()
+        up = oracle.three_interpolate(l_feat[i], idx, w)
+        stacked = np.concatenate([up, l_feat[i - 1]], axis=1)
+        clk.add("interpolate", t0)
+        t0 = time.perf_counter()
+        l_feat[i - 1] = _chunked(bb.FP_modules[i].mlp, _t(stacked).unsqueeze(-1)).squeeze(-1).numpy()
+        clk.add("shared_mlp", t0)
+    t0 = time.perf_counter()
+    f = _t(l_feat[0])
+    rpn_cls = _chunked(model_cpu.rpn.rpn_cls_layer, f).transpose(1, 2).contiguous()
+    rpn_reg = _chunked(model_cpu.rpn.rpn_reg_layer, f).transpose(1, 2).contiguous()
+    clk.add("heads", t0)
+    return {"backbone_xyz": _t(l_xyz[0]), "backbone_features": f, "rpn_cls": rpn_cls, "rpn_reg": rpn_reg}
+
+
+@torch.no_grad()
+def tail_cpu(out, cfg, clk: Clock, ref_roipool=None):
+    """proposal stage + roipool3d of ws3d_amd.stage1.proposals_from_rpn / roipool3d_ops on the host"""
+    import oracle
+    from ws3d_amd import kitti_utils
+    from ws3d_amd.stage1 import decode_center_target, synthetic_orientation
+    xyz, reg, cls = out["backbone_xyz"], out["rpn_reg"], out["rpn_cls"]
+    S, N, _ = xyz.shape
+    K = cfg.rpn_post_nms_top_n
+    h, w, l = cfg.cls_mean_size
+    t0 = time.perf_counter()
+    score = torch.sigmoid(cls[:, :, 0])
+    centre = decode_center_target(xyz.reshape(S * N, 3), reg.reshape(S * N, -1), cfg.loc_scope, cfg.loc_bin_size).view(S, N, 3)
+    ry = synthetic_orientation(N, xyz.device).unsqueeze(0).expand(S, N)
+    box = torch.stack((centre[..., 0], xyz[..., 1] + h / 2, centre[..., 2], torch.full_like(score, h), torch.full_like(score, w),
+                       torch.full_like(score, l), ry), dim=2)
+    sc, order = torch.topk(score, min(cfg.rpn_pre_nms_top_n, N), dim=1, sorted=True)
+    box = torch.gather(box, 1, order.unsqueeze(-1).expand(S, order.size(1), 7))
+    bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(-1, 7)).view(S, -1, 5).numpy()
+    clk.add("proposals", t0)
+    t0 = time.perf_counter()
+    boxes = np.zeros((S, K, 7), np.float32)
+    for b in range(S):
+        keep = oracle.nms_sorted(bev[b], cfg.rpn_nms_thresh, False)[:K]
+        boxes[b, :len(keep)] = box[b].numpy()[keep]
+    clk.add("nms", t0)
+    enl = kitti_utils.enlarge_box3d(_t(boxes).view(-1, 7), cfg.roi_extra_width).view(S, K, 7).contiguous()
+    feats = out["backbone_features"].transpose(1, 2).contiguous()
+    t0 = time.perf_counter()
+    pooled, empty = oracle.roipool3d(xyz.numpy(), enl.numpy(), feats.numpy(), cfg.roi_sampled_pts)       # the port: OpenMP over boxes
+    clk.add("roipool3d", t0)
+    ref = None
+    if ref_roipool is not None:           # the reference's own CPU fallback, as the reference calls it: one scene per call, one thread
+        C = feats.size(2)
+        t0 = time.perf_counter()
+        for b in range(S):
+            pp = torch.zeros((K, cfg.roi_sampled_pts, 3))
+            pf = torch.zeros((K, cfg.roi_sampled_pts, C))
+            pe = torch.zeros((K,), dtype=torch.int64)
+            ref_roipool(xyz[b].contiguous(), enl[b].contiguous(), feats[b].contiguous(), pp, pf, pe)
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(pp.numpy(), pooled[S - 1, :, :, :3]) and np.array_equal(pf.numpy(), pooled[S - 1, :, :, 3:])
+                    and np.array_equal(pe.numpy().astype(np.int32), empty[S - 1]))
+        ref = {"ms_per_scene": dt / S * 1e3, "threads": 1, "equals_the_port": same}
+    return boxes, pooled, empty, ref
+
+
+def load_reference_roipool():
+    """oracle/_ref's `roipool3d_cpu` (the reference's compiled C++), or None when the build is absent on this box"""
+    try:
+        from oracle import build_ref
+        return build_ref.load().roipool3d_cpu
+    except Exception:
+        return None
+
+
+def whole_step_baseline(model, cfg, pc_host, search_only, min_seconds=6.0):
+    """-> cpu_baseline dict: the whole c3 step on this box's host cores, as seconds per scene of its parts, each measured where it can
+    use every core: the SEARCH operators (4 FPS, 8 ball queries, 4 three_nn; OpenMP over scenes / centres) from `search_only` (the
+    batch tiled to one scene per core: bench_c3.C3.cpu_search_only), everything else on the batch itself -- grouping copies and
+    interpolation (OpenMP), SharedMLPs / heads (torch's intra-op pool), top-9000 + rotated NMS (the 9000-box mask is OpenMP over rows)
+    + roipool3d (OpenMP over boxes).  value = 1 / (sum of the parts' seconds per scene).  A bounded sample: one forward pass, one
+    proposal stage (the 8 x 40 M rotated-IoU masks of the literal restatement are ~10 s of a 128-core host)."""
+    import oracle
+    from bench import host_info
+    threads = max(1, min(oracle.max_threads(), len(os.sched_getaffinity(0))))
+    oracle.set_threads(threads)
+    torch_threads = torch.get_num_threads()
+    model_cpu = copy.deepcopy(model).cpu().eval()
+    ref_roipool = load_reference_roipool()
+    B = pc_host.shape[0]
+    clk_f, clk_t = Clock(), Clock()
+    t0 = time.perf_counter()
+    out = forward_cpu(model_cpu, cfg, pc_host, clk_f)
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = tail_cpu(out, cfg, clk_t, ref_roipool)[3]
+    t_tail = time.perf_counter() - t0 - (ref["ms_per_scene"] * B * 1e-3 if ref else 0.0)     # (the extra reference pooling pass is not part of the step)
+    oracle.set_threads(1)
+    parts = {k: v / B for k, v in clk_f.t.items() if k not in ("fps", "ball_query", "three_nn")}
+    parts.update({k: v / B for k, v in clk_t.t.items()})
+    parts["search (fps + ball_query + three_nn, one scene per core)"] = 1.0 / search_only["value"]
+    per_scene = sum(parts.values())
+    return {"value": 1.0 / per_scene, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "sample": "WHOLE step, every part on all %d cores, as s per scene: search operators from search_only (batch tiled to one scene "
+                      "per core) + on the batch of %d scenes one forward pass (grouping, interpolation: oracle/ws3d_oracle.c with OpenMP; "
+                      "SharedMLPs / heads: torch-CPU, %d threads; %.1f s) and one proposal stage (top-9000, rotated NMS, roipool3d; %.1f s)"
+                      % (threads, B, torch_threads, t_fwd, t_tail),
+            "ms_per_scene_by_part": {k: round(v * 1e3, 3) for k, v in sorted(parts.items(), key=lambda kv: -kv[1])},
+            "reference_roipool3d_cpu": ref, "host": host_info(threads)}

@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""Golden fixture for the HEADLINE workload, end to end ("missing" 3 / "next" 6): the 8 `hdl64` scenes bench.py's c3
+step times (bench_c3.C3: seeds 1000*3 + s, weights seeded_state_dict(.., 7)) through the REFERENCE's own Python --
+
+    PointRCNN.rpn_forward                                   lib/net/point_rcnn.py, lib/net/rpn.py:67-81, pointnet2_msg.py:56-70
+    decode_center_target                                    lib/utils/bbox_transform.py:24-61
+    boxes3d_to_bev_torch + iou3d_utils.nms_gpu              lib/utils/kitti_utils.py, lib/utils/iou3d/iou3d_utils.py:59-73
+        at RPN_PRE_NMS_TOP_N 9000 / RPN_NMS_THRESH 0.8 / RPN_POST_NMS_TOP_N 100         tools/cfgs/weaklyRPN.yaml:105-107
+    roipool3d_utils.roipool3d_gpu (extra width 1.0, 512 points)                         lib/utils/roipool3d/roipool3d_utils.py:7-28
+
+imported from /root/reference where it lies and run on the CPU (build container only; the reference never travels).  Its CUDA leaf
+extensions are backed by the CPU oracle exactly as in make_golden.py (install_reference_shims); roipool3d is ADDITIONALLY run through
+the reference's own compiled C++ (`roipool3d_cpu`, oracle/_ref) and must agree bit for bit.
+
+WS3D's Stage-1 regresses centres only (no size / heading), so -- as in ws3d_amd.stage1.proposals_from_rpn, whose docstring is the
+specification -- a proposal is the decoded centre with CLS_MEAN_SIZE and the fixed pseudo-random heading of its point index
+(stage1.synthetic_orientation: part of the workload definition, a function of the index alone), y_bottom = y_point + h / 2.
+
+What is stored (data only): per level the FPS index tensors (sha256 per scene + the first 64 indices), the sha256 of the eight
+ball-query tensors, samples of the four network outputs, per scene the 100 kept point indices + scores in keep order, and per kept
+proposal a ROBUSTNESS record that lets a float32 implementation with other summation orders be compared fairly:
+  * `score_gap`  : distance of the proposal's score to the nearest score among the candidates whose BEV IoU with it exceeds 0.5 (a flip
+                   of their order could change which of the two survives), and to the 9000-th score;
+  * `iou_margin` : min | IoU - 0.8 | over the pairs the greedy sweep decided for this proposal (pairs with the boxes kept before it);
+  * `face_margin`: smallest distance of any scene point to a face of the ENLARGED box (membership flips only within that distance);
+and of the pooled tensor, per RoI: the empty flag, the pooled points' INDICES (first 512 in-box point indices in index order, wrapped --
+roipool3d_kernel.cu:97-160; recovered from the pooled xyz rows), and 8 sampled feature values."""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import oracle  # noqa: E402
+from oracle import build_ref  # noqa: E402
+from make_golden import REF, _np, install_reference_shims, sha  # noqa: E402
+from ws3d_amd import synth  # noqa: E402
+from ws3d_amd.seeded import seeded_state_dict  # noqa: E402
+from ws3d_amd.stage1 import synthetic_orientation  # noqa: E402
+
+B, N, PRE, POST, THRESH, EXTRA, S = 8, 16384, 9000, 100, 0.8, 1.0, 512
+
+
+def main():
+    install_reference_shims()
+    oracle.set_threads(min(oracle.max_threads(), len(os.sched_getaffinity(0))))
+    from pointnet2_lib.pointnet2 import pointnet2_utils as ref_utils
+    from lib.config import cfg, cfg_from_file
+    from lib.utils.iou3d import iou3d_utils as ref_iou
+    from lib.utils.roipool3d import roipool3d_utils as ref_roi
+    from lib.utils.bbox_transform import decode_center_target as ref_decode
+    from lib.utils import kitti_utils as ref_kitti
+    cfg_from_file(os.path.join(REF, "tools", "cfgs", "weaklyRPN.yaml"))
+    from lib.net.point_rcnn import PointRCNN
+    assert cfg.TEST.RPN_PRE_NMS_TOP_N == PRE and cfg.TEST.RPN_POST_NMS_TOP_N == POST and abs(cfg.TEST.RPN_NMS_THRESH - THRESH) < 1e-9
+    assert cfg.RPN.NUM_POINTS == N and cfg.RCNN.POOL_EXTRA_WIDTH == EXTRA and cfg.RCNN.NUM_POINTS == S
+
+    model = PointRCNN(num_classes=2, use_xyz=True, mode='TEST').eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    pc = synth.make_batch("hdl64", B, N, 3)                      # = bench_c3.C3(...).pc_host on rank 0, slot 0
+    pts = torch.from_numpy(pc)
+    taps = {"fps": [], "bq": []}
+
+    def tap_fps(orig):
+        def f(xyz_, npoint):
+            r = orig(xyz_, npoint)
+            taps["fps"].append(_np(r).astype(np.int32))
+            return r
+        return f
+
+    def tap_bq(orig):
+        def f(radius, nsample, xyz_, new_xyz_):
+            r = orig(radius, nsample, xyz_, new_xyz_)
+            taps["bq"].append(sha(_np(r).astype(np.int32)))
+            return r
+        return f
+
+    ref_utils.furthest_point_sample, ref_utils.ball_query = tap_fps(ref_utils.furthest_point_sample), tap_bq(ref_utils.ball_query)
+    with torch.no_grad():
+        out = model.rpn_forward({'pts_input': pts})
+    fx = {}
+    meta = {"generator": "tests/golden/make_golden_headline.py", "kind": "hdl64", "config_id": 3, "batch": B, "n": N, "weights_seed": 7,
+            "pre_nms": PRE, "nms_thresh": THRESH, "post_nms": POST, "extra_width": EXTRA, "sampled": S,
+            "oracle_dist_mode": oracle.dist_mode(), "ball_query_sha256": taps["bq"], "fps_sha256": [], "outputs": {}}
+    for lvl, a in enumerate(taps["fps"]):
+        meta["fps_sha256"].append([sha(a[b]) for b in range(B)])
+        fx["fps_head_%d" % lvl] = a[:, :64].copy()
+    rng = np.random.default_rng(5)
+    for name in ("rpn_cls", "rpn_reg", "backbone_xyz", "backbone_features"):
+        arr = _np(out[name])
+        pos = rng.integers(0, arr.size, 2048)
+        fx[name + "_pos"], fx[name + "_val"] = pos.astype(np.int64), arr.reshape(-1)[pos]
+        meta["outputs"][name] = {"shape": list(arr.shape), "abs_mean": float(np.abs(arr).mean())}
+
+    # ---- proposal stage through the reference's functions
+    h, w, l = [float(v) for v in cfg.CLS_MEAN_SIZE[0]]
+    xyz, reg, cls = out["backbone_xyz"], out["rpn_reg"], out["rpn_cls"]
+    ry = synthetic_orientation(N, torch.device("cpu"))
+    kept_idx = np.full((B, POST), -1, np.int64)
+    kept_score = np.zeros((B, POST), np.float32)
+    count = np.zeros((B,), np.int32)
+    score_gap = np.zeros((B, POST), np.float32)
+    iou_margin = np.zeros((B, POST), np.float32)
+    boxes_all = np.zeros((B, POST, 7), np.float32)
+    cut_score = np.zeros((B,), np.float32)
+    for b in range(B):
+        score = torch.sigmoid(cls[b, :, 0])
+        centre = ref_decode(xyz[b], reg[b], cfg.RPN.LOC_SCOPE, cfg.RPN.LOC_BIN_SIZE)
+        box = torch.stack((centre[:, 0], xyz[b, :, 1] + h / 2, centre[:, 2], torch.full_like(score, h), torch.full_like(score, w),
+                           torch.full_like(score, l), ry), dim=1)
+        sc, order = torch.topk(score, PRE, sorted=True)
+        cand = box[order]
+        bev = ref_kitti.boxes3d_to_bev_torch(cand)
+        keep = ref_iou.nms_gpu(bev, sc, THRESH)[:POST]                   # positions in the score-sorted candidate list
+        k = keep.numel()
+        count[b] = k
+        kept_idx[b, :k] = _np(order[keep])
+        kept_score[b, :k] = _np(sc[keep])
+        boxes_all[b, :k] = _np(cand[keep])
+        cut_score[b] = float(sc[-1])
+        # robustness record of every kept proposal
+        bev_np, sc_np = _np(bev), _np(sc)
+        kp = _np(keep)
+        iou_rows = oracle.boxes_iou_bev(bev_np[kp], bev_np)              # (k, 9000)
+        for j, p in enumerate(kp):
+            near = np.nonzero(iou_rows[j] > 0.5)[0]
+            near = near[near != p]
+            gap = np.abs(sc_np[near] - sc_np[p]).min() if near.size else 1.0
+            score_gap[b, j] = min(gap, sc_np[p] - sc_np[-1])
+            iou_margin[b, j] = np.abs(iou_rows[j][kp[:j]] - THRESH).min() if j else 1.0
+    fx.update(kept_idx=kept_idx, kept_score=kept_score, count=count, score_gap=score_gap, iou_margin=iou_margin, cut_score=cut_score)
+
+    # ---- RoI pooling: the reference wrapper (oracle-backed leaf) AND the reference's compiled C++ CPU twin
+    boxes_t = torch.from_numpy(boxes_all)
+    feats = out["backbone_features"].permute(0, 2, 1).contiguous()       # (B, N, C)
+    pooled, empty = ref_roi.roipool3d_gpu(xyz, feats, boxes_t, EXTRA, sampled_pt_num=S)
+    pooled, empty = _np(pooled), _np(empty).astype(np.int32)
+    enl = ref_kitti.enlarge_box3d(boxes_t.view(-1, 7), EXTRA).view(B, POST, 7).contiguous()
+    p2 = torch.zeros((B, POST, S, 3 + feats.shape[2]))
+    e2 = torch.zeros((B, POST), dtype=torch.int32)
+    for b in range(B):       # roipool_pc_cpu -> roipool3d_cuda.roipool3d_cpu = the reference's compiled C++ (roipool3d.cpp:127-195), one scene per call
+        pp, pf, pe = ref_roi.roipool_pc_cpu(xyz[b], feats[b], enl[b], S)
+        p2[b], e2[b] = torch.cat((pp, pf), dim=2), pe.int()
+    twin = bool(np.array_equal(_np(p2), pooled) and np.array_equal(_np(e2), empty))
+    assert twin, "the reference's compiled roipool3d_cpu disagrees with the oracle-backed wrapper"
+    meta["roipool_checked_against_reference_cpu_twin"] = twin
+    # pooled point indices per RoI, recovered from the pooled xyz rows (every scene point's coordinates are distinct enough: checked)
+    pool_idx = np.full((B, POST, S), -1, np.int32)
+    face_margin = np.ones((B, POST), np.float32)
+    xyz_np, enl_np = _np(xyz), _np(enl)
+    for b in range(B):
+        key = {xyz_np[b, i].tobytes(): i for i in range(N - 1, -1, -1)}      # lowest index wins for exact duplicates
+        for m in range(int(count[b])):
+            if empty[b, m]:
+                continue
+            rows = pooled[b, m, :, :3]
+            pool_idx[b, m] = [key[rows[s].tobytes()] for s in range(S)]
+            # distance of every point to the nearest face of the enlarged box (roipool3d_kernel.cu:14-28: |y - cy| <= h/2 with
+            # cy = bottom_y - h/2, x_rot = dx cos + dz (-sin) in [-l/2, l/2], z_rot = dx sin + dz cos in [-w/2, w/2]); the coarse
+            # max_dis test only rejects points that fail the exact one
+            cx, by, cz, bh, bw, bl, r = enl_np[b, m].astype(np.float64)
+            dx, dz, dy = xyz_np[b, :, 0] - cx, xyz_np[b, :, 2] - cz, xyz_np[b, :, 1] - (by - bh / 2)
+            xr, zr = dx * np.cos(r) - dz * np.sin(r), dx * np.sin(r) + dz * np.cos(r)
+            gx, gy, gz = np.abs(xr) - bl / 2, np.abs(dy) - bh / 2, np.abs(zr) - bw / 2       # > 0 outside along that axis
+            inside = (gx <= 0) & (gy <= 0) & (gz <= 0)
+            # a point changes side only by crossing a face: inside -> its smallest clearance; outside -> its largest excess
+            flip = np.where(inside, np.minimum(np.minimum(-gx, -gy), -gz), np.maximum(np.maximum(gx, gy), gz))
+            face_margin[b, m] = float(flip.min())
+    fx.update(pool_idx=pool_idx, empty=empty, face_margin=face_margin)
+    fpos = rng.integers(0, S * feats.shape[2], (B, POST, 8))
+    fx["pool_feat_pos"] = fpos.astype(np.int32)
+    fx["pool_feat_val"] = np.take_along_axis(pooled[..., 3:].reshape(B, POST, -1), fpos, axis=2)
+    meta["kept_total"] = int(count.sum())
+    meta["non_empty_rois"] = int((empty[np.arange(POST)[None, :] < count[:, None]] == 0).sum())
+    np.savez_compressed(os.path.join(HERE, "headline_c3.npz"), **fx)
+    json.dump(meta, open(os.path.join(HERE, "headline_c3.json"), "w"), indent=1)
+    for f in ("headline_c3.npz", "headline_c3.json"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+    print("count", count.tolist(), "non-empty", meta["non_empty_rois"], "min score_gap", float(score_gap[kept_idx >= 0].min()),
+          "min iou_margin", float(iou_margin[kept_idx >= 0].min()))
+
+
+if __name__ == "__main__":
+    main()
