@@ -47,9 +47,9 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
-#define WS3D_ABI_VERSION 4
+#define WS3D_ABI_VERSION 5
 WS3D_API int ws3d_abi_version(void);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
  * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
@@ -167,6 +167,13 @@ WS3D_API int ws3d_three_nn_weights(long rows, const float *dist2, float *weight,
  * two-launch form, bit for bit): what the FP modules of ws3d_amd/fastpath.py call.                              */
 WS3D_API int ws3d_three_nn_w(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
                              const void *sorted_known, ws3d_stream_t stream);
+/* ws3d_three_nn_w with its QUERIES taken in cell order: sorted_unknown = a binned copy of `unknown` (ws3d_sort_points_x / _grid / _xz
+ * of the same tensor, any flavour: only its n float4 {x, y, z, bits(index)} per scene are read) or NULL.  Lane i searches for the
+ * i-th binned point and writes row bits(index): the rows of dist2 / idx / weight are those of ws3d_three_nn_w bit for bit (a
+ * query's result does not depend on the lane that runs it; interpolate_gpu.cu:9-52), the lanes of a wave walk cells of similar
+ * density.  Applies to the binned search (sorted_known given, 3 <= m <= 16384); 0 < n <= 16384 when sorted_unknown is given. */
+WS3D_API int ws3d_three_nn_wq(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
+                              const void *sorted_known, const void *sorted_unknown, ws3d_stream_t stream);
 
 /* The SA module's pool over nsample (pointnet2_modules.py:50, F.max_pool2d(kernel_size=[1, nsample]))
  * with the position of the maximum kept for the backward pass.  x (rows, nsample) -- the contiguous

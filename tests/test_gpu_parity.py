@@ -523,6 +523,16 @@ def test_three_nn_binned_search_bit_exact(ops, oracle, B, n, m, kind, seed):
     np.testing.assert_array_equal(host(i2b), host(i2))
     dist, idx = ops.pn.three_nn(dev(unk), dev(kn), srt)
     np.testing.assert_array_equal(host(idx), idx_ref)
+    # queries taken in the cell order of a binned copy of the UNKNOWN set (ws3d_three_nn_wq), every flavour of that copy: the rows
+    # of idx / weight are those of the plain call, bit for bit
+    i_plain, w_plain = ops.c.three_nn_with_weights(dev(unk), dev(kn), grid)
+    np.testing.assert_array_equal(host(i_plain), idx_ref)
+    for q_order in (ops.c.sort_points_x(dev(unk), min_n=1), ops.c.sort_points_x(dev(unk), min_n=1, grid=False), ops.c.sort_points_xz(dev(unk), min_n=1)):
+        if q_order is None:
+            continue
+        for binned in (srt, grid):
+            i_q, w_q = ops.c.three_nn_with_weights(dev(unk), dev(kn), binned, q_order)
+            assert torch.equal(i_q, i_plain) and torch.equal(w_q, w_plain)
 
 
 def test_three_interpolate_and_grad(ops, oracle):

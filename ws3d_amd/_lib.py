@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B 
     _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
 E_INVALID, E_LAUNCH, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4      # WS3D_E_* of include/ws3d_ops.h
-ABI_VERSION = 4     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
+ABI_VERSION = 5     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -71,6 +71,7 @@ SIGNATURES = {
     "ws3d_topk_sorted_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_three_nn_weights": (_i, [C.c_long, _vp, _vp, _vp]),
     "ws3d_three_nn_w": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_nn_wq": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_rowmax_bias_act": (_i, [_i, _i, C.c_long, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),

@@ -281,10 +281,11 @@ def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=Tru
     return out
 
 
-def three_nn_with_weights(unknown, known, sorted_known=None):
+def three_nn_with_weights(unknown, known, sorted_known=None, sorted_unknown=None):
     """unknown (B,N,3), known (B,M,3) -> (idx (B,N,3) int32, weight (B,N,3)): three_nn + the FP module's
     normalised inverse-distance weights in ONE launch (ws3d_three_nn_w: the weights are the search kernel's epilogue; bit-identical
-    to three_nn_wrapper + ws3d_three_nn_weights).  ws3d extension."""
+    to three_nn_wrapper + ws3d_three_nn_weights).  sorted_unknown: a binned copy of `unknown` (sort_points_x / sort_points_xz of the
+    same tensor): the queries are then taken in cell order (ws3d_three_nn_wq; same rows).  ws3d extension."""
     dev = _dev(unknown, known)
     _f32(unknown, "unknown"); _f32(known, "known")
     B, N, M = unknown.size(0), unknown.size(1), known.size(1)
@@ -293,8 +294,12 @@ def three_nn_with_weights(unknown, known, sorted_known=None):
     w = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
     lib = _lib.load()
     with _on(dev):
-        check(lib.ws3d_three_nn_w(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx), _p(w),
-                                  _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn_w")
+        if sorted_unknown is not None and sorted_known is not None:
+            check(lib.ws3d_three_nn_wq(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx), _p(w), _p(sorted_known), _p(sorted_unknown),
+                                       _stream()), "three_nn_wq")
+        else:
+            check(lib.ws3d_three_nn_w(B, N, M, _p(unknown), _p(known), _p(d2), _p(idx), _p(w),
+                                      _p(sorted_known) if sorted_known is not None else None, _stream()), "three_nn_w")
     return idx, w
 
 

@@ -188,10 +188,11 @@ __global__ __launch_bounds__(1024) void bin_points_xz_kernel(int n, const float 
 template <bool LDS>
 __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, const float *__restrict__ unknown,
                                                               const char *__restrict__ ws,
-                                                              float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight) {
+                                                              float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight,
+                                                              const char *__restrict__ wsq) {
     extern __shared__ __attribute__((aligned(16))) char smem_nn[];
     const int b = blockIdx.y;
-    const int pi = blockIdx.x * 512 + threadIdx.x;
+    int pi = blockIdx.x * 512 + threadIdx.x;
     const char *base = ws + (size_t)b * bin_scene_stride(m);
     const float4 *sorted = reinterpret_cast<const float4 *>(base);
     const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)m * 16);
@@ -208,8 +209,18 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
         __syncthreads();
     }
     if (pi >= n) return;
-    const float *u = unknown + ((size_t)b * n + pi) * 3;
-    const float ux = u[0], uy = u[1], uz = u[2];
+    float ux, uy, uz;
+    if (wsq) {
+        // queries in CELL order: lane pi takes the pi-th point of a binned copy of the unknown set (any flavour: n float4
+        // {x, y, z, bits(index)} per scene) and writes its row at that index -- the lanes of a wave then walk cells of similar
+        // density and end their searches together (each query's result does not depend on which lane runs it)
+        const float4 q = reinterpret_cast<const float4 *>(wsq + (size_t)b * bin_scene_stride(n))[pi];
+        ux = q.x; uy = q.y; uz = q.z;
+        pi = __float_as_int(q.w);
+    } else {
+        const float *u = unknown + ((size_t)b * n + pi) * 3;
+        ux = u[0]; uy = u[1]; uz = u[2];
+    }
     const float slack = hdr.inv_w > 0.f ? 2.0f / hdr.inv_w : INFINITY;   // two cell widths, see above
 
     float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
@@ -807,7 +818,7 @@ extern "C" int ws3d_sort_points_xz(int b, int n, const float *xyz, void *sorted,
 }
 
 static int three_nn_launch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
-                           const void *sorted_known, ws3d_stream_t stream);
+                           const void *sorted_known, ws3d_stream_t stream, const void *sorted_unknown = nullptr);
 
 extern "C" int ws3d_three_nn(int b, int n, int m, const float *unknown, const float *known,
                              float *dist2, int32_t *idx, const void *sorted_known, ws3d_stream_t stream) {
@@ -820,8 +831,18 @@ extern "C" int ws3d_three_nn_w(int b, int n, int m, const float *unknown, const 
     return three_nn_launch(b, n, m, unknown, known, dist2, idx, weight, sorted_known, stream);
 }
 
+extern "C" int ws3d_three_nn_wq(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
+                                const void *sorted_known, const void *sorted_unknown, ws3d_stream_t stream) {
+    if (!weight) { ws3d::set_error("ws3d_three_nn_wq: weight is NULL"); return WS3D_E_INVALID; }
+    if (sorted_unknown && (n <= 0 || n > ws3d::SORT_MAX_N)) {
+        ws3d::set_error("ws3d_three_nn_wq: sorted_unknown needs 0 < n <= %d (n=%d)", ws3d::SORT_MAX_N, n);
+        return WS3D_E_INVALID;
+    }
+    return three_nn_launch(b, n, m, unknown, known, dist2, idx, weight, sorted_known, stream, sorted_unknown);
+}
+
 static int three_nn_launch(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
-                           const void *sorted_known, ws3d_stream_t stream) {
+                           const void *sorted_known, ws3d_stream_t stream, const void *sorted_unknown) {
     using namespace ws3d;
     if (b < 0 || n < 0 || m < 0 || !unknown || (!known && m > 0) || !dist2 || !idx) {
         set_error("ws3d_three_nn: invalid argument (b=%d n=%d m=%d)", b, n, m);
@@ -833,11 +854,13 @@ static int three_nn_launch(int b, int n, int m, const float *unknown, const floa
         if ((size_t)m * sizeof(float4) <= 64 * 1024) {
             if (int rc = raise_lds_cap((const void *)three_nn_sorted_kernel<true>, 80 * 1024, "ws3d_three_nn")) return rc;
             hipLaunchKernelGGL(three_nn_sorted_kernel<true>, dim3((n + 511) / 512, b), dim3(512), lds, as_stream(stream),
-                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight);
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight,
+                               reinterpret_cast<const char *>(sorted_unknown));
         }
         else
             hipLaunchKernelGGL(three_nn_sorted_kernel<false>, dim3((n + 511) / 512, b), dim3(512), 0, as_stream(stream),
-                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight);
+                               n, m, unknown, reinterpret_cast<const char *>(sorted_known), dist2, idx, weight,
+                               reinterpret_cast<const char *>(sorted_unknown));
         return check_launch("ws3d_three_nn(sorted)");
     }
     hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m,

@@ -75,6 +75,7 @@ FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first laye
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
 # the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
 GRID_MIN_N = 256
+QUERY_CELL_ORDER = True   # 3-NN: queries taken in the cell order of the level's binned copy (ws3d_three_nn_wq; same rows, -15-30 % per search)
 PARALLEL_SCALES = True  # eager side-stream mode: the second scale of a level beside the first
 PARALLEL_HEADS = True  # ... and the regression head beside the classification head + top-k
 
@@ -352,7 +353,8 @@ class _Geometry:
                 self.sa_ready.append(ev)
             self.nn, self.nn_ready = [None] * len(sas), [None] * len(sas)
             for i in range(len(sas) - 1, -1, -1):
-                self.nn[i] = _C.three_nn_with_weights(self.xyz[i], self.xyz[i + 1], pn2_ops.sort_points_xz(self.xyz[i + 1]))
+                self.nn[i] = _C.three_nn_with_weights(self.xyz[i], self.xyz[i + 1], pn2_ops.sort_points_xz(self.xyz[i + 1]),
+                                                      self.sorted[i] if QUERY_CELL_ORDER else None)
                 ev = torch.cuda.Event()
                 ev.record(s_search)
                 self.nn_ready[i] = ev
@@ -369,8 +371,9 @@ class _Geometry:
             s.wait_event(done)
 
 
-def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None):
-    """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O)"""
+def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None, binned: list = None):
+    """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O); `binned` (a list) receives the level's binned
+    copy of xyz (or None): the FP module of this level takes its 3-NN queries in that order"""
     B = xyz.size(0)
     c_feat = 0 if feats is None else feats.size(2)
     if geo is not None:
@@ -387,6 +390,8 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
         sorted_xyz = pn2_ops.sort_points_x(xyz, GRID_MIN_N)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat, zeros)
+    if binned is not None:
+        binned.append(sorted_xyz)
     widths = [_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps]
     if not COMPACT_PAIRS:
         out = torch.empty((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
@@ -528,10 +533,12 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
     return new_xyz, out.view(B, sa.npoint, -1)
 
 
-def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None):
-    """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O)"""
+def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None, sorted_unknown=None):
+    """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O); sorted_unknown: a binned
+    copy of `unknown` (the level's ball-query copy) for the 3-NN's query order"""
     B, n = unknown.size(0), unknown.size(1)
-    idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known))
+    idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known),
+                                                                        sorted_unknown if QUERY_CELL_ORDER else None)
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
     blocks = _blocks(fp.mlp)
@@ -588,10 +595,10 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
     # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
     ahead = _geometry_ahead_now() and (GEOMETRY_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
-    l_xyz, l_feats = [xyz], [feats]
+    l_xyz, l_feats, binned = [xyz], [feats], []
     try:
         for level, sa in enumerate(net.SA_modules):
-            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros)
+            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned)
             l_xyz.append(nx)
             l_feats.append(nf)
         for i in range(-1, -(len(net.FP_modules) + 1), -1):
@@ -600,7 +607,7 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
                 lvl = len(l_xyz) + i - 1                                   # unknown level of this module
                 geo.main.wait_event(geo.nn_ready[lvl])
                 nn3 = geo.nn[lvl]
-            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3)
+            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3, binned[len(l_xyz) + i - 1])
     finally:
         if geo is not None:       # also when a layer raised: the side streams' tensors go back to their pools behind the caller's stream
             geo.release()
