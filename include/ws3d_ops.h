@@ -47,7 +47,7 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 5
 WS3D_API int ws3d_abi_version(void);
@@ -510,6 +510,18 @@ WS3D_API int ws3d_roipool3d_fill(int batch_size, int pts_num, int boxes_num, int
                    int sampled_pts_num, const float *xyz, const float *boxes3d,
                    const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
                    int32_t *pts_idx, ws3d_stream_t stream);
+
+/* ws3d_roipool3d / ws3d_roipool3d_fill (fill != 0) with a caller-provided scratch buffer: for scenes of
+ * ws3d_roipool3d_workspace_bytes(batch, pts_num) > 0 bytes (16384 <= pts_num <= 262144) the scene is counting-sorted once into an
+ * (x, z) grid inside `workspace` and every box tests only the cells under its footprint (roipool3d.hip: roi_bin_kernel +
+ * roipool3d_binned_kernel; the first-S-by-point-index rule of roipool3d_kernel.cu:97-160 is kept by a radix select on the index).
+ * Same outputs as ws3d_roipool3d bit for bit; workspace NULL / too small / not applicable: the scanning kernels run.
+ * 16-byte aligned, contents undefined on return; nothing is allocated or synchronised.  ws3d extension (round 5, ABI 5). */
+WS3D_API size_t ws3d_roipool3d_workspace_bytes(int batch_size, int pts_num);
+WS3D_API int ws3d_roipool3d_ws(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num, const float *xyz,
+                               const float *boxes3d, const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
+                               int32_t *pts_idx, int fill, void *workspace, size_t workspace_bytes, ws3d_stream_t stream);
+
 
 /* Device twin of pts_in_boxes3d_cpu (roipool3d.cpp:97-124): pts (N,3), boxes3d (M,7)
  * -> flag (M,N) int64 in {0,1}.                                                      */

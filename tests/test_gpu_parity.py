@@ -605,6 +605,61 @@ def test_roipool3d_bit_exact(ops, oracle, B, n, m, c, s, cfg):
     np.testing.assert_array_equal(host(bp), rp)
 
 
+def test_roipool3d_degenerate_scenes(ops, oracle):
+    """scenes that stress the binned variant's grid and its radix select (and are just as valid for the scanning kernels): all points
+    on one x / one z / one spot, NaN and inf coordinates, exact duplicates, a box far outside the cloud, boxes holding far more than
+    S points whose indices are scattered (the first S BY INDEX must come out, wrap-padded when fewer), S not a power of two"""
+    rng = np.random.default_rng(77)
+    N, M, C = 40000, 24, 8
+    base = synth.make_batch("lidar", 1, N, 45)[0, :, :3].copy()
+    car = synth.random_boxes3d(15, (1000 * 45) * 7919 + 13)
+    scenes = []
+    a = base.copy(); a[:, 0] = 3.25; scenes.append(a)                                  # one x: a single grid column
+    a = base.copy(); a[:, 2] = 30.0; scenes.append(a)                                  # one z: a single grid row
+    a = base.copy(); a[:] = (1.0, 1.2, 20.0); scenes.append(a)                          # one spot
+    a = base.copy(); a[::7, 0] = np.nan; a[3::11, 2] = np.inf; a[5::13, 1] = -np.inf; a[9::17, 0] = -np.inf; scenes.append(a)
+    a = base.copy(); a[N // 2:] = a[:N // 2][rng.permutation(N // 2)]; scenes.append(a)       # every point twice, scattered
+    a = base.copy(); k = rng.permutation(N)[:6000]; a[k] = car[0, :3] + rng.uniform(-0.4, 0.4, (6000, 3)).astype(np.float32) - (0, 0.8, 0); scenes.append(a)   # 6000 scattered indices inside one box
+    xyz = np.ascontiguousarray(np.stack(scenes).astype(np.float32))
+    B = xyz.shape[0]
+    boxes = synth.proposal_boxes(B, M, 45)
+    boxes[:, :8] = car[:8]
+    boxes[:, 8] = (3.25, 1.7, 30.0, 1.6, 1.7, 4.0, 0.3)
+    boxes[:, 9] = (1.0, 2.0, 20.0, 1.6, 1.7, 4.0, -1.2)
+    boxes[:, 10] = (500.0, 1.7, -300.0, 1.6, 1.7, 4.0, 0.0)                          # nowhere near the cloud
+    boxes[:, 11] = (0.0, 1.7, 30.0, 2.0, 19.0, 19.0, 0.7)                            # wider than the 10 m window
+    boxes[:, 12] = (0.0, 1.7, 30.0, 2.0, 3.0, 5.0, np.pi / 2)                        # cos = 6e-8: one constraint per axis
+    boxes[:, 13] = (0.0, 1.7, 30.0, 2.0, 3.0, 5.0, 0.0)
+    boxes[0, 14, 6] = np.nan
+    boxes[0, 15, 0] = np.inf
+    feat = rng.standard_normal((B, N, C)).astype(np.float32)
+    for S in (512, 4, 700):
+        ref_p, ref_e, ref_s = oracle.roipool3d(xyz, boxes, feat, S, return_idx=True)
+        for fn, init in ((ops.c.roipool3d_forward, 0.0), (ops.c.roipool3d_forward_fill, float("nan"))):
+            pooled = torch.full((B, M, S, 3 + C), init, device="cuda")
+            empty = torch.zeros((B, M), dtype=torch.int32, device="cuda")
+            sel = torch.full((B, M, S), -5, dtype=torch.int32, device="cuda")
+            fn(dev(xyz), dev(boxes), dev(feat), pooled, empty, sel)
+            np.testing.assert_array_equal(host(empty), ref_e)
+            np.testing.assert_array_equal(host(sel), ref_s)
+            got = host(pooled)
+            assert np.array_equal(got, ref_p, equal_nan=True)
+    assert (ref_e == 0).any() and (ref_e == 1).any()
+
+
+@pytest.mark.parametrize("min_n", ["64", "0"])
+def test_roipool3d_other_variant_subprocess(min_n):
+    """every roipool3d test of this file once more with the OTHER kernel family on all sizes: WS3D_ROI_BINNED=64 sends every scene of
+    >= 64 points through roi_bin_kernel + roipool3d_binned_kernel (default: from 16384 points on), WS3D_ROI_BINNED=0 none"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-k", "roipool3d and not subprocess"],
+                       env=dict(os.environ, WS3D_ROI_BINNED=min_n), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
 def test_roipool3d_boxes_wider_than_the_ten_metre_window(ops, oracle):
     """pt_in_box3d drops points more than 10 m from the box centre in x or z before the rotated test (roipool3d_kernel.cu:18-20).
     The kernels leave those two terms out for boxes whose BEV half-diagonal is under 9.9 m (they cannot decide anything there);

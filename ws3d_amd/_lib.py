@@ -99,6 +99,8 @@ SIGNATURES = {
     "ws3d_select_proposals": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_roipool3d_fill": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_roipool3d_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "ws3d_roipool3d_ws": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     "ws3d_pts_in_boxes3d": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
 }
 

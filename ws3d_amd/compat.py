@@ -1018,30 +1018,31 @@ def nms_mask(boxes, thresh, normal=False, full_grid=False):
 
 
 # ------------------------------------------------------------------ roipool3d_cuda
-def roipool3d_forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx=None):
-    """roipool3d.cpp:48-79 (forward) == :15-44 (forward_slow)"""
+def _roipool3d(fill, xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx):
     dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
     _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
     _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
+    lib = _lib.load()
+    B, N = xyz.size(0), xyz.size(1)
     with _on(dev):
-        check(_lib.load().ws3d_roipool3d(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
-                                          pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
-                                          _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
-              "roipool3d")
+        # large scenes: a scratch buffer for the binned copy of the scene (ws3d_roipool3d_ws; from the caching allocator: stream-ordered,
+        # capturable); small ones: 0 bytes, the scanning kernels
+        nbytes = lib.ws3d_roipool3d_workspace_bytes(B, N)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+        check(lib.ws3d_roipool3d_ws(B, N, boxes3d.size(1), pts_feature.size(2), pooled_features.size(2), _p(xyz), _p(boxes3d),
+                                    _p(pts_feature), _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), int(fill),
+                                    _p(ws), nbytes, _stream()), "roipool3d")
     return 1
+
+
+def roipool3d_forward(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx=None):
+    """roipool3d.cpp:48-79 (forward) == :15-44 (forward_slow)"""
+    return _roipool3d(0, xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
 
 
 def roipool3d_forward_fill(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx=None):
     """roipool3d_forward that writes every output element (outputs need not be pre-zeroed).  ws3d extension."""
-    dev = _dev(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
-    _f32(xyz, "xyz"); _f32(boxes3d, "boxes3d"); _f32(pts_feature, "pts_feature")
-    _f32(pooled_features, "pooled_features"); _i32(pooled_empty_flag, "pooled_empty_flag")
-    with _on(dev):
-        check(_lib.load().ws3d_roipool3d_fill(xyz.size(0), xyz.size(1), boxes3d.size(1), pts_feature.size(2),
-                                               pooled_features.size(2), _p(xyz), _p(boxes3d), _p(pts_feature),
-                                               _p(pooled_features), _p(pooled_empty_flag), _p(pts_idx), _stream()),
-              "roipool3d_fill")
-    return 1
+    return _roipool3d(1, xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag, pts_idx)
 
 
 def pts_in_boxes3d_device(pts, boxes3d):

@@ -542,6 +542,332 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// ---- the binned variant (round 5): the scene is counting-sorted ONCE into an (x, z) grid, a box then tests only the cells its
+// footprint covers.  Why: at config 5 (65536 points, 512 boxes per scene) every workgroup of the scanning kernels streams the whole
+// 786 KB scene out of L2 and runs 65536 box tests per box -- 1.6 GB of L2 reads and 2 x 10^9 tests per launch, a lock-step scan
+// phase of 0.26 ms beside a copy phase of 0.25 ms.  A box's enlarged footprint (~6 x 3.6 m) holds ~2,800 points of such a scene.
+//   * The scene is cut into CHUNKS of ROI_CH consecutive point indices, each binned on its own (one workgroup per chunk: the points
+//     stay in registers between the count and the scatter, no cross-workgroup step).  The grid covers the union of the boxes'
+//     footprints only -- the boxes are an input -- and points outside it are dropped: they lie in no box.
+//   * The reference's result is ORDER dependent -- the first S in-box points in point-index order, wrap-padded
+//     (roipool3d_kernel.cu:97-160) -- and a cell list is not in index order, so the selection is a radix select on the index:
+//       pass 1  chunk by chunk, every in-box candidate counts into one of 256 index buckets (bucket = index >> shift); chunks are
+//               index ranges, so the pass ends with the chunk at which the count reaches S (the scanning kernels' early exit);
+//       scan    T = the first bucket at which the running count reaches S (or the last one): buckets < T are taken whole;
+//       pass 2  the candidates of buckets <= T are placed bucket by bucket (<= S - 1 + bucket width of them);
+//       rank    inside its bucket every index counts the smaller ones: position = bucket offset + rank; positions < S are the list.
+// Exact for any input: the in-box test is pt_in_frame itself (same arithmetic as the scanning kernels), the cells visited are a
+// conservative cover of the footprint (roi_row_range), and a point's cell is computed by the same roi_coord in both kernels.
+
+constexpr int ROI_CH = 8192;          // points per chunk
+constexpr int ROI_CELLS = 4096;       // grid cells per chunk
+struct RoiBinHeader { float xmin, inv_wx, zmin, inv_wz; int gx, gz, kept, pad; };    // 32 bytes
+
+__host__ __device__ inline size_t roi_chunk_stride() { return (size_t)ROI_CH * 16 + sizeof(RoiBinHeader) + (size_t)(ROI_CELLS + 4) * sizeof(int); }
+__host__ __device__ inline int roi_chunks(int n) { return (n + ROI_CH - 1) / ROI_CH; }
+__host__ __device__ inline size_t roi_bin_scene_stride(int n) { return (size_t)roi_chunks(n) * roi_chunk_stride(); }
+
+__device__ __forceinline__ int roi_coord(float v, float vmin, float inv_w, int cells) {      // monotone non-decreasing; NaN -> 0
+    const float t = (v - vmin) * inv_w;
+    return t > 0.f ? (t < (float)(cells - 1) ? (int)t : cells - 1) : 0;
+}
+
+// bounding interval of a box's footprint along x and z, and the slack every range of this variant carries.  An in-box point
+// satisfies |x_rot| <= hl, |z_rot| <= hw up to the rounding of the test (relative 2^-22 of |dx| + |dz|); `pad` (1e-3 m + 1e-5 of
+// the magnitudes) is four orders of magnitude above that.  The |dx|, |dz| <= 10 terms of the test bound a box that is not `small`.
+__device__ __forceinline__ void roi_footprint(const BoxFrame &f, bool small, float &ex, float &ez, float &pad) {
+    ex = fabsf(f.cosa) * f.hl + fabsf(f.sina) * f.hw;
+    ez = fabsf(f.sina) * f.hl + fabsf(f.cosa) * f.hw;
+    if (!small) { ex = fminf(ex, 10.0f); ez = fminf(ez, 10.0f); }
+    pad = 1e-3f + 1e-5f * (fabsf(f.cx) + fabsf(f.cz) + ex + ez);
+}
+
+// one workgroup per chunk of ROI_CH points: grid over the union of the scene's box footprints, histogram, scan, scatter.
+// chunk layout: [ROI_CH x {x, y, z, bits(index)}][RoiBinHeader][gx * gz + 1 cell starts]
+__global__ __launch_bounds__(1024) void roi_bin_kernel(int n, int boxes_num, const float *__restrict__ xyz, const float *__restrict__ boxes3d,
+                                                       char *__restrict__ ws) {
+    __shared__ int hist[ROI_CELLS];
+    __shared__ float red[4][16];
+    __shared__ int wsum[16];
+    const int ch = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    xyz += (size_t)b * n * 3;
+    boxes3d += (size_t)b * boxes_num * 7;
+    char *base = ws + (size_t)b * roi_bin_scene_stride(n) + (size_t)ch * roi_chunk_stride();
+    float4 *sorted = reinterpret_cast<float4 *>(base);
+    RoiBinHeader *hdr = reinterpret_cast<RoiBinHeader *>(base + (size_t)ROI_CH * 16);
+    int *start = reinterpret_cast<int *>(base + (size_t)ROI_CH * 16 + sizeof(RoiBinHeader));
+    // ---- the points of the chunk: ONE coalesced 12-byte load each, kept in registers until the scatter
+    constexpr int PPT = ROI_CH / 1024;
+    const int i0 = ch * ROI_CH;
+    float px[PPT], py[PPT], pz[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int i = i0 + u * 1024 + tid;
+        const f3v p = *reinterpret_cast<const f3u *>(xyz + (size_t)min(i, n - 1) * 3);
+        px[u] = i < n ? p.x : __builtin_nanf(""); py[u] = p.y; pz[u] = p.z;          // NaN: dropped below
+    }
+    // ---- union of the footprints of the scene's boxes (every workgroup of the scene computes the same numbers)
+    float lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
+    for (int m = tid; m < boxes_num; m += 1024) {
+        const BoxFrame f = make_frame(boxes3d + (size_t)m * 7);
+        float ex, ez, pad;
+        roi_footprint(f, frame_is_small(f), ex, ez, pad);
+        const float x0 = f.cx - ex - 2.0f * pad, x1 = f.cx + ex + 2.0f * pad, z0 = f.cz - ez - 2.0f * pad, z1 = f.cz + ez + 2.0f * pad;
+        // a box with a non-finite centre, extent or angle holds no point (its test compares NaN or inf): it claims no cell
+        if (fabsf(x0) < INFINITY && fabsf(x1) < INFINITY && fabsf(z0) < INFINITY && fabsf(z1) < INFINITY) {
+            lo_x = fminf(lo_x, x0); hi_x = fmaxf(hi_x, x1); lo_z = fminf(lo_z, z0); hi_z = fmaxf(hi_z, z1);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo_x = fminf(lo_x, __shfl_xor(lo_x, o)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
+        lo_z = fminf(lo_z, __shfl_xor(lo_z, o)); hi_z = fmaxf(hi_z, __shfl_xor(hi_z, o));
+    }
+    if (lane == 0) { red[0][w] = lo_x; red[1][w] = hi_x; red[2][w] = lo_z; red[3][w] = hi_z; }
+    for (int i = tid; i < ROI_CELLS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+        lo_x = fminf(lo_x, red[0][i]); hi_x = fmaxf(hi_x, red[1][i]);
+        lo_z = fminf(lo_z, red[2][i]); hi_z = fmaxf(hi_z, red[3][i]);
+    }
+    const bool none = !(lo_x <= hi_x) || !(lo_z <= hi_z);                           // no box claims a cell: every point is dropped
+    if (none) { lo_x = hi_x = lo_z = hi_z = 0.f; }
+    // near-square cells, gx * gz <= ROI_CELLS; a degenerate extent gives one cell along that axis
+    const float wx = hi_x - lo_x, wz = hi_z - lo_z;
+    int gx = 1, gz = 1;
+    if (wx > 0.f && wz > 0.f) {
+        const float cs = sqrtf(wx * wz / (float)(ROI_CELLS - 128));
+        gx = max(1, min(ROI_CELLS, (int)(wx / cs) + 1));
+        gz = max(1, min(ROI_CELLS / gx, (int)(wz / cs) + 1));
+    } else if (wx > 0.f) gx = ROI_CELLS / 4;
+    else if (wz > 0.f) gz = ROI_CELLS / 4;
+    const float inv_wx = wx > 0.f ? (float)gx / wx : 0.f, inv_wz = wz > 0.f ? (float)gz / wz : 0.f;
+    const int cells = gx * gz;
+    int cell[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const bool keep = !none && px[u] >= lo_x && px[u] <= hi_x && pz[u] >= lo_z && pz[u] <= hi_z;       // false for NaN
+        cell[u] = keep ? roi_coord(pz[u], lo_z, inv_wz, gz) * gx + roi_coord(px[u], lo_x, inv_wx, gx) : -1;
+        if (keep) atomicAdd(&hist[cell[u]], 1);
+    }
+    __syncthreads();
+    // exclusive scan of hist[0 .. cells): 4 consecutive cells per thread, wave scan, 16 wave totals
+    constexpr int CPT = ROI_CELLS / 1024;
+    int v[CPT], run = 0;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) { v[u] = run; run += (tid * CPT + u < cells) ? hist[tid * CPT + u] : 0; }
+    int inc = run;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int i = 0; i < 16; ++i) { if (i < w) woff += wsum[i]; total += wsum[i]; }
+    const int excl = woff + inc - run;
+#pragma unroll
+    for (int u = 0; u < CPT; ++u)
+        if (tid * CPT + u < cells) { hist[tid * CPT + u] = excl + v[u]; start[tid * CPT + u] = excl + v[u]; }
+    if (tid == 0) {
+        start[cells] = total;
+        RoiBinHeader h; h.xmin = lo_x; h.inv_wx = inv_wx; h.zmin = lo_z; h.inv_wz = inv_wz; h.gx = gx; h.gz = gz; h.kept = total; h.pad = 0;
+        *hdr = h;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PPT; ++u)
+        if (cell[u] >= 0) sorted[atomicAdd(&hist[cell[u]], 1)] = make_float4(px[u], py[u], pz[u], __int_as_float(i0 + u * 1024 + tid));
+}
+
+// the candidate range of grid row r for a box frame: cells [c0, c1] of that row, or c0 > c1 when the row cannot hold an in-box point.
+// Conservative by construction: an in-box point's dx, dz lie in the rectangle inflated by `pad` (roi_footprint); the row's z-slab is
+// widened by `slack` cells on both sides against the rounding of roi_coord's own product (the first / last row reach to -inf / +inf:
+// roi_coord clamps); each of the rectangle's two linear constraints gives, over the slab, a lower / upper bound on dx at an end of
+// the slab -- the larger of the lower ones, the smaller of the upper ones -- inside the bounding interval [-ex, ex]; roi_coord is
+// monotone, so every x inside [cx + lo, cx + hi] falls into a cell of [c0, c1].
+__device__ __forceinline__ void roi_row_range(const BoxFrame &f, const RoiBinHeader &h, bool small, float ex, float pad, int r, int &c0, int &c1) {
+    float lo = -ex - pad, hi = ex + pad;
+    if (small) {       // (a box that is not `small` -- BEV half-diagonal >= 9.9 m, or non-finite extents -- keeps the bounding interval)
+        const float cw = h.inv_wz > 0.f ? 1.0f / h.inv_wz : INFINITY;
+        const float slack = 0.01f + 2e-6f * (float)r;            // cells: above the rounding of roi_coord's product for any row index
+        float za = r == 0 ? -INFINITY : h.zmin + ((float)r - slack) * cw - f.cz - pad;
+        float zb = r == h.gz - 1 ? INFINITY : h.zmin + ((float)r + 1.0f + slack) * cw - f.cz + pad;
+        const float c = f.cosa, s = f.sina, hl = f.hl + pad, hw = f.hw + pad;
+        const float ez = fabsf(s) * hl + fabsf(c) * hw + pad;   // the slab clipped to the footprint's own z-extent: finite products
+        za = fmaxf(za, -ez); zb = fminf(zb, ez);
+        if (!(za <= zb)) { c0 = 1; c1 = 0; return; }
+        if (fabsf(c) > 1e-3f) {        // |dx c - dz s| <= hl  ->  dx c in [-hl + dz s, hl + dz s]
+            const float a0 = (-hl + za * s) / c, a1 = (-hl + zb * s) / c, b0 = (hl + za * s) / c, b1 = (hl + zb * s) / c;
+            lo = fmaxf(lo, c > 0.f ? fminf(a0, a1) : fminf(b0, b1));
+            hi = fminf(hi, c > 0.f ? fmaxf(b0, b1) : fmaxf(a0, a1));
+        }
+        if (fabsf(s) > 1e-3f) {        // |dx s + dz c| <= hw  ->  dx s in [-hw - dz c, hw - dz c]
+            const float a0 = (-hw - za * c) / s, a1 = (-hw - zb * c) / s, b0 = (hw - za * c) / s, b1 = (hw - zb * c) / s;
+            lo = fmaxf(lo, s > 0.f ? fminf(a0, a1) : fminf(b0, b1));
+            hi = fminf(hi, s > 0.f ? fmaxf(b0, b1) : fmaxf(a0, a1));
+        }
+        if (!(lo <= hi)) { c0 = 1; c1 = 0; return; }
+    }
+    c0 = roi_coord(f.cx + lo - pad, h.xmin, h.inv_wx, h.gx);
+    c1 = roi_coord(f.cx + hi + pad, h.xmin, h.inv_wx, h.gx);
+}
+
+constexpr int ROI_ROWS_MAX = 256;      // grid rows of one box with a cell range of their own (more: the box takes every kept point of a chunk)
+
+template <int CR>
+__global__ __launch_bounds__(256) void roipool3d_binned_kernel(int pts_num, int boxes_num, int feat_len, int S, int shift,
+                                                               const float *__restrict__ xyz, const char *__restrict__ ws,
+                                                               const float *__restrict__ boxes3d, const float *__restrict__ pts_feature,
+                                                               float *__restrict__ pooled, int32_t *__restrict__ empty_flag,
+                                                               int32_t *__restrict__ pts_idx, int fill, int batch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int row = 3 + feat_len;
+    float *stage = reinterpret_cast<float *>(smem);                                 // 2 * CR * row
+    int *sel = reinterpret_cast<int *>(stage + 2 * CR * row);                       // S
+    int *G = sel + S;                                                               // S + (1 << shift)
+    __shared__ int hist[256], pref[257], rc0[ROI_ROWS_MAX], rc1[ROI_ROWS_MAX], rbeg[ROI_ROWS_MAX], rend[ROI_ROWS_MAX];
+    __shared__ int s_K, s_T, s_cnt;
+    int b, m;
+    roi_scene_group(batch, boxes_num, b, m);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const size_t bm = (size_t)b * boxes_num + m;
+    xyz += (size_t)b * pts_num * 3;
+    pts_feature += (size_t)b * pts_num * feat_len;
+    const char *scene = ws + (size_t)b * roi_bin_scene_stride(pts_num);
+    const RoiBinHeader h = *reinterpret_cast<const RoiBinHeader *>(scene + (size_t)ROI_CH * 16);      // the grid is the same in every chunk of a scene
+    const int chunks = roi_chunks(pts_num);
+    const BoxFrame f = make_frame(boxes3d + bm * 7);
+    const bool small = frame_is_small(f);
+    float ex, ez, pad;
+    roi_footprint(f, small, ex, ez, pad);
+    const int r0 = roi_coord(f.cz - ez - 2.0f * pad, h.zmin, h.inv_wz, h.gz), r1 = roi_coord(f.cz + ez + 2.0f * pad, h.zmin, h.inv_wz, h.gz);
+    const bool whole = r1 - r0 + 1 > ROI_ROWS_MAX;                // a box over more rows than the table holds: every kept point is a candidate
+    const int nrows = whole ? 1 : r1 - r0 + 1;
+    hist[tid] = 0;
+    if (tid == 0) s_cnt = 0;
+    if (!whole)
+        for (int r = tid; r < nrows; r += 256) {
+            int c0, c1;
+            roi_row_range(f, h, small, ex, pad, r0 + r, c0, c1);
+            rc0[r] = c0; rc1[r] = c1;
+        }
+    __syncthreads();
+    // the segments (row ranges) of one chunk -> rbeg / rend
+    auto segments = [&](int ch) {
+        const int *start = reinterpret_cast<const int *>(scene + (size_t)ch * roi_chunk_stride() + (size_t)ROI_CH * 16 + sizeof(RoiBinHeader));
+        if (whole) { if (tid == 0) { rbeg[0] = 0; rend[0] = start[h.gx * h.gz]; } }
+        else
+            for (int r = tid; r < nrows; r += 256) {
+                const int c0 = rc0[r], c1 = rc1[r];
+                const bool any = c0 <= c1;
+                rbeg[r] = any ? start[(r0 + r) * h.gx + c0] : 0;
+                rend[r] = any ? start[(r0 + r) * h.gx + c1 + 1] : 0;
+            }
+    };
+    auto sweep = [&](int ch, auto &&hit) {
+        const float4 *sorted = reinterpret_cast<const float4 *>(scene + (size_t)ch * roi_chunk_stride());
+        for (int r = w; r < nrows; r += 4) {
+            const int e = rend[r];
+            for (int i = rbeg[r] + lane; i < e; i += 64) {
+                const float4 p = sorted[i];
+                const bool in = small ? pt_in_frame<true>(f, p.x, p.y, p.z) : pt_in_frame<false>(f, p.x, p.y, p.z);
+                if (in) hit(__float_as_int(p.w));
+            }
+        }
+    };
+    // ---- pass 1: chunk by chunk (ascending index ranges), in-box candidates count into their index bucket, until S are found
+    int used = 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        segments(ch);
+        __syncthreads();
+        int mine = 0;
+        sweep(ch, [&](int k) { atomicAdd(&hist[k >> shift], 1); ++mine; });
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (lane == 0 && mine) atomicAdd(&s_cnt, mine);
+        __syncthreads();
+        used = ch + 1;
+        if (s_cnt >= S) break;                                     // workgroup-uniform
+    }
+    if (w == 0) {          // inclusive scan of the 256 buckets (4 per lane), T = first bucket whose running count reaches S
+        const int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const int tot = h0 + h1 + h2 + h3;
+        int inc = tot;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        const int ex0 = inc - tot;
+        pref[4 * lane] = ex0; pref[4 * lane + 1] = ex0 + h0; pref[4 * lane + 2] = ex0 + h0 + h1; pref[4 * lane + 3] = ex0 + h0 + h1 + h2;
+        if (lane == 63) { pref[256] = inc; s_K = inc; }
+        const uint64_t reach = __builtin_amdgcn_ballot_w64(inc >= S);
+        if (reach == 0) { if (lane == 0) s_T = 255; }
+        else if (lane == __builtin_ctzll(reach)) {
+            int T = 4 * lane + 3;
+            if (ex0 + h0 >= S) T = 4 * lane; else if (ex0 + h0 + h1 >= S) T = 4 * lane + 1; else if (ex0 + h0 + h1 + h2 >= S) T = 4 * lane + 2;
+            s_T = T;
+        }
+    }
+    __syncthreads();
+    const int K = s_K, T = s_T;
+    if (K == 0) {      // roipool3d_kernel.cu:147-149,181-183: flag the box, leave its rows untouched
+        if (tid == 0) empty_flag[bm] = 1;
+        if (pts_idx)
+            for (int q = tid; q < S; q += 256) pts_idx[bm * S + q] = 0;
+        if (fill) {
+            float4v *o = reinterpret_cast<float4v *>(pooled + bm * (size_t)S * row);
+            const float4v zero = {0.f, 0.f, 0.f, 0.f};
+            for (int q = tid; q < (S * row) >> 2; q += 256) o[q] = zero;
+        }
+        return;
+    }
+    if (fill && tid == 0) empty_flag[bm] = 0;
+    hist[tid] = pref[tid];                                        // cursors
+    __syncthreads();
+    // ---- pass 2: the candidates of buckets <= T, placed bucket by bucket (chunks past the bucket's index range hold none)
+    const int last_idx = ((T + 1) << shift) - 1;
+    for (int ch = 0; ch < used && ch * ROI_CH <= last_idx; ++ch) {
+        if (used > 1 || ch > 0) { __syncthreads(); segments(ch); __syncthreads(); }       // (one chunk used: its segments are still in place)
+        sweep(ch, [&](int k) { const int bk = k >> shift; if (bk <= T) G[atomicAdd(&hist[bk], 1)] = k; });
+    }
+    __syncthreads();
+    // ---- rank inside the bucket -> the list in index order; then wrap-pad (duplicate_idx = k % cnt, roipool3d_kernel.cu:153-157)
+    const int taken = pref[T + 1], cnt = min(K, S);
+    for (int p = tid; p < taken; p += 256) {
+        const int v = G[p], bk = v >> shift, lo = pref[bk], hi = pref[bk + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; ++q) rank += G[q] < v ? 1 : 0;
+        if (lo + rank < S) sel[lo + rank] = v;
+    }
+    __syncthreads();
+    for (int q = cnt + tid; q < S; q += 256) sel[q] = sel[q % cnt];
+    __syncthreads();
+    if (pts_idx)
+        for (int q = tid; q < S; q += 256) pts_idx[bm * S + q] = sel[q];
+    // ---- copy: the S x (3+C) block through LDS in stretches of CR rows (see roipool3d_kernel's copy phase)
+    float *out = pooled + bm * (size_t)S * row;
+    const int half = tid >> 5, l32 = tid & 31, f4 = feat_len >> 2;
+    constexpr int RPH = CR / 8;
+    for (int c0 = 0, it = 0; c0 < S; c0 += CR, ++it) {
+        float *st = stage + (it & 1) * CR * row;
+        const int nr = min(CR, S - c0);
+        float4v v[RPH];
+        float p3[RPH];
+#pragma unroll
+        for (int u = 0; u < RPH; ++u) {
+            const int src = sel[min(c0 + half * RPH + u, S - 1)];
+            if (l32 < f4) v[u] = reinterpret_cast<const float4v *>(pts_feature + (size_t)src * feat_len)[l32];
+            if (l32 < 3) p3[u] = xyz[(size_t)src * 3 + l32];
+        }
+#pragma unroll
+        for (int u = 0; u < RPH; ++u) {
+            const int r = half * RPH + u;
+            if (r < nr) {
+                if (l32 < f4) *reinterpret_cast<float4u *>(st + r * row + 3 + 4 * l32) = v[u];
+                if (l32 < 3) st[r * row + l32] = p3[u];
+            }
+        }
+        __syncthreads();
+        float4v *o4 = reinterpret_cast<float4v *>(out + (size_t)c0 * row);
+        const int units = (nr * row) >> 2;
+        for (int q = tid; q < units; q += 256)
+            __builtin_nontemporal_store(*reinterpret_cast<const float4v *>(st + 4 * q), o4 + q);
+    }
+}
+
 __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int pts_num,
                                                              const float *__restrict__ pts,
                                                              const float *__restrict__ boxes3d,
@@ -556,10 +882,22 @@ __global__ __launch_bounds__(256) void pts_in_boxes3d_kernel(int boxes_num, int 
 
 }  // namespace ws3d
 
+// scenes the binned variant takes (bytes of its workspace, 0: not applicable): large enough that the grid pays, indices that fit
+// 256 buckets of <= 1024
+static size_t roi_binned_bytes(int batch_size, int pts_num) {
+    static const int env = getenv("WS3D_ROI_BINNED") ? atoi(getenv("WS3D_ROI_BINNED")) : -1;     // 0: off; N > 0: from N points on (A/B runs)
+    const int min_n = env > 0 ? env : 16384;      // c3 (16384 points, 100 boxes): +1 % of the step; c5 (65536, 512): 0.365 -> 0.265 ms
+    if (env == 0 || pts_num < min_n || pts_num > 256 * 1024 || batch_size <= 0) return 0;
+    return (size_t)batch_size * ws3d::roi_bin_scene_stride(pts_num);
+}
+
+extern "C" size_t ws3d_roipool3d_workspace_bytes(int batch_size, int pts_num) { return roi_binned_bytes(batch_size, pts_num); }
+
 static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feature_in_len,
                             int sampled_pts_num, const float *xyz, const float *boxes3d,
                             const float *pts_feature, float *pooled_features,
-                            int32_t *pooled_empty_flag, int32_t *pts_idx, int fill, ws3d_stream_t stream) {
+                            int32_t *pooled_empty_flag, int32_t *pts_idx, int fill, ws3d_stream_t stream,
+                            void *workspace = nullptr, size_t workspace_bytes = 0) {
     using namespace ws3d;
     if (batch_size < 0 || pts_num < 0 || boxes_num < 0 || feature_in_len < 0 || sampled_pts_num <= 0 ||
         !xyz || !boxes3d || (!pts_feature && feature_in_len > 0) || !pooled_features || !pooled_empty_flag) {
@@ -584,6 +922,22 @@ static int roipool3d_launch(int batch_size, int pts_num, int boxes_num, int feat
     if (smem > 150 * 1024 || batch_size > 65535) {
         set_error("ws3d_roipool3d: sampled_pts_num=%d / batch=%d unsupported", sampled_pts_num, batch_size);
         return WS3D_E_UNSUPPORTED;
+    }
+    // large scenes with a workspace: bin the scene once, every box tests the cells under its footprint only
+    const size_t need = roi_binned_bytes(batch_size, pts_num);
+    if (workspace && need > 0 && workspace_bytes >= need && cr > 0 && (sampled_pts_num & 3) == 0 && sampled_pts_num <= 2048 &&
+        (long)batch_size * boxes_num < (1L << 31) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0) {
+        int shift = 0;
+        while ((256 << shift) < pts_num) ++shift;
+        const int crb = 16;
+        const size_t lds = sizeof(float) * 2 * (size_t)crb * row + sizeof(int) * ((size_t)2 * sampled_pts_num + ((size_t)1 << shift));
+        hipLaunchKernelGGL(roi_bin_kernel, dim3(roi_chunks(pts_num), batch_size), dim3(1024), 0, as_stream(stream), pts_num, boxes_num, xyz, boxes3d,
+                           reinterpret_cast<char *>(workspace));
+        if (int rc = raise_lds_cap((const void *)roipool3d_binned_kernel<16>, lds, "ws3d_roipool3d")) return rc;
+        hipLaunchKernelGGL((roipool3d_binned_kernel<16>), dim3((unsigned)((long)batch_size * boxes_num)), dim3(256), lds, as_stream(stream),
+                           pts_num, boxes_num, feature_in_len, sampled_pts_num, shift, xyz, reinterpret_cast<const char *>(workspace), boxes3d,
+                           pts_feature, pooled_features, pooled_empty_flag, pts_idx, fill, batch_size);
+        return check_launch("ws3d_roipool3d(binned)");
     }
     // large scenes, 4 boxes per workgroup: the variant that overlaps scan and copy inside the workgroup
     static const int pipe_env = getenv("WS3D_ROI_PIPE") ? atoi(getenv("WS3D_ROI_PIPE")) : -1;   // 0: off; 1 / 2: boxes per pass
@@ -633,6 +987,13 @@ extern "C" int ws3d_roipool3d_fill(int batch_size, int pts_num, int boxes_num, i
                                    int32_t *pooled_empty_flag, int32_t *pts_idx, ws3d_stream_t stream) {
     return roipool3d_launch(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
                             pooled_features, pooled_empty_flag, pts_idx, 1, stream);
+}
+
+extern "C" int ws3d_roipool3d_ws(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num, const float *xyz,
+                                 const float *boxes3d, const float *pts_feature, float *pooled_features, int32_t *pooled_empty_flag,
+                                 int32_t *pts_idx, int fill, void *workspace, size_t workspace_bytes, ws3d_stream_t stream) {
+    return roipool3d_launch(batch_size, pts_num, boxes_num, feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature,
+                            pooled_features, pooled_empty_flag, pts_idx, fill ? 1 : 0, stream, workspace, workspace_bytes);
 }
 
 extern "C" int ws3d_pts_in_boxes3d(int boxes_num, int pts_num, const float *pts, const float *boxes3d,
