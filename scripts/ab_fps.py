@@ -1,4 +1,4 @@
-"""A/B timing of furthest_point_sample shapes (env WS3D_FPS_IMPL=2|3, WS3D_FPS_GEOM3, WS3D_FPS_PAIR read by the library).
+"""A/B timing of furthest_point_sample shapes (env WS3D_FPS_BUCKET / WS3D_FPS_ROUNDS / WS3D_FPS_PAIR read by the library: INTEGRATION.md 4.1).
     python scripts/ab_fps.py [tag]  ->  one line per shape: ms per launch (median of 7), us per step"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,25 +1,21 @@
-"""Random-shape check of the round-2 matrix-core kernels against float64: ws3d_gemm_pool under every output tile, ws3d_mlp2_rows
-(ticket counter), ws3d_interp_gemm under every output tile, and the per-point first layers (ws3d_pgather_gemm2 /
-ws3d_pgather_rows / ws3d_qinterp_rows, every fourth round).
-The tile is a load-time switch, so each tile runs in its own process:  fuzz_mfma2.py --seconds 60  spawns them."""
+"""Random-shape check of the matrix-core kernels against float64: ws3d_gemm_pool, ws3d_mlp2_rows (ticket counter), ws3d_interp_gemm
+and the per-point first layers (ws3d_pgather_gemm2 / ws3d_pgather_rows / ws3d_qinterp_rows, every fourth round).  The output tile is
+chosen by the library from the shape (the per-tile environment switches of round 2 are gone): every third round draws
+a LARGE shape (>= 512 tiles of 128 x 128: rows >= 16384 at o = 512) so that the big-tile dispatch of gemm_pool / interp_gemm is hit
+as well as the small-tile one.    python scripts/fuzz_mfma2.py --seconds 60 [--seed S]"""
 import argparse, os, subprocess, sys, time
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60); ap.add_argument("--seed", type=int, default=0)
-ap.add_argument("--child", default=None)
 a = ap.parse_args()
-if a.child is None:
-    rc = 0
-    for tile in ("11", "21", "12", "22"):
-        env = dict(os.environ, WS3D_GP_TILE=tile, WS3D_IG_TILE=tile)
-        rc |= subprocess.call([sys.executable, __file__, "--child", tile, "--seconds", str(a.seconds / 4), "--seed", str(a.seed)], env=env)
-    sys.exit(rc)
+a.child = "0"
 import numpy as np, torch
 from ws3d_amd import compat as c, synth
-rng = np.random.default_rng(a.seed + int(a.child))
+rng = np.random.default_rng(a.seed)
 pc_all = torch.from_numpy(synth.make_batch("lidar", 8, 16384, 5)[:, :, :3].copy()).cuda()
 t0, rounds, worst = time.time(), 0, {"gemm_pool": 0.0, "mlp2_rows": 0.0, "interp_gemm": 0.0}
 while time.time() - t0 < a.seconds:
     # gemm_pool: rows a multiple of 64 (sometimes of 128 / 256), so both the forced tile and its fallback are hit
-    ns = int(rng.choice([16, 32])); rows = 64 * int(rng.integers(1, 80)); k = 4 * int(rng.integers(1, 150)); o = 64 * int(rng.integers(1, 9))
+    big = rounds % 3 == 2
+    ns = int(rng.choice([16, 32])); rows = 64 * int(rng.integers(256, 400) if big else rng.integers(1, 80)); k = 4 * int(rng.integers(1, 150)); o = 512 if big else 64 * int(rng.integers(1, 9))
     x = torch.randn(rows, k, device="cuda"); wt = torch.randn(k, o, device="cuda") * 0.1
     bias = torch.randn(o, device="cuda") if rng.random() < 0.8 else None
     relu = bool(rng.random() < 0.7)
@@ -48,7 +44,8 @@ while time.time() - t0 < a.seconds:
     assert e < 1e-5, ("mlp2_rows", rows, o2, e)
     # interp_gemm
     B = int(rng.choice([1, 2, 8])); N = 64 * int(rng.integers(1, 40)); M = max(3, N // int(rng.choice([2, 4, 8])))
-    C2 = 4 * int(rng.integers(1, 100)); C1 = int(rng.choice([0, 1, 5, 32, 96])); O = 64 * int(rng.integers(1, 7))
+    if big: B, N, M = 8, 64 * int(rng.integers(160, 256)), 2048
+    C2 = 4 * int(rng.integers(1, 100)); C1 = int(rng.choice([0, 1, 5, 32, 96])); O = 512 if big else 64 * int(rng.integers(1, 7))
     unknown = pc_all[:B, :N].contiguous(); known = unknown[:, :M].contiguous()
     kf = torch.randn(B, M, C2, device="cuda"); uf = torch.randn(B, N, C1, device="cuda") if C1 else None
     idx, weight = c.three_nn_with_weights(unknown, known, None)

@@ -12,7 +12,7 @@ for KIND in $KINDS; do
 for b in 512 8; do
   for c in SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE; do
     rm -rf /tmp/pv_$c
-    (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pv_$c -o pv -- python $OLDPWD/bench.py --workload c2 --kind $KIND --batch $b --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/log_${b}_$c.txt 2>&1)
+    (cd /tmp && timeout 200 rocprofv3 --pmc $c --kernel-trace -d /tmp/pv_$c -o pv -- python $OLDPWD/bench.py --workload c2 --kind $KIND --batch $b --steps 3 --warmup 1 --no-cpu-baseline > $OLDPWD/$OUT/log_${b}_$c.txt 2>&1)
     python - "$(find /tmp/pv_$c -name '*.db' | head -1)" $c $b $KIND >> $OUT/fps_valu_rows.txt <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); c, b = sys.argv[2], sys.argv[3]

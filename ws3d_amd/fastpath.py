@@ -281,7 +281,7 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
     return lists
 
 
-def _side_streams(main: torch.cuda.Stream, count: int = 3):
+def _side_streams(main: torch.cuda.Stream, count: int = 3, fresh: bool = False):
     """the three side streams of a forward pass: the sampling chain, the searches, and one for the second scale of a level / the
     second head.  Taken from the per-device pool that Stage1Pipeline's slots use (ws3d_amd/streams.py) -- never the caller's own
     stream: each HIP stream may claim a hardware queue, and a process that drives more queues than the device has descriptors
@@ -289,8 +289,8 @@ def _side_streams(main: torch.cuda.Stream, count: int = 3):
     limit sits at 24 queues: 20 pipeline slots + the null stream + a pair of its own = 23 was fine, a third one was not).
     Sharing the pool costs nothing: a pass that runs eagerly beside a pipeline in flight merely queues behind its slots -- the side
     streams are taken from the far end of the pool and never one that is capturing a hipGraph (streams.side_streams)."""
-    from .streams import side_streams
-    return side_streams(main, count)
+    from .streams import pass_streams
+    return pass_streams(main, count, fresh)
 
 
 class _Geometry:
@@ -305,7 +305,7 @@ class _Geometry:
     def __init__(self, net, xyz: torch.Tensor, c0: int, zeros=None):
         sas = list(net.SA_modules)
         main = torch.cuda.current_stream(xyz.device)
-        s_fps, s_search, s_aux = _side_streams(main)
+        s_fps, s_search, s_aux = _side_streams(main, fresh=True)      # resolved once per pass: rpn_forward's heads reuse them
         self.aux = s_aux
         self.xyz = [xyz]
         # the binned copy of the input cloud needs the coordinates only: on the search stream BESIDE the first level's sampling kernel

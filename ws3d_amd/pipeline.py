@@ -70,6 +70,10 @@ class Stage1Pipeline:
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
                                    "done": torch.cuda.Event(), "primed": False})
+        from .streams import POOL_SIZE
+        if self.depth > POOL_SIZE:
+            raise ValueError("Stage1Pipeline: depth %d exceeds the per-device stream pool (ws3d_amd.streams.POOL_SIZE = %d): the slots "
+                             "would share streams with the eager pass's side streams" % (self.depth, POOL_SIZE))
         if self.depth > 20:
             import warnings
             warnings.warn("Stage1Pipeline: depth %d -- beyond 23 hardware queues in one process (the slots, the null stream and "

@@ -33,6 +33,21 @@ def _capturing(st: torch.cuda.Stream) -> bool:
         return torch.cuda.is_current_stream_capturing()
 
 
+_PASS = {}          # (device index, main stream handle) -> the side streams the current forward pass of that stream resolved
+
+
+def pass_streams(main: torch.cuda.Stream, count: int = 3, fresh: bool = False):
+    """The side streams of ONE forward pass, resolved once: the first caller of a pass (fastpath._Geometry, `fresh=True`) picks them by
+    the pool's capture state at that moment, later callers of the same pass (fastpath.rpn_forward's heads) get the SAME streams even if
+    a capture started or ended on a pool entry in between -- two independent picks could differ and claim extra hardware queues
+    (ADVICE round 4)."""
+    key = (main.device.index, main.cuda_stream)
+    got = None if fresh else _PASS.get(key)
+    if got is None or len(got) < count:
+        got = _PASS[key] = side_streams(main, count)
+    return got[:count]
+
+
 def side_streams(main: torch.cuda.Stream, count: int = 3):
     """`count` pool streams for side work of a pass whose own stream is `main`: from the top of the pool downwards, never `main`
     itself, never a stream that is being captured"""
