@@ -26,7 +26,7 @@ for kind in ("hdl64", "lidar"):
     print("  bucket updates per round: %.1f in all 16 waves, busiest wave %.2f, average wave %.2f" % (t[:, 7].sum() / rounds, t[:, 7].max() / rounds, t[:, 7].mean() / rounds))
     names = ["box tests", "updates", "re-pick + publish", "wait A", "certify / idle", "wait B", "read samples"]
     cc = temp[0, 512:520].cpu().numpy()
-    print("  certification (wave 0), clk per round: load candidates %.0f  ranks %.0f  scatter + bound + read back %.0f  condition loop %.0f  count + park %.0f  | record exchange between workgroups (WS3D_FPS_SPLIT) %.0f" % tuple(cc[:6] / rounds))
+    print("  certification (wave 0), clk per round: load candidates %.0f  ranks %.0f  scatter + bound + read back %.0f  condition loop %.0f  count + park %.0f" % tuple(cc[:5] / rounds))
     for w in (0, 5, 15):
         print("  wave %2d, clk per round: " % w + "  ".join("%s %.0f" % (names[k], t[w, k] / rounds) for k in range(7)) + "  | sum %.0f" % (t[w, :7].sum() / rounds))
 PY

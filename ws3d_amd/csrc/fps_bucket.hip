@@ -483,56 +483,9 @@ constexpr size_t FR2_SAMPLES_OFF = (FR2_FIXED + 15) & ~(size_t)15;
 constexpr size_t FR2_SAMPLES_MAX_M = 6144;
 static size_t fps_rounds2_smem(int m) { return FR2_SAMPLES_OFF + sizeof(float4) * (size_t)(m + FR2_KQ + 8); }
 
-// ---- round 5: one scene split over G workgroups (fps_rounds2_kernel<G>, G > 1) ---------------------------------------------------
-// Why: phase A of a round (box tests, bucket updates, re-pick) ends when the busiest wave is done, and four waves share every SIMD:
-// a bucket update costs ~850 clk with the SIMD shared against ~350 alone (profiles/r04_fps_rounds2_segments.txt: the slowest wave
-// reaches the barrier 4,800 clk into a 6,800-clk profiled round).  With the scene's 16 waves on G = 4 compute units -- 4 waves per
-// workgroup, one per SIMD -- that phase shrinks to the busiest wave's own work, and a 256-lane workgroup fits BESIDE other kernels'
-// workgroups where the 1024-lane one needs an empty compute unit.  What it costs: the 44-byte records of the waves (two candidates,
-// two keys, one bound) cross workgroups once per round through agent-scope memory (~1,000 clk, profiles/r02_xcu_exchange_latency.txt),
-// and every workgroup runs the certification itself (same inputs, same code: same samples; nothing else has to be agreed on).
-// Plumbing: the scene's idx rows hold the exchange words and its new_xyz rows the order table until workgroup 0 writes the
-// result over them (m >= 2731 for the 32 KB table); fps_sort_kernel -- the counting sort that is stage A of the one-workgroup
-// kernel -- runs first, one workgroup per scene, and clears the words.  Every wait is bounded (FR2X_SPIN_CAP polls): a partner
-// that never arrives makes the scene return idx[0] = -1 instead of hanging the device.  Workgroups are dispatched in order, so
-// the partners of the oldest unfinished scene are always the next to become resident: no deadlock while compute units drain.
-// exchange words (int32 offsets into the scene's idx rows): a done counter, an error flag, then 8-byte GRANULES {epoch, value}
-constexpr int FR2X_DONE = 1, FR2X_ERROR = 2, FR2X_REC = 16, FR2X_TIE = FR2X_REC + 2 * 2 * 11 * 16, FR2X_WORDS = FR2X_TIE + 2 * 2 * 4 * 8;
-constexpr int FR2X_SPIN_CAP = 400000;
-
-// The exchange protocol: every word that crosses workgroups travels as an 8-byte granule {epoch, value}, written and read with ONE
-// agent-scope relaxed 64-bit atomic (served at the coherence point: no cache to flush, no fence).  A reader polls the granule itself
-// until its epoch is the one it waits for -- the data is its own arrival flag, so an exchange costs one store and one load round trip
-// (a separate arrival counter put four dependent round trips on every round: 3.1 instead of 1.6 ms per launch).  Two parities per
-// granule: a workgroup can be at most one exchange ahead of the slowest one.  fps_sort_kernel zeroes the words, epochs start at 1.
-__device__ __forceinline__ void fr2x_put(int *base, int i, int epoch, int value) {
-    const unsigned long long g = ((unsigned long long)(unsigned)value << 32) | (unsigned)epoch;
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(base) + i, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// granules i0, i0 + 64, ... < count of this lane -> out[0 .. 2]; false: timed out (or a partner did)
-__device__ __forceinline__ bool fr2x_get3(int *base, int lane, int count, int epoch, int *error, int (&out)[3]) {
-    bool have[3] = {lane >= count, lane + 64 >= count, lane + 128 >= count};
-    int spins = 0, ok = 1;
-    for (;;) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (!have[u]) {
-                const unsigned long long g = __hip_atomic_load(reinterpret_cast<unsigned long long *>(base) + lane + 64 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(unsigned)g == epoch) { out[u] = (int)(unsigned)(g >> 32); have[u] = true; }
-            }
-        if (__builtin_amdgcn_ballot_w64(!(have[0] && have[1] && have[2])) == 0) break;
-        if (++spins >= FR2X_SPIN_CAP || ((spins & 255) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = 0; break; }
-    }
-    if (!ok && lane == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return ok != 0;
-}
-
-// G > 1 (round 5): ONE SCENE SPLIT OVER G WORKGROUPS of 16 / G waves -- see the block comment in front of fps_sort_kernel below.
-// G == 1 is the kernel as rounds 4 built it (every G-dependent piece is an `if constexpr`).
-template <int G>
-__global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
-                                                               float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S, int batch) {
-    constexpr int NW = 16, SL = 16, NWL = NW / G, NT = 64 * NWL, KQ = FR2_KQ, PER = FR2_PER;
+__global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restrict__ xyz, float *__restrict__ temp, int32_t *__restrict__ idx,
+                                                           float *__restrict__ new_xyz, int n, int m, int bs, int log2bs, int S) {
+    constexpr int NW = 16, SL = 16, NT = 1024, KQ = FR2_KQ, PER = FR2_PER;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t *order = reinterpret_cast<uint16_t *>(smem);            // FB_MAXN: sorted position -> point index
     int *hist = reinterpret_cast<int *>(order + FB_MAXN);            // FB_CELLS
@@ -549,77 +502,57 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
     int *wsum = reinterpret_cast<int *>(red + 64);                   // 16
     float4 *samples = reinterpret_cast<float4 *>(smem + FR2_SAMPLES_OFF);   // m + KQ + 8: every sample {x, y, z, sorted position}, in order
 
-    int b = blockIdx.x, wg = 0;
-    if constexpr (G > 1) {
-        // the G workgroups of a scene on ONE XCD (workgroup g runs on XCD g % 8, observed dispatch order): with a batch that is a
-        // multiple of 8, scene = (g / 8 / G) * 8 + g % 8 and part = (g / 8) % G; correctness does not depend on it (agent-scope exchange)
-        const int g = blockIdx.x;
-        if ((batch & 7) == 0) { const int jq = g >> 3; b = (jq / G) * 8 + (g & 7); wg = jq % G; }
-        else { b = g / G; wg = g % G; }
-    }
+    const int b = blockIdx.x;
     xyz += (size_t)b * n * 3;
     idx += (size_t)b * m;
     if (temp) temp += (size_t)b * n;
     if (new_xyz) new_xyz += (size_t)b * m * 3;
-    const int tid = threadIdx.x, lane = tid & 63, wl = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, grp = lane >> 4;
-    const int w = wg * NWL + wl;        // the wave's number in the SCENE (a scalar: the candidates' positions ((S NW + w) << 6) + lane stay scalar arithmetic)
-    int *xch = reinterpret_cast<int *>(idx);        // G > 1: the scene's exchange words live in its idx rows until the samples are written there
-    int epoch = 0;
-    (void)xch; (void)epoch;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, grp = lane >> 4;      // (w as a scalar: the candidates' positions ((S NW + w) << 6) + lane stay scalar arithmetic)
 
-    if constexpr (G > 1) {
-        // the counting sort ran in fps_sort_kernel: the order table waits in the scene's new_xyz rows (32 KB of their 48)
-        const uint4 *src = reinterpret_cast<const uint4 *>(new_xyz);
-        uint4 *dst = reinterpret_cast<uint4 *>(order);
-        for (int i = tid; i < FB_MAXN * 2 / 16; i += NT) dst[i] = src[i];
-        if (tid < 48) rcnt[tid] = 0;
-        __syncthreads();
-    } else {
-        // ---------------- stage A: Z-order counting sort of the scene into `order` (as in fps_bucket_kernel)
-        float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
-        for (int k = tid; k < n; k += NT) {
-            const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
-            if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
-            if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
-        }
-        xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
-        if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
-        for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
-        for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
-        if (tid < 48) rcnt[tid] = 0;
-        __syncthreads();
-    #pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
-            zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
-        }
-        const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
-        const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
-        for (int k = tid; k < n; k += NT)
-            atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-        __syncthreads();
-        {
-            constexpr int CPT = FB_CELLS / NT;
-            int a[CPT], v = 0;
-    #pragma unroll
-            for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
-            const int mine = v;
-            for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
-            if (lane == 63) wsum[w] = v;
-            __syncthreads();
-            int off = 0;
-            for (int i = 0; i < w; ++i) off += wsum[i];
-            int excl = off + v - mine;
-    #pragma unroll
-            for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
-        }
-        __syncthreads();
-        for (int k = tid; k < n; k += NT) {
-            const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-            order[pos] = (uint16_t)k;
-        }
-        __syncthreads();
+    // ---------------- stage A: Z-order counting sort of the scene into `order` (as in fps_bucket_kernel)
+    float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
+    for (int k = tid; k < n; k += NT) {
+        const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
+        if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
+        if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
     }
+    xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
+    if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
+    for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
+    for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
+    if (tid < 48) rcnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
+        zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
+    }
+    const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
+    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
+    for (int k = tid; k < n; k += NT)
+        atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+    __syncthreads();
+    {
+        constexpr int CPT = FB_CELLS / NT;
+        int a[CPT], v = 0;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
+        const int mine = v;
+        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
+        if (lane == 63) wsum[w] = v;
+        __syncthreads();
+        int off = 0;
+        for (int i = 0; i < w; ++i) off += wsum[i];
+        int excl = off + v - mine;
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += NT) {
+        const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
+        order[pos] = (uint16_t)k;
+    }
+    __syncthreads();
 
     // ---------------- registers: slot s of this lane = sorted position ((s*NW + w)*64 + lane)
     float px[SL], py[SL], pz[SL], t[SL];
@@ -791,41 +724,7 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
         FR2P(2)
         lds_barrier();
         FR2P(3)
-        bool dead = false;
-        if (wl == 0) {
-            if constexpr (G > 1) {
-                // ---- record exchange between the scene's workgroups: publish this workgroup's 11 words per wave, arrive, wait for
-                // the others, read all 16 waves' words into the local record arrays (the same wave goes on to certify: a wave's LDS
-                // operations execute in order).  Two parities: a workgroup can be at most one exchange ahead of the slowest.
-                FR2C0
-                ++epoch;
-                int *X = xch + FR2X_REC + (epoch & 1) * (2 * 11 * NW);
-                for (int i = lane; i < 11 * NWL; i += 64) {
-                    const int lw = i / 11, fld = i - lw * 11, gw = wg * NWL + lw;
-                    int val;
-                    if (fld < 4) val = reinterpret_cast<const int *>(rec + gw)[fld];
-                    else if (fld < 8) val = reinterpret_cast<const int *>(rec + 16 + gw)[fld - 4];
-                    else if (fld == 8) val = keys[gw];
-                    else if (fld == 9) val = keys[16 + gw];
-                    else val = __float_as_int(sbnd[gw]);
-                    fr2x_put(X, gw * 11 + fld, epoch, val);
-                }
-                int got[3] = {0, 0, 0};
-                dead = !fr2x_get3(X, lane, 11 * NW, epoch, xch + FR2X_ERROR, got);
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int i = lane + 64 * u;
-                    if (i < 11 * NW) {
-                        const int gw = i / 11, fld = i - gw * 11, val = got[u];
-                        if (fld < 4) reinterpret_cast<int *>(rec + gw)[fld] = val;
-                        else if (fld < 8) reinterpret_cast<int *>(rec + 16 + gw)[fld - 4] = val;
-                        else if (fld == 8) keys[gw] = val;
-                        else if (fld == 9) keys[16 + gw] = val;
-                        else sbnd[gw] = __int_as_float(val);
-                    }
-                }
-                FR2C(5)
-            }
+        if (w == 0) {
             // ---- certification by wave 0 (see the header).  Every value compared is >= 0 or a negative "nothing" mark: non-negative
             // floats order like their bit patterns, so the comparisons are sign bits of integer differences (marks clamped to -1).
             // Ranks on all four rows at once: row q compares candidate set q >> 1 (0 = the waves' first candidates, 1 = their second)
@@ -889,7 +788,7 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
             if (nk == 0) nk = -1;                                    // the head of the round is tied: resolution round
             // the slots past the accepted samples become the far point (in-order LDS: after the candidates parked there)
             if (pj == 0 && pi >= max(nk, 1)) selq[pi] = make_float4(FR_FAR, FR_FAR, FR_FAR, 0.f);
-            if (lanev == 0) { posr[0] = nk; posr[1] = top; posr[2] = dead ? 1 : 0; }
+            if (lanev == 0) { posr[0] = nk; posr[1] = top; }
             FR2C(4)
         }
         FR2P(4)
@@ -903,7 +802,6 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
 #pragma unroll
             for (int i = 0; i < PER; ++i) { qx[i] = sq[i].x; qy[i] = sq[i].y; qz[i] = sq[i].z; }
         }
-        if constexpr (G > 1) { if (posr[2]) break; }         // an exchange timed out (a partner never arrived): give the CU back; idx[0] = -1 below
         if (K > 0) {
         } else {
             // ---- a tie at the head of the round: smallest reference rank among ALL points holding the maximum (one sample)
@@ -920,17 +818,16 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
                 }
             }
             const unsigned wkey = wave_min_u32(key);
-            if (lane == 0) tiekey[wl] = wkey;
+            if (lane == 0) tiekey[w] = wkey;
             lds_barrier();
-            unsigned gk = tiekey[lane & (NWL - 1)];
+            unsigned gk = tiekey[lane & (NW - 1)];
             gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR1, 0xF, 0xF, false));
             gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_QUAD_XOR2, 0xF, 0xF, false));
             gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_HALF_MIRROR, 0xF, 0xF, false));
             gk = min(gk, (unsigned)__builtin_amdgcn_update_dpp(0, (int)gk, DPP_ROW_MIRROR, 0xF, 0xF, false));
-            gk = (unsigned)__builtin_amdgcn_readfirstlane((int)gk);          // G == 1: the scene's smallest key; G > 1: this workgroup's
-            int ipos = (int)(gk & 0x3FFFu);
+            const int ipos = (int)(__builtin_amdgcn_readfirstlane(gk) & 0x3FFFu);
             const int ob = ipos >> 6, ol = ipos & 63;           // owning bucket / lane
-            if (gk != 0xFFFFFFFFu && (ob & (NW - 1)) == w) {
+            if ((ob & (NW - 1)) == w) {
                 const int os = ob / NW;                       // wave-uniform slot
                 float ox = 0.f, oy = 0.f, oz = 0.f;
 #define FR_OWN(S) case S: ox = readlane_f(px[S], ol); oy = readlane_f(py[S], ol); oz = readlane_f(pz[S], ol); break;
@@ -942,36 +839,6 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
                 if (lane == 0) *tiept = make_float4(ox, oy, oz, 0.f);
             }
             lds_barrier();
-            if constexpr (G > 1) {
-                // the workgroups' {key, x, y, z}: one more exchange, the smallest key of the scene wins
-                if (wl == 0) {
-                    ++epoch;
-                    int *T = xch + FR2X_TIE + (epoch & 1) * (2 * 4 * 8);
-                    if (lane < 4) {
-                        const float4 tp = *tiept;
-                        const int val = lane == 0 ? (int)gk : lane == 1 ? __float_as_int(tp.x) : lane == 2 ? __float_as_int(tp.y) : __float_as_int(tp.z);
-                        fr2x_put(T, wg * 4 + lane, epoch, val);
-                    }
-                    int got[3] = {0, 0, 0};
-                    const bool ok = fr2x_get3(T, lane, 4 * G, epoch, xch + FR2X_ERROR, got);         // lane 4 q + f: field f of workgroup q
-                    unsigned best = 0xFFFFFFFFu;
-                    float bx = 0.f, by = 0.f, bz = 0.f;
-#pragma unroll
-                    for (int q = 0; q < G; ++q) {
-                        const unsigned kq = (unsigned)__builtin_amdgcn_readlane(got[0], 4 * q);
-                        if (kq < best) {
-                            best = kq;
-                            bx = __int_as_float(__builtin_amdgcn_readlane(got[0], 4 * q + 1));
-                            by = __int_as_float(__builtin_amdgcn_readlane(got[0], 4 * q + 2));
-                            bz = __int_as_float(__builtin_amdgcn_readlane(got[0], 4 * q + 3));
-                        }
-                    }
-                    if (lane == 0) { *tiept = make_float4(bx, by, bz, 0.f); posr[3] = (int)(best & 0x3FFFu); if (!ok) posr[2] = 1; }
-                }
-                lds_barrier();
-                ipos = posr[3];
-                if (posr[2]) break;
-            }
             const float4 c = *tiept;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -990,28 +857,13 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
 
     // the samples leave the chip: sorted positions -> point indices, coordinates as stored (pure copies of xyz)
     __syncthreads();
-    if constexpr (G > 1) {
-        // every workgroup holds the whole sample list; workgroup 0 writes it -- over the exchange words (idx) and the order table
-        // (new_xyz) -- once the others have said that they read them for the last time
-        if (wg != 0) {
-            if (tid == 0) __hip_atomic_fetch_add(xch + FR2X_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (tid == 0) {
-                int spins = 0;
-                while (__hip_atomic_load(xch + FR2X_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G - 1 && ++spins < FR2X_SPIN_CAP) __builtin_amdgcn_s_sleep(2);
-            }
-            __syncthreads();
-        }
-    }
-    const bool failed = G > 1 && posr[2] != 0;
-    if (G == 1 || wg == 0)
     for (int jj = tid; jj < m; jj += NT) {
         if (jj == 0) {
-            idx[0] = failed ? -1 : 0;          // (-1: a record exchange timed out -- the scene's rows are not a sampling result)
+            idx[0] = 0;
             if (new_xyz) { new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
         } else {
             const float4 sm = samples[jj];
-            idx[jj] = (int)order[__float_as_int(sm.w) & (FB_MAXN - 1)];
+            idx[jj] = (int)order[__float_as_int(sm.w)];
             if (new_xyz) { new_xyz[jj * 3 + 0] = sm.x; new_xyz[jj * 3 + 1] = sm.y; new_xyz[jj * 3 + 2] = sm.z; }
         }
     }
@@ -1031,67 +883,6 @@ __global__ __launch_bounds__(1024 / G) void fps_rounds2_kernel(const float *__re
         if (w == 0) for (int k = 0; k < 8; ++k) temp[512 + k] = (float)cc[k];
     }
 #endif
-}
-
-// stage A of fps_rounds2_kernel as a kernel of its own (the split form, G > 1): Z-order counting sort of the scene, the order table
-// into the scene's new_xyz rows, the exchange words of its idx rows cleared.  One workgroup per scene.
-__global__ __launch_bounds__(1024) void fps_sort_kernel(const float *__restrict__ xyz, int32_t *__restrict__ idx, float *__restrict__ new_xyz, int n, int m) {
-    constexpr int NW = 16, NT = 1024;
-    __shared__ __attribute__((aligned(16))) uint16_t order[FB_MAXN];
-    __shared__ int hist[FB_CELLS];
-    __shared__ float red[64];
-    __shared__ int wsum[16];
-    const int b = blockIdx.x;
-    xyz += (size_t)b * n * 3;
-    idx += (size_t)b * m;
-    new_xyz += (size_t)b * m * 3;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    float xmn = INFINITY, xmx = -INFINITY, zmn = INFINITY, zmx = -INFINITY;
-    for (int k = tid; k < n; k += NT) {
-        const float x = xyz[(size_t)k * 3], z = xyz[(size_t)k * 3 + 2];
-        if (fabsf(x) < INFINITY) { xmn = fminf(xmn, x); xmx = fmaxf(xmx, x); }
-        if (fabsf(z) < INFINITY) { zmn = fminf(zmn, z); zmx = fmaxf(zmx, z); }
-    }
-    xmn = wave_min(xmn); xmx = wave_max(xmx); zmn = wave_min(zmn); zmx = wave_max(zmx);
-    if (lane == 0) { red[w * 4 + 0] = xmn; red[w * 4 + 1] = xmx; red[w * 4 + 2] = zmn; red[w * 4 + 3] = zmx; }
-    for (int i = tid; i < FB_CELLS; i += NT) hist[i] = 0;
-    for (int i = tid; i < FB_MAXN; i += NT) order[i] = 0xFFFFu;
-    if (tid < FR2X_WORDS) idx[tid] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {
-        xmn = fminf(xmn, red[i * 4 + 0]); xmx = fmaxf(xmx, red[i * 4 + 1]);
-        zmn = fminf(zmn, red[i * 4 + 2]); zmx = fmaxf(zmx, red[i * 4 + 3]);
-    }
-    const float x0 = xmn <= xmx ? xmn : 0.f, z0 = zmn <= zmx ? zmn : 0.f;
-    const float ix = (xmn < xmx) ? (float)FB_GRID / (xmx - xmn) : 0.f, iz = (zmn < zmx) ? (float)FB_GRID / (zmx - zmn) : 0.f;
-    for (int k = tid; k < n; k += NT)
-        atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-    __syncthreads();
-    {
-        constexpr int CPT = FB_CELLS / NT;
-        int a[CPT], v = 0;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) { a[i] = hist[CPT * tid + i]; v += a[i]; }
-        const int mine = v;
-        for (int o = 1; o < 64; o <<= 1) { const int t2 = __shfl_up(v, o); if (lane >= o) v += t2; }
-        if (lane == 63) wsum[w] = v;
-        __syncthreads();
-        int off = 0;
-        for (int i = 0; i < w; ++i) off += wsum[i];
-        int excl = off + v - mine;
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) { hist[CPT * tid + i] = excl; excl += a[i]; }
-    }
-    __syncthreads();
-    for (int k = tid; k < n; k += NT) {
-        const int pos = atomicAdd(&hist[zcell(xyz[(size_t)k * 3], xyz[(size_t)k * 3 + 2], x0, z0, ix, iz)], 1);
-        order[pos] = (uint16_t)k;
-    }
-    __syncthreads();
-    uint4 *dst = reinterpret_cast<uint4 *>(new_xyz);
-    const uint4 *src = reinterpret_cast<const uint4 *>(order);
-    for (int i = tid; i < FB_MAXN * 2 / 16; i += NT) dst[i] = src[i];
 }
 
 size_t fps_bucket_smem() { return FB_SMEM_BYTES; }
@@ -1114,23 +905,8 @@ int fps_bucket_launch(int b, int n, int m, const float *xyz, float *temp, int32_
     // WS3D_FPS_ROUNDS=0: one sample per record exchange (fps_bucket_kernel) also where the rounds kernel is the default (A/B runs, tests)
     static const int rounds = getenv("WS3D_FPS_ROUNDS") ? atoi(getenv("WS3D_FPS_ROUNDS")) : 1;
     if (rounds && (size_t)m <= FR2_SAMPLES_MAX_M) {
-        // WS3D_FPS_SPLIT=G (2 / 4): one scene over G workgroups (round 5) for launches of up to 256 / G scenes (one workgroup per CU at most);
-        // 0 / unset: one workgroup per scene.  Needs the fused gather (new_xyz holds the order table meanwhile) and m >= 2731.
-        static const int split = getenv("WS3D_FPS_SPLIT") ? atoi(getenv("WS3D_FPS_SPLIT")) : 0;
-        if ((split == 2 || split == 4) && new_xyz && (size_t)m * 12 >= (size_t)FB_MAXN * 2 && m >= FR2X_WORDS && (m & 1) == 0 && (long)b * split <= 256 &&
-            ((reinterpret_cast<uintptr_t>(new_xyz) | ((size_t)m * 12)) & 15) == 0) {
-            hipLaunchKernelGGL(fps_sort_kernel, dim3(b), dim3(1024), 0, st, xyz, idx, new_xyz, n, m);
-            if (split == 4) {
-                if (int rc = raise_lds_cap((const void *)fps_rounds2_kernel<4>, fps_rounds2_smem((int)FR2_SAMPLES_MAX_M), "furthest_point_sampling(rounds2 x4)")) return rc;
-                hipLaunchKernelGGL(fps_rounds2_kernel<4>, dim3(b * 4), dim3(256), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S, b);
-            } else {
-                if (int rc = raise_lds_cap((const void *)fps_rounds2_kernel<2>, fps_rounds2_smem((int)FR2_SAMPLES_MAX_M), "furthest_point_sampling(rounds2 x2)")) return rc;
-                hipLaunchKernelGGL(fps_rounds2_kernel<2>, dim3(b * 2), dim3(512), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S, b);
-            }
-            return check_launch("furthest_point_sampling(rounds2 split)");
-        }
-        if (int rc = raise_lds_cap((const void *)fps_rounds2_kernel<1>, fps_rounds2_smem((int)FR2_SAMPLES_MAX_M), "furthest_point_sampling(rounds2)")) return rc;
-        hipLaunchKernelGGL(fps_rounds2_kernel<1>, dim3(b), dim3(1024), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S, b);
+        if (int rc = raise_lds_cap((const void *)fps_rounds2_kernel, fps_rounds2_smem((int)FR2_SAMPLES_MAX_M), "furthest_point_sampling(rounds2)")) return rc;
+        hipLaunchKernelGGL(fps_rounds2_kernel, dim3(b), dim3(1024), fps_rounds2_smem(m), st, xyz, temp, idx, new_xyz, n, m, bs, log2bs, S);
         return check_launch("furthest_point_sampling(rounds2)");
     }
 #endif
