@@ -471,6 +471,7 @@ constexpr size_t FB_SMEM_BYTES = sizeof(uint16_t) * FB_MAXN + sizeof(int) * FB_C
 // of one rank (a fails).  Ties at the head of a round take the resolution round of fps_bucket_kernel (one sample): the smallest
 // reference rank among ALL points holding the maximum.  Bit-exact incl. the tie order.
 // Anatomy: scripts/ubench/fps_rounds2_prof.sh (-DFR2_PROF: clocks per segment, bucket updates, re-picks, samples per round).
+__device__ __forceinline__ float fr2_opaque(float v) { asm volatile("" : "+v"(v)); return v; }     // (ablation builds: a value the optimiser cannot merge)
 #ifndef FR2_KQ
 #define FR2_KQ 8
 #endif
@@ -655,12 +656,27 @@ __global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restri
     if (((G) < 2 ? need_lo : need_hi) & (1u << (16 * ((G) & 1) + (S)))) {                              \
         _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) d = min_f32(sqdist3(px[S] - sx[G][i_], py[S] - sy[G][i_], pz[S] - sz[G][i_]), d); \
     }
+#define FR2_GRP_B(S, G)                                                                                \
+    if (((G) < 2 ? need_lo : need_hi) & (1u << (16 * ((G) & 1) + (S)))) {                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < PER; ++i_) d = min_f32(sqdist3(fr2_opaque(px[S]) - sx[G][i_], fr2_opaque(py[S]) - sy[G][i_], fr2_opaque(pz[S]) - sz[G][i_]), d); \
+    }
+#if defined(FR2_ABL) && FR2_ABL == 1      /* ablation (scripts/ubench/fps_rounds2_prof.sh FR_EXTRA=-DFR2_ABL=1): the wave maximum issued twice */
+#define FR2_WMAX(V) max_f32(wave_max(V), wave_max(fr2_opaque(V)))
+#else
+#define FR2_WMAX(V) wave_max(V)
+#endif
+#if defined(FR2_ABL) && FR2_ABL == 2      /* ... the distance evaluations issued twice */
+#define FR2_DIST2(S) { float d0_ = d; d = INFINITY; { float &d_ = d; (void)d_; } FR2_GRP_B(S, 0) FR2_GRP_B(S, 1) FR2_GRP_B(S, 2) FR2_GRP_B(S, 3) d = min_f32(d, d0_); }
+#else
+#define FR2_DIST2(S)
+#endif
 #define FR2_UPD(S)                                                                                     \
     if (need16 & (1u << (S))) {                                                                        \
         float d = INFINITY;                                                                            \
         FR2_GRP(S, 0) FR2_GRP(S, 1) FR2_GRP(S, 2) FR2_GRP(S, 3)                                        \
+        FR2_DIST2(S)                                                                                   \
         fb_t<S>(tt) = min_f32(d, fb_t<S>(tt));                                                         \
-        const float bm = wave_max(fb_t<S>(tt));                                                        \
+        const float bm = FR2_WMAX(fb_t<S>(tt));                                                        \
         bmax = l15v == (S) ? bm : bmax;                                                                \
     }
 #define FR2_UPD8(G8) if (need16 & (0xFFu << (G8))) { FR2_UPD(G8) FR2_UPD(G8 + 1) FR2_UPD(G8 + 2) FR2_UPD(G8 + 3) FR2_UPD(G8 + 4) FR2_UPD(G8 + 5) FR2_UPD(G8 + 6) FR2_UPD(G8 + 7) }
@@ -668,6 +684,7 @@ __global__ __launch_bounds__(1024) void fps_rounds2_kernel(const float *__restri
 #undef FR2_UPD8
 #undef FR2_UPD
 #undef FR2_GRP
+#undef FR2_GRP_B
             // running distances only fall: the published candidates stay the wave's two best buckets unless one of THEM changed (the
             // published bound may go stale; it stays an upper bound)
             repick = repick || (((need16 >> slot1) | (need16 >> slot2)) & 1u);
