@@ -36,7 +36,7 @@ __device__ __forceinline__ void compact_pool_atomic(const ACC &acc, float bias, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         if (cen[r] < 0) continue;
-        const float v = fmaxf(y[r] + bias, 0.f);          // NaN -> 0, like the dense / list forms' fmaxf: the integer atomicMax below never sees a NaN pattern
+        const float v = fmaxf(y[r] + bias, 0.f);          // NaN -> 0 (fmaxf), as in SA1's dense / list kernels (sa_mlp.hip): the integer atomicMax below never sees a NaN pattern.  (The dense last-layer kernels of SA2-4, gemm_pool.hip, propagate a NaN like torch's relu + max_pool2d do; an atomic integer maximum cannot, so on NON-FINITE activations the two sides of the launch gate differ -- finite inputs and weights never produce one)
         if (cen[r] != prev) {
             if (prev >= 0) atomicMax(reinterpret_cast<int *>(out_col + (long)prev * out_stride), __float_as_int(run));
             prev = cen[r]; run = v;
