@@ -47,7 +47,7 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes, ws3d_furthest_point_sampling_nested_chain; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 5
 WS3D_API int ws3d_abi_version(void);
@@ -85,6 +85,15 @@ WS3D_API int ws3d_furthest_point_sampling_gather(int b, int n, int m, const floa
  * idx (b,m) and new_xyz (b,m,3) are both required (they double as scratch).  No reference counterpart.               */
 WS3D_API int ws3d_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, int32_t *idx, float *new_xyz,
                                         ws3d_stream_t stream);
+
+/* ws3d_furthest_point_sampling_nested for a CHAIN of levels in four launches: level 0 samples m[0] of the n points of xyz (verified in
+ * parallel as above), level l > 0 samples m[l] of level l-1's new_xyz (m non-increasing; host array of `levels` <= 5 counts, host arrays of
+ * `levels` device pointers idx[l] (b, m[l]) / new_xyz[l] (b, m[l], 3)).  When level 0 verifies, the levels below it are verified with it
+ * (their check is a subset of level 0's inequalities on the same floats): one kernel writes their prefixes; a scene that does not verify
+ * takes the literal restatement of sampling_gpu.cu:93-209 level by level.  Same outputs as `levels` calls of the entry above.  (round 5) */
+WS3D_API int ws3d_furthest_point_sampling_nested_chain(int b, int n, int levels, const int *m, const float *xyz, int32_t *const *idx,
+                                                       float *const *new_xyz, ws3d_stream_t stream);
+
 
 /* gather_points_wrapper(b,c,n,npoints,points,idx,out)   sampling.cpp:11-20 ->
  * sampling_gpu.cu:8-37.  points (b,c,n), idx (b,npoints) -> out (b,c,npoints).     */

@@ -7,6 +7,7 @@ import argparse, os, subprocess, sys, time
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60); ap.add_argument("--seed", type=int, default=0)
 a = ap.parse_args()
 a.child = "0"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ws3d_amd import compat as c, synth
 rng = np.random.default_rng(a.seed)

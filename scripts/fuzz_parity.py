@@ -74,6 +74,11 @@ def one_round(rng):
             iw, ww_ = c.three_nn_with_weights(dev(pc), dev(cen), s)          # the one-launch form: same indices, weights of the same distances
             rcp = 1.0 / (torch.sqrt(d2) + 1e-8)
             assert torch.equal(iw, i3) and torch.equal(ww_, rcp / ((rcp[..., 0] + rcp[..., 1]) + rcp[..., 2]).unsqueeze(-1)), ("three_nn_w", B, N, M)
+            if s is not None:        # queries taken in the cell order of a binned copy of the unknown set (ws3d_three_nn_wq): the same rows
+                for q in (c.sort_points_x(dev(pc), min_n=1), c.sort_points_xz(dev(pc), min_n=1)):
+                    if q is not None:
+                        iq, wq = c.three_nn_with_weights(dev(pc), dev(cen), s, q)
+                        assert torch.equal(iq, iw) and torch.equal(wq, ww_), ("three_nn_wq", B, N, M)
         Ck = int(rng.choice([4, 20, 128]))
         kf = rng.standard_normal((B, Ck, M)).astype(np.float32)
         w = rng.uniform(0, 1, (B, N, 3)).astype(np.float32)

@@ -1881,6 +1881,43 @@ def test_fps_nested_equals_plain_fps(ops, oracle):
                                              torch.zeros((1, 10), dtype=torch.int32, device="cuda"), torch.zeros((1, 10, 3), device="cuda"))
 
 
+def test_fps_nested_chain_equals_level_by_level(ops, oracle):
+    """ws3d_furthest_point_sampling_nested_chain (the levels below the first in four launches: when level 0 verifies, the deeper levels
+    are verified with it and one kernel writes their prefixes; a scene that does not verify takes the literal restatement level by
+    level) against the ORACLE's FPS applied level by level, and against chained calls of the one-level entry: sampling-ordered
+    clouds, arbitrary order, duplicates, a mixed batch, one / two / four levels, equal counts, single points"""
+    def sampled(kind, B, N, M, seed, dup=0.0):
+        pc = synth.make_batch(kind, B, N, seed, dup_frac=dup)[:, :, :3].copy()
+        ref = oracle.furthest_point_sample(pc, M)
+        return np.stack([pc[b][ref[b]] for b in range(B)])
+    mixed = np.stack([sampled("lidar", 1, 8192, 2048, 80)[0], synth.make_batch("lidar", 1, 2048, 81)[0, :, :3]])
+    cases = [
+        ("the network's chain", sampled("hdl64", 3, 16384, 4096, 171), [1024, 256, 64]),
+        ("four levels", sampled("lidar", 2, 16384, 4096, 172), [2048, 512, 128, 7]),
+        ("one level", sampled("lidar", 2, 16384, 4096, 173), [1000]),
+        ("equal counts", sampled("uniform", 2, 5000, 1000, 174), [1000, 1000, 333]),
+        ("duplicates: the fallback at every level", sampled("lidar", 2, 700, 700, 175, dup=0.3), [700, 300, 40]),
+        ("arbitrary order", synth.make_batch("lidar", 2, 4096, 176)[:, :, :3].copy(), [512, 100, 9]),
+        ("mixed batch: scene 0 in sampling order, scene 1 not", mixed, [600, 150, 30]),
+        ("tiny", synth.make_batch("uniform", 2, 37, 177)[:, :, :3].copy(), [37, 5, 1]),
+        ("single point", synth.make_batch("uniform", 1, 1, 178)[:, :, :3].copy(), [1, 1]),
+    ]
+    for name, pc, ms in cases:
+        got = ops.pn.furthest_point_sample_gather_nested_chain(dev(pc), ms)
+        assert len(got) == len(ms)
+        cur_host, cur_dev = pc, dev(pc)
+        for (idx, nx), m in zip(got, ms):
+            ref = oracle.furthest_point_sample(cur_host, m)
+            want = np.stack([cur_host[b][ref[b]] for b in range(pc.shape[0])])
+            np.testing.assert_array_equal(host(idx), ref, err_msg="%s, level of %d" % (name, m))
+            np.testing.assert_array_equal(host(nx), want, err_msg="%s, level of %d" % (name, m))
+            i1, x1 = ops.pn.furthest_point_sample_gather_nested(cur_dev, m)
+            assert torch.equal(i1, idx) and torch.equal(x1, nx), name
+            cur_host, cur_dev = want, nx
+    with pytest.raises(Exception):                   # counts must not grow along the chain
+        ops.c.furthest_point_sampling_nested_chain(dev(cases[0][1]), [256, 1024])
+
+
 @pytest.mark.parametrize("B,N,M,ns,C,O1,O2,r", [(2, 4096, 1024, 16, 96, 64, 64, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 1.0), (1, 1024, 256, 16, 256, 128, 196, 1.0),
                                               (2, 256, 64, 32, 512, 256, 384, 4.0), (2, 256, 64, 16, 512, 256, 256, 2.0)])
 def test_gather_gemm2_equals_two_layers(ops, B, N, M, ns, C, O1, O2, r):
@@ -2059,7 +2096,7 @@ def test_fast_path_switches_agree(ops):
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
     names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
-             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD")
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2071,14 +2108,15 @@ def test_fast_path_switches_agree(ops):
     try:
         off = {"FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False,
                "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False, "FUSED_COMPACT3_MAX_LDS": 0, "FUSED_QINTERP_GEMM_MIN_ROWS": 1 << 60,
-               "BIN_INPUT_AHEAD": False}
+               "BIN_INPUT_AHEAD": False, "NESTED_CHAIN": False, "QUERY_CELL_ORDER": False}
         base = run(**off)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
                    {"SA1_FROM_LISTS": True}, {"SA1_FROM_LISTS": True, "COMPACT_PAIRS": True, "PER_POINT_L1": True}, {"PARALLEL_SCALES": True, "PARALLEL_HEADS": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True},
                    {"FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True},
                    {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 64 * 1024}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 160 * 1024},
-                   {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 30000}, {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 1}, {"BIN_INPUT_AHEAD": True, "PARALLEL_SCALES": True}):
+                   {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 30000}, {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 1}, {"BIN_INPUT_AHEAD": True, "PARALLEL_SCALES": True},
+                   {"NESTED_CHAIN": True}, {"QUERY_CELL_ORDER": True}, {"NESTED_CHAIN": True, "QUERY_CELL_ORDER": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
             got = run(**dict(off, **kw))

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ws3d_furthest_point_sampling": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_furthest_point_sampling_gather": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_furthest_point_sampling_nested": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_furthest_point_sampling_nested_chain": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_gather_points_grad": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),

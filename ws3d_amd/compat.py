@@ -122,6 +122,26 @@ def furthest_point_sampling_nested(b, n, m, xyz, idx, new_xyz):
     return 1
 
 
+def furthest_point_sampling_nested_chain(xyz, npoints):
+    """xyz (B, N, 3) in sampling order, npoints = the non-increasing sample counts of the levels below it -> [(idx, new_xyz), ...], one
+    pair per level (level l samples level l-1's new_xyz): what len(npoints) calls of furthest_point_sampling_nested return, in four
+    launches (ws3d_furthest_point_sampling_nested_chain).  ws3d extension."""
+    import ctypes as _ct
+    dev = _dev(xyz)
+    _f32(xyz, "xyz")
+    B, N = xyz.size(0), xyz.size(1)
+    L = len(npoints)
+    idx = [torch.empty((B, int(m)), dtype=torch.int32, device=dev) for m in npoints]
+    new = [torch.empty((B, int(m), 3), dtype=torch.float32, device=dev) for m in npoints]
+    ms = (_ct.c_int * L)(*[int(m) for m in npoints])
+    ip = (_ct.c_void_p * L)(*[t.data_ptr() for t in idx])
+    np_ = (_ct.c_void_p * L)(*[t.data_ptr() for t in new])
+    with _on(dev):
+        check(_lib.load().ws3d_furthest_point_sampling_nested_chain(B, N, L, _ct.cast(ms, _ct.c_void_p), _p(xyz), _ct.cast(ip, _ct.c_void_p),
+                                                                     _ct.cast(np_, _ct.c_void_p), _stream()), "fps_nested_chain")
+    return list(zip(idx, new))
+
+
 def gather_points_wrapper(b, c, n, npoints, points_tensor, idx_tensor, out_tensor):
     """sampling.cpp:11-20"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)

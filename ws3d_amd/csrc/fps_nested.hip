@@ -99,24 +99,11 @@ __global__ __launch_bounds__(256) void fps_nested_check_kernel(int n, int m, con
     if (__ballot(bad && p < n) != 0 && (tid & 63) == 0) atomicOr(reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3), 1);
 }
 
-// C: verified scenes get idx = arange and new_xyz = xyz[:m]; the others the reference kernel, restated literally.
-__global__ __launch_bounds__(1024) void fps_nested_finish_kernel(int n, int m, int bs, const float *__restrict__ xyz, int32_t *__restrict__ idx,
-                                                                 float *__restrict__ new_xyz) {
-    __shared__ float dists[1024];
-    __shared__ int dists_i[1024];
-    __shared__ int verdict;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    xyz += (size_t)b * n * 3;
-    idx += (size_t)b * m;
-    new_xyz += (size_t)b * m * 3;
-    if (tid == 0) verdict = reinterpret_cast<const int32_t *>(new_xyz)[0];
-    __syncthreads();
-    if (verdict == 0) {
-        for (int k = tid; k < m; k += 1024) idx[k] = k;
-        for (int e = tid; e < m * 3; e += 1024) new_xyz[e] = xyz[e];
-        return;
-    }
-    // sampling_gpu.cu:93-209 with temp = 1e10 held in registers: thread tid owns k = tid, tid + bs, ... (at most 4: n <= 4096)
+// sampling_gpu.cu:93-209 restated literally with temp = 1e10 held in registers: thread tid owns k = tid, tid + bs, ... (at most 4:
+// n <= 4096), strict '>', shared-memory tree that keeps the lower slot.  One workgroup of 1024 threads, pointers of ONE scene.
+__device__ __forceinline__ void nested_literal_fps(int n, int m, int bs, const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                   float *__restrict__ new_xyz, float *dists, int *dists_i) {
+    const int tid = threadIdx.x;
     float px[4], py[4], pz[4], tmp[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -162,6 +149,65 @@ __global__ __launch_bounds__(1024) void fps_nested_finish_kernel(int n, int m, i
     }
 }
 
+// C: verified scenes get idx = arange and new_xyz = xyz[:m]; the others the reference kernel, restated literally.
+// keep_verdict (chain entry): the scene's verdict is also left in keep_verdict[b * keep_stride] for fps_nested_tail_kernel.
+__global__ __launch_bounds__(1024) void fps_nested_finish_kernel(int n, int m, int bs, const float *__restrict__ xyz, int32_t *__restrict__ idx,
+                                                                 float *__restrict__ new_xyz, int32_t *__restrict__ keep_verdict, long keep_stride) {
+    __shared__ float dists[1024];
+    __shared__ int dists_i[1024];
+    __shared__ int verdict;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    xyz += (size_t)b * n * 3;
+    idx += (size_t)b * m;
+    new_xyz += (size_t)b * m * 3;
+    if (tid == 0) {
+        verdict = reinterpret_cast<const int32_t *>(new_xyz)[0];
+        if (keep_verdict) keep_verdict[(size_t)b * keep_stride] = verdict;
+    }
+    __syncthreads();
+    if (verdict == 0) {
+        for (int k = tid; k < m; k += 1024) idx[k] = k;
+        for (int e = tid; e < m * 3; e += 1024) new_xyz[e] = xyz[e];
+        return;
+    }
+    nested_literal_fps(n, m, bs, xyz, idx, new_xyz, dists, dists_i);
+}
+
+// The levels BELOW a verified level, all in one launch (round 5).  Level A's check proved, for every point p of its input and every
+// step k < m_A, that p's running minimum stays strictly below the picked point's: the same inequality for p < m_A and k < m_B <= m_A
+// is what level B's own check would ask of level A's OUTPUT (new_xyz_A = xyz[:m_A], the same floats, the same arithmetic) -- so when
+// level A verified, every deeper level of the chain is verified with it: idx = arange, new_xyz = the prefix.  A scene whose level A
+// did NOT verify (ties, or an input that was not in sampling order) takes the literal restatement level by level: exact either way.
+struct NestedTail { int levels; int m[4]; int bs[4]; int32_t *idx[4]; float *new_xyz[4]; };
+__global__ __launch_bounds__(1024) void fps_nested_tail_kernel(int n_a, const float *__restrict__ xyz_a, NestedTail t) {
+    __shared__ float dists[1024];
+    __shared__ int dists_i[1024];
+    __shared__ int verdict;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) verdict = t.idx[0][(size_t)b * t.m[0]];              // left there by level A's finish kernel
+    __syncthreads();
+    const int v = verdict;
+    __syncthreads();
+    const float *src = xyz_a + (size_t)b * n_a * 3;
+    int n_src = n_a;
+    for (int l = 0; l < t.levels; ++l) {
+        const int m = t.m[l];
+        int32_t *idx = t.idx[l] + (size_t)b * m;
+        float *nx = t.new_xyz[l] + (size_t)b * m * 3;
+        if (v == 0) {
+            for (int k = tid; k < m; k += 1024) idx[k] = k;
+            for (int e = tid; e < m * 3; e += 1024) nx[e] = src[e];
+        } else {
+            nested_literal_fps(n_src, m, t.bs[l], src, idx, nx, dists, dists_i);
+            __syncthreads();
+            __threadfence_block();
+        }
+        src = nx;            // (a verified chain keeps reading prefixes of prefixes: the same values)
+        n_src = m;
+        __syncthreads();
+    }
+}
+
 }  // namespace ws3d
 
 extern "C" int ws3d_furthest_point_sampling_nested(int b, int n, int m, const float *xyz, int32_t *idx, float *new_xyz,
@@ -180,6 +226,46 @@ extern "C" int ws3d_furthest_point_sampling_nested(int b, int n, int m, const fl
     const size_t lds = sizeof(float) * 4 * (size_t)m;                                    // <= 64 KB (m <= n <= 4096)
     hipLaunchKernelGGL(fps_nested_w_kernel, dim3((m + 255) / 256, b), dim3(256), lds, st, n, m, xyz, idx, new_xyz);
     hipLaunchKernelGGL(fps_nested_check_kernel, dim3((n + 255) / 256, b), dim3(256), lds, st, n, m, xyz, idx, new_xyz);
-    hipLaunchKernelGGL(fps_nested_finish_kernel, dim3(b), dim3(1024), 0, st, n, m, nested_opt_n_threads(n), xyz, idx, new_xyz);
+    hipLaunchKernelGGL(fps_nested_finish_kernel, dim3(b), dim3(1024), 0, st, n, m, nested_opt_n_threads(n), xyz, idx, new_xyz, (int32_t *)nullptr, 0L);
     return check_launch("furthest_point_sampling_nested");
+}
+
+extern "C" int ws3d_furthest_point_sampling_nested_chain(int b, int n, int levels, const int *m, const float *xyz, int32_t *const *idx,
+                                                         float *const *new_xyz, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || levels < 1 || levels > 5 || !m || !xyz || !idx || !new_xyz) {
+        set_error("ws3d_furthest_point_sampling_nested_chain: invalid argument (b=%d n=%d levels=%d)", b, n, levels);
+        return WS3D_E_INVALID;
+    }
+    int prev = n;
+    for (int l = 0; l < levels; ++l) {
+        if (m[l] <= 0 || m[l] > prev || !idx[l] || !new_xyz[l]) {
+            set_error("ws3d_furthest_point_sampling_nested_chain: level %d: m=%d of %d points (or a NULL output)", l, m[l], prev);
+            return WS3D_E_INVALID;
+        }
+        prev = m[l];
+    }
+    if (b == 0) return WS3D_OK;
+    if (n > 4096 || b > 65535) {
+        set_error("ws3d_furthest_point_sampling_nested_chain: n=%d > 4096 (or b=%d > 65535) is not covered", n, b);
+        return WS3D_E_UNSUPPORTED;
+    }
+    hipStream_t st = as_stream(stream);
+    const int m0 = m[0];
+    const size_t lds = sizeof(float) * 4 * (size_t)m0;
+    hipLaunchKernelGGL(fps_nested_w_kernel, dim3((m0 + 255) / 256, b), dim3(256), lds, st, n, m0, xyz, idx[0], new_xyz[0]);
+    hipLaunchKernelGGL(fps_nested_check_kernel, dim3((n + 255) / 256, b), dim3(256), lds, st, n, m0, xyz, idx[0], new_xyz[0]);
+    int32_t *keep = levels > 1 ? idx[1] : nullptr;           // the verdict waits in the next level's first index slot
+    hipLaunchKernelGGL(fps_nested_finish_kernel, dim3(b), dim3(1024), 0, st, n, m0, nested_opt_n_threads(n), xyz, idx[0], new_xyz[0], keep,
+                       (long)(levels > 1 ? m[1] : 0));
+    if (levels > 1) {
+        NestedTail t;
+        t.levels = levels - 1;
+        for (int l = 1; l < levels; ++l) {
+            t.m[l - 1] = m[l]; t.bs[l - 1] = nested_opt_n_threads(m[l - 1]); t.idx[l - 1] = idx[l]; t.new_xyz[l - 1] = new_xyz[l];
+        }
+        for (int l = levels - 1; l < 4; ++l) { t.m[l] = 0; t.bs[l] = 1; t.idx[l] = nullptr; t.new_xyz[l] = nullptr; }
+        hipLaunchKernelGGL(fps_nested_tail_kernel, dim3(b), dim3(1024), 0, st, m0, (const float *)new_xyz[0], t);
+    }
+    return check_launch("furthest_point_sampling_nested_chain");
 }

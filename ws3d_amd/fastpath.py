@@ -75,6 +75,7 @@ FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first laye
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
 # the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
 GRID_MIN_N = 256
+NESTED_CHAIN = True       # levels 2-4: ONE chain call (ws3d_furthest_point_sampling_nested_chain: four launches) instead of three launches per level
 QUERY_CELL_ORDER = True   # 3-NN: queries taken in the cell order of the level's binned copy (ws3d_three_nn_wq; same rows, -15-30 % per search)
 PARALLEL_SCALES = True  # eager side-stream mode: the second scale of a level beside the first
 PARALLEL_HEADS = True  # ... and the regression head beside the classification head + top-k
@@ -328,13 +329,20 @@ class _Geometry:
         fps_done = [start]
         s_fps.wait_event(start)
         with torch.cuda.stream(s_fps):
-            for sa in sas[1:]:
-                # every level after the first samples the previous level's centres, in the order they were picked
-                _, nx = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS else pn2_ops.furthest_point_sample_gather)(self.xyz[-1], sa.npoint)
-                self.xyz.append(nx)
+            if NESTED_FPS and NESTED_CHAIN and len(sas) > 1:
+                # every level after the first samples the previous level's centres, in the order they were picked: one chain call
+                for _, nx in pn2_ops.furthest_point_sample_gather_nested_chain(self.xyz[-1], [sa.npoint for sa in sas[1:]]):
+                    self.xyz.append(nx)
                 ev = torch.cuda.Event()
                 ev.record(s_fps)
-                fps_done.append(ev)
+                fps_done.extend([ev] * (len(sas) - 1))
+            else:
+                for sa in sas[1:]:
+                    _, nx = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS else pn2_ops.furthest_point_sample_gather)(self.xyz[-1], sa.npoint)
+                    self.xyz.append(nx)
+                    ev = torch.cuda.Event()
+                    ev.record(s_fps)
+                    fps_done.append(ev)
         self.sorted, self.nbr, self.sa_ready = [srt0], [None], [ev0]
         self.nn, self.nn_ready = [], []
         c_feat = [c0] + [sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) for sa in sas]
@@ -371,7 +379,8 @@ class _Geometry:
             s.wait_event(done)
 
 
-def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None, binned: list = None):
+def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None, binned: list = None,
+               new_xyz_pre: torch.Tensor = None):
     """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O); `binned` (a list) receives the level's binned
     copy of xyz (or None): the FP module of this level takes its 3-NN queries in that order"""
     B = xyz.size(0)
@@ -387,7 +396,10 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             sorted_xyz = geo.sorted[0] if geo.sa_ready[0] is not None else pn2_ops.sort_points_x(xyz)
             nbrs = _neighbour_lists(sa, xyz, new_xyz, None, c_feat, zeros)
     else:
-        _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
+        if new_xyz_pre is not None:                  # the caller sampled this level already (the chain call of backbone_forward)
+            new_xyz = new_xyz_pre
+        else:
+            _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
         sorted_xyz = pn2_ops.sort_points_x(xyz, GRID_MIN_N)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat, zeros)
     if binned is not None:
@@ -597,10 +609,15 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats, binned = [xyz], [feats], []
     try:
-        for level, sa in enumerate(net.SA_modules):
-            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned)
+        sas, chain = list(net.SA_modules), None
+        for level, sa in enumerate(sas):
+            pre = chain[level - 1][1] if (chain is not None and level >= 1) else None
+            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned, pre)
             l_xyz.append(nx)
             l_feats.append(nf)
+            if geo is None and level == 0 and NESTED_FPS and NESTED_CHAIN and len(sas) > 1:
+                # serial order (graph capture): the levels below the first in one chain call, right behind the first level's centres
+                chain = pn2_ops.furthest_point_sample_gather_nested_chain(nx, [s_.npoint for s_ in sas[1:]])
         for i in range(-1, -(len(net.FP_modules) + 1), -1):
             nn3 = None
             if geo is not None:
