@@ -59,7 +59,7 @@ def _interp_bytes(cfg):
 # wrappers are installed once and record only while the ACTIVE workload runs a timed step).  What is left of the forward pass after
 # these families is library work: Tensile GEMMs and at::native glue.
 FAMILIES = {
-    "furthest_point_sampling_gather": "fps level 1 (16384 -> 4096)", "furthest_point_sampling_nested": "fps levels 2-4 (verified prefix)",
+    "furthest_point_sampling_gather": "fps level 1 (16384 -> 4096)", "furthest_point_sampling_nested": "fps levels 2-4 (verified prefix)", "furthest_point_sampling_nested_chain": "fps levels 2-4 (verified prefix)",
     "sort_points_x": "binning (grid / x slabs / xz grid)", "sort_points_xz": "binning (grid / x slabs / xz grid)",
     "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "ball_query_pairs": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
     "compact_pairs": "pair compaction",

@@ -67,6 +67,13 @@ def _forward_taps(channels_last):
         bq_log.append((xyz.size(1), nsample, _sha(idx.cpu().numpy().astype(np.int32))))
         return (out, idx) if return_idx else out
 
+    orig_chain = pn2_ops.furthest_point_sample_gather_nested_chain
+
+    def chain_tap(xyz, npoints):          # ... or all of them in one chain call (fastpath.NESTED_CHAIN)
+        r = orig_chain(xyz, npoints)
+        fps_log.extend(i.cpu().numpy() for i, _ in r)
+        return r
+
     orig_nlc = compat.query_and_group_nlc
 
     def nlc_tap(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=True, sorted_xyz=None, idx_out=None):
@@ -99,6 +106,7 @@ def _forward_taps(channels_last):
 
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
     pn2_ops.furthest_point_sample_gather_nested = nested_tap
+    pn2_ops.furthest_point_sample_gather_nested_chain = chain_tap
     compat.query_and_group_nlc = nlc_tap
     if channels_last:
         compat.ball_query_wrapper = bq_tap
@@ -111,6 +119,7 @@ def _forward_taps(channels_last):
     finally:
         pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = orig_fps, orig_qg
         pn2_ops.furthest_point_sample_gather_nested = orig_nested
+        pn2_ops.furthest_point_sample_gather_nested_chain = orig_chain
         compat.query_and_group_nlc = orig_nlc
         compat.ball_query_wrapper = orig_bq
         compat.ball_query_lists = orig_bql
