@@ -47,7 +47,7 @@ extern "C" {
 
 typedef void *ws3d_stream_t;
 
-/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes, ws3d_furthest_point_sampling_nested_chain; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
+/* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes, ws3d_furthest_point_sampling_nested_chain, ws3d_ball_query_pairs2; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 5
 WS3D_API int ws3d_abi_version(void);
@@ -121,6 +121,15 @@ WS3D_API int ws3d_ball_query_fill(int b, int n, int m, float radius, int nsample
  * nsample <= 64 (the kernel that works with one wave per centre), else WS3D_E_UNSUPPORTED.  ws3d extension.                   */
 WS3D_API int ws3d_ball_query_pairs(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz, int32_t *idx,
                           const void *sorted_grid, int32_t *rowc, int32_t *rowsrc, int32_t *total, ws3d_stream_t stream);
+
+/* ws3d_ball_query_pairs for the TWO scales of a set-abstraction level in one launch: same xyz / new_xyz / fine-grid copy, per scale a
+ * radius, an nsample (<= 64) and the four outputs of ws3d_ball_query_pairs (every `total` zero on entry).  Same lists and pair tables as
+ * two calls; WS3D_E_UNSUPPORTED where the one-wave-per-centre kernel does not cover the call (then call per scale).  (round 5) */
+WS3D_API int ws3d_ball_query_pairs2(int b, int n, int m, const float *new_xyz, const float *xyz, const void *sorted_grid,
+                                    float radius0, int nsample0, int32_t *idx0, int32_t *rowc0, int32_t *rowsrc0, int32_t *total0,
+                                    float radius1, int nsample1, int32_t *idx1, int32_t *rowc1, int32_t *rowsrc1, int32_t *total1,
+                                    ws3d_stream_t stream);
+
 
 /* Optional accelerator for ws3d_ball_query / ws3d_query_and_group (no reference counterpart):
  * a per-scene copy of xyz counting-sorted into uniform x cells (float4 {x,y,z,index} x n, a

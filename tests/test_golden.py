@@ -104,6 +104,15 @@ def _forward_taps(channels_last):
             bq_log.append((xyz.size(1), nsample, _sha(both[0].cpu().numpy().astype(np.int32))))
         return both
 
+    orig_bqp2 = compat.ball_query_pairs2
+
+    def bqp2_tap(radii, nsamples, xyz, new_xyz, sorted_grid, totals=None):       # ... or both scales of a level in one launch
+        both = orig_bqp2(radii, nsamples, xyz, new_xyz, sorted_grid, totals)
+        if both is not None:
+            for (lst, _), ns_ in zip(both, nsamples):
+                bq_log.append((xyz.size(1), int(ns_), _sha(lst.cpu().numpy().astype(np.int32))))
+        return both
+
     pn2_ops.furthest_point_sample_gather, pn2_ops.query_and_group = fps_tap, qg_tap
     pn2_ops.furthest_point_sample_gather_nested = nested_tap
     pn2_ops.furthest_point_sample_gather_nested_chain = chain_tap
@@ -112,6 +121,7 @@ def _forward_taps(channels_last):
         compat.ball_query_wrapper = bq_tap
         compat.ball_query_lists = bql_tap
         compat.ball_query_pairs = bqp_tap
+        compat.ball_query_pairs2 = bqp2_tap
     prev = stage1.CHANNELS_LAST_FASTPATH
     stage1.CHANNELS_LAST_FASTPATH = channels_last
     try:
@@ -124,6 +134,7 @@ def _forward_taps(channels_last):
         compat.ball_query_wrapper = orig_bq
         compat.ball_query_lists = orig_bql
         compat.ball_query_pairs = orig_bqp
+        compat.ball_query_pairs2 = orig_bqp2
         stage1.CHANNELS_LAST_FASTPATH = prev
 
 

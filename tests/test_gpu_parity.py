@@ -388,6 +388,22 @@ def test_ball_query_grid_one_wave_per_centre_dense_lists(ops, oracle, N, M, r, n
     for i_, (cm, _) in enumerate(got_pairs):
         pos.setdefault(cm, []).append(i_)
     assert all(v == list(range(v[0], v[0] + len(v))) for v in pos.values())        # a centre's compact rows are contiguous
+    # both scales of a level in ONE launch (ws3d_ball_query_pairs2): this scale beside a second one of another radius / nsample, in
+    # either slot -- the lists of both and their pair tables are those of the single-scale calls
+    r2, ns2 = (r * 3.0, 16) if ns != 16 else (r * 0.5, 32)
+    ref2 = oracle.ball_query(r2, ns2, xyz, new_xyz)
+    for order in ((0, 1), (1, 0)):
+        rr, nn = [(r, r2)[k] for k in order], [(ns, ns2)[k] for k in order]
+        dual = ops.c.ball_query_pairs2(rr, nn, x, c, grid)
+        assert dual is not None
+        for k, (lst, (rc2, rs2, tot2)) in zip(order, dual):
+            want_l = (ref, ref2)[k]
+            np.testing.assert_array_equal(host(lst), want_l)
+            d2_ = (np.diff(want_l, axis=2) > 0).sum(2) + 1
+            n2_ = (ns, ns2)[k]
+            wp = sorted((cm, int(v)) for cm in range(2 * M) for v in want_l.reshape(2 * M, n2_)[cm][:d2_.reshape(-1)[cm]])
+            T2 = int(tot2.item())
+            assert T2 == len(wp) and sorted(zip(host(rc2)[:T2].tolist(), host(rs2)[:T2].tolist())) == wp
     bb = torch.zeros((2, M, ns), dtype=torch.int32, device="cuda")
     ops.c.ball_query_wrapper(2, N, M, r, ns, c, x, bb, None)
     np.testing.assert_array_equal(host(bb), ref)
@@ -2096,7 +2112,7 @@ def test_fast_path_switches_agree(ops):
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
     names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
-             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER")
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2108,7 +2124,7 @@ def test_fast_path_switches_agree(ops):
     try:
         off = {"FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False,
                "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False, "FUSED_COMPACT3_MAX_LDS": 0, "FUSED_QINTERP_GEMM_MIN_ROWS": 1 << 60,
-               "BIN_INPUT_AHEAD": False, "NESTED_CHAIN": False, "QUERY_CELL_ORDER": False}
+               "BIN_INPUT_AHEAD": False, "NESTED_CHAIN": False, "QUERY_CELL_ORDER": False, "DUAL_SCALE_SEARCH": False}
         base = run(**off)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
@@ -2116,7 +2132,8 @@ def test_fast_path_switches_agree(ops):
                    {"FUSED_MLP2_ROWS": True, "FUSED_GATHER_GEMM2": True, "FUSED_INTERP_GEMM": True},
                    {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 64 * 1024}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True, "FUSED_COMPACT3_MAX_LDS": 160 * 1024},
                    {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 30000}, {"PER_POINT_FP": True, "FUSED_QINTERP_GEMM_MIN_ROWS": 1}, {"BIN_INPUT_AHEAD": True, "PARALLEL_SCALES": True},
-                   {"NESTED_CHAIN": True}, {"QUERY_CELL_ORDER": True}, {"NESTED_CHAIN": True, "QUERY_CELL_ORDER": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True}):
+                   {"NESTED_CHAIN": True}, {"QUERY_CELL_ORDER": True}, {"NESTED_CHAIN": True, "QUERY_CELL_ORDER": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True},
+                   {"DUAL_SCALE_SEARCH": True, "PER_POINT_L1": True, "COMPACT_PAIRS": True, "SA1_FROM_LISTS": True}):
             for n, v in saved.items():
                 setattr(fastpath, n, v)
             got = run(**dict(off, **kw))

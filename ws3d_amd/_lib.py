@@ -38,6 +38,7 @@ SIGNATURES = {
     "ws3d_ball_query": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query_fill": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_ball_query_pairs": (_i, [_i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_ball_query_pairs2": (_i, [_i, _i, _i, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp, _vp, C.c_float, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_sorted_points_bytes": (_sz, [_i, _i]),
     "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_xz": (_i, [_i, _i, _vp, _vp, _vp]),

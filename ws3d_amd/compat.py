@@ -252,6 +252,31 @@ def ball_query_pairs(radius, nsample, xyz, new_xyz, sorted_grid, total=None):
     return idx, (rowc, rowsrc, total)
 
 
+def ball_query_pairs2(radii, nsamples, xyz, new_xyz, sorted_grid, totals=None):
+    """ball_query_pairs for the two scales of a level in ONE launch -> [(idx, (rowc, rowsrc, total)), (idx, (rowc, rowsrc, total))], or
+    None when the dual kernel does not cover the call (the caller then takes ball_query_pairs per scale).  `totals`: two 1-element int32
+    tensors that are ZERO, or None.  ws3d extension."""
+    if sorted_grid is None or max(nsamples) > 64 or not BQ_FINE_GRID or len(radii) != 2:
+        return None
+    dev = _dev(xyz, new_xyz, sorted_grid)
+    _f32(xyz, "xyz"); _f32(new_xyz, "new_xyz")
+    B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+    outs = []
+    for k in range(2):
+        ns = int(nsamples[k])
+        outs.append((torch.empty((B, M, ns), dtype=torch.int32, device=dev), torch.empty(B * M * ns, dtype=torch.int32, device=dev),
+                     torch.empty(B * M * ns, dtype=torch.int32, device=dev),
+                     totals[k] if totals is not None else torch.zeros(1, dtype=torch.int32, device=dev)))
+    with _on(dev):
+        rc = _lib.load().ws3d_ball_query_pairs2(B, N, M, _p(new_xyz), _p(xyz), _p(sorted_grid),
+                                                float(radii[0]), int(nsamples[0]), _p(outs[0][0]), _p(outs[0][1]), _p(outs[0][2]), _p(outs[0][3]),
+                                                float(radii[1]), int(nsamples[1]), _p(outs[1][0]), _p(outs[1][1]), _p(outs[1][2]), _p(outs[1][3]), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return None
+    check(rc, "ball_query_pairs2")
+    return [(o[0], (o[1], o[2], o[3])) for o in outs]
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points_tensor, idx_tensor, out_tensor):
     """group_points.cpp:25-36"""
     dev = _dev(points_tensor, idx_tensor, out_tensor)

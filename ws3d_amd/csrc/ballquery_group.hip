@@ -861,13 +861,23 @@ constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the
 // NW waves per workgroup share a tile of 64 centres, CPW = 64 / NW each: 4 x 16 when the launch fills the chip by itself (the c2 block: 32768
 // workgroups), 16 x 4 when it does not (a batch of 8 at level 1: 512 tiles -- sixteen centres in turn per wave left 2 waves per SIMD and a
 // kernel as long as one wave's sixteen searches).
+// blockIdx.y == 1 (ws3d_ball_query_pairs2, round 5): the SECOND scale of a set-abstraction level -- same points, centres and binned copy,
+// its own radius / nsample / outputs -- so that both searches of a level are ONE launch (a launch costs the 20-deep pipeline ~2.3 us).
+struct BqScale2 { float radius; int nsample; int32_t *idx_out, *rowc, *rowsrc, *total; };
 template <bool FUSED, int NW>
-__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius, int nsample, int use_xyz,
+__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius0, int nsample0, int use_xyz,
                                                                    const float *__restrict__ xyz, const char *__restrict__ ws,
                                                                    const float *__restrict__ new_xyz, const float *__restrict__ features,
-                                                                   int32_t *__restrict__ idx_out, float *__restrict__ out,
-                                                                   int32_t *__restrict__ rowc, int32_t *__restrict__ rowsrc,
-                                                                   int32_t *__restrict__ total) {
+                                                                   int32_t *__restrict__ idx_out0, float *__restrict__ out,
+                                                                   int32_t *__restrict__ rowc0, int32_t *__restrict__ rowsrc0,
+                                                                   int32_t *__restrict__ total0, BqScale2 second) {
+    const bool sc2 = !FUSED && blockIdx.y == 1;
+    const float radius = sc2 ? second.radius : radius0;
+    const int nsample = sc2 ? second.nsample : nsample0;
+    int32_t *__restrict__ idx_out = sc2 ? second.idx_out : idx_out0;
+    int32_t *__restrict__ rowc = sc2 ? second.rowc : rowc0;
+    int32_t *__restrict__ rowsrc = sc2 ? second.rowsrc : rowsrc0;
+    int32_t *__restrict__ total = sc2 ? second.total : total0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
     int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
@@ -1148,10 +1158,10 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         if (nsample <= 64 && smem_c <= 64 * 1024) {      // longer lists: one lane per centre (below)
             if (wide)
                 hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 16>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(1024), smem_c, st, b, n, m, c,
-                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
+                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total, BqScale2{});
             else
                 hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, BQC_LARGE_NW>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(64 * BQC_LARGE_NW), smem_c, st, b, n, m, c,
-                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total);
+                                   radius, nsample, use_xyz, xyz, reinterpret_cast<const char *>(sorted), new_xyz, features, idx, out, rowc, rowsrc, total, BqScale2{});
             return check_launch(what);
         }
         if (rowc) { set_error("%s: nsample %d is not covered by the kernel that emits the pairs", what, nsample); return WS3D_E_UNSUPPORTED; }
@@ -1333,6 +1343,38 @@ extern "C" int ws3d_ball_query_pairs(int b, int n, int m, float radius, int nsam
     if (!rowc || !rowsrc || !total || !sorted_grid) { set_error("ws3d_ball_query_pairs: NULL argument"); return WS3D_E_INVALID; }
     return bq_launch<false>(b, n, m, 0, radius, nsample, 4, xyz, new_xyz, nullptr, idx, nullptr, sorted_grid, as_stream(stream),
                             "ws3d_ball_query_pairs", 0, rowc, rowsrc, total);
+}
+
+extern "C" int ws3d_ball_query_pairs2(int b, int n, int m, const float *new_xyz, const float *xyz, const void *sorted_grid,
+                                      float radius0, int nsample0, int32_t *idx0, int32_t *rowc0, int32_t *rowsrc0, int32_t *total0,
+                                      float radius1, int nsample1, int32_t *idx1, int32_t *rowc1, int32_t *rowsrc1, int32_t *total1,
+                                      ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b < 0 || n <= 0 || m < 0 || nsample0 <= 0 || nsample1 <= 0 || !xyz || !new_xyz || !sorted_grid || !idx0 || !rowc0 || !rowsrc0 || !total0 ||
+        !idx1 || !rowc1 || !rowsrc1 || !total1) {
+        set_error("ws3d_ball_query_pairs2: invalid argument (b=%d n=%d m=%d nsample=%d/%d)", b, n, m, nsample0, nsample1);
+        return WS3D_E_INVALID;
+    }
+    if (b == 0 || m == 0) return WS3D_OK;
+    const int ns = nsample0 > nsample1 ? nsample0 : nsample1;
+    const long tiles = (long)b * ((m + 63) / 64);
+    const bool wide = tiles * 2 < BQC_WIDE_BELOW;
+    const int nw = wide ? 16 : BQC_LARGE_NW;
+    const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (ns + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
+    if (n > SORT_MAX_N || b > 65535 || tiles > 0x7fffffffL || ns > 64 || smem_c > 64 * 1024 || !grid_flavour(sorted_grid)) {
+        set_error("ws3d_ball_query_pairs2: not covered (n=%d nsample=%d/%d, or the binned copy is not a fine-grid one): use ws3d_ball_query_pairs per scale", n, nsample0, nsample1);
+        return WS3D_E_UNSUPPORTED;
+    }
+    const BqScale2 second{radius1, nsample1, idx1, rowc1, rowsrc1, total1};
+    hipStream_t st = as_stream(stream);
+    if (wide)
+        hipLaunchKernelGGL((ball_query_grid_coop_kernel<false, 16>), dim3((unsigned)tiles, 2, 1), dim3(1024), smem_c, st, b, n, m, 0, radius0, nsample0, 4, xyz,
+                           reinterpret_cast<const char *>(sorted_grid), new_xyz, (const float *)nullptr, idx0, (float *)nullptr, rowc0, rowsrc0, total0, second);
+    else
+        hipLaunchKernelGGL((ball_query_grid_coop_kernel<false, BQC_LARGE_NW>), dim3((unsigned)tiles, 2, 1), dim3(64 * BQC_LARGE_NW), smem_c, st, b, n, m, 0, radius0,
+                           nsample0, 4, xyz, reinterpret_cast<const char *>(sorted_grid), new_xyz, (const float *)nullptr, idx0, (float *)nullptr, rowc0, rowsrc0,
+                           total0, second);
+    return check_launch("ws3d_ball_query_pairs2");
 }
 
 extern "C" int ws3d_query_and_group(int b, int n, int m, int c, float radius, int nsample,

@@ -75,6 +75,7 @@ FUSED_GATHER_GEMM = True  # ws3d_gather_gemm: grouping fused into the first laye
 # levels with fewer points search by brute force (LDS-tiled scan) without a binned copy.  256: every level of the Stage-1 network takes
 # the fine-grid kernel, which also emits the pair table (2048, the operators' own default: 8 launches more per batch, -0.6 % throughput)
 GRID_MIN_N = 256
+DUAL_SCALE_SEARCH = True  # both ball queries of a level in one launch (ws3d_ball_query_pairs2)
 NESTED_CHAIN = True       # levels 2-4: ONE chain call (ws3d_furthest_point_sampling_nested_chain: four launches) instead of three launches per level
 QUERY_CELL_ORDER = True   # 3-NN: queries taken in the cell order of the level's binned copy (ws3d_three_nn_wq; same rows, -15-30 % per search)
 PARALLEL_SCALES = True  # eager side-stream mode: the second scale of a level beside the first
@@ -269,6 +270,15 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
     drives without loss.)"""
     B = xyz.size(0)
     lists = []
+    want_pairs = [(_gather_gemm_ok(sa, g, _blocks(mlp), c_feat, B) and COMPACT_PAIRS and PER_POINT_L1 and _blocks(mlp)[0].conv.out_channels <= 256
+                   and len(_blocks(mlp)) == 3) for g, mlp in zip(sa.groupers, sa.mlps)]
+    if DUAL_SCALE_SEARCH and len(want_pairs) == 2 and all(want_pairs) and sorted_xyz is not None:
+        totals = [zeros.take((1,), torch.int32) for _ in range(2)] if zeros is not None else None
+        both = _C.ball_query_pairs2([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, sorted_xyz, totals)
+        if both is not None:
+            return [_PairList(nbr, pairs) for nbr, pairs in both]
+        if totals is not None:             # (the arena's two counters stay zero: the per-scale calls below take their own)
+            pass
     for grouper, mlp in zip(sa.groupers, sa.mlps):
         if not _gather_gemm_ok(sa, grouper, _blocks(mlp), c_feat, B):
             lists.append(None)
@@ -413,6 +423,14 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
         out = torch.zeros((B * sa.npoint, sum(widths)), dtype=torch.float32, device=xyz.device)
     cols = [sum(widths[:i]) for i in range(len(widths))]
     pp = [None]
+    # first level: both scales' lists + pair tables in ONE launch when every scale takes the lists-only SharedMLP kernel
+    sa1_pairs = {}
+    if (DUAL_SCALE_SEARCH and COMPACT_PAIRS and FUSED_SA_MLP and SA1_FROM_LISTS and len(widths) == 2 and feats is not None and feats.size(2) == 1
+            and sorted_xyz is not None and all(n_ is None for n_ in nbrs) and all(g_.use_xyz and len(_blocks(m_)) == 3 for g_, m_ in zip(sa.groupers, sa.mlps))):
+        totals = [zeros.take((1,), torch.int32) for _ in range(2)] if zeros is not None else None
+        both = _C.ball_query_pairs2([g_.radius for g_ in sa.groupers], [g_.nsample for g_ in sa.groupers], xyz, new_xyz, sorted_xyz, totals)
+        if both is not None:
+            sa1_pairs = dict(enumerate(both))
 
     def run_scale(si: int) -> None:
         """the SharedMLP + pool of scale si into its column slice of `out`"""
@@ -502,7 +520,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 if _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col):
                     return
             else:
-                nbr1, pairs1 = _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
+                nbr1, pairs1 = sa1_pairs[si] if si in sa1_pairs else _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
                 limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
                 if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
                     if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
