@@ -324,7 +324,8 @@ def c3_side_runs(wl, args, value, latency):
 
     out = {"list_fill": {"generator": wl.kind, "scales": wl.list_fill(),
                          "note": "distinct (centre, sample) pairs / all m * nsample list entries per ball-query scale on the timed batch; the "
-                                 "SharedMLP of a scale runs over the distinct pairs iff its fill <= %.2f, decided on the device per batch" % fastpath.COMPACT_MAX_FILL}}
+                                 "SharedMLP of a scale runs over the distinct pairs iff its fill <= %.2f, decided on the device per batch (in the "
+                                 "graphs: only where the priming batch's fill is above %.2f of that)" % (fastpath.COMPACT_MAX_FILL, fastpath.PRIMED_MARGIN)}}
     wl.release()
     saved = fastpath.COMPACT_PAIRS
     try:

@@ -198,7 +198,9 @@ class C3:
         self.last = None
         self.op_ev = {}
         self._timed = False
-        self.rows_mode = ("distinct pairs / all rows chosen per batch on the device (launch gates, fill <= %.2f -> distinct pairs)" % fastpath.COMPACT_MAX_FILL
+        self.rows_mode = ("distinct pairs / all rows per scale: the graphs keep only the compact kernels of the scales whose fill on the priming "
+                          "batch is <= %.2f x %.2f (Stage1Pipeline pair_dispatch='primed'), the others and the eager pass choose per batch on the "
+                          "device (launch gates, fill <= %.2f -> distinct pairs)" % (fastpath.PRIMED_MARGIN, fastpath.COMPACT_MAX_FILL, fastpath.COMPACT_MAX_FILL)
                           if fastpath.PAIR_DISPATCH == "device" else "distinct pairs of the ball-query lists, always") \
             if fastpath.COMPACT_PAIRS and fastpath.PER_POINT_L1 else "all m*nsample rows"
         _install_hooks()

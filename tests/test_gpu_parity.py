@@ -1651,6 +1651,42 @@ def test_stage1_pipeline_equals_the_plain_step(ops):
         pipe.result(99)
 
 
+def test_pipeline_primed_pair_dispatch_keeps_the_bits(ops):
+    """Stage1Pipeline(pair_dispatch="primed") drops the gated dense twins of the scales its priming batch shows far below the fill
+    threshold (fastpath.primed_compact_scales); "device" keeps both forms in the graph.  Same bits either way -- on the sparse
+    batches the pipeline was primed on AND on a dense batch (a cloud inside a 3 m cube: every list full) sent through the graphs
+    primed on sparse ones, where the compact kernels now run above the threshold the dense form would have taken over at."""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.pipeline import Stage1Pipeline
+    from ws3d_amd.seeded import seeded_state_dict
+    cfg = stage1.RPNConfig(rpn_pre_nms_top_n=2000, rpn_post_nms_top_n=50)
+    model = stage1.Stage1Net(mode="TEST", cfg=cfg).eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    model = model.cuda()
+    sparse = [np.stack([synth.cloud("hdl64", 16384, 6100 + 2 * i + j) for j in range(2)]) for i in range(2)]
+    rng = np.random.default_rng(5)
+    cube = rng.uniform(-1.5, 1.5, size=(2, 16384, 4)).astype(np.float32)
+    cube[:, :, 2] += 20.0
+    batches = sparse + [cube]
+    keys_sparse = fastpath.primed_compact_scales(model.rpn.backbone_net, dev(sparse[0]))
+    keys_dense = fastpath.primed_compact_scales(model.rpn.backbone_net, dev(cube))
+    assert len(keys_sparse) >= 6 and len(keys_dense) < len(keys_sparse), (keys_sparse, keys_dense)
+    outs = {}
+    for mode in ("device", "primed"):
+        pipe = Stage1Pipeline(model, cfg, batch=2, n_points=16384, depth=2, roipool=True, tune_gemms=False, pair_dispatch=mode)
+        got = []
+        for b in batches:
+            o = pipe.result(pipe.submit(b))
+            got.append([o[k].clone() for k in ("boxes", "scores", "count", "pooled", "empty")] + [o["rpn"]["rpn_cls"].clone(), o["rpn"]["rpn_reg"].clone()])
+        assert pipe.graph_error is None
+        assert pipe.compact_only == (keys_sparse if mode == "primed" else frozenset())
+        outs[mode] = got
+    for a, b in zip(outs["device"], outs["primed"]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    with pytest.raises(ValueError):
+        Stage1Pipeline(model, cfg, batch=2, n_points=16384, depth=1, pair_dispatch="host")
+
+
 def test_every_launch_mode_of_the_step_gives_the_same_bits(ops):
     """eager on one stream, eager with the coordinate-only work on side streams, a single-stream hipGraph and a hipGraph with the
     side streams forked and joined INSIDE the capture produce bit-identical outputs -- also on their second and third replay and

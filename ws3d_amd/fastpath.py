@@ -51,6 +51,32 @@ def geometry_ahead(on: bool):
         _AHEAD_OVERRIDE.reset(token)
 
 
+@contextlib.contextmanager
+def compact_only_scales(keys):
+    """inside this block (this thread / task only) the scales (level, scale index) named in `keys` launch ONLY their compact
+    kernels -- no gated dense twin behind them (ten launches of the Stage-1 step that return in their prologue on sparse clouds,
+    0.2 % of the c3 throughput each).  The compact kernels are complete for every batch (the dense form is a speed decision for
+    lists fuller than COMPACT_MAX_FILL), so a denser batch than the caller expected runs slower, not wrong."""
+    token = _COMPACT_ONLY.set(frozenset(keys))
+    try:
+        yield
+    finally:
+        _COMPACT_ONLY.reset(token)
+
+
+def primed_compact_scales(net, pointcloud: torch.Tensor, margin: float = None):
+    """the (level, scale) keys of ``compact_only_scales`` for a caller that primes on `pointcloud`: every scale whose fill on this
+    batch is <= margin * COMPACT_MAX_FILL.  Runs ``list_fill`` (synchronises: set-up time only)."""
+    margin = PRIMED_MARGIN if margin is None else margin
+    keys, per_level = set(), {}
+    for row in list_fill(net, pointcloud):
+        si = per_level.get(row["level"], 0)
+        per_level[row["level"]] = si + 1
+        if row["fill"] <= margin * COMPACT_MAX_FILL:
+            keys.add((row["level"] - 1, si))
+    return frozenset(keys)
+
+
 def _geometry_ahead_now() -> bool:
     v = _AHEAD_OVERRIDE.get()
     return GEOMETRY_AHEAD if v is None else v
@@ -63,8 +89,11 @@ COMPACT_PAIRS = True  # the SharedMLPs over the distinct (centre, sample) pairs 
 #           wrong side of COMPACT_MAX_FILL returns at once (include/ws3d_ops.h "launch gates") -- no host synchronisation, nothing
 #           latched per process, a captured hipGraph adapts per batch;
 #   compact always the compact kernels (A/B runs).
-# COMPACT_PAIRS = False is "always dense".
+# COMPACT_PAIRS = False is "always dense".  A caller that launches the same step many times (Stage1Pipeline's graphs) can drop the
+# dense twin of the scales its priming batch shows to be far from the threshold: ``compact_only_scales`` below.
 PAIR_DISPATCH = "device"
+PRIMED_MARGIN = 0.85       # Stage1Pipeline(pair_dispatch="primed"): scales whose priming fill <= PRIMED_MARGIN * COMPACT_MAX_FILL lose the dense twin
+_COMPACT_ONLY = contextvars.ContextVar("ws3d_compact_only_scales", default=frozenset())
 PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
@@ -167,12 +196,12 @@ def _gather_gemm_ok(sa, grouper, blocks, c_feat: int, B: int) -> bool:
             (B * sa.npoint * grouper.nsample) // 64 <= 65535)        # (the gather-GEMM kernels' grid: one row tile of 64 per workgroup, 16-bit y)
 
 
-def _pair_limit(rows: int, dense_available: bool) -> int:
+def _pair_limit(rows: int, dense_available: bool, key=None) -> int:
     """the launch gate of a scale with `rows` = B * npoint * nsample list entries: the compact kernels run iff the distinct pairs
     of this batch number <= limit, the dense ones iff > limit (-1: no gate, always compact).  The compact path beats the dense
     kernels up to ~55-60 % distinct rows (profiles/r02_compact_vs_dense_fill.txt: 46 vs 133 us at 5 %, 111 vs 129 at 48 %, 180 vs
     122 at 96 %); both are exact, so this is a speed decision only -- taken on the device, per batch."""
-    if PAIR_DISPATCH != "device" or not dense_available:
+    if PAIR_DISPATCH != "device" or not dense_available or (key is not None and key in _COMPACT_ONLY.get()):
         return -1
     return max(0, int(COMPACT_MAX_FILL * rows))          # 0: a batch always holds >= 1 pair, i.e. always dense
 
@@ -460,7 +489,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     rows, ns, o3 = nbr.numel(), grouper.nsample, wt3.size(1)
                     dense_ok = (o1 in (64, 128) and (sa.npoint * ns) % 64 == 0 and rows // 64 <= 65535 and o3 % 64 == 0 and
                                 wt2.size(1) % 4 == 0 and ns in (16, 32))
-                    limit = _pair_limit(rows, dense_ok)
+                    limit = _pair_limit(rows, dense_ok, (level, si))
                     fused = _C.pgather_gemm3_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, wt3, b3, out, col,
                                                      limit=limit, max_lds=FUSED_COMPACT3_MAX_LDS)
                     yc = None if fused else _C.pgather_gemm2_compact(pmat, offs[si], o1, xyz, new_xyz, pairs, w1xs[si], b1, r1, wt2, b2, r2, limit=limit)
@@ -521,7 +550,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                     return
             else:
                 nbr1, pairs1 = sa1_pairs[si] if si in sa1_pairs else _lists_and_pairs(grouper.radius, grouper.nsample, xyz, new_xyz, sorted_xyz, zeros)
-                limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32))
+                limit = _pair_limit(nbr1.numel(), layers[2][2] and nbr1.numel() % 32 == 0 and grouper.nsample in (16, 32), (level, si))
                 if _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=limit):
                     if limit >= 0 and not _C.sa_mlp3_pool_lists(xyz, new_xyz, feats, nbr1, layers, out, col, gate=(pairs1[2], limit)):
                         if not _C.sa_mlp3_pool_compact(xyz, new_xyz, feats, pairs1, layers, out, col, limit=-1):      # (ungated, idempotent: see above)

@@ -57,7 +57,15 @@ def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
-                 channels: int = 4, tune_gemms: bool = None):
+                 channels: int = 4, tune_gemms: bool = None, pair_dispatch: str = "primed"):
+        """pair_dispatch: how a ball-query scale's SharedMLP chooses between its compact-pairs and its dense kernels (both exact,
+        ws3d_amd/fastpath.py PAIR_DISPATCH).  "device": both forms in every graph, the batch's pair total decides in the kernels'
+        prologues.  "primed" (default): the scales whose fill on the FIRST primed batch is <= fastpath.PRIMED_MARGIN x the threshold
+        keep only their compact kernels in the graphs (ten launches fewer per step on LiDAR clouds); a later, denser batch still comes
+        out identical -- the compact kernels are complete -- only slower than the dense form would have been."""
+        if pair_dispatch not in ("primed", "device"):
+            raise ValueError("Stage1Pipeline: pair_dispatch must be 'primed' or 'device', got %r" % (pair_dispatch,))
+        self.pair_dispatch, self.compact_only = pair_dispatch, None
         self.model, self.cfg, self.B, self.depth, self.roipool = model.eval(), cfg, int(batch), max(1, int(depth)), roipool
         self.device = torch.device(device)
         self.hw_queues_raised = ensure_hw_queues()      # False: the runtime already started with its own cap
@@ -139,14 +147,18 @@ class Stage1Pipeline:
             stream = slot["stream"]
             stream.wait_stream(torch.cuda.current_stream(self.device))
             from . import fastpath
+            if self.compact_only is None:        # once per pipeline, on the first primed batch (synchronises: set-up)
+                with torch.cuda.stream(stream):
+                    self.compact_only = (fastpath.primed_compact_scales(self.model.rpn.backbone_net, slot["inp"])
+                                         if self.pair_dispatch == "primed" else frozenset())
             # the priming runs stay on the slot's stream: the eager path's side streams would claim more hardware queues that
             # the graphs never use (a context variable: forward passes of other threads keep their own stream topology)
-            with fastpath.geometry_ahead(False), torch.cuda.stream(stream):
+            with fastpath.geometry_ahead(False), fastpath.compact_only_scales(self.compact_only), torch.cuda.stream(stream):
                 for _ in range(2):
                     self.body(slot["inp"])
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
+            with fastpath.compact_only_scales(self.compact_only), torch.cuda.graph(graph, stream=stream):
                 slot["out"] = self.body(slot["inp"])
             slot["graph"] = graph
         except Exception as exc:      # capture is an optimisation: fall back to eager launches on the slot streams
@@ -189,7 +201,9 @@ class Stage1Pipeline:
                 if slot["graph"] is not None:
                     slot["graph"].replay()
                 else:
-                    slot["out"] = self.body(slot["inp"])
+                    from . import fastpath
+                    with fastpath.compact_only_scales(self.compact_only or frozenset()):
+                        slot["out"] = self.body(slot["inp"])
                 slot["done"].record(slot["stream"])
         self.submitted += 1
         return self.submitted - 1
