@@ -267,8 +267,7 @@ class C3:
             slot = self.pipe.slots[ticket % self.depth]
             res = slot["out"]
             with torch.cuda.stream(slot["stream"]):
-                gathered = wdist.all_gather_proposals(wdist.pack_proposals(res["boxes"], res["scores"]), res["count"],
-                                                      self.B * self.world)
+                gathered = wdist.all_gather_proposals(res["packed"], res["count"], self.B * self.world)      # (packed by the selection kernel)
             self.last = (res["rpn"], res["boxes"], res["scores"], res["count"], res["pooled"], res["empty"], gathered)
             return
         self._timed = timed

@@ -150,6 +150,11 @@ WS3D_API int ws3d_sort_points_xz(int b, int n, const float *xyz, void *sorted, w
  * results bit-identical to the full scan.  Preferred over ws3d_sort_points_x for the ball-query entries; NOT accepted by
  * ws3d_three_nn.                                                                                                   */
 WS3D_API int ws3d_sort_points_grid(int b, int n, const float *xyz, void *sorted, ws3d_stream_t stream);
+/* Several binning jobs in ONE launch (round 5): job i bins the (b, n[i], 3) cloud xyz[i] into sorted[i] (ws3d_sorted_points_bytes(b, n[i])
+ * bytes each) -- kind[i] 0: as ws3d_sort_points_grid, 1: as ws3d_sort_points_xz; at most 8 jobs, 0 < n[i] <= 16384.  The arrays are host
+ * arrays read before the call returns.  Same buffers as one call per job (the levels of a network and both flavours: 6 launches -> 1). */
+WS3D_API int ws3d_sort_points_jobs(int b, int njobs, const int *n, const int *kind, const float *const *xyz, void *const *sorted,
+                                   ws3d_stream_t stream);
 
 /* group_points_wrapper(b,c,n,npoints,nsample,points,idx,out)   group_points.cpp:25-36
  * -> group_points_gpu.cu:47-86.  points (b,c,n), idx (b,npoints,nsample) ->
@@ -483,6 +488,11 @@ WS3D_API int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *o
 WS3D_API size_t ws3d_topk_workspace_bytes(int b, int n);
 WS3D_API int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
                                  size_t workspace_bytes, ws3d_stream_t stream);
+/* The same two sorts over sigmoid(logits[i]) = 1 / (1 + exp(-x)) in fp32, torch.sigmoid's expression, evaluated while the keys are
+ * loaded (round 5): the proposal stage then needs no score tensor and no sigmoid launch; out_scores holds the sigmoid values. */
+WS3D_API int ws3d_topk_sorted_sigmoid(int b, int n, int k, const float *logits, float *out_scores, int64_t *out_idx, ws3d_stream_t stream);
+WS3D_API int ws3d_topk_sorted_sigmoid_ws(int b, int n, int k, const float *logits, float *out_scores, int64_t *out_idx, void *workspace,
+                                         size_t workspace_bytes, ws3d_stream_t stream);
 
 /* Proposal decode (ws3d extension): xyz (b,n,3), rpn_reg (b,n,4*bins) -> boxes (b,n,7)
  * = [x + dx, y + h/2, z + dz, h, w, l, ry] with (dx, dz) = decode_center_target
@@ -498,12 +508,26 @@ WS3D_API int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope, f
  * [x - l/2, z - w/2, x + l/2, z + w/2, ry] (boxes3d_to_bev).                                                        */
 WS3D_API int ws3d_gather_boxes_bev(int b, int n, int top, const float *box, const int64_t *order, float *box_sorted, float *bev,
                           ws3d_stream_t stream);
+/* ws3d_decode_center_boxes + ws3d_gather_boxes_bev in one launch (round 5): only the `top` points that order (b, top) names are decoded
+ * (same arithmetic, bit-identical rows), written in that order with their BEV rectangles; no (b, n, 7) tensor of every point's box. */
+WS3D_API int ws3d_decode_gather_boxes_bev(int b, int n, int top, int bins, float loc_scope, float loc_bin_size, float h, float w, float l,
+                                          const float *xyz, const float *rpn_reg, const int64_t *order, float *box_sorted, float *bev,
+                                          ws3d_stream_t stream);
 /* ws3d_select_proposals: keep (b,keep_stride) int64 / num (b) int32 from ws3d_nms_batched on score-sorted boxes -> the
  * first min(num, k) survivors as boxes_out (b,k,7) and scores_out (b,k), zero-padded (row * 0 for the padding, as the
  * torch composition does), count (b) int64, and (optional) pooled_boxes (b,k,7) = enlarge_box3d(boxes_out, extra_width). */
 WS3D_API int ws3d_select_proposals(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
                           const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
                           int64_t *count, float *pooled_boxes, ws3d_stream_t stream);
+/* ... and additionally packed (b, k, 8) rows = box + score (or NULL): what the multi-GPU gather sends (ws3d_amd/dist.py), written here
+ * instead of by a concatenation launch (round 5). */
+WS3D_API int ws3d_select_proposals_packed(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
+                                          const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
+                                          int64_t *count, float *pooled_boxes, float *packed, ws3d_stream_t stream);
+/* The step's prologue in one launch (round 5): the (rows, c) input rows, c >= 3, split into xyz (rows, 3) and feats (rows, c - 3), and
+ * clear_bytes bytes at `clear` zeroed (16-byte aligned and a multiple of 16; 0: nothing) -- the pass's zero-initialised scratch. */
+WS3D_API int ws3d_split_points_clear(long rows, int c, const float *pc, float *xyz, float *feats, void *clear, size_t clear_bytes,
+                                     ws3d_stream_t stream);
 
 /* ---------------------------------------------------------------- roipool3d_cuda */
 

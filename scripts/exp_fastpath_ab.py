@@ -1,6 +1,6 @@
 """A/B of one module attribute of ws3d_amd.fastpath (two exact forms of the same function) on the c3 step: throughput mode (20 in
 flight) and latency mode, ABAB on one box, both generators; outputs compared to the first run.
-    python scripts/exp_fastpath_ab.py FUSED_COMPACT3_MAX_LDS 0 65536 [steps]"""
+    python scripts/exp_fastpath_ab.py FUSED_COMPACT3_MAX_LDS 0 65536 [steps [reps [kinds]]]"""
 import ast, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,6 +11,9 @@ from ws3d_amd import fastpath
 
 attr, values = sys.argv[1], [ast.literal_eval(v) for v in sys.argv[2:4]]
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 80
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+kinds = sys.argv[6].split(",") if len(sys.argv) > 6 else ["hdl64", "lidar"]
+rates = {}
 assert hasattr(fastpath, attr), attr
 model, ref = None, {}
 
@@ -40,10 +43,13 @@ def run(value, kind):
     diff = max(float((r0[k] - res[k]).abs().max()) for k in res)
     print("%s=%-8s %-6s %.4f ms per batch  %.0f scenes/s   latency %.3f ms   max |output - first run| %.2e" %
           (attr, value, kind, dt / steps * 1e3, wl.scenes() * steps / dt, lat, diff), flush=True)
+    rates.setdefault((kind, value), []).append(wl.scenes() * steps / dt)
     wl.release()
 
 
-for kind in ("hdl64", "lidar"):
-    for rep in range(2):
+for kind in kinds:
+    for rep in range(reps):
         for v in values:
             run(v, kind)
+for (kind, value), r in rates.items():
+    print("mean %-6s %s=%-8s %.0f scenes/s over %d runs" % (kind, attr, value, sum(r) / len(r), len(r)))

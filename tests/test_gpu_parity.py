@@ -1386,6 +1386,57 @@ def test_topk_sorted_kernel(ops, B, n, k, segments):
     assert torch.equal(vals, ref_v[:, :k])
 
 
+@pytest.mark.parametrize("B,n,k,segments", [(3, 16384, 9000, False), (3, 16384, 9000, True), (2, 5000, 5000, False), (2, 5000, 3000, True), (4, 700, 10, False),
+                                            (1, 1024, 1024, False), (2, 2049, 100, True)])
+def test_topk_sorted_over_the_sigmoid_of_logits(ops, B, n, k, segments):
+    """ws3d_topk_sorted_sigmoid[_ws]: the sort over 1 / (1 + exp(-x)) evaluated in the kernel == the sort of torch.sigmoid(x) --
+    the same fp32 values bit for bit (torch evaluates the same expression with the same device library), hence the same order
+    incl. the ties that the sigmoid's rounding creates between distinct logits (ascending index)"""
+    g = torch.Generator().manual_seed(7 * n + k)
+    x = (torch.randn((B, n), generator=g) * 6).cuda()
+    x[0, :min(n, 40)] = torch.linspace(-104.0, 104.0, min(n, 40))          # saturation on both sides, subnormal results
+    if n > 300:
+        x[-1, 100:130] = torch.linspace(17.0, 17.00001, 30)              # distinct logits, equal sigmoids
+        x[-1, 5] = float("inf"); x[-1, 9] = float("-inf"); x[0, 203] = -0.0; x[0, 204] = 0.0
+    ref = torch.sigmoid(x)
+    want_v, want_i = ops.c.topk_sorted(ref, k, spread=segments)
+    vals, idx = ops.c.topk_sorted(x, k, spread=segments, sigmoid=True)
+    assert torch.equal(vals.view(torch.int32), want_v.view(torch.int32))
+    assert torch.equal(idx, want_i)
+
+
+def test_proposal_glue_kernels_of_round_5(ops):
+    """ws3d_decode_gather_boxes_bev == ws3d_decode_center_boxes + ws3d_gather_boxes_bev; ws3d_select_proposals_packed's extra rows ==
+    cat(boxes, scores); ws3d_split_points_clear == the two strided copies + a fill -- each bit for bit"""
+    rng = np.random.default_rng(3)
+    B, N, top = 3, 5000, 1200
+    xyz = dev(rng.uniform(-40, 40, size=(B, N, 3)).astype(np.float32))
+    reg = dev(rng.standard_normal((B, N, 48)).astype(np.float32))
+    reg[0, 7, 3] = float("nan")
+    order = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:top] for b in range(B)]).cuda()
+    box = ops.c.decode_center_boxes(xyz, reg, 3.0, 0.5, (1.5, 1.6, 3.9))
+    want_rows, want_bev = ops.c.gather_boxes_bev(box, order)
+    rows, bev = ops.c.decode_gather_boxes_bev(xyz, reg, order, 3.0, 0.5, (1.5, 1.6, 3.9))
+    assert torch.equal(rows.view(torch.int32), want_rows.view(torch.int32)) and torch.equal(bev.view(torch.int32), want_bev.view(torch.int32))
+    sc = torch.sort(torch.rand((B, top), device="cuda"), dim=1, descending=True)[0]
+    keep = torch.stack([torch.randperm(top, generator=torch.Generator().manual_seed(9 + b)) for b in range(B)]).cuda()
+    num = torch.tensor([0, 17, 900], dtype=torch.int32, device="cuda")
+    a = ops.c.select_proposals(rows, sc, keep, num, 64, 1.0)
+    b_ = ops.c.select_proposals(rows, sc, keep, num, 64, 1.0, packed=True)
+    assert len(b_) == 5 and all(torch.equal(x_, y_) for x_, y_ in zip(a, b_[:4]))
+    assert torch.equal(b_[4].view(torch.int32), torch.cat([a[0], a[1].unsqueeze(-1)], dim=-1).view(torch.int32))
+    for C_ in (4, 3, 7):
+        pc = dev(rng.standard_normal((2, 1237, C_)).astype(np.float32))
+        junk = torch.full((4099 * 4,), float("nan"), device="cuda")
+        x_, f_ = ops.c.split_points_clear(pc, junk)
+        assert torch.equal(x_, pc[..., :3].contiguous()) and (f_ is None if C_ == 3 else torch.equal(f_, pc[..., 3:].contiguous()))
+        assert bool((junk.view(torch.int32) == 0).all())
+        x_, f_ = ops.c.split_points_clear(pc, None)
+        assert torch.equal(x_, pc[..., :3].contiguous())
+    with pytest.raises(ValueError):
+        ops.c.split_points_clear(dev(np.zeros((1, 8, 4), np.float32)), torch.zeros(3, device="cuda"))
+
+
 def test_three_nn_weights_kernel_equals_torch_composition(ops):
     pc = synth.make_batch("lidar", 2, 3000, 12)[:, :, :3].copy()
     kn = pc[:, :700].copy()
@@ -1649,6 +1700,41 @@ def test_stage1_pipeline_equals_the_plain_step(ops):
         pipe.submit(np.zeros((4, 4096, 4), dtype=np.float32))
     with pytest.raises(ValueError):
         pipe.result(99)
+
+
+def test_sort_points_jobs_equals_one_call_per_job(ops, oracle):
+    """ws3d_sort_points_jobs (several clouds / both flavours binned by ONE launch) fills every buffer as the single calls do: the
+    same cell tables and headers byte for byte, the same records per scene (inside a cell their order is the arrival order of an
+    LDS atomic in either form: compared as sets), and the searches on them return the same lists"""
+    rng = np.random.default_rng(11)
+    B = 3
+    clouds = [dev(np.stack([synth.cloud("hdl64", 16384, 900 + j)[:, :3] for j in range(B)])[:, :n].copy()) for n in (4096, 1024, 256)]
+    clouds.append(dev(rng.uniform(-3, 3, size=(B, 700, 3)).astype(np.float32)))
+    jobs = [(c, "grid") for c in clouds] + [(c, "xz") for c in clouds]
+    bufs = ops.c.sort_points_jobs(jobs)
+    assert len(bufs) == len(jobs) and all(b is not None for b in bufs)
+    for (c, kind), buf in zip(jobs, bufs):
+        single = ops.c.sort_points_x(c, 1, grid=True) if kind == "grid" else ops.c.sort_points_xz(c, 1)
+        n = c.size(1)
+        a, b_ = host(buf).reshape(B, -1), host(single).reshape(B, -1)
+        assert a.shape == b_.shape
+        np.testing.assert_array_equal(a[:, n * 16:n * 16 + 16], b_[:, n * 16:n * 16 + 16])     # the header (the cell tables' unused tail is not written: checked through the searches below)
+        for s_ in range(B):
+            ra = np.ascontiguousarray(a[s_, :n * 16]).view(np.uint32).reshape(n, 4)
+            rb = np.ascontiguousarray(b_[s_, :n * 16]).view(np.uint32).reshape(n, 4)
+            np.testing.assert_array_equal(ra[np.argsort(ra[:, 3], kind="stable")], rb[np.argsort(rb[:, 3], kind="stable")])
+    # the searches on the jobs' buffers: every cloud against the centres / queries of the next smaller one
+    for k in range(3):
+        x, c_ = clouds[k], clouds[k + 1][:, :256].contiguous()
+        want = oracle.ball_query(0.8, 16, host(x), host(c_))
+        got = torch.zeros((B, c_.size(1), 16), dtype=torch.int32, device="cuda")
+        ops.c.ball_query_wrapper(B, x.size(1), c_.size(1), 0.8, 16, c_, x, got, bufs[k])
+        np.testing.assert_array_equal(host(got), want)
+        _d2, idx = oracle.three_nn_dist2(host(c_), host(x))
+        idx_g, _w = ops.c.three_nn_with_weights(c_, x, bufs[4 + k], None)
+        np.testing.assert_array_equal(host(idx_g), idx)
+    with pytest.raises(ValueError):
+        ops.c.sort_points_jobs([(clouds[0], "slab")])
 
 
 def test_pipeline_primed_pair_dispatch_keeps_the_bits(ops):
@@ -2148,7 +2234,7 @@ def test_fast_path_switches_agree(ops):
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
     names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
-             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH")
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH", "MERGED_BINNING", "FUSED_PROLOGUE")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2160,7 +2246,7 @@ def test_fast_path_switches_agree(ops):
     try:
         off = {"FUSED_MLP2_ROWS": False, "FUSED_GATHER_GEMM2": False, "FUSED_INTERP_GEMM": False, "PER_POINT_L1": False, "PER_POINT_FP": False, "COMPACT_PAIRS": False,
                "SA1_FROM_LISTS": False, "PARALLEL_SCALES": False, "PARALLEL_HEADS": False, "FUSED_COMPACT3_MAX_LDS": 0, "FUSED_QINTERP_GEMM_MIN_ROWS": 1 << 60,
-               "BIN_INPUT_AHEAD": False, "NESTED_CHAIN": False, "QUERY_CELL_ORDER": False, "DUAL_SCALE_SEARCH": False}
+               "BIN_INPUT_AHEAD": False, "NESTED_CHAIN": False, "QUERY_CELL_ORDER": False, "DUAL_SCALE_SEARCH": False, "MERGED_BINNING": False, "FUSED_PROLOGUE": False}
         base = run(**off)
         scale = [float(t.abs().max()) for t in base]
         for kw in ({"FUSED_MLP2_ROWS": True}, {"FUSED_GATHER_GEMM2": True}, {"FUSED_INTERP_GEMM": True}, {"PER_POINT_L1": True}, {"PER_POINT_FP": True}, {"PER_POINT_L1": True, "PER_POINT_FP": True, "FUSED_MLP2_ROWS": True}, {"PER_POINT_L1": True, "COMPACT_PAIRS": True},
@@ -2175,6 +2261,13 @@ def test_fast_path_switches_agree(ops):
             got = run(**dict(off, **kw))
             for g, b, s in zip(got, base, scale):
                 assert float((g - b).abs().max()) <= 2e-4 * max(s, 1.0), (kw, float((g - b).abs().max()), s)
+        for n, v in saved.items():
+            setattr(fastpath, n, v)
+        with fastpath.geometry_ahead(False):      # the serial order Stage1Pipeline's graphs capture: one binning launch for levels 2.. or one per level and flavour
+            one, per_level = run(MERGED_BINNING=True), run(MERGED_BINNING=False)
+            split = run(FUSED_PROLOGUE=False)
+        assert all(torch.equal(x_, y_) for x_, y_ in zip(one, per_level)) and all(torch.equal(x_, y_) for x_, y_ in zip(one, split))
+        assert all(torch.equal(x_, y_) for x_, y_ in zip(run(FUSED_PROLOGUE=True), run(FUSED_PROLOGUE=False)))        # and with the side streams
     finally:
         for n, v in saved.items():
             setattr(fastpath, n, v)

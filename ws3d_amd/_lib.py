@@ -43,6 +43,7 @@ SIGNATURES = {
     "ws3d_sort_points_x": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_xz": (_i, [_i, _i, _vp, _vp, _vp]),
     "ws3d_sort_points_grid": (_i, [_i, _i, _vp, _vp, _vp]),
+    "ws3d_sort_points_jobs": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_group_points": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_group_points_grad": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_query_and_group": (_i, [_i, _i, _i, _i, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "ws3d_topk_sorted": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_topk_workspace_bytes": (C.c_size_t, [_i, _i]),
     "ws3d_topk_sorted_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "ws3d_topk_sorted_sigmoid": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ws3d_topk_sorted_sigmoid_ws": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_three_nn_weights": (_i, [C.c_long, _vp, _vp, _vp]),
     "ws3d_three_nn_w": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_nn_wq": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -99,6 +102,9 @@ SIGNATURES = {
     "ws3d_interp_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "ws3d_gather_boxes_bev": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_select_proposals": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_decode_gather_boxes_bev": (_i, [_i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_select_proposals_packed": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_split_points_clear": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_roipool3d_fill": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_roipool3d_workspace_bytes": (C.c_size_t, [_i, _i]),

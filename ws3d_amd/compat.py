@@ -206,6 +206,34 @@ def sort_points_xz(xyz, min_n=256):
     return out
 
 
+def sort_points_jobs(jobs):
+    """jobs: [(xyz (B,N_i,3), kind)] with kind "grid" (sort_points_x's fine-grid buffer, the ball query's) or "xz" (sort_points_xz's,
+    three_nn's) -> the list of buffers, all binned by ONE launch (ws3d_sort_points_jobs); same bytes as one call per job.  None for a
+    job whose cloud the binned searches do not take (N > 16384).  ws3d extension."""
+    if not jobs:
+        return []
+    import ctypes as C
+    dev = _dev(*[x for x, _ in jobs])
+    lib = _lib.load()
+    b = jobs[0][0].size(0)
+    outs, n_arr, k_arr, x_arr, o_arr = [], [], [], [], []
+    for xyz, kind in jobs:
+        _f32(xyz, "xyz")
+        if xyz.size(0) != b or kind not in ("grid", "xz"):
+            raise ValueError("sort_points_jobs: every job takes the same batch and kind 'grid' or 'xz'")
+        nbytes = lib.ws3d_sorted_points_bytes(b, xyz.size(1))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+        outs.append(out)
+        if out is not None:
+            n_arr.append(xyz.size(1)); k_arr.append(0 if kind == "grid" else 1); x_arr.append(xyz.data_ptr()); o_arr.append(out.data_ptr())
+    k = len(n_arr)
+    if k:
+        with _on(dev):
+            check(lib.ws3d_sort_points_jobs(b, k, (C.c_int * k)(*n_arr), (C.c_int * k)(*k_arr), (C.c_void_p * k)(*x_arr), (C.c_void_p * k)(*o_arr),
+                                            _stream()), "sort_points_jobs")
+    return outs
+
+
 def ball_query_wrapper(b, n, m, radius, nsample, new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz=None):
     """ball_query.cpp:14-25 (sorted_xyz: optional output of sort_points_x for this xyz)"""
     dev = _dev(new_xyz_tensor, xyz_tensor, idx_tensor, sorted_xyz)
@@ -861,9 +889,10 @@ def three_interpolate_grad_det(b, c, n, m, grad_out_tensor, idx_tensor, weight_t
     return 1
 
 
-def topk_sorted(scores, k, spread=None):
+def topk_sorted(scores, k, spread=None, sigmoid=False):
     """scores (B,N) float32, N <= 16384 -> (values (B,k) descending, indices (B,k) int64); ties in
-    ascending index order (ws3d extension).  spread: the sort of a scene over several workgroups (ws3d_topk_sorted_ws: 107 -> ~25 us
+    ascending index order (ws3d extension).  sigmoid: `scores` holds logits, the sort runs over torch.sigmoid's fp32 expression of
+    them (evaluated in the kernel: same values and order as topk_sorted(torch.sigmoid(scores), k), one launch fewer).  spread: the sort of a scene over several workgroups (ws3d_topk_sorted_ws: 107 -> ~25 us
     at 16384 scores, for ~1.5x the CU time); None: when the call is not being captured into a hipGraph -- a lone batch leaves the
     chip idle beside a one-workgroup sort, the graphs of a full pipeline do not (measured: -2.3 % latency, -1.1 % throughput)."""
     dev = _dev(scores)
@@ -878,9 +907,10 @@ def topk_sorted(scores, k, spread=None):
     with _on(dev):
         if need:        # the sort of a scene spread over its CUs: 2048-key segments side by side, then ranked against each other
             ws = torch.empty(need // 8, dtype=torch.int64, device=dev)
-            check(lib.ws3d_topk_sorted_ws(B, N, k, _p(scores), _p(vals), _p(idx), _p(ws), need, _stream()), "topk_sorted")
+            check((lib.ws3d_topk_sorted_sigmoid_ws if sigmoid else lib.ws3d_topk_sorted_ws)(B, N, k, _p(scores), _p(vals), _p(idx), _p(ws), need,
+                                                                                            _stream()), "topk_sorted")
         else:
-            check(lib.ws3d_topk_sorted(B, N, k, _p(scores), _p(vals), _p(idx), _stream()), "topk_sorted")
+            check((lib.ws3d_topk_sorted_sigmoid if sigmoid else lib.ws3d_topk_sorted)(B, N, k, _p(scores), _p(vals), _p(idx), _stream()), "topk_sorted")
     return vals, idx
 
 
@@ -900,6 +930,44 @@ def decode_center_boxes(xyz, rpn_reg, loc_scope, loc_bin_size, mean_size):
     return boxes
 
 
+def decode_gather_boxes_bev(xyz, rpn_reg, order, loc_scope, loc_bin_size, mean_size):
+    """xyz (B,N,3), rpn_reg (B,N,4*bins), order (B,top) int64 -> (proposal rows of the points `order` names (B,top,7), their BEV
+    rectangles (B,top,5)): decode_center_boxes + gather_boxes_bev in one launch, only `top` rows decoded (ws3d extension)"""
+    dev = _dev(xyz, rpn_reg, order)
+    _f32(xyz, "xyz"); _f32(rpn_reg, "rpn_reg")
+    B, N, top = xyz.size(0), xyz.size(1), order.size(1)
+    bins = int(loc_scope / loc_bin_size) * 2
+    if rpn_reg.size(2) != 4 * bins or not rpn_reg.is_contiguous() or not xyz.is_contiguous():
+        raise ValueError("decode_gather_boxes_bev: rpn_reg must be contiguous (B,N,%d)" % (4 * bins))
+    if order.dtype != torch.int64 or not order.is_contiguous():
+        raise ValueError("decode_gather_boxes_bev: order must be a contiguous int64 tensor")
+    out = torch.empty((B, top, 7), dtype=torch.float32, device=dev)
+    bev = torch.empty((B, top, 5), dtype=torch.float32, device=dev)
+    h, w, l = mean_size
+    with _on(dev):
+        check(_lib.load().ws3d_decode_gather_boxes_bev(B, N, top, bins, float(loc_scope), float(loc_bin_size), float(h), float(w), float(l),
+                                                       _p(xyz), _p(rpn_reg), _p(order), _p(out), _p(bev), _stream()), "decode_gather_boxes_bev")
+    return out, bev
+
+
+def split_points_clear(pointcloud, clear=None):
+    """pointcloud (B,N,C>=3) contiguous -> (xyz (B,N,3), feats (B,N,C-3) or None), and `clear` (a contiguous tensor whose byte size
+    is a multiple of 16, or None) zeroed -- one launch (ws3d_split_points_clear: the step's prologue).  ws3d extension."""
+    dev = _dev(pointcloud) if clear is None else _dev(pointcloud, clear)
+    _f32(pointcloud, "pointcloud")
+    if not pointcloud.is_contiguous() or pointcloud.dim() != 3 or pointcloud.size(2) < 3:
+        raise ValueError("split_points_clear: pointcloud must be a contiguous (B,N,C>=3) tensor")
+    B, N, Cc = pointcloud.shape
+    xyz = torch.empty((B, N, 3), dtype=torch.float32, device=dev)
+    feats = torch.empty((B, N, Cc - 3), dtype=torch.float32, device=dev) if Cc > 3 else None
+    nbytes = 0 if clear is None else clear.numel() * clear.element_size()
+    if clear is not None and (not clear.is_contiguous() or nbytes % 16 or clear.data_ptr() % 16):
+        raise ValueError("split_points_clear: `clear` must be contiguous, 16-byte aligned and a multiple of 16 bytes long")
+    with _on(dev):
+        check(_lib.load().ws3d_split_points_clear(B * N, Cc, _p(pointcloud), _p(xyz), _p(feats), _p(clear), nbytes, _stream()), "split_points_clear")
+    return xyz, feats
+
+
 def gather_boxes_bev(box, order):
     """box (B,N,7), order (B,top) int64 -> (box[order] (B,top,7), its BEV rectangles (B,top,5)) in one launch (ws3d extension)"""
     dev = _dev(box, order)
@@ -914,9 +982,10 @@ def gather_boxes_bev(box, order):
     return box_sorted, bev
 
 
-def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None):
+def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None, packed=False):
     """first min(num, k) NMS survivors of score-sorted boxes -> (boxes (B,k,7), scores (B,k), count (B,) int64,
-    boxes enlarged by extra_width for RoI pooling or None), zero padded; one launch (ws3d extension)"""
+    boxes enlarged by extra_width for RoI pooling or None), zero padded; one launch (ws3d extension).  packed: a fifth result, the
+    (B,k,8) rows box + score (ws3d_amd.dist.pack_proposals' tensor) written by the same launch"""
     dev = _dev(box_sorted, scores_sorted, keep, num)
     _f32(box_sorted, "box_sorted"); _f32(scores_sorted, "scores")
     if keep.dtype != torch.int64 or num.dtype != torch.int32:
@@ -926,11 +995,17 @@ def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None):
     scores = torch.empty((B, k), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=torch.int64, device=dev)
     pooled = torch.empty((B, k, 7), dtype=torch.float32, device=dev) if extra_width is not None else None
+    pk = torch.empty((B, k, 8), dtype=torch.float32, device=dev) if packed else None
     with _on(dev):
-        check(_lib.load().ws3d_select_proposals(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
-                                                _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
-                                                _stream()), "select_proposals")
-    return boxes, scores, count, pooled
+        if packed:
+            check(_lib.load().ws3d_select_proposals_packed(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
+                                                           _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
+                                                           _p(pk), _stream()), "select_proposals")
+        else:
+            check(_lib.load().ws3d_select_proposals(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
+                                                    _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
+                                                    _stream()), "select_proposals")
+    return (boxes, scores, count, pooled, pk) if packed else (boxes, scores, count, pooled)
 
 
 def bias_act_inplace(y, bias, relu=True):
@@ -1007,7 +1082,7 @@ def nms_device_batched(boxes, thresh, normal=False, max_keep=0):
     ws_bytes = lib.ws3d_nms_workspace_bytes(n) * max(B, 1)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     keep = torch.empty((B, max(n, 1)), dtype=torch.int64, device=dev)
-    num = torch.zeros(B, dtype=torch.int32, device=dev)
+    num = torch.empty(B, dtype=torch.int32, device=dev)          # (every scene's count is written by the first sweep, or cleared when n == 0)
     with _on(dev):
         check(lib.ws3d_nms_batched(B, n, _p(boxes), float(thresh), int(bool(normal)), int(max_keep), _p(ws),
                                    ws_bytes, _p(keep), _p(num), _stream()), "nms_batched")

@@ -14,6 +14,7 @@
 
 #include "common.h"
 #include "binning.h"
+#include "bin_kernels.h"
 
 namespace ws3d {
 
@@ -93,81 +94,9 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m,
     }
 }
 
-// ---- (x, z) grid flavour of the binned known set (binning.h), for the 3-NN search only ----
-// One workgroup per scene: bounding box of the finite (x, z), a gx x gz grid of near-square cells with
-// ~2 points each (gx * gz <= BQS_CELLS), LDS histogram, exclusive scan, scatter.
+// ---- (x, z) grid flavour of the binned known set (binning.h), for the 3-NN search only: bin_kernels.h
 __global__ __launch_bounds__(1024) void bin_points_xz_kernel(int n, const float *__restrict__ xyz, char *__restrict__ ws) {
-    __shared__ int hist[BQS_CELLS];
-    __shared__ int wsum[16];
-    __shared__ float red[4][16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    xyz += (size_t)b * n * 3;
-    char *base = ws + (size_t)b * bin_scene_stride(n);
-    float4 *sorted = reinterpret_cast<float4 *>(base);
-    BinHeader *hdr = reinterpret_cast<BinHeader *>(base + (size_t)n * 16);
-    int *start = reinterpret_cast<int *>(base + (size_t)n * 16 + sizeof(BinHeader));
-
-    float lo_x = INFINITY, hi_x = -INFINITY, lo_z = INFINITY, hi_z = -INFINITY;
-    for (int i = tid; i < n; i += 1024) {
-        const float x = xyz[(size_t)i * 3], z = xyz[(size_t)i * 3 + 2];
-        if (fabsf(x) < INFINITY) { lo_x = fminf(lo_x, x); hi_x = fmaxf(hi_x, x); }
-        if (fabsf(z) < INFINITY) { lo_z = fminf(lo_z, z); hi_z = fmaxf(hi_z, z); }
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo_x = fminf(lo_x, __shfl_xor(lo_x, o)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, o));
-        lo_z = fminf(lo_z, __shfl_xor(lo_z, o)); hi_z = fmaxf(hi_z, __shfl_xor(hi_z, o));
-    }
-    if (lane == 0) { red[0][w] = lo_x; red[1][w] = hi_x; red[2][w] = lo_z; red[3][w] = hi_z; }
-    for (int i = tid; i < BQS_CELLS; i += 1024) hist[i] = 0;
-    __syncthreads();
-    lo_x = red[0][0]; hi_x = red[1][0]; lo_z = red[2][0]; hi_z = red[3][0];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) {
-        lo_x = fminf(lo_x, red[0][i]); hi_x = fmaxf(hi_x, red[1][i]);
-        lo_z = fminf(lo_z, red[2][i]); hi_z = fmaxf(hi_z, red[3][i]);
-    }
-    const float xmin = lo_x <= hi_x ? lo_x : 0.f, wx = lo_x <= hi_x ? hi_x - lo_x : 0.f;
-    const float zmin = lo_z <= hi_z ? lo_z : 0.f, wz = lo_z <= hi_z ? hi_z - lo_z : 0.f;
-    // near-square cells, about two points each; a degenerate extent gets one cell along that axis
-    int gx = 1, gz = 1;
-    const int target = max(1, min(BQS_CELLS, n / 2));
-    if (wx > 0.f && wz > 0.f) {
-        const float h = sqrtf(wx * wz / (float)target);
-        gx = max(1, min(BQS_CELLS, (int)ceilf(wx / h)));
-        gz = max(1, min(BQS_CELLS / gx, (int)ceilf(wz / h)));
-    } else if (wx > 0.f) {
-        gx = target;
-    } else if (wz > 0.f) {
-        gz = target;
-    }
-    const float inv_wx = wx > 0.f ? (float)gx / wx : 0.f, inv_wz = wz > 0.f ? (float)gz / wz : 0.f;
-    auto cell_of = [&](const float *p) { return grid_coord(p[2], zmin, inv_wz, gz) * gx + grid_coord(p[0], xmin, inv_wx, gx); };
-    for (int i = tid; i < n; i += 1024) atomicAdd(&hist[cell_of(xyz + (size_t)i * 3)], 1);
-    __syncthreads();
-    const int a0 = hist[2 * tid], a1 = hist[2 * tid + 1];
-    int v = a0 + a1;
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
-    if (lane == 63) wsum[w] = v;
-    __syncthreads();
-    int off = 0;
-    for (int i = 0; i < w; ++i) off += wsum[i];
-    const int excl = off + v - (a0 + a1);
-    __syncthreads();
-    hist[2 * tid] = excl;
-    hist[2 * tid + 1] = excl + a0;
-    start[2 * tid] = excl;
-    start[2 * tid + 1] = excl + a0;
-    if (tid == 0) {
-        start[BQS_CELLS] = n;
-        hdr->xmin = xmin; hdr->inv_w = inv_wx; hdr->n = n; hdr->pad = gx;
-        start[GRID_ZMIN] = __float_as_int(zmin); start[GRID_INV_WZ] = __float_as_int(inv_wz); start[GRID_GZ] = gz;
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const float *p = xyz + (size_t)i * 3;
-        const int pos = atomicAdd(&hist[cell_of(p)], 1);
-        sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
-    }
+    bin_points_xz_body(blockIdx.x, n, xyz, ws);
 }
 
 // Exact 3-NN against an x-binned copy of the known set (binning.h; built once per FP layer by

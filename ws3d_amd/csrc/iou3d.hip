@@ -17,6 +17,7 @@
 // Arithmetic: plain IEEE fp32 in source order (library built with -ffp-contract=off),
 // sin/cos/atan2 = double libm rounded to float.
 #include "common.h"
+#include "decode.h"
 
 namespace ws3d {
 
@@ -558,34 +559,11 @@ __global__ __launch_bounds__(256) void decode_center_boxes_kernel(long total, in
                                                                   float *__restrict__ boxes) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= total) return;
-    const float *r = reg + t * 4 * bins;
-    const float half = bin_size / 2;
-    float pos[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const float *bl = r + a * bins;
-        int best = 0;
-        float bv = bl[0];
-        for (int i = 1; i < bins; ++i) {
-            const float v = bl[i];
-            if (v > bv || (v != v && bv == bv)) { bv = v; best = i; }
-        }
-        float p = (float)best * bin_size;
-        p = p + half;
-        p = p - loc_scope;
-        const float res = r[(2 + a) * bins + best] * half;
-        pos[a] = p + res;
-    }
-    const float *q = xyz + t * 3;
-    const unsigned long long k = (unsigned long long)(t % n);
-    const double hk = (double)((k * 2654435761ull) % 4294967296ull);
-    const float ry = (float)(hk / 4294967296.0 * (2.0 * 3.141592653589793) - 3.141592653589793);
+    float v[7];
+    decode_center_box(t, (int)(t % n), bins, loc_scope, bin_size, h, w, l, xyz, reg, v);
     float *o = boxes + t * 7;
-    o[0] = pos[0] + q[0];
-    o[1] = q[1] + h / 2;
-    o[2] = pos[1] + q[2];
-    o[3] = h; o[4] = w; o[5] = l;
-    o[6] = ry;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) o[q] = v[q];
 }
 
 
@@ -595,7 +573,7 @@ __global__ __launch_bounds__(256) void decode_center_boxes_kernel(long total, in
 // are bitonic-sorted descending -- equal scores keep ascending index order, NaN sorts first like
 // torch.topk -- then the first k are written out.
 __global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow2, const float *__restrict__ scores,
-                                                           float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+                                                           float *__restrict__ out_scores, int64_t *__restrict__ out_idx, bool sig) {
     extern __shared__ __attribute__((aligned(16))) char smem_tk[];
     uint64_t *key = reinterpret_cast<uint64_t *>(smem_tk);
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -603,7 +581,8 @@ __global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow
     for (int i = tid; i < pow2; i += 1024) {
         uint64_t v = 0;                                    // padding: below every real key
         if (i < n) {
-            const float f = sc[i];
+            const float x_ = sc[i];
+            const float f = sig ? 1.0f / (1.0f + expf(-x_)) : x_;
             uint32_t u = f == 0.0f ? 0u : __float_as_uint(f);   // -0.0 ties with +0.0 (torch's comparison)
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // ascending unsigned order == ascending float order
             v = ((uint64_t)u << 32) | (uint64_t)(0xffffffffu - (uint32_t)i);
@@ -627,7 +606,8 @@ __global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow
         const uint64_t v = key[i];
         const uint32_t id = 0xffffffffu - (uint32_t)(v & 0xffffffffu);
         out_idx[(size_t)b * k + i] = (int64_t)id;
-        out_scores[(size_t)b * k + i] = sc[id];
+        const float x_ = sc[id];
+        out_scores[(size_t)b * k + i] = sig ? 1.0f / (1.0f + expf(-x_)) : x_;
     }
 }
 
@@ -638,6 +618,13 @@ __global__ __launch_bounds__(1024) void topk_sorted_kernel(int n, int k, int pow
 //   j >= 64E     : between waves, through LDS in an element-major layout (conflict-free both ways).
 // Of the 105 passes of a 16384-key sort only 10 touch LDS behind a workgroup barrier; the LDS-only
 // kernel above spends 158 us per launch on LDS bandwidth (8 x 4 64-bit LDS ops per thread and pass).
+// score of element i: the tensor's value, or (sig) the sigmoid of the logit stored there -- torch.sigmoid's fp32 expression
+// 1 / (1 + exp(-x)) (ATen UnarySpecialOpsKernel: one / (one + std::exp(-a))), so that the proposal stage needs no score tensor
+__device__ __forceinline__ float topk_score(const float *__restrict__ sc, int i, bool sig) {
+    const float x = sc[i];
+    return sig ? 1.0f / (1.0f + expf(-x)) : x;
+}
+
 __device__ __forceinline__ uint64_t topk_key(float f, int i) {
     uint32_t u = f == 0.0f ? 0u : __float_as_uint(f);       // -0.0 ties with +0.0 (torch's comparison)
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);         // ascending unsigned order == ascending float order
@@ -695,7 +682,7 @@ __device__ __forceinline__ void topk_sort_regs(uint64_t (&v)[E], uint64_t *lds, 
 
 template <int E>
 __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, const float *__restrict__ scores,
-                                                               float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+                                                               float *__restrict__ out_scores, int64_t *__restrict__ out_idx, bool sig) {
     extern __shared__ __attribute__((aligned(16))) char smem_tk[];
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
     const int b = blockIdx.x, t = threadIdx.x;
@@ -704,7 +691,7 @@ __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, con
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int i = t * E + r;
-        v[r] = i < n ? topk_key(sc[i], i) : 0ull;            // padding: below every real key
+        v[r] = i < n ? topk_key(topk_score(sc, i, sig), i) : 0ull;            // padding: below every real key
     }
     topk_sort_regs<E>(v, lds, t);
     // sorted descending; through LDS once more so that the output is written coalesced
@@ -716,7 +703,7 @@ __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, con
         const uint64_t w = lds[i];
         const uint32_t id = 0xffffffffu - (uint32_t)(w & 0xffffffffu);
         out_idx[(size_t)b * k + i] = (int64_t)id;
-        out_scores[(size_t)b * k + i] = sc[id];
+        out_scores[(size_t)b * k + i] = topk_score(sc, (int)id, sig);
     }
 }
 
@@ -727,7 +714,7 @@ __global__ __launch_bounds__(1024) void topk_sorted_reg_kernel(int n, int k, con
 // and writes the elements whose rank is below k.  Keys are distinct (index in the low word), so the ranks are a permutation:
 // the result is the full sort's, bit for bit.
 constexpr int TOPK_SEG = 2048;
-__global__ __launch_bounds__(1024) void topk_sort_segments_kernel(int n, const float *__restrict__ scores, uint64_t *__restrict__ ws, int nseg) {
+__global__ __launch_bounds__(1024) void topk_sort_segments_kernel(int n, const float *__restrict__ scores, uint64_t *__restrict__ ws, int nseg, bool sig) {
     extern __shared__ __attribute__((aligned(16))) char smem_tk[];
     uint64_t *lds = reinterpret_cast<uint64_t *>(smem_tk);
     const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg, t = threadIdx.x;
@@ -736,7 +723,7 @@ __global__ __launch_bounds__(1024) void topk_sort_segments_kernel(int n, const f
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = seg * TOPK_SEG + t * 2 + r;
-        v[r] = i < n ? topk_key(sc[i], i) : 0ull;
+        v[r] = i < n ? topk_key(topk_score(sc, i, sig), i) : 0ull;
     }
     topk_sort_regs<2>(v, lds, t);
     uint64_t *o = ws + ((size_t)b * nseg + seg) * TOPK_SEG;
@@ -744,7 +731,7 @@ __global__ __launch_bounds__(1024) void topk_sort_segments_kernel(int n, const f
 }
 
 __global__ __launch_bounds__(1024) void topk_merge_rank_kernel(int n, int k, const float *__restrict__ scores, const uint64_t *__restrict__ ws,
-                                                               int nseg, float *__restrict__ out_scores, int64_t *__restrict__ out_idx) {
+                                                               int nseg, float *__restrict__ out_scores, int64_t *__restrict__ out_idx, bool sig) {
     extern __shared__ __attribute__((aligned(16))) char smem_tk[];
     uint64_t *all = reinterpret_cast<uint64_t *>(smem_tk);             // nseg * 2048 keys: every segment of the scene, sorted descending
     const int b = blockIdx.x / nseg, seg = blockIdx.x - b * nseg, t = threadIdx.x;
@@ -775,7 +762,7 @@ __global__ __launch_bounds__(1024) void topk_merge_rank_kernel(int n, int k, con
         if (rank < k) {
             const uint32_t id = 0xffffffffu - (uint32_t)(x & 0xffffffffu);
             out_idx[(size_t)b * k + rank] = (int64_t)id;
-            out_scores[(size_t)b * k + rank] = sc[id];
+            out_scores[(size_t)b * k + rank] = topk_score(sc, (int)id, sig);
         }
     }
 }
@@ -894,8 +881,7 @@ extern "C" int ws3d_decode_center_boxes(int b, int n, int bins, float loc_scope,
     return check_launch("ws3d_decode_center_boxes");
 }
 
-extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx,
-                                ws3d_stream_t stream) {
+static int topk_sorted_impl(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, bool sig, ws3d_stream_t stream) {
     using namespace ws3d;
     if (b < 0 || n <= 0 || k < 0 || k > n || !scores || (k > 0 && (!out_scores || !out_idx))) {
         set_error("ws3d_topk_sorted: invalid argument (b=%d n=%d k=%d)", b, n, k);
@@ -911,7 +897,7 @@ extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float 
 #define WS3D_TOPK_REG(E)                                                                                                  \
     do {                                                                                                                  \
         if (int rc = raise_lds_cap((const void *)topk_sorted_reg_kernel<E>, 128 * 1024, "ws3d_topk_sorted")) return rc;   \
-        hipLaunchKernelGGL(topk_sorted_reg_kernel<E>, dim3(b), dim3(1024), smem, st, n, k, scores, out_scores, out_idx);   \
+        hipLaunchKernelGGL(topk_sorted_reg_kernel<E>, dim3(b), dim3(1024), smem, st, n, k, scores, out_scores, out_idx, sig); \
     } while (0)
     switch (pow2) {
     case 16384: WS3D_TOPK_REG(16); break;
@@ -919,10 +905,18 @@ extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float 
     case 4096: WS3D_TOPK_REG(4); break;
     case 2048: WS3D_TOPK_REG(2); break;
     case 1024: WS3D_TOPK_REG(1); break;
-    default: hipLaunchKernelGGL(topk_sorted_kernel, dim3(b), dim3(1024), smem, st, n, k, pow2, scores, out_scores, out_idx);
+    default: hipLaunchKernelGGL(topk_sorted_kernel, dim3(b), dim3(1024), smem, st, n, k, pow2, scores, out_scores, out_idx, sig);
     }
 #undef WS3D_TOPK_REG
     return check_launch("ws3d_topk_sorted");
+}
+
+extern "C" int ws3d_topk_sorted(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, ws3d_stream_t stream) {
+    return topk_sorted_impl(b, n, k, scores, out_scores, out_idx, false, stream);
+}
+
+extern "C" int ws3d_topk_sorted_sigmoid(int b, int n, int k, const float *logits, float *out_scores, int64_t *out_idx, ws3d_stream_t stream) {
+    return topk_sorted_impl(b, n, k, logits, out_scores, out_idx, true, stream);
 }
 
 extern "C" size_t ws3d_topk_workspace_bytes(int b, int n) {
@@ -932,12 +926,12 @@ extern "C" size_t ws3d_topk_workspace_bytes(int b, int n) {
     return (size_t)b * pow2 * sizeof(uint64_t);
 }
 
-extern "C" int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
-                                   size_t workspace_bytes, ws3d_stream_t stream) {
+static int topk_sorted_ws_impl(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
+                               size_t workspace_bytes, bool sig, ws3d_stream_t stream) {
     using namespace ws3d;
     const size_t need = ws3d_topk_workspace_bytes(b, n);
     if (need == 0 || !workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
-        return ws3d_topk_sorted(b, n, k, scores, out_scores, out_idx, stream);       // (it also reports the argument errors)
+        return topk_sorted_impl(b, n, k, scores, out_scores, out_idx, sig, stream);       // (it also reports the argument errors)
     if (k < 0 || k > n || !scores || (k > 0 && (!out_scores || !out_idx)) || b > 65535) {
         set_error("ws3d_topk_sorted_ws: invalid argument (b=%d n=%d k=%d)", b, n, k);
         return WS3D_E_INVALID;
@@ -947,10 +941,20 @@ extern "C" int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, flo
     if (int rc = raise_lds_cap((const void *)topk_merge_rank_kernel, 128 * 1024, "ws3d_topk_sorted")) return rc;
     hipStream_t st = as_stream(stream);
     uint64_t *ws = reinterpret_cast<uint64_t *>(workspace);
-    hipLaunchKernelGGL(topk_sort_segments_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)TOPK_SEG * sizeof(uint64_t), st, n, scores, ws, nseg);
+    hipLaunchKernelGGL(topk_sort_segments_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)TOPK_SEG * sizeof(uint64_t), st, n, scores, ws, nseg, sig);
     hipLaunchKernelGGL(topk_merge_rank_kernel, dim3((unsigned)(b * nseg)), dim3(1024), (size_t)nseg * TOPK_SEG * sizeof(uint64_t), st, n, k, scores, ws,
-                       nseg, out_scores, out_idx);
+                       nseg, out_scores, out_idx, sig);
     return check_launch("ws3d_topk_sorted_ws");
+}
+
+extern "C" int ws3d_topk_sorted_ws(int b, int n, int k, const float *scores, float *out_scores, int64_t *out_idx, void *workspace,
+                                   size_t workspace_bytes, ws3d_stream_t stream) {
+    return topk_sorted_ws_impl(b, n, k, scores, out_scores, out_idx, workspace, workspace_bytes, false, stream);
+}
+
+extern "C" int ws3d_topk_sorted_sigmoid_ws(int b, int n, int k, const float *logits, float *out_scores, int64_t *out_idx, void *workspace,
+                                           size_t workspace_bytes, ws3d_stream_t stream) {
+    return topk_sorted_ws_impl(b, n, k, logits, out_scores, out_idx, workspace, workspace_bytes, true, stream);
 }
 
 extern "C" int ws3d_nms_mask(int boxes_num, const float *boxes, float thresh, int normal, int full_grid,

@@ -94,6 +94,8 @@ COMPACT_PAIRS = True  # the SharedMLPs over the distinct (centre, sample) pairs 
 PAIR_DISPATCH = "device"
 PRIMED_MARGIN = 0.85       # Stage1Pipeline(pair_dispatch="primed"): scales whose priming fill <= PRIMED_MARGIN * COMPACT_MAX_FILL lose the dense twin
 _COMPACT_ONLY = contextvars.ContextVar("ws3d_compact_only_scales", default=frozenset())
+FUSED_PROLOGUE = True   # the coordinate / feature split of the input rows and the clear of the pass's zero arena in ONE launch (ws3d_split_points_clear) instead of two strided copies + a fill
+MERGED_BINNING = True   # serial order (graph capture): the binned copies of levels 2.. (ball query's grid + three_nn's (x, z) grid) in ONE launch behind the sampling chain (ws3d_sort_points_jobs) instead of one per level and flavour
 PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
 FUSED_MLP2_ROWS = True  # ws3d_mlp2_rows: the two layers of a head in one kernel
 FUSED_GATHER_GEMM2 = True  # ws3d_gather_gemm2: layers 1 + 2 of SA2-SA4 in one kernel
@@ -231,9 +233,16 @@ class _ZeroArena:
     reduce into with an atomic max, the pair totals, the heads' tickets -- instead of a fill launch each (13 per batch).  Cleared on
     the caller's stream before the first sampling kernel, so the side streams (which start behind it) see it cleared."""
 
-    def __init__(self, numel: int, device):
-        self.buf = torch.zeros(max(int(numel), 4), dtype=torch.float32, device=device)
+    def __init__(self, numel: int, device, clear: bool = True):
+        n = (max(int(numel), 4) + 3) & ~3                         # whole 16-byte granules (ws3d_split_points_clear clears those)
+        self.buf = (torch.zeros if clear else torch.empty)(n, dtype=torch.float32, device=device)
+        self.dirty = not clear                                    # True: whoever splits the input rows clears it in the same launch
         self.off = 0
+
+    def ensure_clear(self):
+        if self.dirty:
+            self.buf.zero_()
+            self.dirty = False
 
     def take(self, shape, dtype=torch.float32):
         n = 1
@@ -246,13 +255,13 @@ class _ZeroArena:
         return (v if dtype == torch.float32 else v.view(dtype)).view(shape)
 
 
-def _arena_for(net, B: int, device, extra: int = 0) -> _ZeroArena:
+def _arena_for(net, B: int, device, extra: int = 0, clear: bool = True) -> _ZeroArena:
     n = extra + 64
     if COMPACT_PAIRS:
         for sa in net.SA_modules:
             n += B * sa.npoint * sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) + 4
             n += 4 * len(sa.groupers)
-    return _ZeroArena(n, device)
+    return _ZeroArena(n, device, clear)
 
 
 class _PairList:
@@ -419,9 +428,10 @@ class _Geometry:
 
 
 def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None, level: int = 0, zeros: _ZeroArena = None, binned: list = None,
-               new_xyz_pre: torch.Tensor = None):
+               new_xyz_pre: torch.Tensor = None, prebinned=None):
     """xyz (B,N,3), feats (B,N,C) or None -> new_xyz (B,M,3), new_feats (B,M,sum O); `binned` (a list) receives the level's binned
-    copy of xyz (or None): the FP module of this level takes its 3-NN queries in that order"""
+    copy of xyz (or None): the FP module of this level takes its 3-NN queries in that order; prebinned: (that copy,) when the caller
+    binned this level already (backbone_forward's one launch for levels 2..)"""
     B = xyz.size(0)
     c_feat = 0 if feats is None else feats.size(2)
     if geo is not None:
@@ -439,7 +449,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             new_xyz = new_xyz_pre
         else:
             _, new_xyz = (pn2_ops.furthest_point_sample_gather_nested if NESTED_FPS and level >= 1 else pn2_ops.furthest_point_sample_gather)(xyz, sa.npoint)
-        sorted_xyz = pn2_ops.sort_points_x(xyz, GRID_MIN_N)
+        sorted_xyz = prebinned[0] if prebinned is not None else pn2_ops.sort_points_x(xyz, GRID_MIN_N)
         nbrs = _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat, zeros)
     if binned is not None:
         binned.append(sorted_xyz)
@@ -592,11 +602,13 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
     return new_xyz, out.view(B, sa.npoint, -1)
 
 
-def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None, sorted_unknown=None):
+def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None, sorted_unknown=None,
+               known_xz=None):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O); sorted_unknown: a binned
-    copy of `unknown` (the level's ball-query copy) for the 3-NN's query order"""
+    copy of `unknown` (the level's ball-query copy) for the 3-NN's query order; known_xz: (sort_points_xz(known),) when the caller
+    has it already"""
     B, n = unknown.size(0), unknown.size(1)
-    idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, pn2_ops.sort_points_xz(known),
+    idx, weight = nn3 if nn3 is not None else _C.three_nn_with_weights(unknown, known, known_xz[0] if known_xz is not None else pn2_ops.sort_points_xz(known),
                                                                         sorted_unknown if QUERY_CELL_ORDER else None)
     c2 = known_feats.size(2)
     c1 = 0 if unknown_feats is None else unknown_feats.size(2)
@@ -646,32 +658,50 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
 @torch.no_grad()
 def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
     """Pointnet2MSG.forward on channels-last tensors -> xyz (B,N,3), features (B,N,C)"""
-    xyz = pointcloud[..., 0:3].contiguous()
-    feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None
-    if zeros is None:
-        zeros = _arena_for(net, xyz.size(0), xyz.device)
+    if FUSED_PROLOGUE and pointcloud.is_cuda and pointcloud.dim() == 3 and pointcloud.is_contiguous() and pointcloud.size(-1) > 3:
+        if zeros is None:
+            zeros = _arena_for(net, pointcloud.size(0), pointcloud.device, clear=False)
+        xyz, feats = _C.split_points_clear(pointcloud, zeros.buf if zeros.dirty else None)      # the pass's first launch: side streams start behind it
+        zeros.dirty = False
+    else:
+        xyz = pointcloud[..., 0:3].contiguous()
+        feats = pointcloud[..., 3:].contiguous() if pointcloud.size(-1) > 3 else None
+        if zeros is None:
+            zeros = _arena_for(net, xyz.size(0), xyz.device)
+        zeros.ensure_clear()
     # (not while a hipGraph is being captured: a graph with such branches replays slower than one stream on this runtime --
     # measured 1,657 vs 3,813 scenes/s at 8 graphs in flight -- so Stage1Pipeline's graphs keep the serial order)
     ahead = _geometry_ahead_now() and (GEOMETRY_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats, binned = [xyz], [feats], []
     try:
-        sas, chain = list(net.SA_modules), None
+        sas, chain, pre_grid, pre_xz = list(net.SA_modules), None, {}, {}
         for level, sa in enumerate(sas):
             pre = chain[level - 1][1] if (chain is not None and level >= 1) else None
-            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned, pre)
+            nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned, pre, pre_grid.get(level))
             l_xyz.append(nx)
             l_feats.append(nf)
             if geo is None and level == 0 and NESTED_FPS and NESTED_CHAIN and len(sas) > 1:
                 # serial order (graph capture): the levels below the first in one chain call, right behind the first level's centres
                 chain = pn2_ops.furthest_point_sample_gather_nested_chain(nx, [s_.npoint for s_ in sas[1:]])
+                if MERGED_BINNING:
+                    # every level's coordinates exist now: the ball queries' grids of levels 2.. and the (x, z) grids of the FP modules'
+                    # known sets in ONE launch (the decisions of sort_points_x(.., GRID_MIN_N) / sort_points_xz: which levels get one)
+                    lv = [nx] + [c[1] for c in chain]                                  # coordinates of levels 1 .. len(sas)
+                    jobs = [(x_, "grid") for x_ in lv[:-1] if x_.size(1) >= GRID_MIN_N] + [(x_, "xz") for x_ in lv if x_.size(1) >= 256]
+                    bufs = iter(_C.sort_points_jobs(jobs) if _C.BQ_FINE_GRID else [])
+                    if _C.BQ_FINE_GRID:
+                        pre_grid = {k + 1: ((next(bufs),) if x_.size(1) >= GRID_MIN_N else (None,)) for k, x_ in enumerate(lv[:-1])}
+                        pre_xz = {k + 1: (next(bufs) if x_.size(1) >= 256 else None) for k, x_ in enumerate(lv)}
         for i in range(-1, -(len(net.FP_modules) + 1), -1):
             nn3 = None
             if geo is not None:
                 lvl = len(l_xyz) + i - 1                                   # unknown level of this module
                 geo.main.wait_event(geo.nn_ready[lvl])
                 nn3 = geo.nn[lvl]
-            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3, binned[len(l_xyz) + i - 1])
+            known_level = len(l_xyz) + i
+            l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3, binned[len(l_xyz) + i - 1],
+                                        (pre_xz[known_level],) if known_level in pre_xz else None)
     finally:
         if geo is not None:       # also when a layer raised: the side streams' tensors go back to their pools behind the caller's stream
             geo.release()
@@ -684,7 +714,7 @@ def rpn_forward(model, pts_input: torch.Tensor, defer_reg_join: bool = False) ->
     with the flag set the caller's stream is NOT made to wait for it here -- the dict then carries the event ``rpn_reg_ready`` that a
     consumer of ``rpn_reg`` must wait for (stage1.proposals_from_rpn does: the top-k over the scores runs beside the head)."""
     rpn = model.rpn
-    zeros = _arena_for(rpn.backbone_net, pts_input.size(0), pts_input.device, extra=8)      # ONE fill for the whole pass
+    zeros = _arena_for(rpn.backbone_net, pts_input.size(0), pts_input.device, extra=8, clear=not FUSED_PROLOGUE)      # ONE clear for the whole pass (with the prologue: inside its launch)
     xyz, feats = backbone_forward(rpn.backbone_net, pts_input, zeros)     # (B,N,3), (B,N,128)
     B, N, C = feats.shape
     rows = feats.view(B * N, C)

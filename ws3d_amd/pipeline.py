@@ -101,8 +101,8 @@ class Stage1Pipeline:
     @torch.no_grad()
     def body(self, pts: torch.Tensor) -> dict:
         out = self.model.rpn_forward({"pts_input": pts, "defer_reg_join": True})     # (proposals_from_rpn waits for rpn_reg)
-        boxes, scores, count, enlarged = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True)
-        res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count}
+        boxes, scores, count, enlarged, packed = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True, with_packed=True)
+        res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count, "packed": packed}      # packed (B,K,8): box + score, ws3d_amd.dist's rows
         if self.roipool:
             feats = out["backbone_features"].transpose(1, 2).contiguous()
             res["pooled"], res["empty"] = roipool3d_ops.roipool3d_gpu(out["backbone_xyz"], feats, boxes, self.cfg.roi_extra_width,

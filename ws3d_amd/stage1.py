@@ -193,27 +193,42 @@ def synthetic_orientation(n: int, device) -> torch.Tensor:
 
 
 @torch.no_grad()
-def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes: bool = False, fused: bool = True):
+def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes: bool = False, fused: bool = True, with_packed: bool = False):
     """On-device proposal stage for the whole batch (config 3 of BASELINE.json): score =
     sigmoid(rpn_cls), centre = decode_center_target, box = centre + CLS_MEAN_SIZE + synthetic
     heading; top RPN_PRE_NMS_TOP_N by score -> rotated NMS (thresh 0.8) -> first
     RPN_POST_NMS_TOP_N survivors.  Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed
     shapes, zero padded, batched torch ops + ONE NMS launch pair, no host synchronisation.
     with_pool_boxes: also return the (B,K,7) rows enlarged by cfg.roi_extra_width (what roipool3d_gpu would compute);
-    fused=False keeps the torch composition of the gather / BEV / padding steps (parity tests)."""
+    with_packed: also (last) the (B,K,8) rows box + score that ws3d_amd.dist gathers across ranks;
+    fused=False keeps the torch composition of the sigmoid / decode / gather / BEV / padding steps (parity tests)."""
     xyz, reg, cls = out['backbone_xyz'], out['rpn_reg'], out['rpn_cls']
     B, N, _ = xyz.shape
     K = cfg.rpn_post_nms_top_n
     h, w, l = cfg.cls_mean_size
-    score = torch.sigmoid(cls[:, :, 0])                                                   # (B,N)
     top = min(cfg.rpn_pre_nms_top_n, N)
-    sc = order = None
+    on_dev = xyz.is_cuda and top >= K and fused
+    sc = order = score = None
     if xyz.is_cuda and N <= 16384:     # one LDS-resident sort per scene instead of topk's select + gather + merge sort
         from . import compat as _C
-        sc, order = _C.topk_sorted(score.contiguous(), top)      # (scores only: runs beside the regression head when that is deferred)
+        if on_dev:                     # ... over torch.sigmoid's expression of the logits, evaluated while the keys are loaded: no score tensor
+            sc, order = _C.topk_sorted(cls[:, :, 0].contiguous(), top, sigmoid=True)
+        else:
+            score = torch.sigmoid(cls[:, :, 0])                                           # (B,N)
+            sc, order = _C.topk_sorted(score.contiguous(), top)      # (scores only: runs beside the regression head when that is deferred)
+    else:
+        score = torch.sigmoid(cls[:, :, 0])
     ready = out.get('rpn_reg_ready')
     if ready is not None:
         torch.cuda.current_stream(xyz.device).wait_event(ready)   # fastpath.rpn_forward(defer_reg_join=True): rpn_reg comes from a side stream
+    if on_dev and order is not None:
+        # four launches instead of ~30: the rows of the top points decoded in score order + their BEV rectangles, NMS, then the
+        # padded survivors (+ the rows enlarged for RoI pooling / packed with their scores when asked for); bit-identical to the
+        # composition below
+        box_sorted, bev = _C.decode_gather_boxes_bev(xyz.contiguous(), reg.contiguous(), order, cfg.loc_scope, cfg.loc_bin_size, (h, w, l))
+        keep_dev, num = _C.nms_device_batched(bev, cfg.rpn_nms_thresh, False, max_keep=K)
+        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=with_packed)
+        return tuple(res[:3]) + ((res[3],) if with_pool_boxes else ()) + ((res[4],) if with_packed else ())
     if xyz.is_cuda:
         from . import compat as _C        # one kernel instead of ~25 tiny torch launches; bit-identical
         box = _C.decode_center_boxes(xyz.contiguous(), reg.contiguous(), cfg.loc_scope, cfg.loc_bin_size, (h, w, l))
@@ -225,14 +240,11 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
                            torch.full_like(score, w), torch.full_like(score, l), ry), dim=2)     # (B,N,7)
     if sc is None:
         sc, order = torch.topk(score, top, dim=1, sorted=True)                            # (B,top)
-    if xyz.is_cuda and top >= K and fused:
-        # two launches instead of ~25: rows in score order + BEV rectangles, NMS, then the padded survivors (+ the rows
-        # enlarged for RoI pooling when asked for); bit-identical to the composition below
+    if on_dev:                 # (N > 16384: torch.topk above, then the fused gather / NMS / selection)
         box_sorted, bev = _C.gather_boxes_bev(box, order)
         keep_dev, num = _C.nms_device_batched(bev, cfg.rpn_nms_thresh, False, max_keep=K)
-        boxes_out, scores_out, cnt, pooled = _C.select_proposals(box_sorted, sc, keep_dev, num, K,
-                                                                  cfg.roi_extra_width if with_pool_boxes else None)
-        return (boxes_out, scores_out, cnt, pooled) if with_pool_boxes else (boxes_out, scores_out, cnt)
+        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=with_packed)
+        return tuple(res[:3]) + ((res[3],) if with_pool_boxes else ()) + ((res[4],) if with_packed else ())
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
     bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
     keep, cnt = iou3d_ops.nms_gpu_padded_batched(bev, sc, cfg.rpn_nms_thresh, K, scores_sorted=True)   # (B,K), (B,)
@@ -240,9 +252,12 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
     safe = keep.clamp(min=0)
     boxes_out = torch.gather(box, 1, safe.unsqueeze(-1).expand(B, K, 7)) * valid.unsqueeze(-1)
     scores_out = torch.gather(sc, 1, safe) * valid
+    res = (boxes_out, scores_out, cnt)
     if with_pool_boxes:
-        return boxes_out, scores_out, cnt, kitti_utils.enlarge_box3d(boxes_out.view(-1, 7), cfg.roi_extra_width).view(B, K, 7)
-    return boxes_out, scores_out, cnt
+        res += (kitti_utils.enlarge_box3d(boxes_out.view(-1, 7), cfg.roi_extra_width).view(B, K, 7),)
+    if with_packed:
+        res += (torch.cat([boxes_out, scores_out.unsqueeze(-1)], dim=-1).contiguous(),)
+    return res
 
 
 @torch.no_grad()
