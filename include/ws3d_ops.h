@@ -197,6 +197,13 @@ WS3D_API int ws3d_three_nn_w(int b, int n, int m, const float *unknown, const fl
  * density.  Applies to the binned search (sorted_known given, 3 <= m <= 16384); 0 < n <= 16384 when sorted_unknown is given. */
 WS3D_API int ws3d_three_nn_wq(int b, int n, int m, const float *unknown, const float *known, float *dist2, int32_t *idx, float *weight,
                               const void *sorted_known, const void *sorted_unknown, ws3d_stream_t stream);
+/* Several ws3d_three_nn_wq searches in ONE launch (round 5): job k takes the (b, n[k], 3) queries unknown[k] against the binned known set
+ * sorted_known[k] (ws3d_sort_points_xz / _x of a (b, m[k], 3) cloud, 3 <= m[k] <= 4096) and writes dist2[k], idx[k], weight[k] (b, n[k], 3);
+ * sorted_unknown (NULL, or per job NULL / a binned copy of the queries: cell order).  At most 4 jobs; host arrays, read before the call
+ * returns.  Same rows as one call per job (the FP modules of a network: 3 launches -> 1).                                              */
+WS3D_API int ws3d_three_nn_jobs(int b, int njobs, const int *n, const int *m, const float *const *unknown, const void *const *sorted_known,
+                                float *const *dist2, int32_t *const *idx, float *const *weight, const void *const *sorted_unknown,
+                                ws3d_stream_t stream);
 
 /* The SA module's pool over nsample (pointnet2_modules.py:50, F.max_pool2d(kernel_size=[1, nsample]))
  * with the position of the maximum kept for the backward pass.  x (rows, nsample) -- the contiguous
@@ -295,6 +302,29 @@ WS3D_API int ws3d_pgather_gemm3_compact(int b, int n, int m, long max_rows, int 
                                float *out, int out_stride, long limit, ws3d_stream_t stream);
 WS3D_API int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,
                            const float *wt, const float *bias, float *out, int out_stride, long limit, ws3d_stream_t stream);
+/* The two scales of a set-abstraction level in ONE launch (round 5).  Each block restates the arguments of the single-scale entries:
+ * kind 3 = ws3d_pgather_gemm3_compact on both blocks, kind 2 = ws3d_pgather_gemm2_compact (its rows go to `mid`, (max_rows, o2)),
+ * kind 1 = ws3d_gemm_pool_compact (x_rows = mid, k = o2, o = o3, wt = w3t, bias = b3).  Both blocks must name the same o1 (kinds 3, 2);
+ * pmat already points at the scale's first column.  Same results as the two single-scale launches.                                 */
+typedef struct ws3d_compact_mlp_args {
+    int b, n, m;
+    long max_rows;
+    int o1, o2, o3;
+    const float *pmat;
+    int p_stride;
+    const float *xyz, *new_xyz;
+    const int32_t *rowc, *rowsrc, *total;
+    const float *w1x, *b1;
+    int relu1;
+    const float *w2t, *b2;
+    int relu2;
+    const float *w3t, *b3;
+    float *mid;
+    float *out;
+    int out_stride;
+    long limit;
+} ws3d_compact_mlp_args;
+WS3D_API int ws3d_compact_mlp_pair(int kind, const ws3d_compact_mlp_args *scale0, const ws3d_compact_mlp_args *scale1, ws3d_stream_t stream);
 
 /* ws3d_sa_mlp3_pool over compact pairs (see ws3d_compact_pairs_*): the first level's three-layer SharedMLP (16-16-32 or 32-32-64,
  * every layer with bias + ReLU) on rows [x_j - c, f_j] built here from xyz (b, n, 3), new_xyz (b, m, 3) and the ONE feature

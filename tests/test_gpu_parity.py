@@ -1737,6 +1737,27 @@ def test_sort_points_jobs_equals_one_call_per_job(ops, oracle):
         ops.c.sort_points_jobs([(clouds[0], "slab")])
 
 
+def test_three_nn_jobs_equals_one_call_per_job(ops, oracle):
+    """ws3d_three_nn_jobs (the searches of several FP modules in ONE launch) == three_nn_with_weights per module, bit for bit, with
+    and without the queries in cell order, and == the oracle's indices"""
+    B = 2
+    l0 = dev(np.stack([synth.cloud("hdl64", 16384, 1300 + j)[:, :3] for j in range(B)]))
+    levels = [l0, l0[:, ::4].contiguous(), l0[:, ::16].contiguous(), l0[:, ::64].contiguous()]         # 16384, 4096, 1024, 256
+    xz = [None] + [ops.c.sort_points_xz(x) for x in levels[1:]]
+    grid = [ops.c.sort_points_x(x, 1, grid=True) for x in levels]
+    for cell_order in (True, False):
+        jobs = [(levels[k], levels[k + 1], xz[k + 1], grid[k] if cell_order else None) for k in range(3)]
+        got = ops.c.three_nn_jobs(jobs)
+        assert got is not None and len(got) == 3
+        for (un, kn, sk, su), (idx, w) in zip(jobs, got):
+            want_i, want_w = ops.c.three_nn_with_weights(un, kn, sk, su)
+            assert torch.equal(idx, want_i) and torch.equal(w.view(torch.int32), want_w.view(torch.int32))
+            if un.size(1) <= 4096:
+                np.testing.assert_array_equal(host(idx), oracle.three_nn_dist2(host(un), host(kn))[1])
+    assert ops.c.three_nn_jobs([(levels[0], levels[1], None, None)]) is None              # not binned: the caller keeps its own call
+    assert ops.c.three_nn_jobs([(levels[1], levels[0], grid[0], None)]) is None           # 16384 known points: beyond the LDS copy
+
+
 def test_pipeline_primed_pair_dispatch_keeps_the_bits(ops):
     """Stage1Pipeline(pair_dispatch="primed") drops the gated dense twins of the scales its priming batch shows far below the fill
     threshold (fastpath.primed_compact_scales); "device" keeps both forms in the graph.  Same bits either way -- on the sparse
@@ -2234,7 +2255,7 @@ def test_fast_path_switches_agree(ops):
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
     names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
-             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH", "MERGED_BINNING", "FUSED_PROLOGUE")
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH", "MERGED_BINNING", "FUSED_PROLOGUE", "MERGED_THREE_NN", "PAIRED_SCALES")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2266,6 +2287,13 @@ def test_fast_path_switches_agree(ops):
         with fastpath.geometry_ahead(False):      # the serial order Stage1Pipeline's graphs capture: one binning launch for levels 2.. or one per level and flavour
             one, per_level = run(MERGED_BINNING=True), run(MERGED_BINNING=False)
             split = run(FUSED_PROLOGUE=False)
+            for n, v in saved.items():
+                setattr(fastpath, n, v)
+            assert all(torch.equal(x_, y_) for x_, y_ in zip(one, run(MERGED_THREE_NN=False)))
+            for n, v in saved.items():
+                setattr(fastpath, n, v)
+            with fastpath.compact_only_scales({(l_, s_) for l_ in range(4) for s_ in range(2)}):       # (what a primed pipeline captures)
+                assert all(torch.equal(x_, y_) for x_, y_ in zip(run(PAIRED_SCALES=True), run(PAIRED_SCALES=False)))
         assert all(torch.equal(x_, y_) for x_, y_ in zip(one, per_level)) and all(torch.equal(x_, y_) for x_, y_ in zip(one, split))
         assert all(torch.equal(x_, y_) for x_, y_ in zip(run(FUSED_PROLOGUE=True), run(FUSED_PROLOGUE=False)))        # and with the side streams
     finally:
@@ -2385,6 +2413,62 @@ def test_qinterp_gemm_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M,
     if C == O:
         eye = torch.eye(C, device="cuda")
         assert torch.equal(ops.c.qinterp_gemm(q, idx, weight, eye, None, False, relu=relu1, **kw), rows)
+
+
+@pytest.mark.parametrize("B,N,M,C,O1,scales", [(2, 4096, 1024, 96, 64, ((16, 0.5, 64, 128), (32, 1.0, 96, 128))),          # SA2's two scales: the fused kernel
+                                               (2, 1024, 256, 256, 128, ((16, 1.0, 128, 256), (32, 2.0, 196, 256))),      # SA3
+                                               (2, 256, 64, 512, 256, ((16, 2.0, 256, 512), (32, 4.0, 384, 512))),        # SA4: first layer 256 wide, two-kernel form only
+                                               (1, 512, 37, 8, 64, ((16, 0.01, 20, 64), (16, 3.0, 64, 192)))])            # ragged: 37 centres, one-point lists beside full ones
+def test_compact_mlp_pair_equals_the_single_scale_launches(ops, B, N, M, C, O1, scales):
+    """ws3d_compact_mlp_pair (both scales of a level in ONE launch: the fused three-layer kernel, or layers 1 + 2 then layer 3 + pool)
+    == the single-scale launches, bit for bit, incl. the column slices of a shared output and scales of unequal pair counts"""
+    rng = np.random.default_rng(23)
+    pc = synth.make_batch("lidar", B, 16384, 71)[:, :N, :3].copy()
+    xyz = dev(pc)
+    feats = dev(rng.standard_normal((B, N, C)).astype(np.float32))
+    idx = torch.empty((B, M), dtype=torch.int32, device="cuda"); new_xyz = torch.empty((B, M, 3), device="cuda")
+    ops.c.furthest_point_sampling_gather(B, N, M, xyz, None, idx, new_xyz)
+    srt = ops.c.sort_points_x(xyz)
+    w1s = [dev((rng.standard_normal((C + 3, O1)) / np.sqrt(C)).astype(np.float32)) for _ in scales]
+    pmat = feats.view(B * N, C) @ torch.cat([w[:C] for w in w1s], dim=1)
+    width = sum(sc[3] for sc in scales)
+    args, col = [], 0
+    for si, (ns, r, O2, O3) in enumerate(scales):
+        nbr = torch.zeros((B, M, ns), dtype=torch.int32, device="cuda")
+        ops.c.ball_query_wrapper(B, N, M, r, ns, new_xyz, xyz, nbr, srt)
+        args.append({"pmat": pmat, "col0": si * O1, "o1": O1, "xyz": xyz, "new_xyz": new_xyz, "pairs": ops.c.compact_pairs(nbr), "w1x": w1s[si][C:].contiguous(),
+                     "b1": dev(rng.standard_normal(O1).astype(np.float32)), "relu1": True,
+                     "w2t": dev((rng.standard_normal((O1, O2)) / np.sqrt(O1)).astype(np.float32)), "b2": dev(rng.standard_normal(O2).astype(np.float32)), "relu2": True,
+                     "w3t": dev((rng.standard_normal((O2, O3)) / np.sqrt(O2)).astype(np.float32)), "b3": dev(rng.standard_normal(O3).astype(np.float32)),
+                     "col_offset": col})
+        col += O3
+    want = torch.zeros((B * M, width), device="cuda")
+    mids_want = []
+    for a in args:
+        yc = ops.c.pgather_gemm2_compact(a["pmat"], a["col0"], O1, xyz, new_xyz, a["pairs"], a["w1x"], a["b1"], True, a["w2t"], a["b2"], True)
+        assert yc is not None and ops.c.gemm_pool_compact(yc, a["pairs"], a["w3t"], a["b3"], want, a["col_offset"])
+        mids_want.append(yc)
+    totals = [int(a["pairs"][2].item()) for a in args]
+    # the two-kernel form, paired
+    out2 = torch.zeros_like(want)
+    for a in args:
+        a["out2d"] = out2
+    mids = ops.c.compact_mlp_pair(2, args)
+    assert mids is not None and all(torch.equal(m_[:t_], w_[:t_]) for m_, w_, t_ in zip(mids, mids_want, totals))
+    took1 = ops.c.compact_mlp_pair(1, args, mids=mids)
+    assert took1 == all(sc[3] % 64 == 0 for sc in scales)
+    if took1:
+        assert torch.equal(out2, want)
+    # the fused kernel, paired
+    out3 = torch.zeros_like(want)
+    for a in args:
+        a["out2d"] = out3
+    took3 = ops.c.compact_mlp_pair(3, args)
+    assert took3 == (O1 in (64, 128) and all(sc[3] % 128 == 0 for sc in scales))
+    if took3:
+        assert torch.equal(out3, want)
+        assert not ops.c.compact_mlp_pair(3, args, max_lds=16 * 1024) and torch.equal(out3, want)
+    assert not ops.c.compact_mlp_pair(3, [args[0], dict(args[1], o1=O1 * 2)])            # unequal first-layer widths: the caller keeps the per-scale launches
 
 
 @pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),

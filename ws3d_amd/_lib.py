@@ -23,6 +23,13 @@ _i = C.c_int
 _f = C.c_float
 _sz = C.c_size_t
 
+class CompactMlpArgs(C.Structure):
+    """ws3d_compact_mlp_args of include/ws3d_ops.h (ws3d_compact_mlp_pair)"""
+    _fields_ = [("b", _i), ("n", _i), ("m", _i), ("max_rows", C.c_long), ("o1", _i), ("o2", _i), ("o3", _i), ("pmat", _vp), ("p_stride", _i),
+                ("xyz", _vp), ("new_xyz", _vp), ("rowc", _vp), ("rowsrc", _vp), ("total", _vp), ("w1x", _vp), ("b1", _vp), ("relu1", _i),
+                ("w2t", _vp), ("b2", _vp), ("relu2", _i), ("w3t", _vp), ("b3", _vp), ("mid", _vp), ("out", _vp), ("out_stride", _i), ("limit", C.c_long)]
+
+
 # name -> (restype, argtypes); kept in the order of include/ws3d_ops.h
 SIGNATURES = {
     "ws3d_abi_version": (_i, []),
@@ -77,6 +84,7 @@ SIGNATURES = {
     "ws3d_three_nn_weights": (_i, [C.c_long, _vp, _vp, _vp]),
     "ws3d_three_nn_w": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_three_nn_wq": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_three_nn_jobs": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_bias_act_inplace": (_i, [_i, _i, C.c_long, _i, _vp, _vp, _vp]),
     "ws3d_rowmax_bias_act": (_i, [_i, _i, C.c_long, _i, _i, _vp, _vp, _vp, _vp]),
     "ws3d_boxes_overlap_bev": (_i, [_i, _vp, _i, _vp, _vp, _vp]),
@@ -97,6 +105,7 @@ SIGNATURES = {
     "ws3d_pgather_gemm2_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_pgather_gemm3_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_gemm_pool_compact": (_i, [C.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
+    "ws3d_compact_mlp_pair": (_i, [_i, C.POINTER(CompactMlpArgs), C.POINTER(CompactMlpArgs), _vp]),
     "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_sa_mlp3_pool_lists": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_interp_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -354,6 +354,33 @@ def query_and_group_nlc(radius, nsample, xyz, new_xyz, features_nlc, use_xyz=Tru
     return out
 
 
+def three_nn_jobs(jobs):
+    """jobs: [(unknown (B,N_k,3), known (B,M_k,3), sorted_known (sort_points_xz / _x of known), sorted_unknown or None)] ->
+    [(idx (B,N_k,3) int32, weight (B,N_k,3))]: three_nn_with_weights of every job in ONE launch (ws3d_three_nn_jobs), or None when a
+    job does not fit it (more than 4 jobs, a known set that is not binned or larger than 4096 points).  ws3d extension."""
+    import ctypes as C
+    if not jobs or len(jobs) > 4 or any(sk is None or kn.size(1) > 4096 or kn.size(1) < 3 or (su is not None and un.size(1) > 16384) for un, kn, sk, su in jobs):
+        return None
+    dev = _dev(*[t for un, kn, sk, su in jobs for t in (un, kn, sk)])
+    B = jobs[0][0].size(0)
+    k = len(jobs)
+    outs = []
+    for un, kn, sk, su in jobs:
+        _f32(un, "unknown"); _f32(kn, "known")
+        if un.size(0) != B or kn.size(0) != B:
+            raise ValueError("three_nn_jobs: every job takes the same batch")
+        N = un.size(1)
+        outs.append((torch.empty((B, N, 3), dtype=torch.float32, device=dev), torch.empty((B, N, 3), dtype=torch.int32, device=dev),
+                     torch.empty((B, N, 3), dtype=torch.float32, device=dev)))
+    arr = lambda vals: (C.c_void_p * k)(*vals)
+    with _on(dev):
+        check(_lib.load().ws3d_three_nn_jobs(B, k, (C.c_int * k)(*[j[0].size(1) for j in jobs]), (C.c_int * k)(*[j[1].size(1) for j in jobs]),
+                                             arr([j[0].data_ptr() for j in jobs]), arr([j[2].data_ptr() for j in jobs]),
+                                             arr([o[0].data_ptr() for o in outs]), arr([o[1].data_ptr() for o in outs]), arr([o[2].data_ptr() for o in outs]),
+                                             arr([None if j[3] is None else j[3].data_ptr() for j in jobs]), _stream()), "three_nn_jobs")
+    return [(o[1], o[2]) for o in outs]
+
+
 def three_nn_with_weights(unknown, known, sorted_known=None, sorted_unknown=None):
     """unknown (B,N,3), known (B,M,3) -> (idx (B,N,3) int32, weight (B,N,3)): three_nn + the FP module's
     normalised inverse-distance weights in ONE launch (ws3d_three_nn_w: the weights are the search kernel's epilogue; bit-identical
@@ -703,6 +730,48 @@ def gemm_pool_compact(x_rows, pairs, wt, bias, out2d, col_offset, limit=-1):
         check(_lib.load().ws3d_gemm_pool_compact(rows, k, o, _p(x_rows), _p(rowc), _p(total), _p(wt), _p(bias), out2d.data_ptr() + 4 * col_offset,
                                                  out2d.stride(0), int(limit), _stream()), "gemm_pool_compact")
     return True
+
+
+def compact_mlp_pair(kind, scales, max_lds=160 * 1024, mids=None):
+    """The two scales of a set-abstraction level in ONE launch (ws3d_compact_mlp_pair).  scales: two dicts with the arguments of the
+    single-scale calls -- pmat, col0, o1, xyz, new_xyz, pairs, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out2d, col_offset.
+    kind 3: pgather_gemm3_compact of both -> True / False (shape not covered: nothing launched); kind 2: pgather_gemm2_compact of both
+    -> the two (rows, O2) tensors, or None; kind 1: gemm_pool_compact of `mids` (kind 2's result) into out2d -> True / False.  Both
+    scales must have the same first-layer width.  Same results as the single-scale calls, always ungated (limit -1).  ws3d extension."""
+    import ctypes as C
+    if len(scales) != 2 or scales[0]["o1"] != scales[1]["o1"]:
+        return None if kind == 2 else False
+    blocks, keep, outs = [], [], []
+    for si, a in enumerate(scales):
+        rowc, rowsrc, total = a["pairs"]
+        pmat, xyz, new_xyz, w1x, w2t, w3t, out2d, o1, col0, col = a["pmat"], a["xyz"], a["new_xyz"], a["w1x"], a["w2t"], a["w3t"], a["out2d"], a["o1"], a["col0"], a["col_offset"]
+        dev = _dev(pmat, xyz, new_xyz, rowc, w1x, w2t, w3t, out2d)
+        for t_, nm in ((pmat, "pmat"), (xyz, "xyz"), (new_xyz, "new_xyz"), (w1x, "w1x"), (w2t, "w2t"), (w3t, "w3t"), (out2d, "out2d")):
+            _f32(t_, nm)
+        B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+        O2, O3 = w2t.size(1), w3t.size(1)
+        rows = rowc.numel()
+        lds3 = 4 * ((o1 + (O2 + 15) // 16 * 16) * 65 + 2 * 16 * 64)
+        ok = (O2 % 4 == 0 and pmat.dim() == 2 and pmat.size(0) == B * N and pmat.stride(1) == 1 and col0 >= 0 and col0 + o1 <= pmat.size(1) and
+              tuple(w1x.shape) == (3, o1) and w2t.size(0) == o1 and w3t.size(0) == O2 and w1x.is_contiguous() and w2t.is_contiguous() and w3t.is_contiguous() and
+              out2d.dim() == 2 and out2d.stride(1) == 1 and col >= 0 and col + O3 <= out2d.size(1))
+        if kind == 3:
+            ok = ok and o1 in (64, 128) and O3 % 128 == 0 and lds3 <= min(max_lds, 160 * 1024 - 1024)
+        elif kind == 2:
+            ok = ok and o1 in (64, 128, 256)
+        else:
+            ok = ok and O3 % 64 == 0 and mids is not None and tuple(mids[si].shape) == (rows, O2) and mids[si].is_contiguous()
+        if not ok:
+            return None if kind == 2 else False
+        mid = mids[si] if kind == 1 else (torch.empty((rows, O2), dtype=torch.float32, device=dev) if kind == 2 else None)
+        outs.append(mid)
+        keep.append((pmat, xyz, new_xyz, rowc, rowsrc, total, w1x, w2t, w3t, out2d, mid, a["b1"], a["b2"], a["b3"]))
+        blocks.append(_lib.CompactMlpArgs(B, N, M, rows, o1, O2, O3, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc), _p(rowsrc),
+                                          _p(total), _p(w1x), _p(a["b1"]), int(bool(a["relu1"])), _p(w2t), _p(a["b2"]), int(bool(a["relu2"])), _p(w3t), _p(a["b3"]),
+                                          _p(mid), out2d.data_ptr() + 4 * col, out2d.stride(0), -1))
+    with _on(dev):
+        check(_lib.load().ws3d_compact_mlp_pair(int(kind), C.byref(blocks[0]), C.byref(blocks[1]), _stream()), "compact_mlp_pair")
+    return outs if kind == 2 else True
 
 
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):

@@ -742,15 +742,16 @@ __global__ __launch_bounds__(256) void pair_compact_kernel(long centres, int ns,
 
 // pgather_gemm2_kernel over compact rows: (centre, source) per row from rowc / rowsrc, *total rows in all
 template <int NB1>
-__global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int n, int m, const float *__restrict__ pmat, int p_stride,
-                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
-                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
-                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                                    const float *__restrict__ b2, int relu2, float *__restrict__ out, long limit) {
+__device__ __forceinline__ void pgather_gemm2_compact_body(const unsigned bx, const unsigned by, const unsigned gy, int o2, int n, int m,
+                                                           const float *__restrict__ pmat, int p_stride,
+                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                           const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                           const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                           const float *__restrict__ b2, int relu2, float *__restrict__ out, long limit) {
     constexpr int O1 = NB1 * 64;
     const long T = *total;
-    const long row0 = (long)blockIdx.x * 64;
+    const long row0 = (long)bx * 64;
     if (row0 >= T || (limit >= 0 && T > limit)) return;      // workgroup-uniform; beyond the limit the dense kernels run instead
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     float *act = smem2, *w2s = smem2 + O1 * GP_XS;
@@ -795,7 +796,7 @@ __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int 
     const int wk = tid >> 4, wc = (tid & 15) * 4;
     const int nchunk = (o2 + 63) / 64;
     constexpr int nt2 = O1 / GP_KT;
-    for (int c = blockIdx.y; c < nchunk; c += gridDim.y) {       // the 64-column passes of layer 2 are spread over gridDim.y workgroups (each
+    for (int c = by; c < nchunk; c += gy) {       // the 64-column passes of layer 2 are spread over gridDim.y workgroups (each
         const int col0 = c * 64;                                   // rebuilds layer 1's tile: a gather and two matrix steps): compact launches are small
         auto load_w2 = [&](int t) {
             const int col = col0 + wc;
@@ -833,15 +834,48 @@ __global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int 
     }
 }
 
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm2_compact_kernel(int o2, int n, int m, const float *__restrict__ pmat, int p_stride,
+                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                                    const float *__restrict__ b2, int relu2, float *__restrict__ out, long limit) {
+    pgather_gemm2_compact_body<NB1>(blockIdx.x, blockIdx.y, gridDim.y, o2, n, m, pmat, p_stride, xyz, new_xyz, rowc, rowsrc, total, w1x, b1, relu1, w2t, b2,
+                                    relu2, out, limit);
+}
+
+// ---- the two scales of a set-abstraction level in ONE launch (round 5): the kernels of a level's scales differ in their arguments only
+// (same first-layer width), neither fills the chip at batch 8, and a launch costs the 20-deep pipeline ~0.2 % of its throughput.
+// Workgroups [0, split) along x run the first scale's body, the others the second's (x - split).  One argument block serves the three
+// compact kernels: pgather_gemm3 (everything), pgather_gemm2 (rows out -> mid), gemm_pool (mid -> out).
+struct CompactMlpArgs {
+    const float *pmat, *xyz, *new_xyz;
+    const int32_t *rowc, *rowsrc, *total;
+    const float *w1x, *b1, *w2t, *b2, *w3t, *b3;
+    float *mid, *out;
+    long limit;
+    int o2, o3, n, m, p_stride, relu1, relu2, out_stride, gy, pad;
+};
+
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm2_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
+    const bool second = blockIdx.x >= split;
+    const CompactMlpArgs &a = second ? a1 : a0;
+    if (blockIdx.y >= (unsigned)a.gy) return;
+    pgather_gemm2_compact_body<NB1>(second ? blockIdx.x - split : blockIdx.x, blockIdx.y, (unsigned)a.gy, a.o2, a.n, a.m, a.pmat, a.p_stride, a.xyz, a.new_xyz,
+                                    a.rowc, a.rowsrc, a.total, a.w1x, a.b1, a.relu1, a.w2t, a.b2, a.relu2, a.mid, a.limit);
+}
+
 // last layer over compact rows + max over each centre's rows: out[centre, col] = max(out, relu(x W + b)) by integer atomic max
 // (out starts at 0, every candidate is >= 0 after the ReLU: the float order is the integer order)
-__global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o_dim, const float *__restrict__ x, const int32_t *__restrict__ rowc,
-                                                                const int32_t *__restrict__ total, const float *__restrict__ wt,
-                                                                const float *__restrict__ bias, float *__restrict__ out, int out_stride, long limit) {
+__device__ __forceinline__ void gemm_pool_compact_body(const unsigned bx, int k_dim, int o_dim, const float *__restrict__ x, const int32_t *__restrict__ rowc,
+                                                       const int32_t *__restrict__ total, const float *__restrict__ wt,
+                                                       const float *__restrict__ bias, float *__restrict__ out, int out_stride, long limit) {
     const long T = *total;
     const int col_tiles = o_dim / 64;
-    const long row_tile = blockIdx.x / col_tiles;
-    const int col_tile = (int)(blockIdx.x - row_tile * col_tiles);
+    const long row_tile = bx / col_tiles;
+    const int col_tile = (int)(bx - row_tile * col_tiles);
     const long row0 = row_tile * 64;
     if (row0 >= T || (limit >= 0 && T > limit)) return;
     __shared__ float xs[2][GP_KT][GP_XS];
@@ -889,6 +923,18 @@ __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o
     compact_pool_atomic(acc, bv, cen, out + col, out_stride);
 }
 
+__global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o_dim, const float *__restrict__ x, const int32_t *__restrict__ rowc,
+                                                                const int32_t *__restrict__ total, const float *__restrict__ wt,
+                                                                const float *__restrict__ bias, float *__restrict__ out, int out_stride, long limit) {
+    gemm_pool_compact_body(blockIdx.x, k_dim, o_dim, x, rowc, total, wt, bias, out, out_stride, limit);
+}
+
+__global__ __launch_bounds__(256) void gemm_pool_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
+    const bool second = blockIdx.x >= split;
+    const CompactMlpArgs &a = second ? a1 : a0;
+    gemm_pool_compact_body(second ? blockIdx.x - split : blockIdx.x, a.o2, a.o3, a.mid, a.rowc, a.total, a.w3t, a.b3, a.out, a.out_stride, a.limit);
+}
+
 // ---- the WHOLE SharedMLP of a set-abstraction scale over compact rows in one kernel (round 4): pgather_gemm2_compact_kernel's
 // layer 1 (gathered P row + xyz term) and layer 2, layer 2's 64 x O2 tile kept in LDS next to layer 1's (as gather_gemm2_kernel<.., POOL>
 // does for dense rows) and gemm_pool_compact_kernel's last layer + atomic max multiplied straight out of it, 128 output columns per
@@ -897,16 +943,16 @@ __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o
 // The k order of every dot product is the two kernels' (ascending k, two per matrix instruction, zero padding behind o2): the
 // pooled rows are bit-identical to theirs.  LDS: (O1 + O2 rounded up to 16) x 65 + 2 x 16 x 64 floats -- 41 / 50 KB at SA2.
 template <int NB1>
-__global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int o3, int n, int m, const float *__restrict__ pmat, int p_stride,
-                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
-                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
-                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
-                                                                    const float *__restrict__ b2, int relu2, const float *__restrict__ w3t,
-                                                                    const float *__restrict__ b3, float *__restrict__ out, int out_stride, long limit) {
+__device__ __forceinline__ void pgather_gemm3_compact_body(const unsigned bx, int o2, int o3, int n, int m, const float *__restrict__ pmat, int p_stride,
+                                                           const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                           const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                           const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                           const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                           const float *__restrict__ b2, int relu2, const float *__restrict__ w3t,
+                                                           const float *__restrict__ b3, float *__restrict__ out, int out_stride, long limit) {
     constexpr int O1 = NB1 * 64;
     const long T = *total;
-    const long row0 = (long)blockIdx.x * 64;
+    const long row0 = (long)bx * 64;
     if (row0 >= T || (limit >= 0 && T > limit)) return;      // workgroup-uniform; beyond the limit the dense kernels run instead
     extern __shared__ __attribute__((aligned(16))) float smem2[];
     const int o2p = (o2 + GP_KT - 1) / GP_KT * GP_KT;
@@ -1038,6 +1084,26 @@ __global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int 
             compact_pool_atomic(acc3[q], b3 ? b3[col] : 0.f, cidx, out + col, out_stride);
         }
     }
+}
+
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int o3, int n, int m, const float *__restrict__ pmat, int p_stride,
+                                                                    const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                    const int32_t *__restrict__ rowc, const int32_t *__restrict__ rowsrc,
+                                                                    const int32_t *__restrict__ total, const float *__restrict__ w1x,
+                                                                    const float *__restrict__ b1, int relu1, const float *__restrict__ w2t,
+                                                                    const float *__restrict__ b2, int relu2, const float *__restrict__ w3t,
+                                                                    const float *__restrict__ b3, float *__restrict__ out, int out_stride, long limit) {
+    pgather_gemm3_compact_body<NB1>(blockIdx.x, o2, o3, n, m, pmat, p_stride, xyz, new_xyz, rowc, rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out,
+                                    out_stride, limit);
+}
+
+template <int NB1>
+__global__ __launch_bounds__(256) void pgather_gemm3_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
+    const bool second = blockIdx.x >= split;
+    const CompactMlpArgs &a = second ? a1 : a0;
+    pgather_gemm3_compact_body<NB1>(second ? blockIdx.x - split : blockIdx.x, a.o2, a.o3, a.n, a.m, a.pmat, a.p_stride, a.xyz, a.new_xyz, a.rowc, a.rowsrc, a.total,
+                                    a.w1x, a.b1, a.relu1, a.w2t, a.b2, a.relu2, a.w3t, a.b3, a.out, a.out_stride, a.limit);
 }
 
 // ---- first layer of a feature-propagation module WITHOUT its per-point product over the interpolated channels.  Interpolation
@@ -1597,6 +1663,65 @@ extern "C" int ws3d_pgather_gemm3_compact(int b, int n, int m, long max_rows, in
                            rowsrc, total, w1x, b1, relu1, w2t, b2, relu2, w3t, b3, out, out_stride, limit);
     }
     return check_launch("ws3d_pgather_gemm3_compact");
+}
+
+// kind 3: ws3d_pgather_gemm3_compact of both argument blocks, 2: ws3d_pgather_gemm2_compact (rows -> mid), 1: ws3d_gemm_pool_compact (mid -> out)
+extern "C" int ws3d_compact_mlp_pair(int kind, const ws3d_compact_mlp_args *p0, const ws3d_compact_mlp_args *p1, ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (!p0 || !p1 || kind < 1 || kind > 3) { set_error("ws3d_compact_mlp_pair: invalid argument (kind=%d)", kind); return WS3D_E_INVALID; }
+    const ws3d_compact_mlp_args *ps[2] = {p0, p1};
+    CompactMlpArgs a[2];
+    long tiles[2];
+    size_t lds = 0;
+    unsigned gy = 1;
+    for (int i = 0; i < 2; ++i) {
+        const ws3d_compact_mlp_args &q = *ps[i];
+        bool ok = q.max_rows > 0 && q.rowc && q.total && q.o2 > 0 && !(q.o2 & 3);
+        if (kind >= 2) {
+            ok = ok && q.b > 0 && q.n > 0 && q.m > 0 && q.o1 == p0->o1 && (q.o1 == 64 || q.o1 == 128 || (kind == 2 && q.o1 == 256)) && q.p_stride >= q.o1 && q.pmat &&
+                 q.xyz && q.new_xyz && q.rowsrc && q.w1x && q.w2t && !(reinterpret_cast<uintptr_t>(q.w2t) & 15);
+        }
+        if (kind == 3) {
+            const size_t o2p = ((size_t)q.o2 + GP_KT - 1) / GP_KT * GP_KT;
+            lds = std::max(lds, sizeof(float) * (((size_t)q.o1 + o2p) * GP_XS + (size_t)2 * GP_KT * 64));
+            ok = ok && q.o3 > 0 && !(q.o3 & 127) && q.w3t && !(reinterpret_cast<uintptr_t>(q.w3t) & 15) && q.out && q.out_stride >= q.o3 && lds <= 160 * 1024 - 1024;
+        } else if (kind == 2) {
+            lds = sizeof(float) * ((size_t)q.o1 * GP_XS + (size_t)2 * GP_KT * 64);
+            ok = ok && q.mid;
+            gy = std::max(gy, (unsigned)((q.o2 + 63) / 64));
+        } else {
+            ok = ok && q.o3 > 0 && !(q.o3 & 63) && q.mid && q.w3t && q.out && q.out_stride >= q.o3 &&
+                 !((reinterpret_cast<uintptr_t>(q.mid) | reinterpret_cast<uintptr_t>(q.w3t)) & 15);
+        }
+        if (!ok) {
+            set_error("ws3d_compact_mlp_pair(kind %d): block %d not covered (rows<=%ld o1=%d o2=%d o3=%d; the shapes of the single-scale entry, equal o1)", kind, i,
+                      q.max_rows, q.o1, q.o2, q.o3);
+            return WS3D_E_UNSUPPORTED;
+        }
+        tiles[i] = ((q.max_rows + 63) / 64) * (kind == 1 ? q.o3 / 64 : 1);
+        a[i] = CompactMlpArgs{q.pmat, q.xyz, q.new_xyz, q.rowc, q.rowsrc, q.total, q.w1x, q.b1, q.w2t, q.b2, q.w3t, q.b3, q.mid, q.out, q.limit,
+                              q.o2, q.o3, q.n, q.m, q.p_stride, q.relu1, q.relu2, q.out_stride, (q.o2 + 63) / 64, 0};
+    }
+    if (tiles[0] + tiles[1] > 0x7fffffffL) { set_error("ws3d_compact_mlp_pair: too many rows"); return WS3D_E_UNSUPPORTED; }
+    const dim3 grid((unsigned)(tiles[0] + tiles[1]), kind == 2 ? gy : 1u);
+    const unsigned split = (unsigned)tiles[0];
+    hipStream_t st = as_stream(stream);
+#define WS3D_PAIR_GO(KERN)                                                                            \
+    do {                                                                                              \
+        if (int rc = raise_lds_cap((const void *)KERN, lds, "ws3d_compact_mlp_pair")) return rc;      \
+        hipLaunchKernelGGL(KERN, grid, dim3(256), lds, st, a[0], a[1], split);                        \
+    } while (0)
+    if (kind == 3) {
+        if (p0->o1 == 64) WS3D_PAIR_GO(pgather_gemm3_compact_pair_kernel<1>); else WS3D_PAIR_GO(pgather_gemm3_compact_pair_kernel<2>);
+    } else if (kind == 2) {
+        if (p0->o1 == 64) WS3D_PAIR_GO(pgather_gemm2_compact_pair_kernel<1>);
+        else if (p0->o1 == 128) WS3D_PAIR_GO(pgather_gemm2_compact_pair_kernel<2>);
+        else WS3D_PAIR_GO(pgather_gemm2_compact_pair_kernel<4>);
+    } else {
+        hipLaunchKernelGGL(gemm_pool_compact_pair_kernel, grid, dim3(256), 0, st, a[0], a[1], split);
+    }
+#undef WS3D_PAIR_GO
+    return check_launch("ws3d_compact_mlp_pair");
 }
 
 extern "C" int ws3d_gemm_pool_compact(long max_rows, int k_dim, int o_dim, const float *x_rows, const int32_t *rowc, const int32_t *total,

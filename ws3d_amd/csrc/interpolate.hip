@@ -115,13 +115,12 @@ __global__ __launch_bounds__(1024) void bin_points_xz_kernel(int n, const float 
 // walk is bound by the rate of its random 16-byte reads, and LDS serves those an order of
 // magnitude faster than the global gather path (0.20 -> see DESIGN.md 5.3).
 template <bool LDS>
-__global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, const float *__restrict__ unknown,
-                                                              const char *__restrict__ ws,
-                                                              float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight,
-                                                              const char *__restrict__ wsq) {
+__device__ __forceinline__ void three_nn_sorted_body(const int bx, const int b, int n, int m, const float *__restrict__ unknown,
+                                                     const char *__restrict__ ws,
+                                                     float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight,
+                                                     const char *__restrict__ wsq) {
     extern __shared__ __attribute__((aligned(16))) char smem_nn[];
-    const int b = blockIdx.y;
-    int pi = blockIdx.x * 512 + threadIdx.x;
+    int pi = bx * 512 + threadIdx.x;
     const char *base = ws + (size_t)b * bin_scene_stride(m);
     const float4 *sorted = reinterpret_cast<const float4 *>(base);
     const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)m * 16);
@@ -250,6 +249,26 @@ __global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, cons
     od[0] = b1; od[1] = b2; od[2] = b3;
     oi[0] = i1; oi[1] = i2; oi[2] = i3;
     if (weight) nn_weights3(b1, b2, b3, weight + ((size_t)b * n + pi) * 3);
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(512) void three_nn_sorted_kernel(int n, int m, const float *__restrict__ unknown,
+                                                              const char *__restrict__ ws,
+                                                              float *__restrict__ dist2, int32_t *__restrict__ idx, float *__restrict__ weight,
+                                                              const char *__restrict__ wsq) {
+    three_nn_sorted_body<LDS>(blockIdx.x, blockIdx.y, n, m, unknown, ws, dist2, idx, weight, wsq);
+}
+
+// several searches (the FP modules of a network: every level's queries against the next level's binned centres) in ONE launch:
+// job k owns the x tiles [tiles_end of job k - 1, tiles_end of job k); dynamic LDS sized for the largest known set
+struct NnJob { const float *unknown; const char *ws; float *dist2; int32_t *idx; float *weight; const char *wsq; int n, m, tiles_end, pad; };
+constexpr int NN_MAX_JOBS = 4;
+struct NnJobs { NnJob j[NN_MAX_JOBS]; int njobs; };
+__global__ __launch_bounds__(512) void three_nn_sorted_jobs_kernel(const NnJobs jobs) {
+    int k = 0, t0 = 0;
+    while (k + 1 < jobs.njobs && (int)blockIdx.x >= jobs.j[k].tiles_end) { t0 = jobs.j[k].tiles_end; ++k; }
+    const NnJob j = jobs.j[k];
+    three_nn_sorted_body<true>((int)blockIdx.x - t0, blockIdx.y, j.n, j.m, j.unknown, j.ws, j.dist2, j.idx, j.weight, j.wsq);
 }
 
 constexpr int TI_CCH = 16;
@@ -795,6 +814,36 @@ static int three_nn_launch(int b, int n, int m, const float *unknown, const floa
     hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m,
                        unknown, known, dist2, idx, weight);
     return check_launch("ws3d_three_nn");
+}
+
+extern "C" int ws3d_three_nn_jobs(int b, int njobs, const int *n, const int *m, const float *const *unknown, const void *const *sorted_known,
+                                  float *const *dist2, int32_t *const *idx, float *const *weight, const void *const *sorted_unknown,
+                                  ws3d_stream_t stream) {
+    using namespace ws3d;
+    if (b == 0 || njobs == 0) return WS3D_OK;
+    if (b < 0 || b > 65535 || njobs < 0 || njobs > NN_MAX_JOBS || !n || !m || !unknown || !sorted_known || !dist2 || !idx || !weight) {
+        set_error("ws3d_three_nn_jobs: invalid argument (b=%d njobs=%d, at most %d jobs)", b, njobs, NN_MAX_JOBS);
+        return WS3D_E_INVALID;
+    }
+    NnJobs jobs{};
+    size_t lds = 0;
+    int tiles = 0;
+    for (int k = 0; k < njobs; ++k) {
+        if (n[k] <= 0 || m[k] < 3 || (size_t)m[k] * sizeof(float4) > 64 * 1024 || !unknown[k] || !sorted_known[k] || !dist2[k] || !idx[k] || !weight[k] ||
+            (sorted_unknown && sorted_unknown[k] && n[k] > SORT_MAX_N)) {
+            set_error("ws3d_three_nn_jobs: job %d invalid (n=%d m=%d; 3 <= m <= 4096 binned known points, a binned query copy needs n <= %d)", k, n[k], m[k],
+                      SORT_MAX_N);
+            return WS3D_E_INVALID;
+        }
+        tiles += (n[k] + 511) / 512;
+        jobs.j[k] = NnJob{unknown[k], reinterpret_cast<const char *>(sorted_known[k]), dist2[k], idx[k], weight[k],
+                          reinterpret_cast<const char *>(sorted_unknown ? sorted_unknown[k] : nullptr), n[k], m[k], tiles, 0};
+        lds = std::max(lds, (size_t)m[k] * sizeof(float4) + (size_t)(BQS_CELLS + 4) * sizeof(int));
+    }
+    jobs.njobs = njobs;
+    if (int rc = raise_lds_cap((const void *)three_nn_sorted_jobs_kernel, 80 * 1024, "ws3d_three_nn_jobs")) return rc;
+    hipLaunchKernelGGL(three_nn_sorted_jobs_kernel, dim3((unsigned)tiles, b), dim3(512), lds, as_stream(stream), jobs);
+    return check_launch("ws3d_three_nn_jobs");
 }
 
 extern "C" int ws3d_three_interpolate(int b, int c, int m, int n, const float *points,

@@ -94,6 +94,8 @@ COMPACT_PAIRS = True  # the SharedMLPs over the distinct (centre, sample) pairs 
 PAIR_DISPATCH = "device"
 PRIMED_MARGIN = 0.85       # Stage1Pipeline(pair_dispatch="primed"): scales whose priming fill <= PRIMED_MARGIN * COMPACT_MAX_FILL lose the dense twin
 _COMPACT_ONLY = contextvars.ContextVar("ws3d_compact_only_scales", default=frozenset())
+PAIRED_SCALES = True   # the compact SharedMLP kernels of a level's two scales in ONE launch each (ws3d_compact_mlp_pair) where neither scale carries a gated dense twin (Stage1Pipeline's primed graphs, PAIR_DISPATCH "compact")
+MERGED_THREE_NN = True   # serial order: the 3-NN searches of the FP modules whose known set is binned in ONE launch behind that binning launch (ws3d_three_nn_jobs)
 FUSED_PROLOGUE = True   # the coordinate / feature split of the input rows and the clear of the pass's zero arena in ONE launch (ws3d_split_points_clear) instead of two strided copies + a fill
 MERGED_BINNING = True   # serial order (graph capture): the binned copies of levels 2.. (ball query's grid + three_nn's (x, z) grid) in ONE launch behind the sampling chain (ws3d_sort_points_jobs) instead of one per level and flavour
 PER_POINT_FP = True  # FP modules: first layer as (known_feats @ W_a) interpolated + skip @ W_b (ws3d_qinterp_rows)
@@ -581,7 +583,42 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
             if not (FUSED_GEMM_POOL and _C.gemm_pool(y, wt, bias, relu, grouper.nsample, out, col)):
                 _C.rowmax_rows(_layer(y, blocks[-1]), grouper.nsample, out, col)
 
-    if geo is not None and geo.aux is not None and PARALLEL_SCALES and len(widths) == 2:
+    def run_paired() -> bool:
+        """both scales' compact SharedMLP in one launch per kernel (three -> the fused kernel; else layers 1 + 2, then layer 3 + pool);
+        only where neither scale launches a gated dense twin.  False: nothing launched, the per-scale path runs"""
+        if not (PAIRED_SCALES and COMPACT_PAIRS and PER_POINT_L1 and len(widths) == 2 and all(isinstance(n_, _PairList) for n_ in nbrs)):
+            return False
+        blk = [_blocks(m_) for m_ in sa.mlps]
+        if any(len(b_) != 3 or b_[0].conv.out_channels > 256 for b_ in blk) or blk[0][0].conv.out_channels != blk[1][0].conv.out_channels:
+            return False
+        if any(_pair_limit(n_.nbr.numel(), True, (level, si_)) != -1 for si_, n_ in enumerate(nbrs)):
+            return False
+        if pp[0] is None:
+            pp[0] = _per_point_l1(sa, feats, nbrs)
+        pmat, offs, w1xs = pp[0]
+        scales = []
+        for si_ in range(2):
+            _w1, b1, r1 = _row_weights_xyz_last(blk[si_][0])
+            wt2, b2, r2 = _row_weights(blk[si_][1])
+            wt3, b3, r3 = _row_weights(blk[si_][2])
+            if not r3:
+                return False
+            scales.append({"pmat": pmat, "col0": offs[si_], "o1": blk[si_][0].conv.out_channels, "xyz": xyz, "new_xyz": new_xyz, "pairs": nbrs[si_].pairs,
+                           "w1x": w1xs[si_], "b1": b1, "relu1": r1, "w2t": wt2, "b2": b2, "relu2": r2, "w3t": wt3, "b3": b3, "out2d": out, "col_offset": cols[si_]})
+        if _C.compact_mlp_pair(3, scales, max_lds=FUSED_COMPACT3_MAX_LDS):
+            return True
+        mids = _C.compact_mlp_pair(2, scales)
+        if mids is None:
+            return False
+        if not _C.compact_mlp_pair(1, scales, mids=mids):
+            for sc_, mid in zip(scales, mids):
+                if not _C.gemm_pool_compact(mid, sc_["pairs"], sc_["w3t"], sc_["b3"], out, sc_["col_offset"], limit=-1):
+                    raise RuntimeError("ws3d_gemm_pool_compact declined a shape ws3d_pgather_gemm2_compact took")
+        return True
+
+    if run_paired():
+        pass
+    elif geo is not None and geo.aux is not None and PARALLEL_SCALES and len(widths) == 2:
         # the two scales of a multi-scale level are independent and neither fills the chip at batch 8: the second one on a side
         # stream beside the first.  What both read is ready on the caller's stream at this point (the level's features, the
         # per-point product of layer 1 -- taken here, once, for both -- and, waited for above, the neighbour lists)
@@ -675,7 +712,7 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
     geo = _Geometry(net, xyz, 0 if feats is None else feats.size(2), zeros) if ahead else None
     l_xyz, l_feats, binned = [xyz], [feats], []
     try:
-        sas, chain, pre_grid, pre_xz = list(net.SA_modules), None, {}, {}
+        sas, chain, pre_grid, pre_xz, nn_pre = list(net.SA_modules), None, {}, {}, {}
         for level, sa in enumerate(sas):
             pre = chain[level - 1][1] if (chain is not None and level >= 1) else None
             nx, nf = sa_forward(sa, l_xyz[-1], l_feats[-1], geo, level, zeros, binned, pre, pre_grid.get(level))
@@ -693,10 +730,20 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
                     if _C.BQ_FINE_GRID:
                         pre_grid = {k + 1: ((next(bufs),) if x_.size(1) >= GRID_MIN_N else (None,)) for k, x_ in enumerate(lv[:-1])}
                         pre_xz = {k + 1: (next(bufs) if x_.size(1) >= 256 else None) for k, x_ in enumerate(lv)}
+                        if MERGED_THREE_NN:
+                            # ... and behind it the 3-NN of every FP module whose known set got an (x, z) grid (queries of level k
+                            # against the centres of level k + 1; query order: level k's ball-query grid, as fp_forward passes it)
+                            allx = [l_xyz[0]] + lv
+                            qgrid = {0: binned[0]}
+                            qgrid.update({k_: v_[0] for k_, v_ in pre_grid.items()})
+                            lvls = [k_ for k_ in range(len(sas)) if pre_xz.get(k_ + 1) is not None and allx[k_ + 1].size(1) <= 4096]
+                            got = _C.three_nn_jobs([(allx[k_], allx[k_ + 1], pre_xz[k_ + 1], qgrid.get(k_) if QUERY_CELL_ORDER else None) for k_ in lvls])
+                            if got is not None:
+                                nn_pre = dict(zip(lvls, got))
         for i in range(-1, -(len(net.FP_modules) + 1), -1):
-            nn3 = None
+            lvl = len(l_xyz) + i - 1                                       # unknown level of this module
+            nn3 = nn_pre.get(lvl)
             if geo is not None:
-                lvl = len(l_xyz) + i - 1                                   # unknown level of this module
                 geo.main.wait_event(geo.nn_ready[lvl])
                 nn3 = geo.nn[lvl]
             known_level = len(l_xyz) + i
