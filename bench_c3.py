@@ -60,8 +60,9 @@ def _interp_bytes(cfg):
 # these families is library work: Tensile GEMMs and at::native glue.
 FAMILIES = {
     "furthest_point_sampling_gather": "fps level 1 (16384 -> 4096)", "furthest_point_sampling_nested": "fps levels 2-4 (verified prefix)", "furthest_point_sampling_nested_chain": "fps levels 2-4 (verified prefix)",
-    "sort_points_x": "binning (grid / x slabs / xz grid)", "sort_points_xz": "binning (grid / x slabs / xz grid)",
-    "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "ball_query_pairs": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
+    "split_points_clear": "prologue (input split + zero arena, one launch)",
+    "sort_points_x": "binning (grid / x slabs / xz grid)", "sort_points_xz": "binning (grid / x slabs / xz grid)", "sort_points_jobs": "binning (grid / x slabs / xz grid)",
+    "ball_query_wrapper": "ball_query", "ball_query_lists": "ball_query", "ball_query_pairs": "ball_query", "ball_query_pairs2": "ball_query", "query_and_group": "ball_query+group", "query_and_group_nlc": "ball_query+group",
     "compact_pairs": "pair compaction",
     "sa_mlp3_pool": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)", "sa_mlp3_pool_compact": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
     "sa_mlp3_pool_lists": "SharedMLP SA1 (3 layers + pool, own MFMA kernels)",
@@ -71,13 +72,14 @@ FAMILIES = {
     "gather_gemm2": "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)",
     "gemm_pool": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)", "gemm_pool_compact": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
     "rowmax_rows": "SharedMLP SA2-4 last layer + pool (own MFMA kernels)",
-    "three_nn_wrapper": "three_nn (+ weights)", "three_nn_with_weights": "three_nn (+ weights)",
+    "compact_mlp_pair": "SharedMLP SA2-4 both scales per launch (compact rows; primed graphs only)",
+    "three_nn_wrapper": "three_nn (+ weights)", "three_nn_with_weights": "three_nn (+ weights)", "three_nn_jobs": "three_nn (+ weights)",
     "qinterp_gemm": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
     "qinterp_rows": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)", "interp_gemm": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
     "three_interpolate_nlc": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)", "three_interpolate_wrapper": "FP first layer (interpolate + add; at FP1-2 with the second layer: own kernels)",
     "mlp2_rows": "heads (2 layers, own MFMA kernel)",
     "decode_center_boxes": "proposals: decode + top-k + gather + select", "topk_sorted": "proposals: decode + top-k + gather + select",
-    "gather_boxes_bev": "proposals: decode + top-k + gather + select", "select_proposals": "proposals: decode + top-k + gather + select",
+    "gather_boxes_bev": "proposals: decode + top-k + gather + select", "decode_gather_boxes_bev": "proposals: decode + top-k + gather + select", "select_proposals": "proposals: decode + top-k + gather + select",
     "nms_device_batched": "nms(mask+sweep)", "roipool3d_forward": "roipool3d", "roipool3d_forward_fill": "roipool3d"}
 # rows whose alg_bytes are the REFERENCE operator's byte model while the own kernels that replace it move far less:
 # bench.py reports them as effective GB/s without a fraction of the HBM roof
@@ -156,7 +158,7 @@ def _install_hooks():
             if _DOUBLE and _DOUBLE in __key:
                 # diagnostic (scripts/throughput_marginal.py): issue this family's launches twice -- same inputs, same outputs -- so
                 # that the change of the throughput-mode step time is what the family costs with 20 batches in flight
-                if __name == "ball_query_pairs":
+                if __name in ("ball_query_pairs", "ball_query_pairs2"):
                     __orig(*a[:5], None)                       # its own cleared pair counter
                 else:
                     __orig(*a, **kw)

@@ -9,5 +9,5 @@ import sys, json
 d = json.loads(sys.stdin.readlines()[-1])
 print('%-58s %8.4f ms/batch  latency %6.3f ms' % (sys.argv[1] or '(plain)', d['ms_per_step'], d['latency_mode']['ms_per_batch']))" "$1"; }
 run ""
-for fam in "fps level 1" "fps levels 2-4" "binning" "ball_query" "SharedMLP SA1" "SharedMLP SA2 whole" "SharedMLP SA2-4 layers" "SharedMLP SA2-4 last" "three_nn" "FP first layer" "heads" "proposals" "nms" "roipool3d" "library"; do run "$fam"; done
+for fam in "prologue" "fps level 1" "fps levels 2-4" "binning" "ball_query" "SharedMLP SA1" "SharedMLP SA2-4 both scales" "three_nn" "FP first layer" "heads" "proposals" "nms" "roipool3d" "library"; do run "$fam"; done
 run ""
