@@ -317,8 +317,7 @@ def _neighbour_lists(sa, xyz, new_xyz, sorted_xyz, c_feat: int, zeros=None):
         both = _C.ball_query_pairs2([g.radius for g in sa.groupers], [g.nsample for g in sa.groupers], xyz, new_xyz, sorted_xyz, totals)
         if both is not None:
             return [_PairList(nbr, pairs) for nbr, pairs in both]
-        if totals is not None:             # (the arena's two counters stay zero: the per-scale calls below take their own)
-            pass
+        # (declined: the arena's two counters stay zero and unused, the per-scale calls below take their own)
     for grouper, mlp in zip(sa.groupers, sa.mlps):
         if not _gather_gemm_ok(sa, grouper, _blocks(mlp), c_feat, B):
             lists.append(None)
