@@ -35,6 +35,24 @@ while time.time() - t0 < a.seconds:
         e = float((u - v).abs().max()) / max(float(v.abs().max()), 1.0)
         worst = max(worst, e)
         assert e <= 5e-5, (kind, B, e)
+    # the serial order a primed Stage1Pipeline captures (one stream, no dense twins): its merged launches -- one binning launch, the FP
+    # modules' 3-NN as jobs, both scales per compact SharedMLP kernel, the prologue -- against one launch each: the same bits
+    fastpath.COMPACT_MAX_FILL = 0.55
+    every = {(l_, s_) for l_ in range(4) for s_ in range(2)}
+    sw = ("MERGED_BINNING", "MERGED_THREE_NN", "PAIRED_SCALES", "FUSED_PROLOGUE", "DUAL_SCALE_SEARCH", "NESTED_CHAIN")
+    res = []
+    for on in (True, False):
+        saved = {n_: getattr(fastpath, n_) for n_ in sw}
+        for n_ in sw:
+            setattr(fastpath, n_, on)
+        try:
+            with torch.no_grad(), fastpath.geometry_ahead(False), fastpath.compact_only_scales(every):
+                o = model.rpn_forward({"pts_input": x})
+        finally:
+            for n_, v_ in saved.items():
+                setattr(fastpath, n_, v_)
+        res.append((o["rpn_cls"].clone(), o["rpn_reg"].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), ("merged launches", kind, B)
     rounds += 1
 fastpath.COMPACT_MAX_FILL = 0.55
-print(f"fuzz_compact: {rounds} forward passes (lidar wedges, uniform boxes 0.5-60 m, duplicate-laden grids), compact vs dense SharedMLPs: worst relative difference {worst:.1e} (seed {a.seed})")
+print(f"fuzz_compact: {rounds} forward passes (lidar wedges, uniform boxes 0.5-60 m, duplicate-laden grids), compact vs dense SharedMLPs: worst relative difference {worst:.1e}; merged launches of the serial order bit-identical to one launch each (seed {a.seed})")

@@ -88,6 +88,27 @@ def one_round(rng):
         assert np.array_equal(host(o), refi), ("interp", B, Ck, M, N)
         assert np.array_equal(host(c.three_interpolate_nlc(dev(np.ascontiguousarray(kf.transpose(0, 2, 1))), dev(ir), dev(w))),
                               refi.transpose(0, 2, 1)), ("interp nlc", B, Ck, M, N)
+    # round 5's merged launches on the same cloud / centres: several binning jobs, several 3-NN searches, both radii of a ball query
+    if 3 <= M and N <= 16384:
+        half = np.ascontiguousarray(pc[:, :max(N // 2, 1)])
+        bufs = c.sort_points_jobs([(dev(pc), "grid"), (dev(cen), "xz"), (dev(half), "grid"), (dev(pc), "xz")])
+        if ns <= 64:
+            r2 = float(rng.choice([0.05, 0.3, 1.0, 3.0])); ns2 = int(rng.choice([1, 16, 32, 64]))
+            two = c.ball_query_pairs2([r, r2], [ns, ns2], dev(pc), dev(cen), bufs[0])
+            assert two is not None
+            for (lst, (rc_, rs_, tt_)), (rr_, nn_) in zip(two, ((r, ns), (r2, ns2))):
+                want_l = ref_bq if rr_ == r and nn_ == ns else oracle.ball_query(rr_, nn_, pc, cen)
+                assert np.array_equal(host(lst), want_l), ("ball_query_pairs2 lists", B, N, M, rr_, nn_)
+                dl = (np.diff(want_l.reshape(-1, nn_), axis=1) > 0).sum(1) + 1
+                assert int(tt_.item()) == int(dl.sum()), ("ball_query_pairs2 total", B, N, M, rr_, nn_)
+        if M <= 4096:
+            jobs = [(dev(pc), dev(cen), bufs[1], bufs[0] if rng.random() < 0.5 else None), (dev(half), dev(cen), bufs[1], bufs[2])]
+            got = c.three_nn_jobs(jobs)
+            assert got is not None
+            for (un, kn, sk_, su_), (ij, wj) in zip(jobs, got):
+                wi, ww2 = c.three_nn_with_weights(un, kn, sk_, su_)
+                assert torch.equal(ij, wi) and torch.equal(wj, ww2), ("three_nn_jobs", B, N, M)
+            assert np.array_equal(host(got[0][0]), ir), ("three_nn_jobs vs oracle", B, N, M)
     # roipool3d
     m = int(rng.integers(1, 80)); S = int(rng.choice([1, 16, 64, 512])); Cf = int(rng.choice([0, 3, 8, 128]))
     boxes = synth.proposal_boxes(B, m, int(rng.integers(1, 10 ** 6)))
@@ -153,6 +174,21 @@ def one_round(rng):
     ref_box = torch.stack((ctr[..., 0], xyz_t[..., 1] + h / 2, ctr[..., 2], torch.full_like(ctr[..., 0], h), torch.full_like(ctr[..., 0], w),
                            torch.full_like(ctr[..., 0], l), stage1.synthetic_orientation(Np, xyz_t.device).unsqueeze(0).expand(Bp, Np)), dim=2)
     assert torch.equal(box, ref_box), ("decode", Bp, Np)
+    if Np <= 16384:
+        lg = sc * float(rng.choice([1.0, 8.0, 40.0]))                 # logits up to saturation: equal sigmoids of distinct logits
+        for spread in (False, True):
+            vs, is_ = c.topk_sorted(lg, kk, spread=spread, sigmoid=True)
+            wv, wi_ = c.topk_sorted(torch.sigmoid(lg), kk, spread=spread)
+            assert torch.equal(vs.view(torch.int32), wv.view(torch.int32)) and torch.equal(is_, wi_), ("topk sigmoid", Bp, Np, kk, spread)
+        if kk > 0:
+            rows, bev_ = c.decode_gather_boxes_bev(xyz_t, reg_t, i, 4.0, 0.8, (h, w, l))
+            wr, wb_ = c.gather_boxes_bev(box, i)
+            assert torch.equal(rows.view(torch.int32), wr.view(torch.int32)) and torch.equal(bev_.view(torch.int32), wb_.view(torch.int32)), ("decode_gather", Bp, Np, kk)
+    Cc = int(rng.choice([3, 4, 9]))
+    pcl = torch.from_numpy(rng.standard_normal((Bp, Np, Cc)).astype(np.float32)).cuda()
+    junk = torch.full((int(rng.integers(1, 5000)) * 4,), float("nan"), device="cuda")
+    sx, sf = c.split_points_clear(pcl, junk)
+    assert torch.equal(sx, pcl[..., :3].contiguous()) and (sf is None if Cc == 3 else torch.equal(sf, pcl[..., 3:].contiguous())) and bool((junk.view(torch.int32) == 0).all()), ("split_points_clear", Bp, Np, Cc)
     # training-step kernels: deterministic scatter (bit-equal to the sequential loop), pool (bit-equal to F.max_pool2d)
     Bg, Cg = int(rng.integers(1, 4)), int(rng.choice([1, 7, 31, 32, 33, 64, 96, 129, 256, 300, 513]))
     Ng, Mg, nsg = int(rng.integers(1, 600)), int(rng.integers(0, 80)), int(rng.choice([1, 3, 16, 32]))
