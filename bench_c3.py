@@ -247,7 +247,7 @@ class C3:
         hipGraph per slot, `depth` batches in flight on separate HIP streams; returns True on success."""
         from ws3d_amd.pipeline import Stage1Pipeline
         self.pipe = Stage1Pipeline(self.model, self.cfg, batch=self.B, n_points=self.pts.size(1), depth=self.depth,
-                                   roipool=True, device=self.pts.device)
+                                   roipool=True, device=self.pts.device, exchange_global_batch=self.B * self.world if self.world > 1 else 0)
         for slot in self.pipe.slots:
             slot["inp"].copy_(self.pts)
         ok = self.pipe.capture_all()
@@ -268,8 +268,9 @@ class C3:
             ticket = self.pipe.submit(pts)                 # None: the slot's own batch, already resident in its input buffer
             slot = self.pipe.slots[ticket % self.depth]
             res = slot["out"]
-            with torch.cuda.stream(slot["stream"]):
-                gathered = wdist.all_gather_proposals(res["packed"], res["count"], self.B * self.world)      # (packed by the selection kernel)
+            # world > 1: the slot's ProposalExchange gathered inside submit() -- one collective on resident buffers (the selection kernel
+            # wrote the rows + counts into the send buffer); (proposals, float counts)
+            gathered = res["gathered"] if "gathered" in res else (res["packed"], res["count"])
             self.last = (res["rpn"], res["boxes"], res["scores"], res["count"], res["pooled"], res["empty"], gathered)
             return
         self._timed = timed

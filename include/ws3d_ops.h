@@ -49,7 +49,7 @@ typedef void *ws3d_stream_t;
 
 /* bumped whenever an entry point is added or a signature changes (5: ws3d_three_nn_wq, ws3d_roipool3d_ws / ws3d_roipool3d_workspace_bytes, ws3d_furthest_point_sampling_nested_chain, ws3d_ball_query_pairs2; 4: ws3d_pgather_gemm3_compact, ws3d_qinterp_gemm; 3: ws3d_topk_sorted_ws / ws3d_topk_workspace_bytes; 2: launch gates
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
-#define WS3D_ABI_VERSION 5
+#define WS3D_ABI_VERSION 6
 WS3D_API int ws3d_abi_version(void);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
  * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
@@ -325,6 +325,19 @@ typedef struct ws3d_compact_mlp_args {
     long limit;
 } ws3d_compact_mlp_args;
 WS3D_API int ws3d_compact_mlp_pair(int kind, const ws3d_compact_mlp_args *scale0, const ws3d_compact_mlp_args *scale1, ws3d_stream_t stream);
+/* The same function as kind 3 (three layers + pool of one or two scales over their compact rows; scale1 may be NULL) on the round-6
+ * kernel (csrc/chain_mlp.hip, ABI 6): a wave owns 32 rows from the gather to the pooled atomics, the activations stay in registers
+ * between the layers (transposed products + v_permlane32_swap), the weights of both scales are resident in LDS, 32-row tiles are handed
+ * out by ticket counters.  blob0 / blob1: the scales' weights packed by ws3d_chain_mlp3_pack (once per weight set,
+ * ws3d_chain_mlp3_blob_floats(o2) floats, 16-byte aligned); ticket: ws3d_chain_mlp3_ticket_ints() int32, ZERO on entry, consumed.
+ * Covered: o1 = 64, o2 <= 96, o3 = 128, 16-byte aligned P rows (SA2 of the Stage-1 network: pointnet2_msg.py's MLPS[1]); anything else
+ * WS3D_E_UNSUPPORTED, nothing launched.  workgroups: 0 = one per compute unit.  Pooled rows bit-identical to
+ * ws3d_pgather_gemm3_compact's (the same fmaf chains in the same k order). */
+WS3D_API int ws3d_chain_mlp3_ticket_ints(void);
+WS3D_API size_t ws3d_chain_mlp3_blob_floats(int o2);
+WS3D_API int ws3d_chain_mlp3_pack(const ws3d_compact_mlp_args *scale, float *blob, ws3d_stream_t stream);
+WS3D_API int ws3d_chain_mlp3(const ws3d_compact_mlp_args *scale0, const ws3d_compact_mlp_args *scale1, const float *blob0, const float *blob1,
+                             int32_t *ticket, int workgroups, ws3d_stream_t stream);
 
 /* ws3d_sa_mlp3_pool over compact pairs (see ws3d_compact_pairs_*): the first level's three-layer SharedMLP (16-16-32 or 32-32-64,
  * every layer with bias + ReLU) on rows [x_j - c, f_j] built here from xyz (b, n, 3), new_xyz (b, m, 3) and the ONE feature
@@ -554,6 +567,13 @@ WS3D_API int ws3d_select_proposals(int b, int top, int keep_stride, int k, const
 WS3D_API int ws3d_select_proposals_packed(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
                                           const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
                                           int64_t *count, float *pooled_boxes, float *packed, ws3d_stream_t stream);
+/* ... the packed rows written straight into the multi-GPU exchange's send buffer (round 6, ABI 6): scene i's k rows of 8 floats at
+ * send + i * send_stride, the scene's count as the float behind them (send_stride >= k * 8 + 1 floats; counts < 2^24 are exact), so
+ * that the step's one all-gather (ws3d_amd/dist.py ProposalExchange; replaces nn.DataParallel's gather, tools/train_rpn.py:175-176)
+ * sends a buffer no other launch packs. */
+WS3D_API int ws3d_select_proposals_send(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
+                                        const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
+                                        int64_t *count, float *pooled_boxes, float *send, long send_stride, ws3d_stream_t stream);
 /* The step's prologue in one launch (round 5): the (rows, c) input rows, c >= 3, split into xyz (rows, 3) and feats (rows, c - 3), and
  * clear_bytes bytes at `clear` zeroed (16-byte aligned and a multiple of 16; 0: nothing) -- the pass's zero-initialised scratch. */
 WS3D_API int ws3d_split_points_clear(long rows, int c, const float *pc, float *xyz, float *feats, void *clear, size_t clear_bytes,

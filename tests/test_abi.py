@@ -33,7 +33,7 @@ def test_python_binding_covers_header():
     from ws3d_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     handle = _lib.load()
-    assert handle.ws3d_abi_version() == _lib.ABI_VERSION == 5
+    assert handle.ws3d_abi_version() == _lib.ABI_VERSION == 6
     assert handle.ws3d_nms_workspace_bytes(9000) >= 9000 * 141 * 8
     assert handle.ws3d_nms_workspace_bytes(0) > 0
 

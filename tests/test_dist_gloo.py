@@ -67,11 +67,23 @@ def test_more_rccl_ranks_than_devices_raises_instead_of_wrapping(monkeypatch):
     import torch
     from ws3d_amd import dist as wdist
     monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
-    for world, local in ((4, 3), (4, 1), (3, 2)):
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    # a LOCAL_RANK beyond the node's devices, or more ranks ON THIS NODE than devices (LOCAL_WORLD_SIZE, as torchrun exports it)
+    for world, local, lws in ((4, 3, None), (3, 2, None), (4, 1, 4), (3, 0, 3)):
         with pytest.raises(RuntimeError, match="one device per rank"):
-            wdist._local_device(local, world, "nccl")
-    assert [wdist._local_device(l, 2, "nccl") for l in (0, 1)] == [0, 1]
-    assert [wdist._local_device(l, 4, "gloo") for l in range(4)] == [0, 1, 0, 1]
+            wdist._local_device(local, world, "nccl", lws)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")            # ... read from the environment when not passed
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        wdist._local_device(1, 4, "nccl")
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert [wdist._local_device(l, 2, "nccl", 2) for l in (0, 1)] == [0, 1]
+    assert [wdist._local_device(l, 4, "gloo", 4) for l in range(4)] == [0, 1, 0, 1]
+    # multi-node jobs: the GLOBAL world size says nothing about this node: 2 nodes x 8 GPUs
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    assert wdist._local_device(3, 16, "nccl", 8) == 3
+    assert [wdist._local_device(l, 16, "nccl") for l in range(8)] == list(range(8))
+    with pytest.raises(RuntimeError, match="one device per rank"):
+        wdist._local_device(8, 16, "nccl", 8)
 
 
 def test_rccl_without_a_device_is_an_error(monkeypatch):

@@ -2418,7 +2418,9 @@ def test_qinterp_gemm_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M,
 @pytest.mark.parametrize("B,N,M,C,O1,scales", [(2, 4096, 1024, 96, 64, ((16, 0.5, 64, 128), (32, 1.0, 96, 128))),          # SA2's two scales: the fused kernel
                                                (2, 1024, 256, 256, 128, ((16, 1.0, 128, 256), (32, 2.0, 196, 256))),      # SA3
                                                (2, 256, 64, 512, 256, ((16, 2.0, 256, 512), (32, 4.0, 384, 512))),        # SA4: first layer 256 wide, two-kernel form only
-                                               (1, 512, 37, 8, 64, ((16, 0.01, 20, 64), (16, 3.0, 64, 192)))])            # ragged: 37 centres, one-point lists beside full ones
+                                               (1, 512, 37, 8, 64, ((16, 0.01, 20, 64), (16, 3.0, 64, 192))),             # ragged: 37 centres, one-point lists beside full ones
+                                               (3, 2048, 300, 12, 64, ((16, 0.3, 20, 128), (32, 2.5, 84, 128))),          # the register-chained kernel's ragged widths (o2 = 20, 84) and 300 centres
+                                               (1, 1024, 256, 32, 64, ((32, 40.0, 96, 128), (16, 0.2, 32, 128)))])        # full lists beside sparse ones, widths 96 / 32
 def test_compact_mlp_pair_equals_the_single_scale_launches(ops, B, N, M, C, O1, scales):
     """ws3d_compact_mlp_pair (both scales of a level in ONE launch: the fused three-layer kernel, or layers 1 + 2 then layer 3 + pool)
     == the single-scale launches, bit for bit, incl. the column slices of a shared output and scales of unequal pair counts"""
@@ -2469,6 +2471,34 @@ def test_compact_mlp_pair_equals_the_single_scale_launches(ops, B, N, M, C, O1, 
         assert torch.equal(out3, want)
         assert not ops.c.compact_mlp_pair(3, args, max_lds=16 * 1024) and torch.equal(out3, want)
     assert not ops.c.compact_mlp_pair(3, [args[0], dict(args[1], o1=O1 * 2)])            # unequal first-layer widths: the caller keeps the per-scale launches
+    # the register-chained kernel of round 6 (ws3d_chain_mlp3: activations in registers, weights resident in LDS, ticketed tiles):
+    # the same fmaf chains in the same k order -> the same bits; both scales in one launch, each scale alone, few and many workgroups
+    covered = O1 == 64 and all(sc[2] <= 96 and sc[3] == 128 for sc in scales)
+    for wgs in (0, 1, 7):
+        out4 = torch.zeros_like(want)
+        for a in args:
+            a["out2d"] = out4
+        ops.c.CHAIN_WORKGROUPS = wgs
+        try:
+            took4 = ops.c.chain_mlp3(args, torch.zeros(ops.c.chain_ticket_ints(), dtype=torch.int32, device="cuda"))
+        finally:
+            ops.c.CHAIN_WORKGROUPS = 0
+        assert took4 == covered
+        if took4:
+            assert torch.equal(out4, want)
+    if covered:
+        out5 = torch.zeros_like(want)
+        for a in args:
+            a["out2d"] = out5
+            assert ops.c.chain_mlp3([a], torch.zeros(ops.c.chain_ticket_ints(), dtype=torch.int32, device="cuda"))
+        assert torch.equal(out5, want)
+        # behind the launch gate's limit a scale does nothing (the dense twin runs instead)
+        out6 = torch.zeros_like(want)
+        for a in args:
+            a["out2d"] = out6
+        assert ops.c.chain_mlp3([dict(args[0], limit=0), args[1]], torch.zeros(ops.c.chain_ticket_ints(), dtype=torch.int32, device="cuda"))
+        w0 = args[0]["col_offset"]
+        assert not out6[:, w0:w0 + 128].any() and torch.equal(out6[:, args[1]["col_offset"]:args[1]["col_offset"] + 128], want[:, args[1]["col_offset"]:args[1]["col_offset"] + 128])
 
 
 @pytest.mark.parametrize("B,N,M,ns,C,O1,O2,O3,r", [(2, 4096, 1024, 16, 96, 64, 64, 128, 0.5), (2, 4096, 1024, 32, 96, 64, 96, 128, 1.0),

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("WS3D_HIP_LIB") or os.path.join(  # WS3D_HIP_LIB: A/B 
     _HERE, "libws3d_hip.so" if DIST_MODE == 0 else "libws3d_hip_dm%d.so" % DIST_MODE)
 
 E_INVALID, E_LAUNCH, E_WORKSPACE, E_UNSUPPORTED = -1, -2, -3, -4      # WS3D_E_* of include/ws3d_ops.h
-ABI_VERSION = 5     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
+ABI_VERSION = 6     # = WS3D_ABI_VERSION of include/ws3d_ops.h, the header SIGNATURES below restates
 
 _vp = C.c_void_p
 _i = C.c_int
@@ -106,6 +106,10 @@ SIGNATURES = {
     "ws3d_pgather_gemm3_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_gemm_pool_compact": (_i, [C.c_long, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_compact_mlp_pair": (_i, [_i, C.POINTER(CompactMlpArgs), C.POINTER(CompactMlpArgs), _vp]),
+    "ws3d_chain_mlp3_ticket_ints": (_i, []),
+    "ws3d_chain_mlp3_blob_floats": (_sz, [_i]),
+    "ws3d_chain_mlp3_pack": (_i, [C.POINTER(CompactMlpArgs), _vp, _vp]),
+    "ws3d_chain_mlp3": (_i, [C.POINTER(CompactMlpArgs), C.POINTER(CompactMlpArgs), _vp, _vp, _vp, _i, _vp]),
     "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_sa_mlp3_pool_lists": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_interp_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
@@ -113,6 +117,7 @@ SIGNATURES = {
     "ws3d_select_proposals": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_decode_gather_boxes_bev": (_i, [_i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_select_proposals_packed": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ws3d_select_proposals_send": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, C.c_long, _vp]),
     "ws3d_split_points_clear": (_i, [C.c_long, _i, _vp, _vp, _vp, _vp, C.c_size_t, _vp]),
     "ws3d_roipool3d": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ws3d_roipool3d_fill": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -32,7 +32,7 @@ DIST_MODES = (0, 1, 2)   # squared-distance conventions (csrc/common.h); 0 is th
 def lib_path(dist_mode: int = 0) -> str:
     return LIB if dist_mode == 0 else os.path.join(HERE, "libws3d_hip_dm%d.so" % dist_mode)
 ARCH = "gfx950"
-SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "fps_nested.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "proposals.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip"]
+SOURCES = ["core.hip", "fps.hip", "fps_v3.hip", "fps_bucket.hip", "fps_nested.hip", "ballquery_group.hip", "interpolate.hip", "roipool3d.hip", "iou3d.hip", "proposals.hip", "scatter_det.hip", "sa_mlp.hip", "bn_relu.hip", "gemm_pool.hip", "conv_wgrad.hip", "chain_mlp.hip"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
             "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
@@ -55,7 +55,8 @@ def _compile(src: str, force: bool, verbose: bool, dist_mode: int = 0) -> str:
     if not force and os.path.exists(obj) and all(
             os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps(path)):
         return obj
-    cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, f"-DWS3D_DIST_MODE={dist_mode}", "-c", path, "-o", obj]
+    # WS3D_EXTRA_DEFS: extra -D switches for A/B builds of the kernels' tuning macros (scripts/r06/*.sh; pair with --force)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", *CXXFLAGS, f"-DWS3D_DIST_MODE={dist_mode}", *os.environ.get("WS3D_EXTRA_DEFS", "").split(), "-c", path, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -84,13 +85,32 @@ def build(force: bool = False, verbose: bool = False, dist_mode: int = 0) -> str
     return LIB
 
 
+def rebuild_one(src: str, verbose: bool = False) -> str:
+    """recompile ONE translation unit (forced; with WS3D_EXTRA_DEFS if set) and relink the default library from the objects that
+    are there -- the A/B loops of scripts/r06/*.sh, where a full mtime-driven rebuild per variant would cost minutes"""
+    _compile(src, True, verbose)
+    objs = [os.path.join(OBJ, os.path.splitext(s_)[0] + ".o") for s_ in SOURCES]
+    missing = [o for o in objs if not os.path.exists(o)]
+    if missing:
+        return build(False, verbose)
+    cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--dist-mode", type=int, default=0, choices=DIST_MODES)
     ap.add_argument("--all-dist-modes", action="store_true")
+    ap.add_argument("--only", default=None, help="recompile this one source (forced) and relink")
     a = ap.parse_args()
+    if a.only:
+        print(rebuild_one(a.only, a.verbose))
+        sys.exit(0)
     for dm in (DIST_MODES if a.all_dist_modes else (a.dist_mode,)):
         print(build(a.force, a.verbose, dm))
     sys.exit(0)

@@ -206,6 +206,9 @@ def sort_points_xz(xyz, min_n=256):
     return out
 
 
+SORT_JOBS_MAX = 8     # = BIN_MAX_JOBS of csrc/bin_kernels.h
+
+
 def sort_points_jobs(jobs):
     """jobs: [(xyz (B,N_i,3), kind)] with kind "grid" (sort_points_x's fine-grid buffer, the ball query's) or "xz" (sort_points_xz's,
     three_nn's) -> the list of buffers, all binned by ONE launch (ws3d_sort_points_jobs); same bytes as one call per job.  None for a
@@ -226,11 +229,14 @@ def sort_points_jobs(jobs):
         outs.append(out)
         if out is not None:
             n_arr.append(xyz.size(1)); k_arr.append(0 if kind == "grid" else 1); x_arr.append(xyz.data_ptr()); o_arr.append(out.data_ptr())
-    k = len(n_arr)
-    if k:
+    # at most SORT_JOBS_MAX jobs per launch (csrc/bin_kernels.h BIN_MAX_JOBS: the kernel's argument block); a deeper backbone -- five
+    # or more levels of >= 256 points make nine or more jobs -- takes one launch per chunk instead of an E_INVALID
+    for c0 in range(0, len(n_arr), SORT_JOBS_MAX):
+        k = min(SORT_JOBS_MAX, len(n_arr) - c0)
+        sl = slice(c0, c0 + k)
         with _on(dev):
-            check(lib.ws3d_sort_points_jobs(b, k, (C.c_int * k)(*n_arr), (C.c_int * k)(*k_arr), (C.c_void_p * k)(*x_arr), (C.c_void_p * k)(*o_arr),
-                                            _stream()), "sort_points_jobs")
+            check(lib.ws3d_sort_points_jobs(b, k, (C.c_int * k)(*n_arr[sl]), (C.c_int * k)(*k_arr[sl]), (C.c_void_p * k)(*x_arr[sl]),
+                                            (C.c_void_p * k)(*o_arr[sl]), _stream()), "sort_points_jobs")
     return outs
 
 
@@ -770,8 +776,75 @@ def compact_mlp_pair(kind, scales, max_lds=160 * 1024, mids=None):
                                           _p(total), _p(w1x), _p(a["b1"]), int(bool(a["relu1"])), _p(w2t), _p(a["b2"]), int(bool(a["relu2"])), _p(w3t), _p(a["b3"]),
                                           _p(mid), out2d.data_ptr() + 4 * col, out2d.stride(0), -1))
     with _on(dev):
-        check(_lib.load().ws3d_compact_mlp_pair(int(kind), C.byref(blocks[0]), C.byref(blocks[1]), _stream()), "compact_mlp_pair")
+        rc = _lib.load().ws3d_compact_mlp_pair(int(kind), C.byref(blocks[0]), C.byref(blocks[1]), _stream())
+    if rc == _lib.E_UNSUPPORTED:        # a condition the C side checks and this restatement does not (alignment of w2t / w3t / mid, the o1
+        return None if kind == 2 else False      # rule per kind): nothing was launched, the caller's per-scale path runs
+    check(rc, "compact_mlp_pair")
     return outs if kind == 2 else True
+
+
+CHAIN_WORKGROUPS = 0      # ws3d_chain_mlp3: workgroups per launch (0 = one per compute unit)
+
+
+_CHAIN_BLOBS = {}         # (data pointers + versions of a scale's six weight tensors) -> (packed blob, the tensors: kept alive so that the pointers stay theirs)
+
+
+def chain_ticket_ints() -> int:
+    """int32 elements of chain_mlp3's (zeroed) ticket tensor"""
+    return int(_lib.load().ws3d_chain_mlp3_ticket_ints())
+
+
+def _chain_blob(block, tensors, dev):
+    import ctypes as C
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+    hit = _CHAIN_BLOBS.get(key)
+    if hit is None:
+        n = int(_lib.load().ws3d_chain_mlp3_blob_floats(block.o2))
+        blob = torch.empty(n, dtype=torch.float32, device=dev)
+        with _on(dev):
+            check(_lib.load().ws3d_chain_mlp3_pack(C.byref(block), _p(blob), _stream()), "chain_mlp3_pack")
+        if torch.cuda.is_current_stream_capturing():        # packed inside a capture: valid for this graph's replays only, not cached
+            return blob
+        hit = _CHAIN_BLOBS[key] = (blob, tensors)         # never evicted: a captured hipGraph may hold the blob's address (50-76 KB per weight set)
+    return hit[0]
+
+
+def chain_mlp3(scales, ticket):
+    """The whole SharedMLP (three layers + pool) of one or two scales over their compact rows on the register-chained kernel
+    (ws3d_chain_mlp3, csrc/chain_mlp.hip).  scales: compact_mlp_pair's dicts (one or two); ticket: a ZEROED int32 tensor of
+    chain_ticket_ints() elements, consumed.  The scales' weights are packed once per weight set (ws3d_chain_mlp3_pack, cached here).
+    True, or False when a shape is not covered (o1 = 64, o2 <= 96, o3 = 128): nothing launched.  Bit-identical to
+    compact_mlp_pair(3, ..) / pgather_gemm3_compact.  ws3d extension."""
+    import ctypes as C
+    if len(scales) not in (1, 2) or ticket is None or ticket.dtype != torch.int32 or ticket.numel() < chain_ticket_ints() or not ticket.is_contiguous():
+        return False
+    blocks, keep, blobs = [], [], []
+    for a in scales:
+        rowc, rowsrc, total = a["pairs"]
+        pmat, xyz, new_xyz, w1x, w2t, w3t, out2d, o1, col0, col = a["pmat"], a["xyz"], a["new_xyz"], a["w1x"], a["w2t"], a["w3t"], a["out2d"], a["o1"], a["col0"], a["col_offset"]
+        dev = _dev(pmat, xyz, new_xyz, rowc, w1x, w2t, w3t, out2d, ticket)
+        for t_, nm in ((pmat, "pmat"), (xyz, "xyz"), (new_xyz, "new_xyz"), (w1x, "w1x"), (w2t, "w2t"), (w3t, "w3t"), (out2d, "out2d")):
+            _f32(t_, nm)
+        B, N, M = xyz.size(0), xyz.size(1), new_xyz.size(1)
+        O2, O3 = w2t.size(1), w3t.size(1)
+        ok = (o1 == 64 and O2 <= 96 and O3 == 128 and pmat.dim() == 2 and pmat.size(0) == B * N and pmat.stride(1) == 1 and pmat.stride(0) % 4 == 0 and
+              col0 >= 0 and col0 % 4 == 0 and col0 + o1 <= pmat.size(1) and tuple(w1x.shape) == (3, o1) and w2t.size(0) == o1 and w3t.size(0) == O2 and
+              w1x.is_contiguous() and w2t.is_contiguous() and w3t.is_contiguous() and out2d.dim() == 2 and out2d.stride(1) == 1 and col >= 0 and
+              col % 4 == 0 and col + O3 <= out2d.size(1) and xyz.is_contiguous() and new_xyz.is_contiguous())
+        if not ok:
+            return False
+        keep.append((pmat, xyz, new_xyz, rowc, rowsrc, total, w1x, w2t, w3t, out2d, a["b1"], a["b2"], a["b3"]))
+        blocks.append(_lib.CompactMlpArgs(B, N, M, rowc.numel(), o1, O2, O3, pmat.data_ptr() + 4 * col0, pmat.stride(0), _p(xyz), _p(new_xyz), _p(rowc), _p(rowsrc),
+                                          _p(total), _p(w1x), _p(a["b1"]), int(bool(a["relu1"])), _p(w2t), _p(a["b2"]), int(bool(a["relu2"])), _p(w3t), _p(a["b3"]),
+                                          None, out2d.data_ptr() + 4 * col, out2d.stride(0), int(a.get("limit", -1))))
+        blobs.append(_chain_blob(blocks[-1], (w1x, a["b1"], w2t, a["b2"], w3t, a["b3"]), dev))
+    with _on(dev):
+        rc = _lib.load().ws3d_chain_mlp3(C.byref(blocks[0]), C.byref(blocks[1]) if len(blocks) > 1 else None, _p(blobs[0]), _p(blobs[1]) if len(blobs) > 1 else None,
+                                         _p(ticket), int(CHAIN_WORKGROUPS), _stream())
+    if rc == _lib.E_UNSUPPORTED:
+        return False
+    check(rc, "chain_mlp3")
+    return True
 
 
 def interp_gemm(known_feats, unknown_feats, idx, weight, wt, bias, relu):
@@ -1054,7 +1127,9 @@ def gather_boxes_bev(box, order):
 def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None, packed=False):
     """first min(num, k) NMS survivors of score-sorted boxes -> (boxes (B,k,7), scores (B,k), count (B,) int64,
     boxes enlarged by extra_width for RoI pooling or None), zero padded; one launch (ws3d extension).  packed: a fifth result, the
-    (B,k,8) rows box + score (ws3d_amd.dist.pack_proposals' tensor) written by the same launch"""
+    (B,k,8) rows box + score (ws3d_amd.dist.pack_proposals' tensor) written by the same launch.  packed = a float32 tensor
+    (>= B, k * 8 + 1): the send buffer of ws3d_amd.dist.ProposalExchange -- the rows and, behind each scene's rows, its count go straight
+    into it (ws3d_select_proposals_send) and the fifth result is a (B,k,8) VIEW of that buffer: nothing is allocated or packed later"""
     dev = _dev(box_sorted, scores_sorted, keep, num)
     _f32(box_sorted, "box_sorted"); _f32(scores_sorted, "scores")
     if keep.dtype != torch.int64 or num.dtype != torch.int32:
@@ -1064,6 +1139,16 @@ def select_proposals(box_sorted, scores_sorted, keep, num, k, extra_width=None, 
     scores = torch.empty((B, k), dtype=torch.float32, device=dev)
     count = torch.empty((B,), dtype=torch.int64, device=dev)
     pooled = torch.empty((B, k, 7), dtype=torch.float32, device=dev) if extra_width is not None else None
+    send = packed if torch.is_tensor(packed) else None
+    if send is not None:
+        if send.dtype != torch.float32 or send.device != dev or send.dim() != 2 or send.size(0) < B or send.size(1) != k * 8 + 1 or not send.is_contiguous():
+            raise ValueError("select_proposals: the send buffer must be a contiguous float32 (>= %d, %d) tensor on %s, got %s %s"
+                             % (B, k * 8 + 1, dev, tuple(send.shape), send.dtype))
+        with _on(dev):
+            check(_lib.load().ws3d_select_proposals_send(B, top, keep.size(1), k, _p(box_sorted.contiguous()), _p(scores_sorted.contiguous()),
+                                                         _p(keep), _p(num), float(extra_width or 0.0), _p(boxes), _p(scores), _p(count), _p(pooled),
+                                                         _p(send), k * 8 + 1, _stream()), "select_proposals")
+        return boxes, scores, count, pooled, send[:B, :k * 8].unflatten(1, (k, 8))
     pk = torch.empty((B, k, 8), dtype=torch.float32, device=dev) if packed else None
     with _on(dev):
         if packed:

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void select_proposals_kernel(int nb, int top, 
                                                                const int32_t *__restrict__ num, float extra2, float extra,
                                                                float *__restrict__ boxes_out, float *__restrict__ scores_out,
                                                                int64_t *__restrict__ count, float *__restrict__ pooled_boxes,
-                                                               float *__restrict__ packed) {
+                                                               float *__restrict__ packed, long packed_stride, int count_in_row) {
     const int i = blockIdx.x * 256 + threadIdx.x;             // (scene, slot)
     if (i >= nb * K) return;
     const int b = i / K, pos = i - b * K;
@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void select_proposals_kernel(int nb, int top, 
     const float s_ = sc[(size_t)b * top + (size_t)src] * m;
     scores_out[i] = s_;
     if (packed) {                                             // (K, 8) rows = box + score: what ws3d_amd.dist gathers across ranks
-        float *g = packed + (size_t)i * 8;
+        // packed_stride floats per scene (K * 8: the dense (B, K, 8) tensor; K * 8 + 1 with count_in_row: the exchange's send row,
+        // the scene's count as the float behind its K rows -- exact, counts are < 2^24)
+        float *g = packed + (size_t)b * packed_stride + (size_t)pos * 8;
+        if (count_in_row && pos == 0) packed[(size_t)b * packed_stride + (size_t)K * 8] = (float)cnt;
 #pragma unroll
         for (int q = 0; q < 7; ++q) g[q] = v[q];
         g[7] = s_;
@@ -160,7 +163,8 @@ extern "C" int ws3d_split_points_clear(long rows, int c, const float *pc, float 
 
 static int select_proposals_impl(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
                                  const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
-                                 int64_t *count, float *pooled_boxes, float *packed, ws3d_stream_t stream) {
+                                 int64_t *count, float *pooled_boxes, float *packed, long packed_stride, int count_in_row,
+                                 ws3d_stream_t stream) {
     using namespace ws3d;
     if (b < 0 || top <= 0 || k <= 0 || keep_stride < (k < top ? k : top) || !box_sorted || !scores_sorted || !keep || !num || !boxes_out ||
         !scores_out || !count) {
@@ -171,7 +175,7 @@ static int select_proposals_impl(int b, int top, int keep_stride, int k, const f
     // extra_width * 2 is formed in double and rounded once, as `large[:, 3:6] += extra_width * 2` does with a Python float
     hipLaunchKernelGGL(select_proposals_kernel, dim3((unsigned)(((long)b * k + 255) / 256)), dim3(256), 0, as_stream(stream), b, top,
                        keep_stride, k, box_sorted, scores_sorted, keep, num, (float)((double)extra_width * 2.0), extra_width, boxes_out,
-                       scores_out, count, pooled_boxes, packed);
+                       scores_out, count, pooled_boxes, packed, packed_stride, count_in_row);
     return check_launch("ws3d_select_proposals");
 }
 
@@ -179,12 +183,23 @@ extern "C" int ws3d_select_proposals(int b, int top, int keep_stride, int k, con
                                      const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
                                      int64_t *count, float *pooled_boxes, ws3d_stream_t stream) {
     return select_proposals_impl(b, top, keep_stride, k, box_sorted, scores_sorted, keep, num, extra_width, boxes_out, scores_out, count,
-                                 pooled_boxes, nullptr, stream);
+                                 pooled_boxes, nullptr, 0, 0, stream);
 }
 
 extern "C" int ws3d_select_proposals_packed(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
                                             const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
                                             int64_t *count, float *pooled_boxes, float *packed, ws3d_stream_t stream) {
     return select_proposals_impl(b, top, keep_stride, k, box_sorted, scores_sorted, keep, num, extra_width, boxes_out, scores_out, count,
-                                 pooled_boxes, packed, stream);
+                                 pooled_boxes, packed, (long)k * 8, 0, stream);
+}
+
+extern "C" int ws3d_select_proposals_send(int b, int top, int keep_stride, int k, const float *box_sorted, const float *scores_sorted,
+                                          const int64_t *keep, const int32_t *num, float extra_width, float *boxes_out, float *scores_out,
+                                          int64_t *count, float *pooled_boxes, float *send, long send_stride, ws3d_stream_t stream) {
+    if (!send || send_stride < (long)k * 8 + 1) {
+        ws3d::set_error("ws3d_select_proposals_send: send rows need k * 8 + 1 = %ld floats (stride %ld)", (long)k * 8 + 1, send_stride);
+        return WS3D_E_INVALID;
+    }
+    return select_proposals_impl(b, top, keep_stride, k, box_sorted, scores_sorted, keep, num, extra_width, boxes_out, scores_out, count,
+                                 pooled_boxes, send, send_stride, 1, stream);
 }

@@ -18,15 +18,20 @@ import torch
 import torch.distributed as dist
 
 
-def _local_device(local: int, world: int, backend: str) -> int:
-    """The device of local rank `local`.  Over RCCL every rank needs a device of its own: more ranks than devices raises instead of
-    wrapping (two ranks on one device hang or fail late inside the collective library).  Only the explicit test mode
-    (backend "gloo": control-flow runs of the multi-rank paths with the ranks sharing a device) wraps."""
+def _local_device(local: int, world: int, backend: str, local_world: int = None) -> int:
+    """The device of local rank `local`.  Over RCCL every rank needs a device of its own ON ITS NODE: a LOCAL_RANK beyond the node's
+    devices, or more ranks on this node (``LOCAL_WORLD_SIZE``, when the launcher exports it) than devices, raises instead of wrapping
+    (two ranks on one device hang or fail late inside the collective library).  The global WORLD_SIZE is not part of the check -- a
+    2-node x 8-GPU job has WORLD_SIZE 16 and 8 devices per node.  Only the explicit test mode (backend "gloo":
+    control-flow runs of the multi-rank paths with the ranks sharing a device) wraps."""
     ndev = torch.cuda.device_count()
-    if backend == "nccl" and (world > ndev or local >= ndev):
-        raise RuntimeError("ws3d_amd.dist.init: backend 'nccl' (RCCL) needs one device per rank, but WORLD_SIZE=%d / LOCAL_RANK=%d and "
-                           "this node shows %d device(s); WS3D_DIST_BACKEND=gloo is the test mode that lets ranks share a device"
-                           % (world, local, ndev))
+    if local_world is None:
+        lw = os.environ.get("LOCAL_WORLD_SIZE")
+        local_world = int(lw) if lw else None
+    if backend == "nccl" and (local >= ndev or (local_world is not None and local_world > ndev)):
+        raise RuntimeError("ws3d_amd.dist.init: backend 'nccl' (RCCL) needs one device per rank, but LOCAL_RANK=%d / LOCAL_WORLD_SIZE=%s "
+                           "(WORLD_SIZE=%d) and this node shows %d device(s); WS3D_DIST_BACKEND=gloo is the test mode that lets ranks "
+                           "share a device" % (local, local_world, world, ndev))
     return local % max(ndev, 1)
 
 
@@ -102,6 +107,59 @@ def all_gather_proposals(packed: torch.Tensor, count: torch.Tensor, global_batch
             rows.append(torch.arange(r * bmax, r * bmax + (e - s), device=packed.device))
         out = out[torch.cat(rows)]
     return out[:, :K * F].reshape(-1, K, F), out[:, K * F].round().to(count.dtype)
+
+
+class ProposalExchange:
+    """The step's ONE collective with nothing allocated per step.
+
+    ``send`` (bmax, K*8 + 1) and ``recv`` (world * bmax, K*8 + 1) are allocated once (per pipeline slot): the selection kernel writes a
+    scene's K packed rows and, behind them, its count straight into ``send`` (``ws3d_select_proposals_send`` through
+    ``stage1.proposals_from_rpn(with_packed=exchange.send)``), so ``gather()`` is exactly one ``all_gather_into_tensor`` on two resident
+    buffers -- no pack launch, no slice writes, no allocator traffic -- issued on the caller's current stream (the slot's stream, behind
+    the graph replay that filled ``send``).  Even shards return views of ``recv``; uneven shards (global_batch % world != 0) drop the
+    padding rows with one pre-built index (``index_select``: the only allocation, and only in that case).  ``collectives`` counts the
+    calls (tests/test_dist_gloo.py asserts one per step).  Rows of ``send`` beyond this rank's scenes stay zero from construction."""
+
+    def __init__(self, local_batch: int, K: int, global_batch: int, device, world: int = None, rank: int = None, F: int = 8):
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.K, self.F, self.b, self.global_batch = int(K), int(F), int(local_batch), int(global_batch)
+        self.bmax = -(-self.global_batch // self.world)
+        if self.b > self.bmax:
+            raise ValueError("ProposalExchange: %d local scenes but the largest shard of %d over %d ranks holds %d" % (self.b, global_batch, self.world, self.bmax))
+        cols = self.K * self.F + 1
+        self.send = torch.zeros((self.bmax, cols), dtype=torch.float32, device=device)
+        self.recv = torch.zeros((self.world * self.bmax, cols), dtype=torch.float32, device=device)
+        self._host = torch.empty(self.recv.shape, dtype=torch.float32) if self.send.is_cuda else None      # gloo test mode only
+        self.index = None
+        if self.global_batch != self.world * self.bmax:
+            rows = []
+            for r in range(self.world):
+                s_, e_ = shard_range(self.global_batch, self.world, r)
+                rows.extend(range(r * self.bmax, r * self.bmax + (e_ - s_)))
+            self.index = torch.tensor(rows, dtype=torch.long, device=device)
+        self.collectives = 0
+
+    def fill(self, packed: torch.Tensor, count: torch.Tensor) -> None:
+        """for producers that do not write ``send`` themselves (the torch composition, tests): two copies into the resident buffer"""
+        b = packed.size(0)
+        self.send[:b, :self.K * self.F].copy_(packed.reshape(b, self.K * self.F))
+        self.send[:b, self.K * self.F].copy_(count)
+
+    def gather(self, force: bool = False):
+        """-> (global_batch, K, F) proposals, (global_batch,) float counts (exact integers), in scene order, on every rank"""
+        KF = self.K * self.F
+        if not (dist.is_available() and dist.is_initialized()) or (self.world == 1 and not force):
+            out = self.send[:self.b]
+            return out[:, :KF].unflatten(1, (self.K, self.F)), out[:, KF]
+        self.collectives += 1
+        if self.send.is_cuda and dist.get_backend() == "gloo":      # explicit, synchronising test mode: ranks sharing one GPU
+            dist.all_gather_into_tensor(self._host, self.send.cpu())
+            self.recv.copy_(self._host)
+        else:
+            dist.all_gather_into_tensor(self.recv, self.send)
+        out = self.recv if self.index is None else self.recv.index_select(0, self.index)
+        return out[:, :KF].unflatten(1, (self.K, self.F)), out[:, KF]
 
 
 def run_sharded(global_batch: int, compute: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]):

@@ -94,6 +94,7 @@ COMPACT_PAIRS = True  # the SharedMLPs over the distinct (centre, sample) pairs 
 PAIR_DISPATCH = "device"
 PRIMED_MARGIN = 0.85       # Stage1Pipeline(pair_dispatch="primed"): scales whose priming fill <= PRIMED_MARGIN * COMPACT_MAX_FILL lose the dense twin
 _COMPACT_ONLY = contextvars.ContextVar("ws3d_compact_only_scales", default=frozenset())
+CHAIN_MLP = True       # SA2 (o1 = 64, o2 <= 96, o3 = 128): the whole SharedMLP of the level's two scales on the register-chained kernel (ws3d_chain_mlp3, round 6: activations in registers, weights resident in LDS, ticketed 32-row tiles) instead of ws3d_compact_mlp_pair(3); bit-identical
 PAIRED_SCALES = True   # the compact SharedMLP kernels of a level's two scales in ONE launch each (ws3d_compact_mlp_pair) where neither scale carries a gated dense twin (Stage1Pipeline's primed graphs, PAIR_DISPATCH "compact")
 MERGED_THREE_NN = True   # serial order: the 3-NN searches of the FP modules whose known set is binned in ONE launch behind that binning launch (ws3d_three_nn_jobs)
 FUSED_PROLOGUE = True   # the coordinate / feature split of the input rows and the clear of the pass's zero arena in ONE launch (ws3d_split_points_clear) instead of two strided copies + a fill
@@ -263,6 +264,8 @@ def _arena_for(net, B: int, device, extra: int = 0, clear: bool = True) -> _Zero
         for sa in net.SA_modules:
             n += B * sa.npoint * sum(_blocks(mlp)[-1].conv.out_channels for mlp in sa.mlps) + 4
             n += 4 * len(sa.groupers)
+        if CHAIN_MLP:
+            n += _C.chain_ticket_ints() + 4          # the ticket counters of ws3d_chain_mlp3 (SA2)
     return _ZeroArena(n, device, clear)
 
 
@@ -604,6 +607,8 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 return False
             scales.append({"pmat": pmat, "col0": offs[si_], "o1": blk[si_][0].conv.out_channels, "xyz": xyz, "new_xyz": new_xyz, "pairs": nbrs[si_].pairs,
                            "w1x": w1xs[si_], "b1": b1, "relu1": r1, "w2t": wt2, "b2": b2, "relu2": r2, "w3t": wt3, "b3": b3, "out2d": out, "col_offset": cols[si_]})
+        if CHAIN_MLP and zeros is not None and _C.chain_mlp3(scales, zeros.take((_C.chain_ticket_ints(),), torch.int32)):
+            return True
         if _C.compact_mlp_pair(3, scales, max_lds=FUSED_COMPACT3_MAX_LDS):
             return True
         mids = _C.compact_mlp_pair(2, scales)

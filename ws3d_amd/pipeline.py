@@ -57,17 +57,32 @@ def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
-                 channels: int = 4, tune_gemms: bool = None, pair_dispatch: str = "primed"):
-        """pair_dispatch: how a ball-query scale's SharedMLP chooses between its compact-pairs and its dense kernels (both exact,
+                 channels: int = 4, tune_gemms: bool = None, pair_dispatch: str = "primed", exchange_global_batch: int = None):
+        """exchange_global_batch: the global batch of a multi-rank job (``batch`` x world for even shards).  Every slot then owns a
+        ``dist.ProposalExchange`` -- send / receive buffers allocated HERE, once; the captured step's selection kernel writes the packed
+        rows + counts straight into the slot's send buffer, and ``submit`` issues the step's ONE all-gather on the slot's stream right
+        behind the replay: ``result(ticket)["gathered"]`` = ((global_batch, K, 8) proposals, (global_batch,) counts).  None: on when
+        torch.distributed is initialised with more than one rank (global batch = batch x world), off otherwise.
+        pair_dispatch: how a ball-query scale's SharedMLP chooses between its compact-pairs and its dense kernels (both exact,
         ws3d_amd/fastpath.py PAIR_DISPATCH).  "device": both forms in every graph, the batch's pair total decides in the kernels'
         prologues.  "primed" (default): the scales whose fill on the FIRST primed batch is <= fastpath.PRIMED_MARGIN x the threshold
         keep only their compact kernels in the graphs (ten launches fewer per step on LiDAR clouds); a later, denser batch still comes
         out identical -- the compact kernels are complete -- only slower than the dense form would have been."""
         if pair_dispatch not in ("primed", "device"):
             raise ValueError("Stage1Pipeline: pair_dispatch must be 'primed' or 'device', got %r" % (pair_dispatch,))
-        self.pair_dispatch, self.compact_only = pair_dispatch, None
+        from .streams import POOL_SIZE
+        if max(1, int(depth)) > POOL_SIZE:          # (before any slot claims a pooled stream -- ADVICE round 5)
+            raise ValueError("Stage1Pipeline: depth %d exceeds the per-device stream pool (ws3d_amd.streams.POOL_SIZE = %d): the slots "
+                             "would share streams with the eager pass's side streams; beyond ~23 hardware queues in one process this "
+                             "runtime time-slices the queues and every kernel slows down" % (int(depth), POOL_SIZE))
+        self.pair_dispatch, self.compact_only, self.compact_only_source = pair_dispatch, None, None     # compact_only: the (level, scale) keys whose dense twin the graphs drop -- read it to see what priming decided
         self.model, self.cfg, self.B, self.depth, self.roipool = model.eval(), cfg, int(batch), max(1, int(depth)), roipool
         self.device = torch.device(device)
+        if exchange_global_batch is None:
+            import torch.distributed as tdist
+            w = tdist.get_world_size() if (tdist.is_available() and tdist.is_initialized()) else 1
+            exchange_global_batch = self.B * w if w > 1 else 0
+        self.exchange_global_batch = int(exchange_global_batch)
         self.hw_queues_raised = ensure_hw_queues()      # False: the runtime already started with its own cap
         self.submitted = 0
         self.graph_error = None
@@ -76,17 +91,12 @@ class Stage1Pipeline:
             for j in range(self.depth):
                 stream = _slot_stream(self.device, j)
                 inp = torch.zeros((self.B, n_points, channels), dtype=torch.float32, device=self.device)
+                exch = None
+                if self.exchange_global_batch > 0:
+                    from . import dist as wdist
+                    exch = wdist.ProposalExchange(self.B, cfg.rpn_post_nms_top_n, self.exchange_global_batch, self.device)
                 self.slots.append({"stream": stream, "inp": inp, "graph": None, "out": None,
-                                   "done": torch.cuda.Event(), "primed": False})
-        from .streams import POOL_SIZE
-        if self.depth > POOL_SIZE:
-            raise ValueError("Stage1Pipeline: depth %d exceeds the per-device stream pool (ws3d_amd.streams.POOL_SIZE = %d): the slots "
-                             "would share streams with the eager pass's side streams" % (self.depth, POOL_SIZE))
-        if self.depth > 20:
-            import warnings
-            warnings.warn("Stage1Pipeline: depth %d -- beyond 23 hardware queues in one process (the slots, the null stream and "
-                          "the eager path's two side streams) this runtime time-slices the queues and every kernel slows down "
-                          "(measured: 24 queues ran the eager step in 7.5 instead of 5.4 ms)." % self.depth, RuntimeWarning, stacklevel=2)
+                                   "done": torch.cuda.Event(), "primed": False, "exchange": exch})
         if tune_gemms is None:      # WS3D_TUNE_GEMMS=0: keep the library's heuristic GEMM solutions (identical in every process)
             tune_gemms = os.environ.get("WS3D_TUNE_GEMMS", "1") != "0"
         self.use_graph, self.tune_gemms = use_graph, tune_gemms
@@ -99,9 +109,10 @@ class Stage1Pipeline:
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
-    def body(self, pts: torch.Tensor) -> dict:
+    def body(self, pts: torch.Tensor, exchange=None) -> dict:
         out = self.model.rpn_forward({"pts_input": pts, "defer_reg_join": True})     # (proposals_from_rpn waits for rpn_reg)
-        boxes, scores, count, enlarged, packed = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True, with_packed=True)
+        boxes, scores, count, enlarged, packed = stage1.proposals_from_rpn(out, self.cfg, with_pool_boxes=True,
+                                                                           with_packed=exchange.send if exchange is not None else True)
         res = {"rpn": out, "boxes": boxes, "scores": scores, "count": count, "packed": packed}      # packed (B,K,8): box + score, ws3d_amd.dist's rows
         if self.roipool:
             feats = out["backbone_features"].transpose(1, 2).contiguous()
@@ -149,17 +160,21 @@ class Stage1Pipeline:
             from . import fastpath
             if self.compact_only is None:        # once per pipeline, on the first primed batch (synchronises: set-up)
                 with torch.cuda.stream(stream):
+                    # an all-zero input buffer (submit(None) before any batch was copied in) says nothing about the data: keep both
+                    # forms of every scale in the graphs, as pair_dispatch="device" does, instead of deciding on padding
+                    blank = not bool(slot["inp"].any().item())
                     self.compact_only = (fastpath.primed_compact_scales(self.model.rpn.backbone_net, slot["inp"])
-                                         if self.pair_dispatch == "primed" else frozenset())
+                                         if (self.pair_dispatch == "primed" and not blank) else frozenset())
+                    self.compact_only_source = "blank input: both forms kept" if blank else ("fills of the first primed batch" if self.pair_dispatch == "primed" else "pair_dispatch=device")
             # the priming runs stay on the slot's stream: the eager path's side streams would claim more hardware queues that
             # the graphs never use (a context variable: forward passes of other threads keep their own stream topology)
             with fastpath.geometry_ahead(False), fastpath.compact_only_scales(self.compact_only), torch.cuda.stream(stream):
                 for _ in range(2):
-                    self.body(slot["inp"])
+                    self.body(slot["inp"], slot["exchange"])
             stream.synchronize()
             graph = torch.cuda.CUDAGraph()
             with fastpath.compact_only_scales(self.compact_only), torch.cuda.graph(graph, stream=stream):
-                slot["out"] = self.body(slot["inp"])
+                slot["out"] = self.body(slot["inp"], slot["exchange"])
             slot["graph"] = graph
         except Exception as exc:      # capture is an optimisation: fall back to eager launches on the slot streams
             self.graph_error = repr(exc)
@@ -189,6 +204,8 @@ class Stage1Pipeline:
             if not slot["primed"]:
                 if pts is not None:
                     slot["inp"][:t.size(0)].copy_(t)
+                    if t.size(0) < self.B:       # pad BEFORE priming: the primed pair dispatch reads the fills of this buffer, and zero
+                        slot["inp"][t.size(0):] = slot["inp"][t.size(0) - 1]      # scenes (fill 1.0) are padding, not data
                 self._prime(slot)
             if pts is not None and t.is_cuda:       # produced on the caller's stream: order the slot's copy behind it
                 slot["stream"].wait_stream(torch.cuda.current_stream(self.device))
@@ -203,7 +220,9 @@ class Stage1Pipeline:
                 else:
                     from . import fastpath
                     with fastpath.compact_only_scales(self.compact_only or frozenset()):
-                        slot["out"] = self.body(slot["inp"])
+                        slot["out"] = self.body(slot["inp"], slot["exchange"])
+                if slot["exchange"] is not None:         # the step's one collective: resident buffers, the slot's stream, behind the replay
+                    slot["out"]["gathered"] = slot["exchange"].gather()
                 slot["done"].record(slot["stream"])
         self.submitted += 1
         return self.submitted - 1

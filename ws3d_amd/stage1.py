@@ -200,10 +200,13 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
     RPN_POST_NMS_TOP_N survivors.  Returns boxes (B,K,7), scores (B,K), count (B,) -- fixed
     shapes, zero padded, batched torch ops + ONE NMS launch pair, no host synchronisation.
     with_pool_boxes: also return the (B,K,7) rows enlarged by cfg.roi_extra_width (what roipool3d_gpu would compute);
-    with_packed: also (last) the (B,K,8) rows box + score that ws3d_amd.dist gathers across ranks;
+    with_packed: also (last) the (B,K,8) rows box + score that ws3d_amd.dist gathers across ranks; a tensor: the send buffer of a
+    ``dist.ProposalExchange`` -- rows and counts are written straight into it and the last result is a view of it;
     fused=False keeps the torch composition of the sigmoid / decode / gather / BEV / padding steps (parity tests)."""
     xyz, reg, cls = out['backbone_xyz'], out['rpn_reg'], out['rpn_cls']
     B, N, _ = xyz.shape
+    send = with_packed if torch.is_tensor(with_packed) else None
+    with_packed = send is not None or bool(with_packed)
     K = cfg.rpn_post_nms_top_n
     h, w, l = cfg.cls_mean_size
     top = min(cfg.rpn_pre_nms_top_n, N)
@@ -227,7 +230,7 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
         # composition below
         box_sorted, bev = _C.decode_gather_boxes_bev(xyz.contiguous(), reg.contiguous(), order, cfg.loc_scope, cfg.loc_bin_size, (h, w, l))
         keep_dev, num = _C.nms_device_batched(bev, cfg.rpn_nms_thresh, False, max_keep=K)
-        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=with_packed)
+        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=send if send is not None else with_packed)
         return tuple(res[:3]) + ((res[3],) if with_pool_boxes else ()) + ((res[4],) if with_packed else ())
     if xyz.is_cuda:
         from . import compat as _C        # one kernel instead of ~25 tiny torch launches; bit-identical
@@ -243,7 +246,7 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
     if on_dev:                 # (N > 16384: torch.topk above, then the fused gather / NMS / selection)
         box_sorted, bev = _C.gather_boxes_bev(box, order)
         keep_dev, num = _C.nms_device_batched(bev, cfg.rpn_nms_thresh, False, max_keep=K)
-        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=with_packed)
+        res = _C.select_proposals(box_sorted, sc, keep_dev, num, K, cfg.roi_extra_width if with_pool_boxes else None, packed=send if send is not None else with_packed)
         return tuple(res[:3]) + ((res[3],) if with_pool_boxes else ()) + ((res[4],) if with_packed else ())
     box = torch.gather(box, 1, order.unsqueeze(-1).expand(B, top, 7))
     bev = kitti_utils.boxes3d_to_bev_torch(box.reshape(B * top, 7)).view(B, top, 5)
@@ -256,7 +259,12 @@ def proposals_from_rpn(out: dict, cfg: RPNConfig = DEFAULT_CFG, with_pool_boxes:
     if with_pool_boxes:
         res += (kitti_utils.enlarge_box3d(boxes_out.view(-1, 7), cfg.roi_extra_width).view(B, K, 7),)
     if with_packed:
-        res += (torch.cat([boxes_out, scores_out.unsqueeze(-1)], dim=-1).contiguous(),)
+        pk = torch.cat([boxes_out, scores_out.unsqueeze(-1)], dim=-1).contiguous()
+        if send is not None:            # (the composition's form of ws3d_select_proposals_send: rows, then the count, per scene)
+            send[:B, :K * 8] = pk.view(B, K * 8)
+            send[:B, K * 8] = cnt.to(send.dtype)
+            pk = send[:B, :K * 8].unflatten(1, (K, 8))
+        res += (pk,)
     return res
 
 
