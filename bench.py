@@ -242,6 +242,9 @@ def compact_line(out, detail_path):
         line["cpu_baseline"] = {k: (_short(v, 280) if isinstance(v, str) else v) for k, v in cb.items() if k not in ("host", "ms_per_scene_by_part", "search_only")}
         if isinstance(cb.get("search_only"), dict):
             line["cpu_baseline"]["search_only_value"] = cb["search_only"].get("value")
+        parts = cb.get("ms_per_scene_by_part")
+        if isinstance(parts, dict):      # the two NMS figures side by side (the literal mask is a straw man as a CPU algorithm): ms per scene
+            line["cpu_baseline"]["nms_ms_per_scene"] = {("literal_mask" if k.startswith("nms (literal") else "lazy_sweep"): v for k, v in parts.items() if k.startswith("nms (")}
         if isinstance(cb.get("host"), dict):
             line["cpu_baseline"]["host_cpu"] = _short(cb["host"].get("cpu", ""), 60)
     lat, c2 = out.get("latency_mode"), out.get("c2")

@@ -110,10 +110,20 @@ def tail_cpu(out, cfg, clk: Clock, ref_roipool=None):
     clk.add("proposals", t0)
     t0 = time.perf_counter()
     boxes = np.zeros((S, K, 7), np.float32)
+    keeps = []
     for b in range(S):
         keep = oracle.nms_sorted(bev[b], cfg.rpn_nms_thresh, False)[:K]
+        keeps.append(keep)
         boxes[b, :len(keep)] = box[b].numpy()[keep]
-    clk.add("nms", t0)
+    clk.add("nms (literal 9000 x 141-word mask + sweep, iou3d.cpp:73-120; OpenMP over rows)", t0)
+    # the same keep list the way a CPU caller would get it: IoUs against the kept boxes only, stop at K survivors (VERDICT round 5,
+    # item 9: the literal mask is 2/3 of the whole-step figure and a straw man as a CPU algorithm)
+    t0 = time.perf_counter()
+    lazy_same = True
+    for b in range(S):
+        lazy_same = lazy_same and np.array_equal(oracle.nms_sorted_lazy(bev[b], cfg.rpn_nms_thresh, False, K), keeps[b])
+    clk.add("nms (lazy greedy sweep, one thread: same keep list)", t0)
+    clk.t["_lazy_nms_equal"] = bool(lazy_same)
     enl = kitti_utils.enlarge_box3d(_t(boxes).view(-1, 7), cfg.roi_extra_width).view(S, K, 7).contiguous()
     feats = out["backbone_features"].transpose(1, 2).contiguous()
     t0 = time.perf_counter()
@@ -167,11 +177,16 @@ def whole_step_baseline(model, cfg, pc_host, search_only, min_seconds=6.0):
     ref = tail_cpu(out, cfg, clk_t, ref_roipool)[3]
     t_tail = time.perf_counter() - t0 - (ref["ms_per_scene"] * B * 1e-3 if ref else 0.0)     # (the extra reference pooling pass is not part of the step)
     oracle.set_threads(1)
+    lazy_equal = clk_t.t.pop("_lazy_nms_equal", None)
     parts = {k: v / B for k, v in clk_f.t.items() if k not in ("fps", "ball_query", "three_nn")}
     parts.update({k: v / B for k, v in clk_t.t.items()})
     parts["search (fps + ball_query + three_nn, one scene per core)"] = 1.0 / search_only["value"]
-    per_scene = sum(parts.values())
+    lazy_key = "nms (lazy greedy sweep, one thread: same keep list)"
+    literal_key = [k for k in parts if k.startswith("nms (literal")][0]
+    per_scene = sum(v for k, v in parts.items() if k != lazy_key)                  # `value`: the literal restatement of the reference's host path
+    per_scene_lazy = per_scene - parts[literal_key] + parts[lazy_key]              # ... and with the NMS a CPU caller would write
     return {"value": 1.0 / per_scene, "unit": "scenes/s", "cores": threads, "kind": "port",
+            "value_lazy_nms": 1.0 / per_scene_lazy, "lazy_nms_keep_lists_equal": lazy_equal,
             "sample": "WHOLE step, every part on all %d cores, as s per scene: search operators from search_only (batch tiled to one scene "
                       "per core) + on the batch of %d scenes one forward pass (grouping, interpolation: oracle/ws3d_oracle.c with OpenMP; "
                       "SharedMLPs / heads: torch-CPU, %d threads; %.1f s) and one proposal stage (top-9000, rotated NMS, roipool3d; %.1f s)"

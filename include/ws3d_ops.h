@@ -51,6 +51,10 @@ typedef void *ws3d_stream_t;
  * of the SharedMLP kernels, ws3d_sa_mlp3_pool_lists, ws3d_ball_query_pairs, ws3d_three_nn_w; 1: rounds 1-2); ws3d_amd/_lib.py refuses a library whose version differs from the header it was written against */
 #define WS3D_ABI_VERSION 6
 WS3D_API int ws3d_abi_version(void);
+/* Launch-geometry knobs of the persistent kernels (round 6): key 0 = workgroups of ws3d_chain_mlp3, 1 = of ws3d_mlp2_rows, 2 = of
+ * ws3d_sa_mlp3_pool_compact, 3 = of ws3d_chain_fp; value 0 restores the built-in choice, a negative value only reads.  Returns the
+ * previous value (WS3D_E_INVALID for an unknown key).  Speed only: results do not depend on these. Process-wide, not thread-safe. */
+WS3D_API int ws3d_tune(int key, int value);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
  * dx*dx + dy*dy + dz*dz, sampling_gpu.cu:133 / ball_query_gpu.cu:33 / interpolate_gpu.cu:36, and nvcc's contraction of it
  * cannot be captured without a CUDA device): 0 = fma(dz,dz,fma(dx,dx,dy*dy)) [default], 1 = no contraction,

@@ -291,6 +291,16 @@ def nms_sorted(boxes: np.ndarray, thresh: float, normal: bool = False) -> np.nda
     return keep[:cnt].copy()
 
 
+def nms_sorted_lazy(boxes: np.ndarray, thresh: float, normal: bool = False, max_keep: int = 0) -> np.ndarray:
+    """nms_sorted's keep list (its first max_keep entries when max_keep > 0) from IoUs against the kept boxes only -- no (n, n/64)
+    mask; the CPU-side baseline a caller would actually run (ws3d_oracle_nms_lazy)."""
+    boxes, pb = _f(boxes)
+    n = boxes.shape[0]
+    keep = np.zeros((max(n, 1),), dtype=np.int64)
+    cnt = lib().ws3d_oracle_nms_lazy(pb, keep.ctypes.data_as(_i64p), n, C.c_float(thresh), int(normal), int(max_keep))
+    return keep[:cnt].copy()
+
+
 def nms(boxes: np.ndarray, scores: np.ndarray, thresh: float, normal: bool = False) -> np.ndarray:
     """Python-level nms_gpu (iou3d_utils.py:59-90) with a STABLE descending sort."""
     order = np.argsort(-np.asarray(scores, dtype=np.float32), kind="stable")

@@ -9,18 +9,33 @@ import torch
 from bench_c3 import C3
 from ws3d_amd import fastpath
 
-attr, values = sys.argv[1], [ast.literal_eval(v) for v in sys.argv[2:4]]
+attr, values = sys.argv[1], [ast.literal_eval(v) for v in sys.argv[2].split(",")] if "," in sys.argv[2] else [ast.literal_eval(v) for v in sys.argv[2:4]]
+if "," in sys.argv[2]:          # "v1,v2,v3,.." as ONE argument: any number of values; the remaining arguments move up by one
+    sys.argv.insert(3, None)
+target = fastpath
+tune_name = None
+if attr.startswith("tune:"):    # "tune:mlp2_wgs": a launch-geometry knob of the library (compat.tune / ws3d_tune)
+    from ws3d_amd import compat as _compat
+    tune_name = attr[5:]
+    assert tune_name in _compat.TUNE_KEYS, tune_name
+elif "." in attr:                 # "compat.CHAIN_WORKGROUPS": an attribute of another module of the package
+    import importlib
+    modname, attr = attr.rsplit(".", 1)
+    target = importlib.import_module("ws3d_amd." + modname)
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 80
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 kinds = sys.argv[6].split(",") if len(sys.argv) > 6 else ["hdl64", "lidar"]
 rates = {}
-assert hasattr(fastpath, attr), attr
+assert tune_name or hasattr(target, attr), attr
 model, ref = None, {}
 
 
 def run(value, kind):
     global model
-    setattr(fastpath, attr, value)
+    if tune_name:
+        _compat.tune(tune_name, value)
+    else:
+        setattr(target, attr, value)
     wl = C3(8, 0, 1, kind, depth=20, model=model)
     model = wl.model
     for _ in range(3):

@@ -60,6 +60,63 @@ def test_two_process_gloo_all_gather(tmp_path, gb):
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
 
 
+EXCHANGE_WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from ws3d_amd import dist as wd
+    world, rank, local = wd.init("gloo")
+    GB, K, STEPS = int(os.environ["GB"]), 5, 4
+    s, e = wd.shard_range(GB, world, rank)
+    b = e - s
+    calls = {"n": 0}
+    real = dist.all_gather_into_tensor
+
+    def counted(*a, **kw):
+        calls["n"] += 1
+        return real(*a, **kw)
+
+    dist.all_gather_into_tensor = counted
+    ex = wd.ProposalExchange(b, K, GB, "cpu")
+    send_ptr, recv_ptr = ex.send.data_ptr(), ex.recv.data_ptr()
+    for step in range(STEPS):
+        scene = torch.arange(s, e, dtype=torch.float32) + 100 * step
+        packed = scene.view(b, 1, 1).expand(b, K, 8) * 10 + torch.arange(8, dtype=torch.float32)
+        count = (torch.arange(s, e) + step) %% (K + 1)
+        ex.fill(packed, count)                    # (on the GPU the selection kernel writes ex.send itself: ws3d_select_proposals_send)
+        got, cnt = ex.gather()
+        # exactly ONE collective per step, on the SAME two buffers every step
+        assert calls["n"] == step + 1 == ex.collectives
+        assert ex.send.data_ptr() == send_ptr and ex.recv.data_ptr() == recv_ptr
+        if GB %% world == 0:                       # even shards: the results are VIEWS of the receive buffer, nothing is allocated
+            assert got.data_ptr() == recv_ptr and cnt.untyped_storage().data_ptr() == ex.recv.untyped_storage().data_ptr()
+        full = (torch.arange(GB, dtype=torch.float32) + 100 * step).view(GB, 1, 1).expand(GB, K, 8) * 10 + torch.arange(8, dtype=torch.float32)
+        assert got.shape == (GB, K, 8) and torch.equal(got, full)
+        assert torch.equal(cnt, ((torch.arange(GB) + step) %% (K + 1)).to(torch.float32))
+        # ... and equal to the allocate-per-step form of rounds 1-5
+        want, wcnt = wd.all_gather_proposals(packed.contiguous(), count, GB)
+        calls["n"] -= 1
+        assert torch.equal(want, got) and torch.equal(wcnt.to(torch.float32), cnt)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(os.environ["OUT"], "rank%%d.ok" %% rank), "w").write("ok")
+""")
+
+
+@pytest.mark.parametrize("gb", [8, 5])
+def test_proposal_exchange_is_one_collective_on_resident_buffers(tmp_path, gb):
+    """the step's exchange allocates nothing and issues exactly one collective (world 2, gloo, even and
+    uneven shards); its results equal all_gather_proposals' (the allocate-per-step form)"""
+    script = tmp_path / "worker.py"
+    script.write_text(EXCHANGE_WORKER % ROOT)
+    env = dict(os.environ, GB=str(gb), MASTER_ADDR="127.0.0.1", OUT=str(tmp_path))
+    cmd = [sys.executable, "-B", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29620 + gb), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
 def test_more_rccl_ranks_than_devices_raises_instead_of_wrapping(monkeypatch):
     """dist.init over RCCL never puts two ranks on one device: the device pick raises; only the
     explicit gloo test mode wraps LOCAL_RANK onto the devices there are"""

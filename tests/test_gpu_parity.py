@@ -2678,3 +2678,31 @@ def test_ball_query_fill_equals_ball_query_on_a_cleared_tensor(ops):
             _lib.check(_lib.load().ws3d_ball_query_fill(2, n, m, float(r), ns, new_xyz.data_ptr(), xyz.data_ptr(), got2.data_ptr(),
                                                         srt.data_ptr() if srt is not None else None, torch.cuda.current_stream().cuda_stream))
             assert torch.equal(got, want) and torch.equal(got2, want)
+
+
+@pytest.mark.gpu
+def test_proposal_stage_writes_the_send_rows_of_the_exchange(ops):
+    """stage1.proposals_from_rpn(with_packed=<send buffer of dist.ProposalExchange>): ws3d_select_proposals_send (ABI 6) writes the packed
+    rows and, behind each scene's rows, its count straight into the buffer the step's one all-gather sends -- the same rows as
+    ws3d_select_proposals_packed, the same boxes / scores / counts; the fifth result is a view of the buffer; nothing else packs"""
+    from ws3d_amd import dist as wd
+    from ws3d_amd import stage1
+    cfg = stage1.DEFAULT_CFG
+    g = torch.Generator().manual_seed(5)
+    B, N, K = 3, 16384, cfg.rpn_post_nms_top_n
+    bins = int(cfg.loc_scope / cfg.loc_bin_size) * 2
+    pc = synth.make_batch("hdl64", B, N, 31)
+    out = {"backbone_xyz": dev(pc[:, :, :3].copy()), "rpn_reg": (torch.randn(B, N, bins * 4, generator=g) * 0.5).cuda(), "rpn_cls": torch.randn(B, N, 1, generator=g).cuda()}
+    boxes, scores, count, enl, packed = stage1.proposals_from_rpn(out, cfg, with_pool_boxes=True, with_packed=True)
+    ex = wd.ProposalExchange(B, K, B + 2, "cuda", world=1, rank=0)          # (a send buffer with more rows than this rank's scenes)
+    ex.send.fill_(7.0)
+    b2, s2, c2, e2, view = stage1.proposals_from_rpn(out, cfg, with_pool_boxes=True, with_packed=ex.send)
+    torch.cuda.synchronize()
+    assert torch.equal(b2, boxes) and torch.equal(s2, scores) and torch.equal(c2, count) and torch.equal(e2, enl)
+    assert view.data_ptr() == ex.send.data_ptr() and torch.equal(view, packed) and int(count.max()) > 0
+    assert torch.equal(ex.send[:B, K * 8], count.to(torch.float32)) and torch.equal(ex.send[:B, :K * 8].reshape(B, K, 8), packed)
+    assert bool((ex.send[B:] == 7.0).all())                                 # rows behind this rank's scenes are not touched
+    got, cnt = ex.gather()                                                  # world 1: the send rows themselves, no collective
+    assert torch.equal(got, packed) and torch.equal(cnt, count.to(torch.float32)) and ex.collectives == 0
+    with pytest.raises(ValueError, match="send buffer"):
+        stage1.proposals_from_rpn(out, cfg, with_packed=torch.zeros((B, K * 8), device="cuda"))

@@ -243,6 +243,9 @@ def test_nms_mask_and_sweep(oracle, n, thresh, normal, seed):
     keep = oracle.nms_sweep(mask)
     np.testing.assert_array_equal(keep, H.greedy_nms_from_iou(iou, thresh))
     np.testing.assert_array_equal(oracle.nms_sorted(boxes, thresh, normal), keep)
+    # the mask-free greedy sweep (bench_cpu.py's lazy CPU baseline): the same keep list, also when it stops early
+    np.testing.assert_array_equal(oracle.nms_sorted_lazy(boxes, thresh, normal), keep)
+    np.testing.assert_array_equal(oracle.nms_sorted_lazy(boxes, thresh, normal, max_keep=7), keep[:7])
     scores = synth.distinct_scores(n, seed)
     order = np.argsort(-scores, kind="stable")
     np.testing.assert_array_equal(oracle.nms(boxes, scores, thresh, normal),

@@ -33,6 +33,7 @@ class CompactMlpArgs(C.Structure):
 # name -> (restype, argtypes); kept in the order of include/ws3d_ops.h
 SIGNATURES = {
     "ws3d_abi_version": (_i, []),
+    "ws3d_tune": (_i, [_i, _i]),
     "ws3d_dist_mode": (_i, []),
     "ws3d_last_error": (C.c_char_p, []),
     "ws3d_device_info": (_i, [C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i)]),

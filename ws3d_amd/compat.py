@@ -783,7 +783,16 @@ def compact_mlp_pair(kind, scales, max_lds=160 * 1024, mids=None):
     return outs if kind == 2 else True
 
 
-CHAIN_WORKGROUPS = 0      # ws3d_chain_mlp3: workgroups per launch (0 = one per compute unit)
+CHAIN_WORKGROUPS = 0      # ws3d_chain_mlp3: workgroups per launch (0 = the library's choice, ws3d_tune key 0)
+TUNE_KEYS = {"chain_wgs": 0, "mlp2_wgs": 1, "sa1_wgs": 2, "fp_wgs": 3}
+
+
+def tune(name: str, value: int = -1) -> int:
+    """ws3d_tune: set (value >= 0; 0 = built-in) or read (value < 0) a launch-geometry knob of the persistent kernels -> previous value"""
+    rc = _lib.load().ws3d_tune(TUNE_KEYS[name], int(value))
+    if rc < 0:
+        check(rc, "tune")
+    return rc
 
 
 _CHAIN_BLOBS = {}         # (data pointers + versions of a scale's six weight tensors) -> (packed blob, the tensors: kept alive so that the pointers stay theirs)

@@ -204,7 +204,10 @@ __device__ __forceinline__ void chain3_tile(const ChainScale &a, const float *__
 #endif
 constexpr int CHAIN_THREADS = WS3D_CHAIN_THREADS;      // 12 waves, 3 per SIMD (<= 168 registers)
 
-constexpr int CHAIN_TICKET_STRIDE = 32, CHAIN_STEALS = 2;
+#ifndef WS3D_CHAIN_ABL
+#define WS3D_CHAIN_ABL 0       // timing ablations (NOT the operator): 1 = no weight staging, 2 = no stealing, 4 = static tile assignment (no tickets)
+#endif
+constexpr int CHAIN_TICKET_STRIDE = 32;
 constexpr int CHAIN_COUNTERS = 32;      // ticket counters: tiles t = k (mod 32) are handed out by counter k (one address serialises its atomics:
                                         // 4,432 tickets on ONE counter cost the first form of this kernel ~45 us of a 136 us launch)
 
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void chain_pack_kernel(const ChainScale a, flo
     chain_load_scale(a, blob, threadIdx.x, 256);
 }
 
-// grid = workgroups (one per CU fits: 124 KB of LDS at SA2), CHAIN_THREADS / 64 waves each; ticket[0 .. CHAIN_COUNTERS * CHAIN_TICKET_STRIDE) must be ZERO on entry
+// grid = workgroups (one per CU fits: 124 KB of LDS at SA2), CHAIN_THREADS / 64 waves each; ticket[0 .. ws3d_chain_mlp3_ticket_ints()) must be ZERO on entry
 template <int J2A, int J2B>
 __global__ __launch_bounds__(CHAIN_THREADS) void chain_mlp3_pair_kernel(const ChainScale a0, const ChainScale a1, const int nscales, const float *__restrict__ blob0,
                                                                         const float *__restrict__ blob1, int *__restrict__ ticket) {
@@ -245,29 +248,47 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_mlp3_pair_kernel(const Ch
     if (nscales > 1 && a1.limit >= 0 && T1 > a1.limit) T1 = 0;
     const long tiles0 = (T0 + 31) / 32, tiles = tiles0 + (T1 + 31) / 32;
     // tiles k, k + 32, k + 64, .. belong to counter k (the counters sit CHAIN_TICKET_STRIDE ints apart: one cache line each).  The waves
-    // of workgroup g start at counter g % 32 -- eight workgroups share a counter dynamically -- and try CHAIN_STEALS other counters when
-    // theirs runs dry (each probe is a memory-side round trip: the tail only)
+    // of workgroup g start at counter g % 32 -- eight workgroups share a counter dynamically -- and move on to the counters that are
+    // still live when theirs runs dry (a bit mask of dry counters behind the counters)
     int k = (int)(blockIdx.x % CHAIN_COUNTERS);
-    int tried = 0;
     auto subset = [&](int kk) { return (long)((tiles - kk + CHAIN_COUNTERS - 1) / CHAIN_COUNTERS); };      // tiles of counter kk (kk < tiles)
     int next = 0;
     if (lane == 0) next = atomicAdd(ticket + k * CHAIN_TICKET_STRIDE, 1);      // first ticket: its round trip runs under the staging of the weights
     float *lds0 = chain_smem, *lds1 = chain_smem + chain_lds_floats(J2A);
+#if !(WS3D_CHAIN_ABL & 1)
     if (T0 > 0) chain_stage_blob(blob0, lds0, chain_lds_floats(J2A), tid, (int)(blockIdx.x % CHAIN_COUNTERS));
     if (T1 > 0) chain_stage_blob(blob1, lds1, chain_lds_floats(J2B), tid, (int)(blockIdx.x % CHAIN_COUNTERS));
+#endif
     __syncthreads();
+#if WS3D_CHAIN_ABL & 4
+    for (long tile = (long)blockIdx.x * (CHAIN_THREADS / 64) + (tid >> 6); tile < tiles; tile += (long)gridDim.x * (CHAIN_THREADS / 64)) {
+        if (tile < tiles0) chain3_tile<J2A>(a0, lds0, tile, T0, h, c);
+        else chain3_tile<J2B>(a1, lds1, tile - tiles0, T1, h, c);
+    }
+    return;
+#endif
+    unsigned *dry = reinterpret_cast<unsigned *>(ticket + CHAIN_COUNTERS * CHAIN_TICKET_STRIDE);      // bit k: counter k has run dry
+    const unsigned never = tiles >= CHAIN_COUNTERS ? 0u : ~0u << (unsigned)tiles;                     // counters without a tile
     for (;;) {
         long i = __builtin_amdgcn_readfirstlane(next);
-        while ((k >= tiles || i >= subset(k)) && tried <= CHAIN_STEALS) {
-            k = (k + 11) % CHAIN_COUNTERS;
-            ++tried;
-            if (tried <= CHAIN_STEALS) {
-                int t2 = 0;
-                if (lane == 0 && k < tiles) t2 = atomicAdd(ticket + k * CHAIN_TICKET_STRIDE, 1);
-                i = __builtin_amdgcn_readfirstlane(t2);
-            }
+        bool done = false;
+        while (k >= tiles || i >= subset(k)) {
+            // this counter is dry: say so, learn which others are, move to the next live one (two memory-side round trips per move --
+            // the tail only; every counter is reached whatever the grid, so any number of workgroups completes the launch)
+            unsigned m = 0;
+            if (lane == 0) m = atomicOr(dry, 1u << k) | (1u << k) | never;
+            m = __builtin_amdgcn_readfirstlane(m);
+#if WS3D_CHAIN_ABL & 2
+            m = ~0u;
+#endif
+            if (m == ~0u) { done = true; break; }
+            const unsigned rot = (m >> ((k + 1) & 31)) | (k == 31 ? 0u : m << (31 - k));      // bit j = counter (k + 1 + j) % 32
+            k = (k + 1 + __builtin_ctz(~rot)) & 31;
+            int t2 = 0;
+            if (lane == 0) t2 = atomicAdd(ticket + k * CHAIN_TICKET_STRIDE, 1);
+            i = __builtin_amdgcn_readfirstlane(t2);
         }
-        if (tried > CHAIN_STEALS) break;
+        if (done) break;
         const long tile = k + i * CHAIN_COUNTERS;
         if (lane == 0) next = atomicAdd(ticket + k * CHAIN_TICKET_STRIDE, 1);           // the next tile's ticket: its round trip runs under this tile's chain
         if (tile < tiles0) chain3_tile<J2A>(a0, lds0, tile, T0, h, c);
@@ -276,6 +297,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_mlp3_pair_kernel(const Ch
 }
 
 }  // namespace ws3d
+
+// 64 workgroups: the launch then runs its tiles at ~0.75 of the matrix pipes of the CUs it holds (256 workgroups: 0.45 -- most waves get
+// one tile and the second round runs nearly empty) and leaves three quarters of the chip to the other batches in flight: +2-3 % on the
+// 20-deep c3 step against one workgroup per CU, which is 2.5 x faster in isolation (profiles/r06_chain_mlp3_workgroups.txt)
+constexpr long CHAIN_DEFAULT_WGS = 64;
 
 static int chain_cu_count() {
     static int cus[64] = {0};
@@ -305,7 +331,7 @@ static int chain_scale_from(const ws3d_compact_mlp_args &q, ws3d::ChainScale &a,
     return WS3D_OK;
 }
 
-extern "C" int ws3d_chain_mlp3_ticket_ints(void) { return ws3d::CHAIN_COUNTERS * ws3d::CHAIN_TICKET_STRIDE; }
+extern "C" int ws3d_chain_mlp3_ticket_ints(void) { return ws3d::CHAIN_COUNTERS * ws3d::CHAIN_TICKET_STRIDE + 32; }
 
 extern "C" size_t ws3d_chain_mlp3_blob_floats(int o2) { return o2 > 0 && o2 <= 96 ? (size_t)ws3d::chain_lds_floats((o2 + 31) / 32) : 0; }
 
@@ -343,7 +369,7 @@ extern "C" int ws3d_chain_mlp3(const ws3d_compact_mlp_args *p0, const ws3d_compa
     }
     if (nscales == 1) { a[1] = a[0]; blob1 = blob0; }
     if (lds > 160 * 1024) { set_error("ws3d_chain_mlp3: %zu B of LDS", lds); return WS3D_E_UNSUPPORTED; }
-    long wgs = workgroups > 0 ? workgroups : chain_cu_count();
+    long wgs = workgroups > 0 ? workgroups : (g_tune[TUNE_CHAIN_WGS] > 0 ? g_tune[TUNE_CHAIN_WGS] : CHAIN_DEFAULT_WGS);
     wgs = std::max(1L, std::min(wgs, (max_tiles + CHAIN_THREADS / 64 - 1) / (CHAIN_THREADS / 64)));
     hipStream_t st = as_stream(stream);
 #define WS3D_CHAIN_GO(JA, JB)                                                                                                       \

@@ -11,6 +11,7 @@
 namespace ws3d {
 
 static thread_local char g_err[512] = "";
+int g_tune[TUNE_COUNT] = {0};
 
 void set_error(const char *fmt, ...) {
     va_list ap;
@@ -50,6 +51,13 @@ int raise_lds_cap(const void *fn, size_t bytes, const char *what) {
 }  // namespace ws3d
 
 extern "C" int ws3d_abi_version(void) { return WS3D_ABI_VERSION; }
+
+extern "C" int ws3d_tune(int key, int value) {
+    if (key < 0 || key >= ws3d::TUNE_COUNT) { ws3d::set_error("ws3d_tune: unknown key %d", key); return WS3D_E_INVALID; }
+    const int prev = ws3d::g_tune[key];
+    if (value >= 0) ws3d::g_tune[key] = value;
+    return prev;
+}
 
 extern "C" int ws3d_dist_mode(void) { return WS3D_DIST_MODE; }
 

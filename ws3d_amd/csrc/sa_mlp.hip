@@ -510,7 +510,8 @@ extern "C" int ws3d_sa_mlp3_pool(long rows, int nsample, int c1, int c2, int c3,
     // on the matrix cores when the rows fill whole 32-row tiles (the VALU kernel below serves the ragged shapes)
     if (rows % 32 == 0) {
         const long tiles = rows / 32;
-        const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);          // 3 workgroups per CU, waves walk over tiles
+        const long cap1 = g_tune[TUNE_SA1_WGS] > 0 ? g_tune[TUNE_SA1_WGS] : 768;          // (ws3d_tune key 2)
+    const unsigned grid = (unsigned)(tiles / 4 < cap1 ? (tiles + 3) / 4 : cap1);          // 3 workgroups per CU, waves walk over tiles
 #define WS3D_SA_MFMA_CASE(A, B, C, N)                                                                                     \
         if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                              \
             hipLaunchKernelGGL((sa_mlp3_pool_mfma_kernel<A, B, C, N>), dim3(grid), dim3(256), 0, st, tiles, x_rows4, w1t, b1, w2t, b2, \
@@ -548,7 +549,8 @@ extern "C" int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float 
     }
     if (rows == 0) return WS3D_OK;
     const long tiles = rows / 32;
-    const unsigned grid = (unsigned)(tiles / 8 < 256 ? (tiles + 7) / 8 : 256);        // one 8-wave workgroup per CU, waves walk over tiles
+    const long cap = g_tune[TUNE_MLP2_WGS] > 0 ? g_tune[TUNE_MLP2_WGS] : 256;         // one 8-wave workgroup per CU, waves walk over tiles (ws3d_tune key 1)
+    const unsigned grid = (unsigned)(tiles / 8 < cap ? (tiles + 7) / 8 : cap);
     const int o2b = o2 <= 32 ? 1 : 2;
     const size_t lds = sizeof(float) * (128 * 128 + 128 * (size_t)(o2b == 1 ? 40 : 72) + 128);
     auto go = [&](auto kern) -> int {
@@ -571,7 +573,8 @@ extern "C" int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int
         return WS3D_E_INVALID;
     }
     const long tiles = (max_rows + 31) / 32;
-    const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);
+    const long cap1 = g_tune[TUNE_SA1_WGS] > 0 ? g_tune[TUNE_SA1_WGS] : 768;          // (ws3d_tune key 2)
+    const unsigned grid = (unsigned)(tiles / 4 < cap1 ? (tiles + 3) / 4 : cap1);
 #define WS3D_SA_COMPACT(A, B, C)                                                                                                        \
     if (c1 == A && c2 == B && c3 == C) {                                                                                                \
         hipLaunchKernelGGL((sa_mlp3_compact_mfma_kernel<A, B, C>), dim3(grid), dim3(256), 0, as_stream(stream), n, m, xyz, new_xyz, feat, rowc, \
@@ -597,7 +600,8 @@ extern "C" int ws3d_sa_mlp3_pool_lists(int b, int n, int m, int nsample, int c1,
         return WS3D_E_INVALID;
     }
     const long tiles = rows / 32;
-    const unsigned grid = (unsigned)(tiles / 4 < 768 ? (tiles + 3) / 4 : 768);
+    const long cap1 = g_tune[TUNE_SA1_WGS] > 0 ? g_tune[TUNE_SA1_WGS] : 768;          // (ws3d_tune key 2)
+    const unsigned grid = (unsigned)(tiles / 4 < cap1 ? (tiles + 3) / 4 : cap1);
 #define WS3D_SA_LISTS(A, B, C, N)                                                                                                       \
     if (c1 == A && c2 == B && c3 == C && nsample == N) {                                                                                \
         hipLaunchKernelGGL((sa_mlp3_lists_mfma_kernel<A, B, C, N>), dim3(grid), dim3(256), 0, as_stream(stream), tiles, n, m, xyz, new_xyz, feat, nbr, \
