@@ -199,7 +199,10 @@ def c3_step_roofline(out, kernels, wl, kind):
                  "frac": traffic / sec / HBM_PEAK if traffic else None,
                  "a_min_bytes_per_step": a_min, "a_min_frac": a_min / sec / HBM_PEAK,
                  "traffic_source": "profiles/traffic_c3.json (rocprofv3 --pmc, eager step)" if traffic else
-                                   "null: the committed --pmc pass is for batch %s / %s" % (traffic_batch("c3:x"), traffic_kind("c3:x"))}}
+                                   ("stale" if traffic_state("c3:x") == "stale" else
+                                    "null: the committed --pmc pass is for batch %s / %s" % (traffic_batch("c3:x"), traffic_kind("c3:x")))}}
+    if traffic is None and traffic_state("c3:x") == "stale":
+        r["traffic_source"] = "stale"
     fps = next((k for k in kernels if k.get("bound") == "valu"), None)
     if fps is not None:
         us = fps.get("us_per_fps_step")

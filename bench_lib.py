@@ -451,6 +451,46 @@ def _traffic_file(kernel_key):
     return os.path.join(ROOT, "profiles", "traffic.json"), kernel_key
 
 
+# The sources a counter pass describes: the pass records their git blob hashes (`_source_blobs`) and a figure
+# taken on other sources than the ones on disk is NOT quoted -- `traffic: null`, `traffic_source: "stale"` -- instead of silently
+# describing code that no longer exists.  c2 (traffic.json): sampling + ball query + binning; c5: roipool3d + iou3d; c3: every kernel
+# source and the forward pass's dispatch logic.
+_CSRC = "ws3d_amd/csrc/"
+TRAFFIC_SOURCES = {
+    "traffic.json": tuple(_CSRC + f for f in ("fps_bucket.hip", "ballquery_group.hip", "bin_kernels.h", "binning.h", "common.h")),
+    "traffic_c5.json": tuple(_CSRC + f for f in ("roipool3d.hip", "iou3d.hip", "common.h")),
+    "traffic_c3.json": None,          # all of csrc/*.hip, csrc/*.h + ws3d_amd/fastpath.py (resolved in traffic_source_blobs)
+}
+
+
+def traffic_source_blobs(file_name):
+    """{repo-relative path: git blob sha1} of the sources the counter file `file_name` (profiles/<file_name>) describes"""
+    files = TRAFFIC_SOURCES.get(os.path.basename(file_name))
+    if files is None:
+        d = os.path.join(ROOT, "ws3d_amd", "csrc")
+        files = tuple(sorted(_CSRC + f for f in os.listdir(d) if f.endswith((".hip", ".h")))) + ("ws3d_amd/fastpath.py",)
+    return {f: git_blob_sha1(os.path.join(ROOT, f)) for f in files}
+
+
+_TRAFFIC_STATE = {}
+
+
+def traffic_state(kernel_key=None):
+    """'fresh' (the pass names the sources on disk), 'stale' (it names others, or none: taken before round 6), 'absent'"""
+    p = _traffic_file(kernel_key)[0]
+    if p not in _TRAFFIC_STATE:
+        try:
+            j = json.load(open(p))
+            want = j.get("_source_blobs")
+            _TRAFFIC_STATE[p] = "fresh" if want and want == traffic_source_blobs(p) else "stale"
+            if _TRAFFIC_STATE[p] == "stale":
+                print("bench.py: WARNING %s was taken on other kernel sources than the ones on disk: its figures are not quoted "
+                      "(traffic: null, traffic_source: stale); re-run scripts/gpu_refresh_lite.sh" % os.path.relpath(p, ROOT), file=sys.stderr, flush=True)
+        except Exception:
+            _TRAFFIC_STATE[p] = "absent"
+    return _TRAFFIC_STATE[p]
+
+
 def traffic_batch(kernel_key=None):
     try:
         return int(json.load(open(_traffic_file(kernel_key)[0])).get("_scenes_per_launch", 256))
@@ -460,9 +500,9 @@ def traffic_batch(kernel_key=None):
 
 def load_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic*.json),
-    already corrected as MI355X_MICROARCH.md prescribes; None when not measured."""
+    already corrected as MI355X_MICROARCH.md prescribes; None when not measured OR measured on other sources (traffic_state)."""
     p, key = _traffic_file(kernel_key)
-    if key and os.path.exists(p):
+    if key and os.path.exists(p) and traffic_state(kernel_key) == "fresh":
         try:
             return json.load(open(p)).get(key)
         except Exception:
@@ -506,6 +546,8 @@ def finish_kernel_rows(kernels, scenes, kind=None):
             k["valu_frac"] = phys / sec / VALU_PEAK if phys else None
         tkey = k.pop("traffic_key", None)
         tr = load_traffic(tkey)
+        if tkey and tr is None:
+            k["traffic_state"] = traffic_state(tkey)
         # the committed PMC passes were taken at one batch size: only comparable at that batch
         k["traffic_bytes_per_launch"] = tr if scenes == traffic_batch(tkey) and traffic_kind(tkey) in (None, kind) else None
     return kernels
@@ -517,6 +559,8 @@ def roofline_of(k, where):
     traffic = k["traffic_bytes_per_launch"].get("hbm_bytes") if isinstance(k.get("traffic_bytes_per_launch"), dict) else None
     sec = k["ms_per_step"] * 1e-3
     r = {"kernel": k["name"], "measured_in": where, "ms_per_launch": k["ms_per_step"] / launches, "traffic": traffic}
+    if traffic is None and k.get("traffic_state"):
+        r["traffic_source"] = k["traffic_state"]
     if k.get("bound") == "valu":
         have = k["valu_lane_instr_per_s"] is not None
         r.update({"bound": "valu", "achieved": k["valu_lane_instr_per_s"] / 1e12 if have else None, "peak": VALU_PEAK / 1e12, "unit": "Tlane-instr/s",

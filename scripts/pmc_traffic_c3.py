@@ -9,8 +9,10 @@ kernel (one per step), so the figures are bytes PER STEP (= per batch of <batch>
 under-reports wide 16 B/lane streams by 2x, other widths uncalibrated: the doubled figure is the upper bound); WRITE_SIZE matches
 known byte counts to the byte (scripts/pmc_traffic.py).  bench.py reads the result as profiles/traffic_c3.json."""
 import json
+import os
 import sqlite3
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # kernel-name fragment -> family name of bench_c3.FAMILIES (first match wins)
 FAMILY_OF = [
@@ -20,6 +22,7 @@ FAMILY_OF = [
     ("ball_query_", "ball_query"),
     ("pair_", "pair compaction"),
     ("sa_mlp3_", "SharedMLP SA1 (3 layers + pool, own MFMA kernels)"),
+    ("chain_mlp3_", "SharedMLP SA2 whole scale over compact rows (one own MFMA kernel)"), ("chain_pack_", "SharedMLP SA2 whole scale over compact rows (one own MFMA kernel)"),
     ("pgather_gemm3_", "SharedMLP SA2 whole scale over compact rows (one own MFMA kernel)"),
     ("pgather_", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"), ("gather_gemm", "SharedMLP SA2-4 layers 1+2 (gather + own MFMA kernels)"),
     ("gemm_pool_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"), ("rowmax_", "SharedMLP SA2-4 last layer + pool (own MFMA kernels)"),
@@ -59,6 +62,8 @@ def main(fetch_db, write_db, out, kind, batch):
     res = {"_note": "c3 eager step, batch %s, generator %s: HBM bytes PER STEP per launch family (sum over the family's dispatches / steps "
                     "traced), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; fetch raw (gfx950: wide streams under-reported 2x)" % (batch, kind),
            "_scenes_per_launch": int(batch), "_kind": kind, "_steps_traced": [steps_f, steps_w]}
+    import bench_lib
+    res["_source_blobs"] = bench_lib.traffic_source_blobs(out)
     fam = {}
     for name in sorted(set(f) | set(w)):
         e = fam.setdefault(family(name), {"fetch_bytes_raw": 0.0, "write_bytes": 0.0, "launches_per_step": 0.0, "kernels": []})

@@ -104,7 +104,11 @@ def test_compact_line_fits_the_drivers_parser():
         assert k in line, k
     assert {"workload", "batch_per_gpu", "n_points", "ranks_seen", "generator", "backend"} <= set(line["config"])
     r = line["roofline"]
-    assert r["bound"] == "mfma" and abs(r["frac"] - 0.302) < 0.01 and abs(r["hbm"]["frac"] - 0.122) < 0.01      # the verdict's own recomputation
+    assert r["bound"] == "mfma" and abs(r["frac"] - 0.302) < 0.01                                              # the verdict's own recomputation
+    if bench.traffic_state("c3:x") == "fresh":        # the counter bytes are quoted only when the committed pass names the sources on disk
+        assert 0.05 < r["hbm"]["frac"] < 0.2 and r["traffic"] > 5e8
+    else:
+        assert r["traffic"] is None and r["hbm"]["frac"] is None and r["traffic_source"] == "stale"
     assert "c3_stage1" in r["measured_in"] and r["dominant_kernel"]["workgroups"] == 8
 
     def strings(x):
@@ -117,3 +121,49 @@ def test_compact_line_fits_the_drivers_parser():
         elif isinstance(x, str):
             yield x
     assert max(len(t) for t in strings(line)) <= 300
+
+
+def test_counter_figures_are_quoted_only_for_the_sources_they_were_taken_on(tmp_path, monkeypatch):
+    """a profiles/traffic*.json carries the git blob hashes of the kernel sources it describes; on other sources
+    bench.py quotes `traffic: null` + `traffic_source: stale` instead of a figure of code that no longer exists"""
+    import json
+    import bench
+    import bench_lib
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench_lib, "_TRAFFIC_STATE", {})
+    real_file = bench_lib._traffic_file
+
+    def fake_file(key):
+        p, k = real_file(key)
+        return str(prof / os.path.basename(p)), k
+
+    monkeypatch.setattr(bench_lib, "_traffic_file", fake_file)
+    blobs = bench_lib.traffic_source_blobs("traffic_c5.json")
+    assert set(blobs) == {"ws3d_amd/csrc/roipool3d.hip", "ws3d_amd/csrc/iou3d.hip", "ws3d_amd/csrc/common.h"} and all(len(v) == 40 for v in blobs.values())
+    c3 = bench_lib.traffic_source_blobs("traffic_c3.json")
+    assert "ws3d_amd/fastpath.py" in c3 and "ws3d_amd/csrc/chain_mlp.hip" in c3 and "ws3d_amd/csrc/gemm_pool.hip" in c3
+    entry = {"kernel": "k", "hbm_bytes": 1.0e9}
+    # fresh: named sources == the ones on disk
+    (prof / "traffic_c5.json").write_text(json.dumps({"_scenes_per_launch": 8, "_source_blobs": blobs, "roipool3d_kernel": entry}))
+    assert bench_lib.traffic_state("c5:roipool3d_kernel") == "fresh" and bench_lib.load_traffic("c5:roipool3d_kernel") == entry
+    # stale: one hash differs / no hashes at all (a pass of rounds 1-5)
+    for doc in ({"_scenes_per_launch": 8, "_source_blobs": dict(blobs, **{"ws3d_amd/csrc/roipool3d.hip": "0" * 40}), "roipool3d_kernel": entry},
+                {"_scenes_per_launch": 8, "roipool3d_kernel": entry}):
+        bench_lib._TRAFFIC_STATE.clear()
+        (prof / "traffic_c5.json").write_text(json.dumps(doc))
+        assert bench_lib.traffic_state("c5:roipool3d_kernel") == "stale" and bench_lib.load_traffic("c5:roipool3d_kernel") is None
+        rows = bench_lib.finish_kernel_rows([{"name": "roipool3d", "ms_per_step": 0.25, "launches_per_step": 1, "alg_bytes_per_step": 1.1e9,
+                                              "traffic_key": "c5:roipool3d_kernel", "bound": "hbm"}], 8)
+        roof = bench_lib.roofline_of(rows[0], "test")
+        assert roof["traffic"] is None and roof["traffic_source"] == "stale"
+    bench_lib._TRAFFIC_STATE.clear()
+    assert bench_lib.traffic_state("c3:x") == "absent"
+    # the committed passes of THIS tree either name the sources on disk or are reported stale -- never quoted blindly
+    monkeypatch.setattr(bench_lib, "_traffic_file", real_file)
+    bench_lib._TRAFFIC_STATE.clear()
+    for key in ("ball_query_grid_coop_kernel", "c5:roipool3d_kernel", "c3:_total_hbm_bytes_per_step"):
+        st = bench_lib.traffic_state(key)
+        assert st in ("fresh", "stale", "absent")
+        assert (bench_lib.load_traffic(key) is not None) <= (st == "fresh")
+    assert bench.traffic_state is bench_lib.traffic_state
