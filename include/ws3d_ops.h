@@ -52,7 +52,7 @@ typedef void *ws3d_stream_t;
 #define WS3D_ABI_VERSION 6
 WS3D_API int ws3d_abi_version(void);
 /* Launch-geometry knobs of the persistent kernels (round 6): key 0 = workgroups of ws3d_chain_mlp3, 1 = of ws3d_mlp2_rows, 2 = of
- * ws3d_sa_mlp3_pool_compact, 3 = of ws3d_chain_fp; value 0 restores the built-in choice, a negative value only reads.  Returns the
+ * ws3d_sa_mlp3_pool_compact; value 0 restores the built-in choice, a negative value only reads.  Returns the
  * previous value (WS3D_E_INVALID for an unknown key).  Speed only: results do not depend on these. Process-wide, not thread-safe. */
 WS3D_API int ws3d_tune(int key, int value);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells
@@ -475,18 +475,6 @@ WS3D_API int ws3d_mlp2_rows(long rows, int k_dim, int o1, int o2, const float *x
 WS3D_API int ws3d_qinterp_gemm(int b, int n, int m, int c, int o_dim, const float *q, const int32_t *idx, const float *weight, const float *lin,
                       const float *skip, int c1, const float *wb, const float *b1, int relu1, const float *w2t, const float *b2, int relu2,
                       float *out, ws3d_stream_t stream);
-/* The same function on the register-chained kernel of round 6 (csrc/chain_mlp.hip, ABI 6): a wave builds the first layer's 32 rows in
- * registers (the same fmaf expressions), turns them into k-pair operands with v_permlane32_swap and multiplies them with the second
- * layer's weights, resident in LDS per block of 128 output columns; tiles are handed out by ticket counters.  blob =
- * ws3d_chain_fp_pack(c, o_dim, w2t, b2) (once per weight set, ws3d_chain_fp_blob_floats(c, o_dim) floats, 16-byte aligned); ticket:
- * ws3d_chain_fp_ticket_ints(o_dim) int32, ZERO on entry, consumed.  c in {128, 256}, any row count, any o_dim; otherwise
- * WS3D_E_UNSUPPORTED.  workgroups: 0 = the library's choice (ws3d_tune key 3).  Rows bit-identical to ws3d_qinterp_gemm's. */
-WS3D_API int ws3d_chain_fp_ticket_ints(int o_dim);
-WS3D_API size_t ws3d_chain_fp_blob_floats(int c, int o_dim);
-WS3D_API int ws3d_chain_fp_pack(int c, int o_dim, const float *w2t, const float *b2, float *blob, ws3d_stream_t stream);
-WS3D_API int ws3d_chain_fp(int b, int n, int m, int c, int o_dim, const float *q, const int32_t *idx, const float *weight, const float *lin,
-                           const float *skip, int c1, const float *wb, const float *b1, int relu1, const float *blob, int relu2, float *out,
-                           int32_t *ticket, int workgroups, ws3d_stream_t stream);
 
 /* -------------------------------------------------------------------- iou3d_cuda */
 

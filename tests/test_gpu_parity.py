@@ -2255,7 +2255,7 @@ def test_fast_path_switches_agree(ops):
     model = model.cuda().eval()
     pts = dev(np.stack([synth.velodyne_scan(16384, seed=300 + j) for j in range(8)]))
     names = ("FUSED_MLP2_ROWS", "FUSED_GATHER_GEMM2", "FUSED_INTERP_GEMM", "PER_POINT_L1", "PER_POINT_FP", "COMPACT_PAIRS", "SA1_FROM_LISTS", "PARALLEL_SCALES", "PARALLEL_HEADS",
-             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH", "MERGED_BINNING", "FUSED_PROLOGUE", "MERGED_THREE_NN", "PAIRED_SCALES", "CHAIN_MLP", "CHAIN_FP")
+             "FUSED_COMPACT3_MAX_LDS", "FUSED_QINTERP_GEMM_MIN_ROWS", "BIN_INPUT_AHEAD", "NESTED_CHAIN", "QUERY_CELL_ORDER", "DUAL_SCALE_SEARCH", "MERGED_BINNING", "FUSED_PROLOGUE", "MERGED_THREE_NN", "PAIRED_SCALES", "CHAIN_MLP")
     saved = {n: getattr(fastpath, n) for n in names}
 
     def run(**kw):
@@ -2300,10 +2300,6 @@ def test_fast_path_switches_agree(ops):
                 assert all(torch.equal(x_, y_) for x_, y_ in zip(run(CHAIN_MLP=True), run(CHAIN_MLP=False)))
                 for n, v in saved.items():
                     setattr(fastpath, n, v)
-            # ... and the two-layer FP modules on ws3d_chain_fp or ws3d_qinterp_gemm
-            assert all(torch.equal(x_, y_) for x_, y_ in zip(run(CHAIN_FP=True), run(CHAIN_FP=False)))
-            for n, v in saved.items():
-                setattr(fastpath, n, v)
         assert all(torch.equal(x_, y_) for x_, y_ in zip(one, per_level)) and all(torch.equal(x_, y_) for x_, y_ in zip(one, split))
         assert all(torch.equal(x_, y_) for x_, y_ in zip(run(FUSED_PROLOGUE=True), run(FUSED_PROLOGUE=False)))        # and with the side streams
     finally:
@@ -2390,8 +2386,7 @@ def test_qinterp_rows_equals_interpolate_then_linear(ops, B, N, M, C2, C1, O):
 
 
 @pytest.mark.parametrize("B,N,M,C2,C1,C,O,relu1", [(1, 16384, 4096, 256, 1, 128, 128, True), (2, 4096, 1024, 512, 96, 256, 256, True), (2, 1024, 256, 512, 256, 512, 512, True),
-                                                     (2, 256, 64, 64, 0, 64, 128, False), (1, 1000, 256, 64, 3, 64, 128, True), (2, 1024, 256, 64, 2, 48, 64, True),
-                                                     (1, 1000, 256, 64, 3, 128, 40, True), (3, 333, 100, 32, 40, 256, 200, False), (1, 4096, 1024, 32, 0, 128, 384, True)])
+                                                     (2, 256, 64, 64, 0, 64, 128, False), (1, 1000, 256, 64, 3, 64, 128, True), (2, 1024, 256, 64, 2, 48, 64, True)])
 def test_qinterp_gemm_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M, C2, C1, C, O, relu1):
     """ws3d_qinterp_gemm (both layers of a two-layer FP module in one kernel: the first layer's rows are built in the A operand of the
     second layer's product): with an identity second layer it returns ws3d_qinterp_rows' rows to the bit -- both skip forms -- and with a
@@ -2415,24 +2410,6 @@ def test_qinterp_gemm_is_qinterp_rows_followed_by_the_second_layer(ops, B, N, M,
     w2 = dev((rng.standard_normal((C, O)) / np.sqrt(C)).astype(np.float32))
     b2 = dev(rng.standard_normal(O).astype(np.float32))
     got = ops.c.qinterp_gemm(q, idx, weight, w2, b2, True, relu=relu1, **kw)
-    # the register-chained kernel of round 6 (ws3d_chain_fp): C in {128, 256}, ANY row count and width; the same fmaf chains -> the same
-    # bits as ws3d_qinterp_gemm where that one covers the shape, the float64 product of qinterp_rows' rows elsewhere; any grid completes
-    for wgs in (0, 1, 5):
-        ops.c.CHAIN_FP_WORKGROUPS = wgs
-        try:
-            got_c = ops.c.chain_fp(q, idx, weight, w2, b2, True, torch.zeros(ops.c.chain_fp_ticket_ints(O), dtype=torch.int32, device="cuda"), relu=relu1, **kw)
-        finally:
-            ops.c.CHAIN_FP_WORKGROUPS = 0
-        assert (got_c is not None) == (C in (128, 256))
-        if got_c is not None:
-            assert tuple(got_c.shape) == (B * N, O)
-            if got is not None:
-                assert torch.equal(got_c, got)
-            want_c = torch.relu(rows.double() @ w2.double() + b2.double())
-            assert (got_c.double() - want_c).abs().max().item() <= 2e-5 * max(want_c.abs().max().item(), 1.0) * np.sqrt(max(C, 128) / 128)
-            if C == O:
-                assert torch.equal(ops.c.chain_fp(q, idx, weight, torch.eye(C, device="cuda"), None, False,
-                                                  torch.zeros(ops.c.chain_fp_ticket_ints(O), dtype=torch.int32, device="cuda"), relu=relu1, **kw), rows)
     if (B * N) % 64 or C % 16 or O % 128:
         assert got is None
         return

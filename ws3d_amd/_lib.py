@@ -111,10 +111,6 @@ SIGNATURES = {
     "ws3d_chain_mlp3_blob_floats": (_sz, [_i]),
     "ws3d_chain_mlp3_pack": (_i, [C.POINTER(CompactMlpArgs), _vp, _vp]),
     "ws3d_chain_mlp3": (_i, [C.POINTER(CompactMlpArgs), C.POINTER(CompactMlpArgs), _vp, _vp, _vp, _i, _vp]),
-    "ws3d_chain_fp_ticket_ints": (_i, [_i]),
-    "ws3d_chain_fp_blob_floats": (_sz, [_i, _i]),
-    "ws3d_chain_fp_pack": (_i, [_i, _i, _vp, _vp, _vp, _vp]),
-    "ws3d_chain_fp": (_i, [_i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
     "ws3d_sa_mlp3_pool_compact": (_i, [_i, _i, _i, C.c_long, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, C.c_long, _vp]),
     "ws3d_sa_mlp3_pool_lists": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, C.c_long, _vp]),
     "ws3d_interp_gemm": (_i, [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

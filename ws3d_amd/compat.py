@@ -642,51 +642,6 @@ def qinterp_gemm(q, idx, weight, w2t, b2, relu2, lin=None, skip=None, wb=None, b
     return out
 
 
-_CHAIN_FP_BLOBS = {}      # (pointers + versions of w2t / b2) -> (packed blob, the tensors); never evicted (a captured hipGraph may hold the address)
-CHAIN_FP_WORKGROUPS = 0   # ws3d_chain_fp: workgroups per launch (0 = the library's choice, ws3d_tune key 3)
-
-
-def chain_fp_ticket_ints(o_dim: int) -> int:
-    return int(_lib.load().ws3d_chain_fp_ticket_ints(int(o_dim)))
-
-
-def chain_fp(q, idx, weight, w2t, b2, relu2, ticket, lin=None, skip=None, wb=None, bias=None, relu=True):
-    """qinterp_gemm on the register-chained kernel (ws3d_chain_fp, csrc/chain_mlp.hip): the same arguments + ticket, a ZEROED int32 tensor
-    of chain_fp_ticket_ints(O) elements (consumed).  q (B, M, C) with C in {128, 256}; any row count, any O.  The second layer's weights
-    are packed once per weight set (ws3d_chain_fp_pack, cached here).  -> (B*N, O), or None when the shape is not covered.  Bit-identical
-    to qinterp_gemm / qinterp_rows + the second layer's fmaf chains.  ws3d extension."""
-    dev = _dev(q, idx, weight, w2t)
-    _f32(q, "q"); _i32(idx, "idx"); _f32(weight, "weight"); _f32(w2t, "w2t")
-    B, M, C = q.shape
-    N = idx.size(1)
-    O = w2t.size(1)
-    c1 = 0 if skip is None else skip.size(2)
-    if (C not in (128, 256) or w2t.size(0) != C or not q.is_contiguous() or not w2t.is_contiguous() or not idx.is_contiguous() or not weight.is_contiguous() or
-            ticket is None or ticket.dtype != torch.int32 or not ticket.is_contiguous() or ticket.numel() < chain_fp_ticket_ints(O) or
-            (lin is None and c1 > 4) or (lin is not None and (tuple(lin.shape) != (B * N, C) or not lin.is_contiguous())) or
-            (lin is None and c1 > 0 and (wb is None or tuple(wb.shape) != (c1, C) or not wb.is_contiguous() or not skip.is_contiguous())) or
-            (b2 is not None and not b2.is_contiguous()) or (bias is not None and not bias.is_contiguous())):
-        return None
-    lib = _lib.load()
-    key = (w2t.data_ptr(), w2t._version, None if b2 is None else (b2.data_ptr(), b2._version))
-    hit = _CHAIN_FP_BLOBS.get(key)
-    if hit is None:
-        blob = torch.empty(int(lib.ws3d_chain_fp_blob_floats(C, O)), dtype=torch.float32, device=dev)
-        with _on(dev):
-            check(lib.ws3d_chain_fp_pack(C, O, _p(w2t), _p(b2), _p(blob), _stream()), "chain_fp_pack")
-        hit = (blob, (w2t, b2))
-        if not torch.cuda.is_current_stream_capturing():
-            _CHAIN_FP_BLOBS[key] = hit
-    out = torch.empty((B * N, O), dtype=torch.float32, device=dev)
-    with _on(dev):
-        rc = lib.ws3d_chain_fp(B, N, M, C, O, _p(q), _p(idx), _p(weight), _p(lin), _p(skip), c1, _p(wb), _p(bias), int(bool(relu)), _p(hit[0]), int(bool(relu2)),
-                               _p(out), _p(ticket), int(CHAIN_FP_WORKGROUPS), _stream())
-    if rc == _lib.E_UNSUPPORTED:
-        return None
-    check(rc, "chain_fp")
-    return out
-
-
 def compact_pairs(nbr, ordered=False):
     """(B, M, ns) ball-query lists -> (rowc, rowsrc, total): the DISTINCT (centre, source point) pairs as compact rows (int32
     tensors of B*M*ns entries, the first `total` -- a 1-element device tensor -- valid); a list's padding repeats its first hit
@@ -829,7 +784,7 @@ def compact_mlp_pair(kind, scales, max_lds=160 * 1024, mids=None):
 
 
 CHAIN_WORKGROUPS = 0      # ws3d_chain_mlp3: workgroups per launch (0 = the library's choice, ws3d_tune key 0)
-TUNE_KEYS = {"chain_wgs": 0, "mlp2_wgs": 1, "sa1_wgs": 2, "fp_wgs": 3}
+TUNE_KEYS = {"chain_wgs": 0, "mlp2_wgs": 1, "sa1_wgs": 2}
 
 
 def tune(name: str, value: int = -1) -> int:

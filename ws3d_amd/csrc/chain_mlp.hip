@@ -308,181 +308,6 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_mlp3_pair_kernel(const Ch
     }
 }
 
-// ===================================================================================================================================
-// Feature-propagation module, both layers (ws3d_qinterp_gemm's function on the register-chained design): the first layer's rows
-//   x = relu1?( w0 Q[i0] + w1 Q[i1] + w2 Q[i2] + (lin  |  skip @ wb + b1) )          (ws3d_qinterp_rows' expression, to the bit)
-// are built by the wave in the accumulator layout (lane (p, h): channels 8 q + 4 h .. + 3 of row p: one 16-byte load per source row and
-// q), turned into k-pair operands by the swaps above, and multiplied the straight way round with the second layer's weights out of LDS:
-//   out = relu2?( x @ w2t + b2 ),  ascending k, two per matrix instruction -- the fmaf chains of interp_gemm_big_kernel<.., PRE>.
-// A workgroup holds the weights of ONE block of 128 output columns (K x 128 floats: 64 KB at FP0, 128 KB at FP1) and its waves take
-// 32-row tiles of that block's ticket set; with two column blocks (O = 256) the rows are built once per block.
-struct ChainFp {
-    const float *q, *w3, *lin, *skip, *wb, *b1;
-    const int32_t *idx3;
-    float *out;
-    long rows;
-    int n, m, c1, relu1, relu2, o_dim;
-};
-
-// blob of one column block cb (floats): b2 [128] | WL [K / 8][2][128][4],  WL[blk][h][o][e] = w2t[k = 2 (4 blk + e) + h][128 cb + o]
-__host__ __device__ constexpr int chain_fp_blob_floats(int kt) { return 128 + 32 * kt * 128; }
-
-__global__ __launch_bounds__(256) void chain_fp_pack_kernel(int k_dim, int o_dim, const float *__restrict__ w2t, const float *__restrict__ b2,
-                                                            float *__restrict__ blob) {
-    const int cb = blockIdx.x;
-    float *dst = blob + (size_t)cb * chain_fp_blob_floats(k_dim / 32);
-    for (int i = threadIdx.x; i < 128; i += 256) dst[i] = (b2 && 128 * cb + i < o_dim) ? b2[128 * cb + i] : 0.f;
-    float *wl = dst + 128;
-    for (int i = threadIdx.x; i < k_dim * 128; i += 256) {
-        const int k = i >> 7, o = i & 127;
-        const int s2 = k >> 1, h = k & 1;
-        wl[(((s2 >> 2) * 2 + h) * 128 + o) * 4 + (s2 & 3)] = 128 * cb + o < o_dim ? w2t[(long)k * o_dim + 128 * cb + o] : 0.f;
-    }
-}
-
-template <int KT>      // K = 32 KT input channels
-__device__ __forceinline__ void chain_fp_tile(const ChainFp &a, const float *__restrict__ lds, const long tile, const int cb, const int h, const int c) {
-    constexpr int K = 32 * KT;
-    const float *b2s = lds;
-    const float4 *wl = reinterpret_cast<const float4 *>(lds + 128);
-    const float *wbs = lds + chain_fp_blob_floats(KT), *b1s = wbs + 4 * K;      // the first layer's skip weights (c1 <= 4 rows) and bias, staged by the kernel
-    float ops[KT][16];
-    {
-        const long r = min(tile * 32 + c, a.rows - 1);            // rows behind the end repeat the last one (never stored)
-        const long scene = r / a.n;
-        const int i0 = a.idx3[r * 3 + 0], i1 = a.idx3[r * 3 + 1], i2 = a.idx3[r * 3 + 2];
-        const float w0 = a.w3[r * 3 + 0], w1 = a.w3[r * 3 + 1], w2 = a.w3[r * 3 + 2];
-        const float *qb = a.q + (size_t)scene * a.m * K + 4 * h;
-        const float *p0 = qb + (size_t)i0 * K, *p1 = qb + (size_t)i1 * K, *p2 = qb + (size_t)i2 * K;
-        const bool has_lin = a.lin != nullptr;                    // (launch-uniform)
-        const float *lrow = has_lin ? a.lin + (size_t)r * K + 4 * h : a.q;
-        float sv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!has_lin)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) if (j < a.c1) sv[j] = a.skip[r * (long)a.c1 + j];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            // every load of this 32-channel block is issued before the first value is used: one memory round trip per block instead of
-            // one per 16 bytes (the interpolation below would otherwise be scheduled load by load)
-            float4 v0[4], v1[4], v2[4], ex[4];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int ch = 32 * kt + 8 * qq;
-                v0[qq] = *reinterpret_cast<const float4 *>(p0 + ch);
-                v1[qq] = *reinterpret_cast<const float4 *>(p1 + ch);
-                v2[qq] = *reinterpret_cast<const float4 *>(p2 + ch);
-                if (has_lin) ex[qq] = *reinterpret_cast<const float4 *>(lrow + ch);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            chain_f16 x;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int ch = 32 * kt + 8 * qq;
-                float y[4] = {__builtin_fmaf(w2, v2[qq].x, __builtin_fmaf(w0, v0[qq].x, w1 * v1[qq].x)), __builtin_fmaf(w2, v2[qq].y, __builtin_fmaf(w0, v0[qq].y, w1 * v1[qq].y)),
-                              __builtin_fmaf(w2, v2[qq].z, __builtin_fmaf(w0, v0[qq].z, w1 * v1[qq].z)), __builtin_fmaf(w2, v2[qq].w, __builtin_fmaf(w0, v0[qq].w, w1 * v1[qq].w))};
-                if (has_lin) {
-                    y[0] += ex[qq].x; y[1] += ex[qq].y; y[2] += ex[qq].z; y[3] += ex[qq].w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (j < a.c1) {
-                            const float4 wv = *reinterpret_cast<const float4 *>(wbs + j * K + ch + 4 * h);
-                            y[0] = __builtin_fmaf(sv[j], wv.x, y[0]); y[1] = __builtin_fmaf(sv[j], wv.y, y[1]);
-                            y[2] = __builtin_fmaf(sv[j], wv.z, y[2]); y[3] = __builtin_fmaf(sv[j], wv.w, y[3]);
-                        }
-                    if (a.b1) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(b1s + ch + 4 * h);
-                        y[0] += bv.x; y[1] += bv.y; y[2] += bv.z; y[3] += bv.w;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) x[4 * qq + i] = (a.relu1 && y[i] < 0.f) ? 0.f : y[i];
-            }
-            chain_pair_operands(x, ops[kt]);
-        }
-    }
-    // ---- the second layer, the straight way round: two 32-column blocks per pass over k
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        chain_f16 acc[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-#pragma unroll
-        for (int blk = 0; blk < 4 * KT; ++blk) {
-            float4 w[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) w[j] = wl[(blk * 2 + h) * 128 + 64 * g + 32 * j + c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = ops[blk >> 2][4 * (blk & 3) + e];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float wb2 = e == 0 ? w[j].x : e == 1 ? w[j].y : e == 2 ? w[j].z : w[j].w;
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, wb2, acc[j], 0, 0, 0);
-                }
-            }
-            if (blk & 1) __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int lcol = 64 * g + 32 * j + c, col = 128 * cb + lcol;
-            if (col < a.o_dim) {
-                const float bv = b2s[lcol];
-                float *o = a.out + (tile * 32 + 4 * h) * (long)a.o_dim + col;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const long rr = tile * 32 + 4 * h + 8 * (v / 4) + (v % 4);
-                    float y = acc[j][v] + bv;
-                    if (a.relu2) y = y < 0.f ? 0.f : y;
-                    if (rr < a.rows) o[(long)(8 * (v / 4) + (v % 4)) * a.o_dim] = y;
-                }
-            }
-        }
-    }
-}
-
-template <int KT> struct ChainFpThreads { static constexpr int value = KT <= 4 ? 768 : 512; };      // K = 256 holds 128 operand registers: 2 waves per SIMD
-
-// grid = workgroups, workgroup g serves column block g % ncb; ticket: ncb blocks of CHAIN_TICKET_INTS ints, ZERO on entry
-template <int KT>
-__global__ __launch_bounds__(ChainFpThreads<KT>::value) void chain_fp_kernel(const ChainFp a, const float *__restrict__ blob, const int ncb, int *__restrict__ ticket) {
-    extern __shared__ __attribute__((aligned(16))) float chain_smem[];
-    constexpr int THREADS = ChainFpThreads<KT>::value;
-    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, c = lane & 31;
-    const int cb = (int)(blockIdx.x % ncb);
-    const long tiles = (a.rows + 31) / 32;
-    ChainTickets tk;
-    tk.start(ticket + cb * CHAIN_TICKET_INTS, tiles, (int)(blockIdx.x / ncb), lane);
-    {
-        const int nvec = chain_fp_blob_floats(KT) / 4;
-        const float4 *src = reinterpret_cast<const float4 *>(blob + (size_t)cb * chain_fp_blob_floats(KT));
-        float4 *dst = reinterpret_cast<float4 *>(chain_smem);
-        const int start = (int)(((long)(blockIdx.x % CHAIN_COUNTERS) * nvec) / CHAIN_COUNTERS);
-        for (int i0 = 0; i0 < nvec; i0 += 4 * THREADS) {
-            float4 v[4];
-            int idx[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * THREADS + tid;
-                idx[u] = i < nvec ? (i + start) % nvec : -1;
-                if (idx[u] >= 0) v[u] = src[idx[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (idx[u] >= 0) dst[idx[u]] = v[u];
-        }
-    }
-    if (!a.lin) {
-        float *wbs = chain_smem + chain_fp_blob_floats(KT), *b1s = wbs + 4 * 32 * KT;
-        for (int i = tid; i < 4 * 32 * KT; i += THREADS) wbs[i] = i < a.c1 * 32 * KT ? a.wb[i] : 0.f;
-        for (int i = tid; i < 32 * KT; i += THREADS) b1s[i] = a.b1 ? a.b1[i] : 0.f;
-    }
-    __syncthreads();
-    for (long tile = tk.take(); tile >= 0; tile = tk.take()) chain_fp_tile<KT>(a, chain_smem, tile, cb, h, c);
-}
-
 }  // namespace ws3d
 
 // 64 workgroups: the launch then runs its tiles at ~0.75 of the matrix pipes of the CUs it holds (256 workgroups: 0.45 -- most waves get
@@ -580,54 +405,3 @@ extern "C" int ws3d_chain_mlp3(const ws3d_compact_mlp_args *p0, const ws3d_compa
     return check_launch("ws3d_chain_mlp3");
 }
 
-extern "C" int ws3d_chain_fp_ticket_ints(int o_dim) { return o_dim > 0 ? ((o_dim + 127) / 128) * ws3d::CHAIN_TICKET_INTS : 0; }
-
-extern "C" size_t ws3d_chain_fp_blob_floats(int c, int o_dim) {
-    return (c == 128 || c == 256) && o_dim > 0 ? (size_t)((o_dim + 127) / 128) * ws3d::chain_fp_blob_floats(c / 32) : 0;
-}
-
-// The second layer's weights w2t (c, o_dim) + bias b2 in the order the lanes read them out of LDS, one block of 128 output columns after
-// the other: ws3d_chain_fp_blob_floats(c, o_dim) floats at `blob` (16-byte aligned).  Once per weight set.
-extern "C" int ws3d_chain_fp_pack(int c, int o_dim, const float *w2t, const float *b2, float *blob, ws3d_stream_t stream) {
-    using namespace ws3d;
-    if ((c != 128 && c != 256) || o_dim <= 0 || !w2t || !blob || (reinterpret_cast<uintptr_t>(blob) & 15)) {
-        set_error("ws3d_chain_fp_pack: unsupported shape (c=%d o=%d; c in {128, 256})", c, o_dim);
-        return WS3D_E_UNSUPPORTED;
-    }
-    hipLaunchKernelGGL(chain_fp_pack_kernel, dim3((unsigned)((o_dim + 127) / 128)), dim3(256), 0, as_stream(stream), c, o_dim, w2t, b2, blob);
-    return check_launch("ws3d_chain_fp_pack");
-}
-
-// ws3d_qinterp_gemm's function (both layers of a two-layer feature-propagation module) on the register-chained kernel: the same
-// arguments with the second layer's weights as ws3d_chain_fp_pack's blob; c in {128, 256}, any row count; ticket:
-// ws3d_chain_fp_ticket_ints(o_dim) int32, ZERO on entry.  workgroups: 0 = the library's choice (ws3d_tune key 3).
-extern "C" int ws3d_chain_fp(int b, int n, int m, int c, int o_dim, const float *q, const int32_t *idx, const float *weight, const float *lin,
-                             const float *skip, int c1, const float *wb, const float *b1, int relu1, const float *blob, int relu2, float *out,
-                             int32_t *ticket, int workgroups, ws3d_stream_t stream) {
-    using namespace ws3d;
-    const long rows = (long)b * n;
-    const uintptr_t al = reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(blob) | reinterpret_cast<uintptr_t>(lin) | reinterpret_cast<uintptr_t>(wb) |
-                         reinterpret_cast<uintptr_t>(b1);
-    if (b < 0 || n <= 0 || m <= 0 || (c != 128 && c != 256) || o_dim <= 0 || !q || !idx || !weight || !blob || !out || !ticket || (al & 15) ||
-        (!lin && (c1 < 0 || c1 > 4 || (c1 > 0 && (!skip || !wb))))) {
-        set_error("ws3d_chain_fp: unsupported shape (b=%d n=%d m=%d c=%d o=%d c1=%d; c in {128, 256}, lin or c1 <= 4)", b, n, m, c, o_dim, c1);
-        return WS3D_E_UNSUPPORTED;
-    }
-    if (rows == 0) return WS3D_OK;
-    const int ncb = (o_dim + 127) / 128, kt = c / 32;
-    const ChainFp a{q, weight, lin, lin ? nullptr : skip, wb, b1, idx, out, rows, n, m, lin ? 0 : c1, relu1, relu2, o_dim};
-    const size_t lds = sizeof(float) * ((size_t)chain_fp_blob_floats(kt) + 5 * (size_t)c);
-    const long tiles = (rows + 31) / 32;
-    long wgs = workgroups > 0 ? workgroups : (g_tune[TUNE_FP_WGS] > 0 ? g_tune[TUNE_FP_WGS] : 128);
-    hipStream_t st = as_stream(stream);
-    if (kt == 4) {
-        wgs = std::max((long)ncb, std::min(wgs, (tiles * ncb + 11) / 12) / ncb * ncb);
-        if (int rc = raise_lds_cap((const void *)chain_fp_kernel<4>, lds, "ws3d_chain_fp")) return rc;
-        hipLaunchKernelGGL(chain_fp_kernel<4>, dim3((unsigned)wgs), dim3(768), lds, st, a, blob, ncb, ticket);
-    } else {
-        wgs = std::max((long)ncb, std::min(wgs, (tiles * ncb + 7) / 8) / ncb * ncb);
-        if (int rc = raise_lds_cap((const void *)chain_fp_kernel<8>, lds, "ws3d_chain_fp")) return rc;
-        hipLaunchKernelGGL(chain_fp_kernel<8>, dim3((unsigned)wgs), dim3(512), lds, st, a, blob, ncb, ticket);
-    }
-    return check_launch("ws3d_chain_fp");
-}

@@ -95,7 +95,6 @@ PAIR_DISPATCH = "device"
 PRIMED_MARGIN = 0.85       # Stage1Pipeline(pair_dispatch="primed"): scales whose priming fill <= PRIMED_MARGIN * COMPACT_MAX_FILL lose the dense twin
 _COMPACT_ONLY = contextvars.ContextVar("ws3d_compact_only_scales", default=frozenset())
 CHAIN_MLP = True       # SA2 (o1 = 64, o2 <= 96, o3 = 128): the whole SharedMLP of the level's two scales on the register-chained kernel (ws3d_chain_mlp3, round 6: activations in registers, weights resident in LDS, ticketed 32-row tiles) instead of ws3d_compact_mlp_pair(3); bit-identical
-CHAIN_FP = True        # two-layer FP modules (FP0, FP1 at batch 8): ws3d_chain_fp (round 6, register-chained, weights resident in LDS, ticketed tiles) instead of ws3d_qinterp_gemm; bit-identical
 PAIRED_SCALES = True   # the compact SharedMLP kernels of a level's two scales in ONE launch each (ws3d_compact_mlp_pair) where neither scale carries a gated dense twin (Stage1Pipeline's primed graphs, PAIR_DISPATCH "compact")
 MERGED_THREE_NN = True   # serial order: the 3-NN searches of the FP modules whose known set is binned in ONE launch behind that binning launch (ws3d_three_nn_jobs)
 FUSED_PROLOGUE = True   # the coordinate / feature split of the input rows and the clear of the pass's zero arena in ONE launch (ws3d_split_points_clear) instead of two strided copies + a fill
@@ -267,8 +266,6 @@ def _arena_for(net, B: int, device, extra: int = 0, clear: bool = True) -> _Zero
             n += 4 * len(sa.groupers)
         if CHAIN_MLP:
             n += _C.chain_ticket_ints() + 4          # the ticket counters of ws3d_chain_mlp3 (SA2)
-    if CHAIN_FP:
-        n += sum(_C.chain_fp_ticket_ints(_blocks(fp.mlp)[-1].conv.out_channels) + 4 for fp in net.FP_modules if len(_blocks(fp.mlp)) == 2)
     return _ZeroArena(n, device, clear)
 
 
@@ -647,7 +644,7 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
 
 
 def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, known_feats: torch.Tensor, nn3=None, sorted_unknown=None,
-               known_xz=None, zeros: _ZeroArena = None):
+               known_xz=None):
     """unknown (B,n,3), known (B,m,3), unknown_feats (B,n,C1) or None, known_feats (B,m,C2) -> (B,n,O); sorted_unknown: a binned
     copy of `unknown` (the level's ball-query copy) for the 3-NN's query order; known_xz: (sort_points_xz(known),) when the caller
     has it already"""
@@ -669,22 +666,15 @@ def fp_forward(fp, unknown: torch.Tensor, known: torch.Tensor, unknown_feats, kn
         fuse2 = len(blocks) == 2 and B * n >= FUSED_QINTERP_GEMM_MIN_ROWS
         if fuse2:
             wt2, b2, r2 = _row_weights(blocks[1])
-        chain = fuse2 and CHAIN_FP and zeros is not None and q.size(2) in (128, 256)
-
-        def both_layers(**kw):
-            """the module's two layers in one kernel: the register-chained one where it covers the shape, else ws3d_qinterp_gemm"""
-            y_ = _C.chain_fp(q, idx, weight, wt2, b2, r2, zeros.take((_C.chain_fp_ticket_ints(wt2.size(1)),), torch.int32), relu=r1, **kw) if chain else None
-            return y_ if y_ is not None else _C.qinterp_gemm(q, idx, weight, wt2, b2, r2, relu=r1, **kw)
-
         if c1 > 4:
             lin = torch.mm(unknown_feats.reshape(B * n, c1), wb) if b1 is None else torch.addmm(b1, unknown_feats.reshape(B * n, c1), wb)
-            y = both_layers(lin=lin) if fuse2 else None
+            y = _C.qinterp_gemm(q, idx, weight, wt2, b2, r2, lin=lin, relu=r1) if fuse2 else None
             if y is not None:
                 return y.view(B, n, -1)
             y = _C.qinterp_rows(q, idx, weight, lin=lin, relu=r1)
         else:
             sk = None if c1 == 0 else unknown_feats.contiguous()
-            y = both_layers(skip=sk, wb=wb if c1 else None, bias=b1) if fuse2 else None
+            y = _C.qinterp_gemm(q, idx, weight, wt2, b2, r2, skip=sk, wb=wb if c1 else None, bias=b1, relu=r1) if fuse2 else None
             if y is not None:
                 return y.view(B, n, -1)
             y = _C.qinterp_rows(q, idx, weight, skip=sk, wb=wb if c1 else None, bias=b1, relu=r1)
@@ -762,7 +752,7 @@ def backbone_forward(net, pointcloud: torch.Tensor, zeros: _ZeroArena = None):
                 nn3 = geo.nn[lvl]
             known_level = len(l_xyz) + i
             l_feats[i - 1] = fp_forward(net.FP_modules[i], l_xyz[i - 1], l_xyz[i], l_feats[i - 1], l_feats[i], nn3, binned[len(l_xyz) + i - 1],
-                                        (pre_xz[known_level],) if known_level in pre_xz else None, zeros)
+                                        (pre_xz[known_level],) if known_level in pre_xz else None)
     finally:
         if geo is not None:       # also when a layer raised: the side streams' tensors go back to their pools behind the caller's stream
             geo.release()
