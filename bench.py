@@ -261,6 +261,14 @@ def compact_line(out, detail_path):
         line["latency_ms_" + og["generator"]] = og.get("latency_ms_per_batch")
     if "value_all_rows" in out:
         line["value_all_rows"] = out["value_all_rows"]
+    if "value_reference_layout" in out:       # CHANNELS_LAST_FASTPATH = False, eager, one batch in flight (beside latency_scenes_per_s)
+        line["value_reference_layout"] = out["value_reference_layout"]
+    if "ops_hbm_frac" in out:
+        line["ops_hbm_frac"] = out["ops_hbm_frac"]
+    if "value_steady" in out:                 # 160 more steps of the same replay loop, outside the contract's timed region
+        line["value_steady"] = out["value_steady"]
+    if isinstance(out.get("step_ms_percentiles"), dict):
+        line["step_ms_percentiles"] = out["step_ms_percentiles"]
     if c2:
         line["c2_batch"], line["c2_scenes_per_s"] = c2["batch_per_gpu"], c2["scenes_per_s_per_gpu"]
         for k in c2["kernels"]:
@@ -315,7 +323,7 @@ def c3_side_runs(wl, args, value, latency):
             w.step()
         if not w.capture():
             return None
-        for _ in range(2):
+        for _ in range(max(2, w.depth)):
             w.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -333,6 +341,32 @@ def c3_side_runs(wl, args, value, latency):
                                  "SharedMLP of a scale runs over the distinct pairs iff its fill <= %.2f, decided on the device per batch (in the "
                                  "graphs: only where the priming batch's fill is above %.2f of that)" % (fastpath.COMPACT_MAX_FILL, fastpath.PRIMED_MARGIN)}}
     wl.release()
+    # (c) what a drop-in caller of the reference layout gets: stage1.CHANNELS_LAST_FASTPATH = False -- the
+    # network's modules as the reference composes them (pointnet2_modules.py:19-55,116-156 on (B, C, N) tensors: QueryAndGroup's
+    # ball_query -> group -> sub -> group -> cat through the operators' API names, Conv2d SharedMLPs on the library, max_pool), the
+    # same proposal stage and roipool3d behind it; eager launches, one batch in flight, median of 20 batches
+    from ws3d_amd import stage1
+    try:
+        stage1.CHANNELS_LAST_FASTPATH = False
+        w0 = C3(wl.B, wl.rank, 1, wl.kind, depth=1, model=wl.model)
+        for _ in range(3):
+            w0.step(eager=True)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            w0.step(eager=True)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts))
+        out["reference_layout"] = {"value": w0.scenes() / med, "unit": "scenes/s", "ms_per_batch": med * 1e3, "batches_in_flight": 1, "batches_timed": 20,
+                                   "what": "stage1.CHANNELS_LAST_FASTPATH = False: the reference's module composition on (B, C, N) tensors through "
+                                           "the API-named operators; eager, one batch in flight (compare with latency_ms, not with value)"}
+        out["value_reference_layout"] = out["reference_layout"]["value"]
+    except Exception as e:      # a diagnostic figure: never a reason to lose the line
+        out["reference_layout"] = {"error": repr(e)}
+    finally:
+        stage1.CHANNELS_LAST_FASTPATH = True
     saved = fastpath.COMPACT_PAIRS
     try:
         fastpath.COMPACT_PAIRS = False
@@ -364,7 +398,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps; default 80 for c3 (four rounds over the 20 slots: the fill and the drain of the pipeline are inside the timed region), 40 otherwise")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5", "s2", "t1"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5", "s2", "t1", "ops"],
                     help="c3 (default) = BASELINE.json's headline: Stage-1 RPN forward + NMS + roipool3d, batch 8/GPU, with the c2 block")
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (c3/c5 default 8, c2 default 512, s2 default 800)")
     ap.add_argument("--c2-batch", type=int, default=512, help="c3: scenes per launch of the embedded c2 block (0 = skip it)")
@@ -403,6 +437,9 @@ def main():
     elif args.workload == "t1":
         from bench_t1 import T1
         wl = T1(args.batch or 8, rank, world, args.kind, prefetch=not args.no_prefetch)
+    elif args.workload == "ops":
+        from bench_ops import OPS
+        wl = OPS(args.batch or 8, rank, args.kind)
     else:
         wl = C2(args.batch or 512, rank, args.kind)
 
@@ -410,7 +447,9 @@ def main():
         wl.step()
     use_graph = hasattr(wl, "capture") and not args.no_graph and wl.capture()
     if use_graph:
-        for _ in range(2):
+        # every slot's graph replayed once, untimed, before the clock starts: the timed region then begins
+        # with all `depth` batches' buffers, code objects and library workspaces touched -- steady state from its first step on
+        for _ in range(max(2, getattr(wl, "depth", 2))):
             wl.step()
     barrier_sync(world)
     t0 = time.perf_counter()
@@ -432,10 +471,21 @@ def main():
         latency = {"batches_in_flight": 1, "ms_per_batch": lat_ms, "value": wl.scenes() * world / (lat_ms * 1e-3),
                    "unit": getattr(wl, "unit", "scenes/s"), "batches_timed": 20, "statistic": "median",
                    "launch": min(lat_detail, key=lat_detail.get)[:-3], "rank0_ms_by_launch": lat_detail}
+    steady = None
+    if use_graph and args.workload == "c3" and args.steps >= 20 and not args.no_side_runs:
+        # the same replay loop once more over 160 steps (eight rounds over the slots), OUTSIDE the contract's timed region: the
+        # driver's flags time one pipeline fill (20 steps at depth 20); this says what the loop sustains
+        barrier_sync(world)
+        t1 = time.perf_counter()
+        for _ in range(160):
+            wl.step()
+        barrier_sync(world)
+        dt1 = max_over_ranks(time.perf_counter() - t1, world)
+        steady = {"value": wl.scenes() * world * 160 / dt1, "ms_per_step": dt1 / 160 * 1e3, "steps": 160}
     if use_graph:
-        # per-kernel HIP-event table from a few EAGER steps (events cannot be recorded inside a graph);
-        # `value` above is the graph-replay throughput
-        for _ in range(min(args.steps, 5)):
+        # per-kernel HIP-event table from EAGER steps (events cannot be recorded inside a graph): >= 50 of them at the driver's flags
+        # (median + p10 / p90 over >= 50 iterations); `value` above is the graph-replay throughput
+        for _ in range(50 if args.steps >= 20 else min(args.steps, 5)):
             wl.step(timed=True)
         torch.cuda.synchronize()
     if os.environ.get("WS3D_BENCH_DUMP") and hasattr(wl, "dump"):
@@ -468,6 +518,9 @@ def main():
                                                   "exchange, tests/test_bench_contract.py) and by RCCL at world size 1"},
                            **wl.config()),  # (c5 overrides n_points)
         }
+        if steady is not None:
+            out["steady_state"] = steady
+            out["value_steady"] = steady["value"]
         if latency is not None:
             out["throughput_mode"] = {"batches_in_flight": getattr(wl, "depth", 1), "ms_per_batch": ms_per_step, "value": value,
                                       "unit": out["unit"]}
@@ -478,6 +531,10 @@ def main():
             c2dom = max(c2blk["kernels"], key=lambda k: k["ms_per_step"])
             c2blk["roofline"] = roofline_of(c2dom, "c2 block of this run (batch %d per launch)" % c2blk["batch_per_gpu"])
             out["c2"] = c2blk
+        if args.workload == "ops":
+            # the copy operator FURTHEST from its HBM roof: SURVEY 8(d) applies the 40 % target to each of them literally
+            dom = min((k for k in kernels if k.get("bound") == "hbm"), key=lambda k: k["frac_of_8TBps"])
+            out["ops_hbm_frac"] = {k["name"].split(" ")[0]: k["frac_of_8TBps"] for k in kernels if k.get("bound") == "hbm"}
         if args.workload != "c3":
             out["roofline"] = roofline_of(dom, "the timed region of this line (HIP events on the launch stream)")
         out.update(side)

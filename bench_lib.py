@@ -459,6 +459,8 @@ _CSRC = "ws3d_amd/csrc/"
 TRAFFIC_SOURCES = {
     "traffic.json": tuple(_CSRC + f for f in ("fps_bucket.hip", "ballquery_group.hip", "bin_kernels.h", "binning.h", "common.h")),
     "traffic_c5.json": tuple(_CSRC + f for f in ("roipool3d.hip", "iou3d.hip", "common.h")),
+    "traffic_ops.json": tuple(_CSRC + f for f in ("ballquery_group.hip", "interpolate.hip", "fps.hip", "common.h")),
+    "traffic_ops256.json": tuple(_CSRC + f for f in ("ballquery_group.hip", "interpolate.hip", "fps.hip", "common.h")),
     "traffic_c3.json": None,          # all of csrc/*.hip, csrc/*.h + ws3d_amd/fastpath.py (resolved in traffic_source_blobs)
 }
 

@@ -51,7 +51,9 @@ from ws3d_amd.stage1 import synthetic_orientation  # noqa: E402
 B, N, PRE, POST, THRESH, EXTRA, S = 8, 16384, 9000, 100, 0.8, 1.0, 512
 
 
-def main():
+def main(kind="hdl64"):
+    """kind: the scene generator -- "hdl64" (bench.py's default line) -> headline_c3.*, "lidar" (the line's value_lidar) -> headline_c3_lidar.*"""
+    stem = "headline_c3" if kind == "hdl64" else "headline_c3_" + kind
     install_reference_shims()
     oracle.set_threads(min(oracle.max_threads(), len(os.sched_getaffinity(0))))
     from pointnet2_lib.pointnet2 import pointnet2_utils as ref_utils
@@ -67,7 +69,7 @@ def main():
 
     model = PointRCNN(num_classes=2, use_xyz=True, mode='TEST').eval()
     model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
-    pc = synth.make_batch("hdl64", B, N, 3)                      # = bench_c3.C3(...).pc_host on rank 0, slot 0
+    pc = synth.make_batch(kind, B, N, 3)                      # = bench_c3.C3(...).pc_host on rank 0, slot 0
     pts = torch.from_numpy(pc)
     taps = {"fps": [], "bq": []}
 
@@ -89,7 +91,7 @@ def main():
     with torch.no_grad():
         out = model.rpn_forward({'pts_input': pts})
     fx = {}
-    meta = {"generator": "tests/golden/make_golden_headline.py", "kind": "hdl64", "config_id": 3, "batch": B, "n": N, "weights_seed": 7,
+    meta = {"generator": "tests/golden/make_golden_headline.py", "kind": kind, "config_id": 3, "batch": B, "n": N, "weights_seed": 7,
             "pre_nms": PRE, "nms_thresh": THRESH, "post_nms": POST, "extra_width": EXTRA, "sampled": S,
             "oracle_dist_mode": oracle.dist_mode(), "ball_query_sha256": taps["bq"], "fps_sha256": [], "outputs": {}}
     for lvl, a in enumerate(taps["fps"]):
@@ -182,13 +184,13 @@ def main():
     fx["pool_feat_val"] = np.take_along_axis(pooled[..., 3:].reshape(B, POST, -1), fpos, axis=2)
     meta["kept_total"] = int(count.sum())
     meta["non_empty_rois"] = int((empty[np.arange(POST)[None, :] < count[:, None]] == 0).sum())
-    np.savez_compressed(os.path.join(HERE, "headline_c3.npz"), **fx)
-    json.dump(meta, open(os.path.join(HERE, "headline_c3.json"), "w"), indent=1)
-    for f in ("headline_c3.npz", "headline_c3.json"):
+    np.savez_compressed(os.path.join(HERE, stem + ".npz"), **fx)
+    json.dump(meta, open(os.path.join(HERE, stem + ".json"), "w"), indent=1)
+    for f in (stem + ".npz", stem + ".json"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
     print("count", count.tolist(), "non-empty", meta["non_empty_rois"], "min score_gap", float(score_gap[kept_idx >= 0].min()),
           "min iou_margin", float(iou_margin[kept_idx >= 0].min()))
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1] if len(sys.argv) > 1 else "hdl64")

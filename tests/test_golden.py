@@ -310,22 +310,25 @@ def _recover_indices(rows, table):
 
 
 @pytest.mark.gpu
-def test_gpu_headline_c3_matches_the_reference_end_to_end():
-    """BASELINE configs[2] on the very batch bench.py times (8 `hdl64` scenes, seeds 3000..3007, weights seed 7), against the fixture
+@pytest.mark.parametrize("stem,min_pooled", [("headline_c3", 550), ("headline_c3_lidar", 300)])
+def test_gpu_headline_c3_matches_the_reference_end_to_end(stem, min_pooled):
+    """BASELINE configs[2] on the very batch bench.py times (8 `hdl64` scenes, seeds 3000..3007, weights seed 7; round 6: also the 8
+    `lidar` scenes behind the line's value_lidar, fixture headline_c3_lidar.*), against the fixture
     the REFERENCE's Python produced for it (tests/golden/make_golden_headline.py: PointRCNN.rpn_forward -> decode_center_target ->
     iou3d_utils.nms_gpu at 9000 / 0.8 / 100 -> roipool3d_utils.roipool3d_gpu, the pooling also through the reference's compiled C++):
       * the eager fast path: all 4 x 8 FPS index tensors and the 8 ball-query tensors exact, the four network outputs within 1e-4;
       * ``Stage1Pipeline`` (hipGraph, 20 slots, roipool on) on the same batch: its proposals are exactly what the ORACLE's NMS keeps on
         the pipeline's own scores and boxes, and they are the reference's proposals wherever the reference's decision has a margin a
         float32 pass with another summation order cannot cross (score gap to every overlapping candidate > 5e-4, IoU margin > 5e-3);
-        overall >= 90 % of the reference's kept point indices are kept (measured: see the assertion message on failure);
+        overall >= 99 % of the reference's kept point indices are kept and >= 99 % sit at the SAME RANK (measured 800 / 800 on hdl64
+        since round 5, 800 / 800 kept and 796 at the same rank on lidar: the assertion message says what a failing run found);
       * RoI pooling: for every proposal both sides keep whose enlarged box has no scene point within 2e-3 of a face, the pooled point
         INDICES (first 512 in-box points in index order, wrapped) are exact and the sampled features agree within 1e-4."""
     import oracle
     from ws3d_amd import compat, kitti_utils, stage1
     from ws3d_amd.pipeline import Stage1Pipeline
-    meta_h = json.load(open(os.path.join(G, "headline_c3.json")))
-    gold = np.load(os.path.join(G, "headline_c3.npz"))
+    meta_h = json.load(open(os.path.join(G, stem + ".json")))
+    gold = np.load(os.path.join(G, stem + ".npz"))
     B, N, K, S = meta_h["batch"], meta_h["n"], meta_h["post_nms"], meta_h["sampled"]
     cfg = stage1.DEFAULT_CFG
     assert (cfg.rpn_pre_nms_top_n, cfg.rpn_nms_thresh, cfg.rpn_post_nms_top_n, cfg.roi_extra_width, cfg.roi_sampled_pts) == \
@@ -388,8 +391,11 @@ def test_gpu_headline_c3_matches_the_reference_end_to_end():
     msg = "kept point indices: %d / %d of the reference's are kept (%d at the same rank); robust decisions %d, of them kept %d" % (
         int(in_got[ref_idx >= 0].sum()), int((ref_idx >= 0).sum()), int(same_rank[ref_idx >= 0].sum()), int(robust.sum()), int(in_got[robust].sum()))
     print(msg)
+    # every robust decision is reproduced; >= 99 % of ALL the reference's proposals are kept, >= 99 % at the very rank (a proposal's rank
+    # also depends on the order of two near-tied neighbours above it, so "same rank" is asserted as a share: measured 800 / 800 on hdl64,
+    # 796 / 800 on lidar, where 7 pairs of kept proposals have scores within 5e-4 of each other)
     assert in_got[robust].all(), msg
-    assert in_got[ref_idx >= 0].mean() >= 0.90, msg
+    assert in_got[ref_idx >= 0].mean() >= 0.99 and same_rank[ref_idx >= 0].mean() >= 0.99, msg
 
     # ---- 3. RoI pooling of the proposals both sides keep at the same rank
     feats = rpn["backbone_features"].transpose(1, 2)
@@ -409,7 +415,7 @@ def test_gpu_headline_c3_matches_the_reference_end_to_end():
             np.testing.assert_allclose(pooled[b, j, :, 3:].reshape(-1)[fpos], gold["pool_feat_val"][b, j], atol=1e-4, rtol=1e-4)
             checked += 1
     print("RoIs compared with the reference's pooled tensors:", checked)
-    assert checked >= 400, checked
+    assert checked >= min_pooled, checked
 
 
 # ------------------------------------------------------------------------------- BASELINE configs[0] ("C1")
