@@ -2712,3 +2712,16 @@ def test_proposal_stage_writes_the_send_rows_of_the_exchange(ops):
     assert torch.equal(got, packed) and torch.equal(cnt, count.to(torch.float32)) and ex.collectives == 0
     with pytest.raises(ValueError, match="send buffer"):
         stage1.proposals_from_rpn(out, cfg, with_packed=torch.zeros((B, K * 8), device="cuda"))
+
+
+@pytest.mark.parametrize("B,C,N,M,ns", [(2, 96, 4096, 1024, 16), (3, 99, 4096, 1024, 32), (2, 7, 1024, 600, 12), (1, 4, 512, 300, 4), (2, 96, 8192, 1024, 32), (1, 5, 100, 64, 16)])
+def test_group_points_with_the_rows_staged_in_lds(ops, B, C, N, M, ns):
+    """group_points_wrapper (group_points_gpu.cu:47-66): the round-6 kernel that stages a channel group's source rows in LDS (n <= 4096,
+    plane >= 2 n, c >= 4) and the gather kernel it replaces there (other shapes) are exact copies: compared with torch's own indexing"""
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C)
+    pts = torch.randn((B, C, N), device="cuda", generator=g)
+    idx = torch.randint(0, N, (B, M, ns), device="cuda", generator=g, dtype=torch.int32)
+    out = torch.full((B, C, M, ns), float("nan"), device="cuda")
+    ops.c.group_points_wrapper(B, C, N, M, ns, pts, idx, out)
+    want = torch.gather(pts, 2, idx.long().view(B, 1, M * ns).expand(B, C, M * ns)).view(B, C, M, ns)
+    assert torch.equal(out, want)

@@ -1131,6 +1131,40 @@ __global__ __launch_bounds__(256) void group_points_vec4_kernel(int c, int n, in
     }
 }
 
+// The channel rows of the gather staged in LDS (round 6): the kernel above fetches every output word with a 4-byte gather out of
+// L1 / L2 -- about one lane per clock and CU, 2.6 TB/s of output whatever the batch (bench.py --workload ops: 0.32-0.34 of 8 TB/s at SA2's
+// 96 channels x 1024 x 48) -- while the source of a channel group is only GRL_CCH x n floats.  Here a workgroup copies its GRL_CCH
+// channel rows of ONE scene into LDS with coalesced 16-byte loads (64 KB at n = 4096) and then walks the whole (m, s) plane: one
+// 16-byte index load per lane and trip, four LDS reads and one 16-byte store per channel.  grid (channel groups, scenes).
+constexpr int GRL_CCH = 4, GRL_THREADS = 1024;
+__global__ __launch_bounds__(GRL_THREADS) void group_points_lds_kernel(int c, int n, int plane, const float *__restrict__ points,
+                                                                       const int32_t *__restrict__ idx, float *__restrict__ out, int stream) {
+    extern __shared__ __attribute__((aligned(16))) float grl_rows[];          // [cc][n]
+    const int b = blockIdx.y, c0 = blockIdx.x * GRL_CCH, tid = threadIdx.x;
+    const int cc = min(GRL_CCH, c - c0);
+    const float *src = points + ((size_t)b * c + c0) * n;
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        for (int i = tid; i < cc * n / 4; i += GRL_THREADS) reinterpret_cast<float4 *>(grl_rows)[i] = reinterpret_cast<const float4 *>(src)[i];
+    } else {
+        for (int i = tid; i < cc * n; i += GRL_THREADS) grl_rows[i] = src[i];
+    }
+    __syncthreads();
+    const int32_t *ib = idx + (size_t)b * plane;
+    float *dst = out + ((size_t)b * c + c0) * plane;
+    for (int e = tid * 4; e < plane; e += GRL_THREADS * 4) {
+        const int4 id = *reinterpret_cast<const int4 *>(ib + e);
+        float4 v[GRL_CCH];
+#pragma unroll
+        for (int u = 0; u < GRL_CCH; ++u) {
+            const float *f = grl_rows + (u < cc ? u : 0) * n;
+            v[u] = make_float4(f[id.x], f[id.y], f[id.z], f[id.w]);
+        }
+#pragma unroll
+        for (int u = 0; u < GRL_CCH; ++u)
+            if (u < cc) st4(dst + (size_t)u * plane + e, v[u], stream);
+    }
+}
+
 __global__ __launch_bounds__(256) void group_points_grad_kernel(int c, int n, int plane,
                                                                 const float *__restrict__ grad_out,
                                                                 const int32_t *__restrict__ idx,
@@ -1161,6 +1195,14 @@ static int group_launch(bool grad, int b, int c, int n, int npoints, int nsample
     dim3 grid((unsigned)((plane + 255) / 256), (c + GRP_CCH - 1) / GRP_CCH, b);
     if (!grad && (plane & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(idx)) & 15) == 0) {
         const int stream = (size_t)b * c * plane * sizeof(float) > STREAM_STORE_BYTES;
+        // LDS-staged rows where a channel group's source fits (<= 64 KB: n <= 4096) and the plane is long enough to pay for the staging
+        // (every output word needs its index in range: the reference's kernel does not check either, group_points_gpu.cu:47-66)
+        static const bool no_lds = getenv("WS3D_GROUP_NO_LDS") != nullptr;
+        if (!no_lds && c >= GRL_CCH && (size_t)n * GRL_CCH * sizeof(float) <= 64 * 1024 && plane >= 2L * n) {
+            const size_t lds = (size_t)n * GRL_CCH * sizeof(float);
+            hipLaunchKernelGGL(group_points_lds_kernel, dim3((c + GRL_CCH - 1) / GRL_CCH, b), dim3(GRL_THREADS), lds, st, c, n, (int)plane, src, idx, dst, stream);
+            return check_launch(what);
+        }
         grid.x = (unsigned)((plane / 4 + 255) / 256);
         hipLaunchKernelGGL(group_points_vec4_kernel, grid, dim3(256), 0, st, c, n, (int)plane, src, idx, dst, stream);
         return check_launch(what);

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <cmath>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "binning.h"
 #include "bin_kernels.h"
@@ -343,8 +345,8 @@ __global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(int c, int 
 // global gathers run at a fraction of the store bandwidth).  One workgroup = CH rows x all n points
 // (4 consecutive points per lane and trip): rows staged once with 16-byte loads, every output
 // written with 16-byte stores.  Same fmaf expression as the scalar kernel.
-template <int CH>
-__global__ __launch_bounds__(512) void three_interpolate_lds_kernel(int c, int m, int n,
+template <int CH, int NT = 512>
+__global__ __launch_bounds__(NT) void three_interpolate_lds_kernel(int c, int m, int n,
                                                                     const float *__restrict__ points,
                                                                     const int32_t *__restrict__ idx,
                                                                     const float *__restrict__ weight,
@@ -357,14 +359,14 @@ __global__ __launch_bounds__(512) void three_interpolate_lds_kernel(int c, int m
     const float *p = points + ((size_t)b * c + c0) * m;
     const int tot = cc * m;   // the cc rows are contiguous in global memory
     if ((m & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-        for (int i = threadIdx.x; i < tot / 4; i += 512) reinterpret_cast<float4 *>(rows)[i] = reinterpret_cast<const float4 *>(p)[i];
+        for (int i = threadIdx.x; i < tot / 4; i += NT) reinterpret_cast<float4 *>(rows)[i] = reinterpret_cast<const float4 *>(p)[i];
     } else {
-        for (int i = threadIdx.x; i < tot; i += 512) rows[i] = p[i];
+        for (int i = threadIdx.x; i < tot; i += NT) rows[i] = p[i];
     }
     __syncthreads();
     const int per_x = (n / 4 + (int)gridDim.x - 1) / (int)gridDim.x;   // groups of 4 points per x-slice
     const int g_lo = blockIdx.x * per_x, g_hi = min(n / 4, g_lo + per_x);
-    for (int g = g_lo + threadIdx.x; g < g_hi; g += 512) {
+    for (int g = g_lo + threadIdx.x; g < g_hi; g += NT) {
         const int pi = 4 * g;
         int id[12];
         float w[12];
@@ -856,7 +858,19 @@ extern "C" int ws3d_three_interpolate(int b, int c, int m, int n, const float *p
     }
     if (b == 0 || c == 0 || n == 0) return WS3D_OK;
     const uintptr_t al = reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(out);
-    if ((n & 3) == 0 && (al & 15) == 0 && (size_t)m * 4 * 4 <= 64 * 1024 && n >= 1024) {
+    static const bool wide_ok = getenv("WS3D_TI_NO_WIDE") == nullptr;
+    if (wide_ok && (n & 3) == 0 && (al & 15) == 0 && c >= 16 && (size_t)m * 8 * 4 <= 128 * 1024 && n >= 4096) {
+        // round 6: 8 rows per workgroup of 16 waves -- the 6 x 16 bytes of indices and weights a lane reads per trip are shared by 8
+        // channels instead of 4 (they are re-read by every channel group: at 4 channels that stream is 1.5 x the output), the rows are
+        // staged once per scene and group unless the launch would leave CUs empty
+        constexpr int CH = 8;
+        const int rows_wg = (c + CH - 1) / CH;
+        int gx = 1;
+        while ((long)gx * rows_wg * b < 256 && (n / 4) / (gx * 2) >= 1024) gx *= 2;
+        const size_t lds = (size_t)CH * m * sizeof(float);
+        if (int rc = raise_lds_cap((const void *)three_interpolate_lds_kernel<CH, 1024>, lds, "ws3d_three_interpolate")) return rc;
+        hipLaunchKernelGGL((three_interpolate_lds_kernel<CH, 1024>), dim3(gx, rows_wg, b), dim3(1024), lds, as_stream(stream), c, m, n, points, idx, weight, out);
+    } else if ((n & 3) == 0 && (al & 15) == 0 && (size_t)m * 4 * 4 <= 64 * 1024 && n >= 1024) {
         // rows in LDS: 4 channels per workgroup; split n over x only as far as needed to fill the chip
         constexpr int CH = 4;
         const int rows_wg = (c + CH - 1) / CH;
