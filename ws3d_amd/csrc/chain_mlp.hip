@@ -310,11 +310,6 @@ __global__ __launch_bounds__(CHAIN_THREADS) void chain_mlp3_pair_kernel(const Ch
 
 }  // namespace ws3d
 
-// 64 workgroups: the launch then runs its tiles at ~0.75 of the matrix pipes of the CUs it holds (256 workgroups: 0.45 -- most waves get
-// one tile and the second round runs nearly empty) and leaves three quarters of the chip to the other batches in flight: +2-3 % on the
-// 20-deep c3 step against one workgroup per CU, which is 2.5 x faster in isolation (profiles/r06_chain_mlp3_workgroups.txt)
-constexpr long CHAIN_DEFAULT_WGS = 64;
-
 static int chain_cu_count() {
     static int cus[64] = {0};
     int dev = 0;
@@ -361,7 +356,7 @@ extern "C" int ws3d_chain_mlp3_pack(const ws3d_compact_mlp_args *scale, float *b
 // The whole SharedMLP (three layers + pool) of one or two ball-query scales of a set-abstraction level over their compact rows:
 // the argument blocks of ws3d_compact_mlp_pair / ws3d_pgather_gemm3_compact (o1 = 64, o2 <= 96, o3 = 128: SA2 of the Stage-1 network),
 // scale1 may be NULL; blob0 / blob1 = ws3d_chain_mlp3_pack of the scales' weights.  ticket: ws3d_chain_mlp3_ticket_ints() int32, ZERO on entry; workgroups = 0
-// picks one per CU.
+// picks ws3d_tune key 0, else one per CU (a caller with many batches in flight asks for fewer: ws3d_amd/pipeline.py).
 extern "C" int ws3d_chain_mlp3(const ws3d_compact_mlp_args *p0, const ws3d_compact_mlp_args *p1, const float *blob0, const float *blob1, int32_t *ticket,
                                int workgroups, ws3d_stream_t stream) {
     using namespace ws3d;
@@ -381,7 +376,7 @@ extern "C" int ws3d_chain_mlp3(const ws3d_compact_mlp_args *p0, const ws3d_compa
     }
     if (nscales == 1) { a[1] = a[0]; blob1 = blob0; }
     if (lds > 160 * 1024) { set_error("ws3d_chain_mlp3: %zu B of LDS", lds); return WS3D_E_UNSUPPORTED; }
-    long wgs = workgroups > 0 ? workgroups : (g_tune[TUNE_CHAIN_WGS] > 0 ? g_tune[TUNE_CHAIN_WGS] : CHAIN_DEFAULT_WGS);
+    long wgs = workgroups > 0 ? workgroups : (g_tune[TUNE_CHAIN_WGS] > 0 ? g_tune[TUNE_CHAIN_WGS] : chain_cu_count());
     wgs = std::max(1L, std::min(wgs, (max_tiles + CHAIN_THREADS / 64 - 1) / (CHAIN_THREADS / 64)));
     hipStream_t st = as_stream(stream);
 #define WS3D_CHAIN_GO(JA, JB)                                                                                                       \

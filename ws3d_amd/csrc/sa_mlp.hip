@@ -573,9 +573,9 @@ extern "C" int ws3d_sa_mlp3_pool_compact(int b, int n, int m, long max_rows, int
         return WS3D_E_INVALID;
     }
     const long tiles = (max_rows + 31) / 32;
-    // 192 workgroups (768 waves walking the tiles): +2 % on the 20-deep c3 step against 768 -- the kernel then leaves most of the chip
-    // to the other batches in flight (profiles/r06_tune_workgroups.txt); ws3d_tune key 2
-    const long cap1 = g_tune[TUNE_SA1_WGS] > 0 ? g_tune[TUNE_SA1_WGS] : 192;
+    // 3 workgroups per CU, waves walk over tiles; ws3d_tune key 2 (a caller with many batches in flight asks for 192: +2 % on the
+    // 20-deep c3 step, profiles/r06_tune_workgroups.txt -- ws3d_amd/pipeline.py)
+    const long cap1 = g_tune[TUNE_SA1_WGS] > 0 ? g_tune[TUNE_SA1_WGS] : 768;
     const unsigned grid = (unsigned)(tiles / 4 < cap1 ? (tiles + 3) / 4 : cap1);
 #define WS3D_SA_COMPACT(A, B, C)                                                                                                        \
     if (c1 == A && c2 == B && c3 == C) {                                                                                                \

@@ -54,6 +54,34 @@ def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
     return pooled_stream(device, j)
 
 
+# Launch geometry of the persistent kernels while a pipeline with several batches in flight captures its graphs (ws3d_tune): a launch that
+# holds a quarter of the chip at ~0.75 of its matrix pipes and leaves the rest to the other batches beats one that holds all of it at
+# ~0.45 -- measured on the 20-deep c3 step: ws3d_chain_mlp3 64 workgroups +3-4 % against 256, ws3d_sa_mlp3_pool_compact 192 +2 % against 768
+# (profiles/r06_chain_mlp3_workgroups.txt, r06_tune_workgroups.txt).  A lone batch (depth < 4, eager callers) keeps the full-chip grids,
+# which are 2.5 x faster in isolation.  The grids are baked into the graphs at capture; the library's knobs are restored behind it.
+THROUGHPUT_GEOMETRY = {"chain_wgs": 64, "sa1_wgs": 192}
+THROUGHPUT_GEOMETRY_MIN_DEPTH = 4
+
+
+class _LaunchGeometry:
+    def __init__(self, on: bool):
+        self.on, self.prev = on, {}
+
+    def __enter__(self):
+        if self.on:
+            from . import compat
+            for k, v in THROUGHPUT_GEOMETRY.items():
+                self.prev[k] = compat.tune(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            from . import compat
+            for k, v in self.prev.items():
+                compat.tune(k, v)
+        return False
+
+
 class Stage1Pipeline:
     def __init__(self, model: stage1.Stage1Net, cfg: stage1.RPNConfig = stage1.DEFAULT_CFG, batch: int = 8,
                  n_points: int = 16384, depth: int = 6, roipool: bool = False, device="cuda:0", use_graph: bool = True,
@@ -147,7 +175,8 @@ class Stage1Pipeline:
             return
         prev = self._tunable(True)
         try:
-            self._prime_capture(slot)
+            with _LaunchGeometry(self.depth >= THROUGHPUT_GEOMETRY_MIN_DEPTH):
+                self._prime_capture(slot)
         finally:
             if prev is not None:
                 torch.cuda.tunable.enable(prev[0])
