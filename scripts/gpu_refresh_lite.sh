@@ -9,7 +9,7 @@ OUT=gpurun_out/refresh
 mkdir -p $OUT
 export TMPDIR=/tmp
 T="timeout 900"
-python -m ws3d_amd.build > /dev/null
+python -m ws3d_amd.build --all-dist-modes > /dev/null
 $T python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 for w in c2 c3 c5; do
   extra=""; [ $w = c3 ] && extra="--pipeline-depth 1 --no-graph --c2-batch 0"

@@ -2725,3 +2725,22 @@ def test_group_points_with_the_rows_staged_in_lds(ops, B, C, N, M, ns):
     ops.c.group_points_wrapper(B, C, N, M, ns, pts, idx, out)
     want = torch.gather(pts, 2, idx.long().view(B, 1, M * ns).expand(B, C, M * ns)).view(B, C, M, ns)
     assert torch.equal(out, want)
+
+
+def test_the_zero_arena_serves_every_take_of_the_forward_pass(ops):
+    """one cleared buffer per forward pass (fastpath._ZeroArena) holds every pooled output, pair total and ticket block of the default
+    network: a take it cannot serve falls back to a fill launch of its own (round 6 found one: the tickets of ws3d_chain_mlp3 were taken
+    for levels the kernel does not cover) -- asserted zero for the eager dispatch and for what a primed pipeline captures"""
+    from ws3d_amd import fastpath, stage1
+    from ws3d_amd.seeded import seeded_state_dict
+    model = stage1.Stage1Net(mode='TEST').eval()
+    model.load_state_dict(seeded_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 7))
+    model.cuda()
+    pts = dev(synth.make_batch("hdl64", 8, 16384, 3))
+    with torch.no_grad():
+        model.rpn_forward({"pts_input": pts})
+        assert fastpath.LAST_ARENA_FALLBACKS == 0, fastpath.LAST_ARENA_FALLBACKS
+        keys = fastpath.primed_compact_scales(model.rpn.backbone_net, pts)
+        with fastpath.geometry_ahead(False), fastpath.compact_only_scales(keys):
+            model.rpn_forward({"pts_input": pts})
+        assert fastpath.LAST_ARENA_FALLBACKS == 0, fastpath.LAST_ARENA_FALLBACKS

@@ -241,6 +241,7 @@ class _ZeroArena:
         self.buf = (torch.zeros if clear else torch.empty)(n, dtype=torch.float32, device=device)
         self.dirty = not clear                                    # True: whoever splits the input rows clears it in the same launch
         self.off = 0
+        self.fallbacks = 0                                        # takes the arena was too small for (a fill launch each: tests assert 0)
 
     def ensure_clear(self):
         if self.dirty:
@@ -252,10 +253,15 @@ class _ZeroArena:
         for d in shape:
             n *= int(d)
         if self.off + n > self.buf.numel():                     # (not sized for this caller: a fill of its own)
+            self.fallbacks += 1
+            self.fallback_shapes = getattr(self, "fallback_shapes", []) + [(tuple(shape), self.off, self.buf.numel())]
             return torch.zeros(shape, dtype=dtype, device=self.buf.device)
         v = self.buf[self.off:self.off + n]
         self.off += (n + 3) & ~3                                 # 16-byte aligned pieces
         return (v if dtype == torch.float32 else v.view(dtype)).view(shape)
+
+
+LAST_ARENA_FALLBACKS = 0      # of the last rpn_forward: takes its zero arena could not serve (diagnostic; 0 for the networks _arena_for sizes)
 
 
 def _arena_for(net, B: int, device, extra: int = 0, clear: bool = True) -> _ZeroArena:
@@ -607,7 +613,8 @@ def sa_forward(sa, xyz: torch.Tensor, feats: torch.Tensor, geo: _Geometry = None
                 return False
             scales.append({"pmat": pmat, "col0": offs[si_], "o1": blk[si_][0].conv.out_channels, "xyz": xyz, "new_xyz": new_xyz, "pairs": nbrs[si_].pairs,
                            "w1x": w1xs[si_], "b1": b1, "relu1": r1, "w2t": wt2, "b2": b2, "relu2": r2, "w3t": wt3, "b3": b3, "out2d": out, "col_offset": cols[si_]})
-        if CHAIN_MLP and zeros is not None and _C.chain_mlp3(scales, zeros.take((_C.chain_ticket_ints(),), torch.int32)):
+        if (CHAIN_MLP and zeros is not None and all(sc_["o1"] == 64 and sc_["w2t"].size(1) <= 96 and sc_["w3t"].size(1) == 128 for sc_ in scales)      # (the widths ws3d_chain_mlp3 covers: checked before the tickets are taken out of the arena)
+                and _C.chain_mlp3(scales, zeros.take((_C.chain_ticket_ints(),), torch.int32))):
             return True
         if _C.compact_mlp_pair(3, scales, max_lds=FUSED_COMPACT3_MAX_LDS):
             return True
@@ -792,6 +799,8 @@ def rpn_forward(model, pts_input: torch.Tensor, defer_reg_join: bool = False) ->
     else:
         rpn_cls = mlp_rows(rows, rpn.rpn_cls_layer, tickets[0:1]).view(B, N, -1)
         rpn_reg = mlp_rows(rows, rpn.rpn_reg_layer, tickets[1:2]).view(B, N, -1)
+    global LAST_ARENA_FALLBACKS
+    LAST_ARENA_FALLBACKS = zeros.fallbacks if not zeros.fallbacks else getattr(zeros, "fallback_shapes", zeros.fallbacks)
     out = {"rpn_cls": rpn_cls, "rpn_reg": rpn_reg, "backbone_xyz": xyz,
            "backbone_features": feats.transpose(1, 2),                   # (B,C,N) view of the (B,N,C) tensor
            "backbone_features_nlc": feats}
