@@ -161,6 +161,8 @@ def _install_hooks():
                 # that the change of the throughput-mode step time is what the family costs with 20 batches in flight
                 if __name in ("ball_query_pairs", "ball_query_pairs2"):
                     __orig(*a[:5], None)                       # its own cleared pair counter
+                elif __name == "mlp2_rows" and len(a) >= 8 and a[7] is not None:
+                    __orig(*a[:7], torch.zeros_like(a[7]))     # its own cleared ticket (round 5's table showed the heads at zero cost: the second launch found the ticket consumed and returned)
                 elif __name == "chain_mlp3":
                     __orig(a[0], torch.zeros_like(a[1]))       # its own cleared tickets (the launch consumes them)
                 else:

@@ -22,7 +22,7 @@ int raise_lds_cap(const void *fn, size_t bytes, const char *what);
 
 // Launch-geometry knobs (ws3d_tune, include/ws3d_ops.h): 0 = the built-in choice.  Speed only: every kernel that reads one is complete
 // for any value (persistent workgroups walking tiles).
-enum : int { TUNE_CHAIN_WGS = 0, TUNE_MLP2_WGS = 1, TUNE_SA1_WGS = 2, TUNE_COUNT = 8 };
+enum : int { TUNE_CHAIN_WGS = 0, TUNE_MLP2_WGS = 1, TUNE_SA1_WGS = 2, TUNE_FP_WGS = 3, TUNE_PAIR_WGS = 4, TUNE_COUNT = 8 };
 extern int g_tune[TUNE_COUNT];
 
 static inline hipStream_t as_stream(ws3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

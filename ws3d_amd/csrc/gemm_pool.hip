@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void gemm_pool_big_kernel(int k_dim, int o_dim
 // keeps (i) all tiles of a scene on ONE XCD -- the rows they gather (4 MB of features per scene at FP1) stay in that L2 instead
 // of being pulled through all eight -- and (ii) the col tiles of a row tile, which gather the SAME rows, next to each other on
 // that XCD (with the 2-D grid they ran on col_tiles different XCDs and each fetched the rows again).  tps = 0: plain order.
-__device__ __forceinline__ void gg_tile(int col_tiles, int tps, long &row_tile, int &col_tile) {
-    const long g = blockIdx.x;
+__device__ __forceinline__ void gg_tile(int col_tiles, int tps, long &row_tile, int &col_tile, long g = -1) {
+    if (g < 0) g = blockIdx.x;
     if (tps > 0) {
         const long j = g >> 3;
         col_tile = (int)(j % col_tiles);
@@ -859,12 +859,18 @@ struct CompactMlpArgs {
 };
 
 template <int NB1>
-__global__ __launch_bounds__(256) void pgather_gemm2_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
-    const bool second = blockIdx.x >= split;
-    const CompactMlpArgs &a = second ? a1 : a0;
-    if (blockIdx.y >= (unsigned)a.gy) return;
-    pgather_gemm2_compact_body<NB1>(second ? blockIdx.x - split : blockIdx.x, blockIdx.y, (unsigned)a.gy, a.o2, a.n, a.m, a.pmat, a.p_stride, a.xyz, a.new_xyz,
-                                    a.rowc, a.rowsrc, a.total, a.w1x, a.b1, a.relu1, a.w2t, a.b2, a.relu2, a.mid, a.limit);
+__global__ __launch_bounds__(256) void pgather_gemm2_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split,
+                                                                         const unsigned total_x) {
+    // round 6: a workgroup walks the x tiles bx = blockIdx.x, + gridDim.x, .. (the grid is sized for the lists' capacity: three quarters of
+    // its tiles lie behind *total on LiDAR clouds and return at once -- with ws3d_tune key 4 they are not launched at all)
+    for (unsigned bx = blockIdx.x; bx < total_x; bx += gridDim.x) {
+        const bool second = bx >= split;
+        const CompactMlpArgs &a = second ? a1 : a0;
+        if (blockIdx.y < (unsigned)a.gy)
+            pgather_gemm2_compact_body<NB1>(second ? bx - split : bx, blockIdx.y, (unsigned)a.gy, a.o2, a.n, a.m, a.pmat, a.p_stride, a.xyz, a.new_xyz,
+                                            a.rowc, a.rowsrc, a.total, a.w1x, a.b1, a.relu1, a.w2t, a.b2, a.relu2, a.mid, a.limit);
+        __syncthreads();
+    }
 }
 
 // last layer over compact rows + max over each centre's rows: out[centre, col] = max(out, relu(x W + b)) by integer atomic max
@@ -929,10 +935,13 @@ __global__ __launch_bounds__(256) void gemm_pool_compact_kernel(int k_dim, int o
     gemm_pool_compact_body(blockIdx.x, k_dim, o_dim, x, rowc, total, wt, bias, out, out_stride, limit);
 }
 
-__global__ __launch_bounds__(256) void gemm_pool_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
-    const bool second = blockIdx.x >= split;
-    const CompactMlpArgs &a = second ? a1 : a0;
-    gemm_pool_compact_body(second ? blockIdx.x - split : blockIdx.x, a.o2, a.o3, a.mid, a.rowc, a.total, a.w3t, a.b3, a.out, a.out_stride, a.limit);
+__global__ __launch_bounds__(256) void gemm_pool_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split, const unsigned total_x) {
+    for (unsigned bx = blockIdx.x; bx < total_x; bx += gridDim.x) {        // (see pgather_gemm2_compact_pair_kernel)
+        const bool second = bx >= split;
+        const CompactMlpArgs &a = second ? a1 : a0;
+        gemm_pool_compact_body(second ? bx - split : bx, a.o2, a.o3, a.mid, a.rowc, a.total, a.w3t, a.b3, a.out, a.out_stride, a.limit);
+        __syncthreads();
+    }
 }
 
 // ---- the WHOLE SharedMLP of a set-abstraction scale over compact rows in one kernel (round 4): pgather_gemm2_compact_kernel's
@@ -1099,7 +1108,7 @@ __global__ __launch_bounds__(256) void pgather_gemm3_compact_kernel(int o2, int 
 }
 
 template <int NB1>
-__global__ __launch_bounds__(256) void pgather_gemm3_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split) {
+__global__ __launch_bounds__(256) void pgather_gemm3_compact_pair_kernel(const CompactMlpArgs a0, const CompactMlpArgs a1, const unsigned split, const unsigned total_x) {
     const bool second = blockIdx.x >= split;
     const CompactMlpArgs &a = second ? a1 : a0;
     pgather_gemm3_compact_body<NB1>(second ? blockIdx.x - split : blockIdx.x, a.o2, a.o3, a.n, a.m, a.pmat, a.p_stride, a.xyz, a.new_xyz, a.rowc, a.rowsrc, a.total,
@@ -1238,7 +1247,7 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
                                                               const float *__restrict__ w3, const float *__restrict__ wt,
                                                               const float *__restrict__ bias, int relu, float *__restrict__ out, int tps,
                                                               const float *__restrict__ lin = nullptr, const float *__restrict__ wb = nullptr,
-                                                              const float *__restrict__ b1 = nullptr, int relu_a = 0) {
+                                                              const float *__restrict__ b1 = nullptr, int relu_a = 0, long total_tiles = 0) {
     // PRE (ws3d_qinterp_gemm): the A operand is the FIRST layer of the module, built on the fly as ws3d_qinterp_rows builds it --
     //   x[r, k] = relu_a?( w0 Q[i0, k] + w1 Q[i1, k] + w2 Q[i2, k] + (lin[r, k]  |  sum_j skip[r, j] wb[j, k] + b1[k]) )
     // with known_feats = Q (c2 = the layer's width), unknown_feats = the c1 <= 4 skip channels of the second form -- and this kernel's
@@ -1248,9 +1257,13 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
     __shared__ float ws[2][GP_KT][TN];        // [k][col]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1;
+    // round 6: a workgroup walks tiles vb = blockIdx.x, + gridDim.x, .. (total_tiles = 0: one tile per workgroup, the launch of rounds
+    // 2-5); gridDim.x is a multiple of 8 then, so a workgroup's tiles stay on its XCD's scenes (gg_tile)
+    const long n_tiles = total_tiles > 0 ? total_tiles : (long)gridDim.x;
+    for (long vb = blockIdx.x; vb < n_tiles; vb += gridDim.x) {
     long row_tile;
     int col_tile;
-    gg_tile(o_dim / TN, tps, row_tile, col_tile);
+    gg_tile(o_dim / TN, tps, row_tile, col_tile, vb);
     const long row0 = row_tile * TM;
     const int col0 = col_tile * TN;
     const int k_dim = PRE ? c2 : c2 + c1;
@@ -1375,6 +1388,7 @@ __global__ __launch_bounds__(256) void interp_gemm_big_kernel(int c2, int c1, in
                 o[(long)(8 * (v / 4) + (v % 4)) * o_dim] = y;
             }
         }
+    }
 }
 
 }  // namespace ws3d
@@ -1494,9 +1508,13 @@ extern "C" int ws3d_qinterp_gemm(int b, int n, int m, int c, int o_dim, const fl
     }
     if (rows == 0) return WS3D_OK;
     const int tpsb = ((b & 7) == 0 && n % 64 == 0) ? n / 64 : 0;
-    const dim3 grid((unsigned)((o_dim / 128) * (rows / 64)));
+    const long tiles = (long)(o_dim / 128) * (rows / 64);
+    // ws3d_tune key 3: at most that many workgroups (rounded to a multiple of 8), each walking its share of the tiles
+    long wgs = g_tune[TUNE_FP_WGS] > 0 ? std::min((long)g_tune[TUNE_FP_WGS], tiles) : tiles;
+    if (wgs < tiles) wgs = std::max(8L, wgs / 8 * 8);
+    const dim3 grid((unsigned)wgs);
     hipLaunchKernelGGL((interp_gemm_big_kernel<1, 2, true>), grid, dim3(256), 0, as_stream(stream), c, lin ? 0 : c1, o_dim, n, m, q, lin ? nullptr : skip, idx,
-                       weight, w2t, b2, relu2, out, tpsb, lin, wb, b1, relu1);
+                       weight, w2t, b2, relu2, out, tpsb, lin, wb, b1, relu1, wgs < tiles ? tiles : 0L);
     return check_launch("ws3d_qinterp_gemm");
 }
 
@@ -1703,13 +1721,16 @@ extern "C" int ws3d_compact_mlp_pair(int kind, const ws3d_compact_mlp_args *p0, 
                               q.o2, q.o3, q.n, q.m, q.p_stride, q.relu1, q.relu2, q.out_stride, (q.o2 + 63) / 64, 0};
     }
     if (tiles[0] + tiles[1] > 0x7fffffffL) { set_error("ws3d_compact_mlp_pair: too many rows"); return WS3D_E_UNSUPPORTED; }
-    const dim3 grid((unsigned)(tiles[0] + tiles[1]), kind == 2 ? gy : 1u);
+    const unsigned total_x = (unsigned)(tiles[0] + tiles[1]);
+    // kinds 2 and 1 walk their tiles: ws3d_tune key 4 caps the workgroups along x (0: one per tile, the launch of round 5)
+    const unsigned cap = (kind != 3 && g_tune[TUNE_PAIR_WGS] > 0) ? (unsigned)g_tune[TUNE_PAIR_WGS] : total_x;
+    const dim3 grid(std::max(1u, std::min(total_x, cap)), kind == 2 ? gy : 1u);
     const unsigned split = (unsigned)tiles[0];
     hipStream_t st = as_stream(stream);
 #define WS3D_PAIR_GO(KERN)                                                                            \
     do {                                                                                              \
         if (int rc = raise_lds_cap((const void *)KERN, lds, "ws3d_compact_mlp_pair")) return rc;      \
-        hipLaunchKernelGGL(KERN, grid, dim3(256), lds, st, a[0], a[1], split);                        \
+        hipLaunchKernelGGL(KERN, grid, dim3(256), lds, st, a[0], a[1], split, total_x);               \
     } while (0)
     if (kind == 3) {
         if (p0->o1 == 64) WS3D_PAIR_GO(pgather_gemm3_compact_pair_kernel<1>); else WS3D_PAIR_GO(pgather_gemm3_compact_pair_kernel<2>);
@@ -1718,7 +1739,7 @@ extern "C" int ws3d_compact_mlp_pair(int kind, const ws3d_compact_mlp_args *p0, 
         else if (p0->o1 == 128) WS3D_PAIR_GO(pgather_gemm2_compact_pair_kernel<2>);
         else WS3D_PAIR_GO(pgather_gemm2_compact_pair_kernel<4>);
     } else {
-        hipLaunchKernelGGL(gemm_pool_compact_pair_kernel, grid, dim3(256), 0, st, a[0], a[1], split);
+        hipLaunchKernelGGL(gemm_pool_compact_pair_kernel, grid, dim3(256), 0, st, a[0], a[1], split, total_x);
     }
 #undef WS3D_PAIR_GO
     return check_launch("ws3d_compact_mlp_pair");

@@ -56,10 +56,10 @@ def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
 
 # Launch geometry of the persistent kernels while a pipeline with several batches in flight captures its graphs (ws3d_tune): a launch that
 # holds a quarter of the chip at ~0.75 of its matrix pipes and leaves the rest to the other batches beats one that holds all of it at
-# ~0.45 -- measured on the 20-deep c3 step: ws3d_chain_mlp3 64 workgroups +3-4 % against 256, ws3d_sa_mlp3_pool_compact 192 +2 % against 768
-# (profiles/r06_chain_mlp3_workgroups.txt, r06_tune_workgroups.txt).  A lone batch (depth < 4, eager callers) keeps the full-chip grids,
+# ~0.45 -- measured on the 20-deep c3 step: ws3d_chain_mlp3 64 workgroups +3-4 % against 256, ws3d_sa_mlp3_pool_compact 192 +2 % against 768,
+# ws3d_mlp2_rows 128 +0.7 % against 256 (profiles/r06_chain_mlp3_workgroups.txt, r06_tune_workgroups.txt, r06_tune_workgroups2.txt).  A lone batch (depth < 4, eager callers) keeps the full-chip grids,
 # which are 2.5 x faster in isolation.  The grids are baked into the graphs at capture; the library's knobs are restored behind it.
-THROUGHPUT_GEOMETRY = {"chain_wgs": 64, "sa1_wgs": 192}
+THROUGHPUT_GEOMETRY = {"chain_wgs": 64, "sa1_wgs": 192, "mlp2_wgs": 128}
 THROUGHPUT_GEOMETRY_MIN_DEPTH = 4
 
 
