@@ -99,53 +99,86 @@ __global__ __launch_bounds__(256) void fps_nested_check_kernel(int n, int m, con
     if (__ballot(bad && p < n) != 0 && (tid & 63) == 0) atomicOr(reinterpret_cast<int32_t *>(new_xyz + (size_t)b * m * 3), 1);
 }
 
-// sampling_gpu.cu:93-209 restated literally with temp = 1e10 held in registers: thread tid owns k = tid, tid + bs, ... (at most 4:
-// n <= 4096), strict '>', shared-memory tree that keeps the lower slot.  One workgroup of 1024 threads, pointers of ONE scene.
+// The fallback of a scene whose check failed: sampling_gpu.cu:93-209 with temp = 1e10 held in registers and the SAME selection -- the
+// reference's launch picks, among the points holding the maximum, the one whose owner thread has the smallest bit-reversed tid (its
+// shared-memory tree keeps the lower slot at every level: the lowest differing bit decides) and, inside a thread, the smallest k
+// (strict '>' over k = tid, tid + bs, ..): a total order (value descending, rank = bitrev(tid) * 4 + s ascending), so ANY reduction
+// order finds the reference's pick.  Round 6: a wave reduces with DPP (wave_max, then wave_min_u32 of the ranks that hold it), the 16
+// waves exchange one 32-byte record each through double-buffered LDS -- the picked point's coordinates travel in the record, so a step
+// reads no global memory -- ONE barrier per step instead of the tree's ten: 1.6 ms -> ~0.5 ms for 4096 -> 1024 (the literal tree was
+// 1.5 us per step; 6 % of the hdl64 scenes take this path, profiles/r06_nested_fallback.txt).  One workgroup of 1024 threads, pointers
+// of ONE scene; n <= 4096.
+static __device__ __forceinline__ unsigned nested_wave_min_u32(unsigned v) {
+    unsigned r;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0xf" : "=v"(v) : "v"(r));
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+struct NestedRec { float v; unsigned rank; int k; float x, y, z; int pad0, pad1; };
 __device__ __forceinline__ void nested_literal_fps(int n, int m, int bs, const float *__restrict__ xyz, int32_t *__restrict__ idx,
                                                    float *__restrict__ new_xyz, float *dists, int *dists_i) {
-    const int tid = threadIdx.x;
+    NestedRec *rec = reinterpret_cast<NestedRec *>(dists);          // [2][16] records: 1 KB of the caller's 4 KB
+    (void)dists_i;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int lb = 0;
+    while ((1 << (lb + 1)) <= bs) ++lb;                              // bs is a power of two (cuda_utils.h:10-14)
+    const unsigned brev = lb == 0 ? 0u : (__builtin_bitreverse32((unsigned)tid) >> (32 - lb));
     float px[4], py[4], pz[4], tmp[4];
+    bool own[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int k = tid + s * bs;
-        const bool own = tid < bs && k < n;
-        px[s] = own ? xyz[k * 3 + 0] : 0.f; py[s] = own ? xyz[k * 3 + 1] : 0.f; pz[s] = own ? xyz[k * 3 + 2] : 0.f;
+        own[s] = tid < bs && k < n;
+        px[s] = own[s] ? xyz[k * 3 + 0] : 0.f; py[s] = own[s] ? xyz[k * 3 + 1] : 0.f; pz[s] = own[s] ? xyz[k * 3 + 2] : 0.f;
         tmp[s] = 1e10f;
     }
-    int old = 0;
-    if (tid == 0) { idx[0] = 0; new_xyz[0] = xyz[0]; new_xyz[1] = xyz[1]; new_xyz[2] = xyz[2]; }
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    if (tid == 0) { idx[0] = 0; new_xyz[0] = x1; new_xyz[1] = y1; new_xyz[2] = z1; }
     for (int j = 1; j < m; ++j) {
-        const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
         float best = -1.f;
-        int besti = 0;
+        int bs_ = 0;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int k = tid + s * bs;
-            if (tid < bs && k < n) {
+            if (own[s]) {
                 const float d = sqdist3(px[s] - x1, py[s] - y1, pz[s] - z1);
                 const float d2 = min_f32(d, tmp[s]);
                 tmp[s] = d2;
-                besti = d2 > best ? k : besti;
+                bs_ = d2 > best ? s : bs_;
                 best = d2 > best ? d2 : best;
             }
         }
-        if (tid < bs) { dists[tid] = best; dists_i[tid] = besti; }
-        __syncthreads();
-        for (int s = bs / 2; s >= 1; s >>= 1) {
-            if (tid < s) {
-                const float v1 = dists[tid], v2 = dists[tid + s];
-                const int i1 = dists_i[tid], i2 = dists_i[tid + s];
-                dists[tid] = max_f32(v1, v2);
-                dists_i[tid] = v2 > v1 ? i2 : i1;
-            }
-            __syncthreads();
+        const unsigned rank = tid < bs ? brev * 4u + (unsigned)bs_ : 0xffffffffu;
+        const float vmax = wave_max(best);
+        const unsigned rmin = nested_wave_min_u32(best == vmax ? rank : 0xffffffffu);
+        float4 *slot = reinterpret_cast<float4 *>(rec + (j & 1) * 16);      // two 16-byte halves per record: {v, rank, k, x} {y, z, -, -}
+        if (rank == rmin && rmin != 0xffffffffu) {
+            const float qx = bs_ == 0 ? px[0] : bs_ == 1 ? px[1] : bs_ == 2 ? px[2] : px[3];
+            const float qy = bs_ == 0 ? py[0] : bs_ == 1 ? py[1] : bs_ == 2 ? py[2] : py[3];
+            const float qz = bs_ == 0 ? pz[0] : bs_ == 1 ? pz[1] : bs_ == 2 ? pz[2] : pz[3];
+            slot[2 * w] = make_float4(vmax, __uint_as_float(rmin), __int_as_float(tid + bs_ * bs), qx);
+            slot[2 * w + 1] = make_float4(qy, qz, 0.f, 0.f);
+        } else if (lane == 0 && rmin == 0xffffffffu) {
+            slot[2 * w] = make_float4(-2.f, __uint_as_float(0xffffffffu), 0.f, 0.f);       // a wave without a point of its own
+            slot[2 * w + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        old = dists_i[0];
-        __syncthreads();                                       // dists_i[0] is rewritten by the next step
-        if (tid == 0) {
-            idx[j] = old;
-            new_xyz[j * 3 + 0] = xyz[old * 3 + 0]; new_xyz[j * 3 + 1] = xyz[old * 3 + 1]; new_xyz[j * 3 + 2] = xyz[old * 3 + 2];
-        }
+        lds_barrier();
+        // every wave folds the 16 records once more with the same two DPP reductions -- lane q < 16 holds record q -- instead of every
+        // THREAD reading all of them (16 waves x 32 broadcast reads per step kept the LDS pipe busy for 2-4 k clocks: 2.8 ms per scene in
+        // the first build); scalars, not a struct: a select between two aggregates goes through scratch memory
+        const float4 a0 = lane < 16 ? slot[2 * lane] : make_float4(-3.f, __uint_as_float(0xffffffffu), 0.f, 0.f);
+        const float4 a1 = lane < 16 ? slot[2 * lane + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float gmax = wave_max(a0.x);
+        const unsigned gmin = nested_wave_min_u32(a0.x == gmax ? __float_as_uint(a0.y) : 0xffffffffu);
+        const int src = __builtin_ctzll(__ballot(a0.x == gmax && __float_as_uint(a0.y) == gmin));      // exactly one lane
+        const int rk = __builtin_amdgcn_readlane(__float_as_int(a0.z), src);
+        const float rx = readlane_f(a0.w, src), ry = readlane_f(a1.x, src), rz = readlane_f(a1.y, src);
+        x1 = rx; y1 = ry; z1 = rz;
+        if (tid == 0) { idx[j] = rk; new_xyz[j * 3 + 0] = x1; new_xyz[j * 3 + 1] = y1; new_xyz[j * 3 + 2] = z1; }
     }
 }
 
