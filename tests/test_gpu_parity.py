@@ -2667,6 +2667,43 @@ def test_compact_and_dense_sharedmlps_give_the_same_network_outputs(ops):
         fastpath.COMPACT_MAX_FILL, fastpath.COMPACT_PAIRS, fastpath.PER_POINT_L1 = saved
 
 
+@pytest.mark.parametrize("B,N,M,r,ns,kind,grid,misalign", [
+    (2, 16384, 4096, 0.1, 64, "hdl64", True, False), (1, 16384, 4096, 0.5, 32, "hdl64", True, False), (2, 4096, 1000, 0.5, 16, "lidar", True, False),
+    (1, 2048, 333, 1.0, 12, "lidar", True, False), (1, 2048, 333, 1.0, 12, "lidar", False, False), (2, 3000, 257, 0.8, 20, "uniform", True, True),
+    (1, 900, 70, 2.0, 8, "lidar", None, False), (1, 4096, 1024, 0.5, 6, "lidar", True, False)])
+def test_query_and_group_one_feature_channel_with_lists(ops, oracle, B, N, M, r, ns, kind, grid, misalign):
+    """the (3 xyz + 1 feature channel) shape of the c2 block / the first SA level through ws3d_query_and_group with the lists written
+    beside the grouped rows (round 6: four entries per lane as one 16-byte store, entry -> centre by a shift): list lengths that are
+    and are not powers of two / multiples of four, centre counts that do not fill the last tile of 64, every search kernel behind it
+    (fine grid, x slabs, brute force) and a list tensor that is only 4-byte aligned -- grouped rows and lists equal the reference
+    composition (pointnet2_utils.py:241-264: ball_query -> grouping_operation -> subtract) bit for bit"""
+    pc = synth.make_batch(kind, B, N, 57)
+    xyz = pc[:, :, :3].copy()
+    feats = np.ascontiguousarray(np.transpose(pc[:, :, 3:4], (0, 2, 1)))
+    cidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(B)])
+    ref_idx = oracle.ball_query(r, ns, xyz, new_xyz)
+    xyz_t = np.ascontiguousarray(np.transpose(xyz, (0, 2, 1)))
+    ref = np.concatenate([oracle.grouping_operation(xyz_t, ref_idx) - np.transpose(new_xyz, (0, 2, 1))[..., None],
+                          oracle.grouping_operation(feats, ref_idx)], 1)
+    x, c, f = dev(xyz), dev(new_xyz), dev(feats)
+    srt = None if grid is None else ops.c.sort_points_x(x, grid=grid)
+    flat = torch.full((B * M * ns + 4,), -7, dtype=torch.int32, device="cuda")
+    nbr = flat[1:1 + B * M * ns].view(B, M, ns) if misalign else flat[4:].view(B, M, ns)
+    out = torch.full((B, 4, M, ns), float("nan"), device="cuda")
+    ops.c.query_and_group(B, N, M, 1, r, ns, True, x, c, f, nbr, out, srt)
+    np.testing.assert_array_equal(host(nbr), ref_idx)
+    np.testing.assert_array_equal(host(out), ref)
+    assert int(flat[0].item()) == -7 and (misalign or bool((flat[:4] == -7).all().item()))
+    # without the lists (idx_out = NULL): the same rows
+    out2 = torch.full((B, 4, M, ns), float("nan"), device="cuda")
+    ops.c.query_and_group(B, N, M, 1, r, ns, True, x, c, f, None, out2, srt)
+    np.testing.assert_array_equal(host(out2), ref)
+    # the list-only entry points take the same quad stores
+    got = ops.pn.ball_query(r, ns, x, c)
+    np.testing.assert_array_equal(host(got), ref_idx)
+
+
 def test_ball_query_fill_equals_ball_query_on_a_cleared_tensor(ops):
     """ws3d_ball_query_fill into an UNCLEARED tensor == ws3d_ball_query into zeros, for every search kernel (grid, x slabs, brute
     force) and with centres that have no hit at all (NaN centres, a radius of 0)"""

@@ -17,6 +17,7 @@
 // the feature channels straight into the (B, 3+C, M, ns) tensor the SharedMLP consumes.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 #include "common.h"
@@ -45,6 +46,10 @@ static bool grid_flavour(const void *p) {
 // cache (stage-2 shapes: 3.4 GB per launch, 0.98 -> 0.75 ms), plain otherwise so that the SharedMLP
 // GEMM that follows still finds a small tensor in L2 / MALL
 __device__ __forceinline__ void st4(float *p, const float4 v, const bool stream) {
+#ifdef WS3D_BQ_NO_NT      // A/B build (scripts/r06/bq_variants.sh): plain stores everywhere
+    *reinterpret_cast<float4 *>(p) = v;
+    return;
+#endif
     if (stream) {
         typedef float f4v __attribute__((ext_vector_type(4)));
         f4v t = {v.x, v.y, v.z, v.w};
@@ -62,16 +67,32 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
                                         int use_xyz, const float *__restrict__ xyz /* scene base */,
                                         const float *__restrict__ features, int32_t *__restrict__ idx_out,
                                         float *__restrict__ out, const IDX *rows, int rstride,
-                                        const int *cnt_s, const float4 *cen, int nbatch = -1) {
+                                        const int *cnt_s, const float4 *cen, int nbatch = -1, float4 *pad4 = nullptr /* NC float4 of LDS or NULL */,
+                                        const bool pad_ready = false /* pad4 holds every centre's centred first hit already: no barrier in here */) {
     if (nbatch < 0) nbatch = (int)gridDim.y;      // scenes of the launch (the 1-D grid kernel passes it)
     const int total_e = NC * nsample;
+    // round 6: entry e -> (centre, sample) by a shift where nsample is a power of two (every list length of the network; a run-time
+    // integer division is ~20 VALU instructions per entry), and the lists leave the chip four entries per lane as 16-byte stores
+    const int ns_sh = (nsample & (nsample - 1)) == 0 ? (int)__builtin_ctz((unsigned)nsample) : -1;
+    auto centre_of = [&](const int e) { return ns_sh >= 0 ? e >> ns_sh : e / nsample; };
+    const bool idx_quads = (nsample & 3) == 0 && (reinterpret_cast<uintptr_t>(idx_out) & 15) == 0;
     if (!FUSED) {
         // ball_query contract: rows without any hit are left untouched (ball_query_gpu.cu:29-44); use_xyz bit 2 (the _fill entry
         // point): such rows are written as zeros -- what the reference's callers get from their zero-initialised idx tensor
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
         const bool fill = (use_xyz & 4) != 0;
+        if (idx_quads) {
+            for (int q = tid; q < total_e / 4; q += NT) {
+                const int e = 4 * q, c = centre_of(e);
+                if (m0 + c >= m) continue;
+                const IDX *r = rows + (size_t)c * rstride + (e - c * nsample);
+                if (cnt_s[c] > 0) *reinterpret_cast<int4 *>(o + e) = make_int4((int)r[0], (int)r[1], (int)r[2], (int)r[3]);
+                else if (fill) *reinterpret_cast<int4 *>(o + e) = make_int4(0, 0, 0, 0);
+            }
+            return;
+        }
         for (int e = tid; e < total_e; e += NT) {
-            const int c = e / nsample, s = e - c * nsample;
+            const int c = centre_of(e), s = e - c * nsample;
             if (m0 + c < m) {
                 if (cnt_s[c] > 0) o[e] = (int32_t)rows[(size_t)c * rstride + s];
                 else if (fill) o[e] = 0;
@@ -79,11 +100,23 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
         }
         return;
     }
-    if (idx_out && blockIdx.z == 0) {
+    // (the 3 + 1 channel shape below writes the lists beside the grouped rows: it holds the four indices of a store in registers anyway)
+    const bool lists_in_fast_path = !(use_xyz & 2) && c_feat == 1 && (use_xyz & 1) && gridDim.z == 1 && idx_quads &&
+                                    (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    if (idx_out && blockIdx.z == 0 && !lists_in_fast_path) {
         int32_t *o = idx_out + ((size_t)b * m + m0) * nsample;
-        for (int e = tid; e < total_e; e += NT) {
-            const int c = e / nsample, s = e - c * nsample;
-            if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+        if (idx_quads) {
+            for (int q = tid; q < total_e / 4; q += NT) {
+                const int e = 4 * q, c = centre_of(e);
+                if (m0 + c >= m) continue;
+                const IDX *r = rows + (size_t)c * rstride + (e - c * nsample);
+                *reinterpret_cast<int4 *>(o + e) = make_int4((int)r[0], (int)r[1], (int)r[2], (int)r[3]);
+            }
+        } else {
+            for (int e = tid; e < total_e; e += NT) {
+                const int c = centre_of(e), s = e - c * nsample;
+                if (m0 + c < m) o[e] = (int32_t)rows[(size_t)c * rstride + s];
+            }
         }
     }
     if (use_xyz & 2) {
@@ -171,49 +204,116 @@ __device__ __forceinline__ void bq_emit(int b, int tid, int m0, int n, int m, in
         // gathers per channel, two channels in flight
         if (c_feat == 1 && use_xyz && gridDim.z == 1) {
             // the c2 / first-SA-level shape (3 xyz + 1 feature channel): two groups of 4 samples per trip, all 16 gathers
-            // issued before the first store -- the emit is latency-bound on its gathers
+            // issued before the first store -- the emit is latency-bound on its gathers.  Round 6: the eight list entries of a trip
+            // are read from LDS unconditionally (a lane without work reads row 0: its `ok ? r[u] : 0` was eight exec-masked branches,
+            // each with its own LDS round trip before the gather could issue), the gathers and stores take 32-bit offsets from scalar
+            // bases, the streaming / plain store choice is made once per launch instead of once per store, and the lists go out here
+            // (ws3d_query_and_group writes them too) as one 16-byte store per lane and group.
             typedef float f3v __attribute__((ext_vector_type(3)));
             typedef f3v f3u __attribute__((aligned(4)));
-            for (int q0 = tid; q0 < total_e / 4; q0 += 2 * NT) {
-                int e[2], cc[2];
-                bool ok[2];
-                f3v p[2][4];
-                float f[2][4];
+            const bool lists = idx_out && lists_in_fast_path;
+            int32_t *ib = lists ? idx_out + ((size_t)b * m + m0) * nsample : nullptr;
+            const char *xb = reinterpret_cast<const char *>(xyz), *fbb = reinterpret_cast<const char *>(fb);
+            char *o0 = reinterpret_cast<char *>(ob), *o1 = reinterpret_cast<char *>(ob + plane), *o2 = reinterpret_cast<char *>(ob + 2 * plane),
+                 *o3 = reinterpret_cast<char *>(ob + 3 * plane);
+            // The PADDING of a list (entries >= the centre's hit count repeat its first hit: 50-62 of the 64 entries of an r = 0.1 m
+            // ball on a KITTI-density scan) needs no gather of its own: the first hit of every centre is fetched ONCE, centred, parked
+            // in LDS (pad4), and a group of four entries that lies wholly in the padding stores that value four times.  Measured
+            // (scripts/r06/bq_variants.sh): the store pattern alone runs at 6.8 TB/s, the emit with a 12-byte and a 4-byte gather
+            // per entry at half of that (0.83 ms with the search compiled out), with the gathers of the real entries only 0.64, without
+            // any gather 0.52 (profiles/r06_bq_emit_anatomy.txt).
+            const bool skip_pad = pad4 != nullptr;
+            if (skip_pad && !pad_ready) {
+                if (tid < NC) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (m0 + tid < m) {
+                        const unsigned id0 = (unsigned)rows[(size_t)tid * rstride];          // (a centre without a hit: its row is all zeros -> point 0, as below)
+                        const f3v p0 = *reinterpret_cast<const f3u *>(xb + id0 * 12u);
+                        const float4 ce = cen[tid];
+                        v = make_float4(p0.x - ce.x, p0.y - ce.y, p0.z - ce.z, *reinterpret_cast<const float *>(fbb + id0 * 4u));
+                    }
+                    pad4[tid] = v;
+                }
+                __syncthreads();
+            }
+            auto trips = [&](auto stream_tag) {
+                constexpr bool ST = decltype(stream_tag)::value;
+                const int nq = total_e / 4;
+                for (int q0 = tid; q0 < nq; q0 += 2 * NT) {
+                    unsigned eo[2];
+                    int cc[2], id[2][4];
+                    bool ok[2], pad[2];
+                    f3v p[2][4];
+                    float f[2][4];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int q = q0 + h * NT;
-                    e[h] = 4 * min(q, total_e / 4 - 1);
-                    cc[h] = e[h] / nsample;
-                    ok[h] = q < total_e / 4 && m0 + cc[h] < m;
-                    const IDX *r = rows + (size_t)cc[h] * rstride + (e[h] - cc[h] * nsample);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int id = ok[h] ? (int)r[u] : 0;
-#ifdef WS3D_BQG_PACKED_ABL    // ablation (scripts/ablate_bq.sh): what ONE aligned 16-byte gather per sample would cost (values are wrong)
-                        const float4 v = reinterpret_cast<const float4 *>(xyz)[id * 3 / 4];
-                        p[h][u] = f3v{v.x, v.y, v.z};
-                        f[h][u] = v.w;
+                    for (int h = 0; h < 2; ++h) {
+                        const int q = q0 + h * NT;
+                        const int e = 4 * min(q, nq - 1);
+                        cc[h] = centre_of(e);
+                        ok[h] = q < nq && m0 + cc[h] < m;
+                        eo[h] = (unsigned)e * 4u;
+                        const int s0 = e - cc[h] * nsample;
+#ifdef WS3D_BQG_ALL_PAD        // ablation: no gather at all (every group of four entries takes the parked first hit; values are wrong)
+                        pad[h] = skip_pad;
 #else
-                        p[h][u] = *reinterpret_cast<const f3u *>(xyz + (size_t)id * 3);
-                        f[h][u] = fb[id];
+                        pad[h] = skip_pad && s0 >= cnt_s[cc[h]];
+#endif
+                        const IDX *r = rows + (ok[h] ? cc[h] * rstride + s0 : 0);     // (rows of absent centres are uninitialised: row 0 instead)
+#ifdef WS3D_BQG_NO_IDS         // ablation: the list entries are not read (values are wrong)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) id[h][u] = e + u;
+#else
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) id[h][u] = (int)r[u];
 #endif
                     }
-                }
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (!ok[h]) continue;
-                    const float4 ce = cen[cc[h]];
-                    st4(ob + e[h], make_float4(p[h][0].x - ce.x, p[h][1].x - ce.x, p[h][2].x - ce.x, p[h][3].x - ce.x), stream);
-                    st4(ob + plane + e[h], make_float4(p[h][0].y - ce.y, p[h][1].y - ce.y, p[h][2].y - ce.y, p[h][3].y - ce.y), stream);
-                    st4(ob + 2 * plane + e[h], make_float4(p[h][0].z - ce.z, p[h][1].z - ce.z, p[h][2].z - ce.z, p[h][3].z - ce.z), stream);
-                    st4(ob + 3 * plane + e[h], make_float4(f[h][0], f[h][1], f[h][2], f[h][3]), stream);
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { p[h][u] = f3v{0.f, 0.f, 0.f}; f[h][u] = 0.f; }
+                        if (!pad[h]) {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+#ifdef WS3D_BQG_PACKED_ABL    // ablation (scripts/ablate_bq.sh): what ONE aligned 16-byte gather per sample would cost (values are wrong)
+                                const float4 v = reinterpret_cast<const float4 *>(xyz)[id[h][u] * 3 / 4];
+                                p[h][u] = f3v{v.x, v.y, v.z};
+                                f[h][u] = v.w;
+#else
+                                p[h][u] = *reinterpret_cast<const f3u *>(xb + (unsigned)id[h][u] * 12u);
+                                f[h][u] = *reinterpret_cast<const float *>(fbb + (unsigned)id[h][u] * 4u);
+#endif
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (!ok[h]) continue;
+                        if (lists) *reinterpret_cast<int4 *>(reinterpret_cast<char *>(ib) + eo[h]) = make_int4(id[h][0], id[h][1], id[h][2], id[h][3]);
+                        float4 vx, vy, vz, vf;
+                        if (pad[h]) {
+                            const float4 pv = pad4[cc[h]];
+                            vx = make_float4(pv.x, pv.x, pv.x, pv.x); vy = make_float4(pv.y, pv.y, pv.y, pv.y);
+                            vz = make_float4(pv.z, pv.z, pv.z, pv.z); vf = make_float4(pv.w, pv.w, pv.w, pv.w);
+                        } else {
+                            const float4 ce = cen[cc[h]];
+                            vx = make_float4(p[h][0].x - ce.x, p[h][1].x - ce.x, p[h][2].x - ce.x, p[h][3].x - ce.x);
+                            vy = make_float4(p[h][0].y - ce.y, p[h][1].y - ce.y, p[h][2].y - ce.y, p[h][3].y - ce.y);
+                            vz = make_float4(p[h][0].z - ce.z, p[h][1].z - ce.z, p[h][2].z - ce.z, p[h][3].z - ce.z);
+                            vf = make_float4(f[h][0], f[h][1], f[h][2], f[h][3]);
+                        }
+                        st4(reinterpret_cast<float *>(o0 + eo[h]), vx, ST);
+                        st4(reinterpret_cast<float *>(o1 + eo[h]), vy, ST);
+                        st4(reinterpret_cast<float *>(o2 + eo[h]), vz, ST);
+                        st4(reinterpret_cast<float *>(o3 + eo[h]), vf, ST);
+                    }
                 }
-            }
+            };
+            if (stream) trips(std::true_type{}); else trips(std::false_type{});
             return;
         }
         for (int q = tid; q < total_e / 4; q += NT) {
             const int e = 4 * q;
-            const int c = e / nsample, s = e - c * nsample;
+            const int c = centre_of(e), s = e - c * nsample;
             if (m0 + c >= m) continue;
             const IDX *r = rows + (size_t)c * rstride + s;
             const int i0 = (int)r[0], i1 = (int)r[1], i2 = (int)r[2], i3 = (int)r[3];
@@ -742,48 +842,31 @@ constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the
 // kernel as long as one wave's sixteen searches).
 // blockIdx.y == 1 (ws3d_ball_query_pairs2, round 5): the SECOND scale of a set-abstraction level -- same points, centres and binned copy,
 // its own radius / nsample / outputs -- so that both searches of a level are ONE launch (a launch costs the 20-deep pipeline ~2.3 us).
-struct BqScale2 { float radius; int nsample; int32_t *idx_out, *rowc, *rowsrc, *total; };
-template <bool FUSED, int NW>
-__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius0, int nsample0, int use_xyz,
-                                                                   const float *__restrict__ xyz, const char *__restrict__ ws,
-                                                                   const float *__restrict__ new_xyz, const float *__restrict__ features,
-                                                                   int32_t *__restrict__ idx_out0, float *__restrict__ out,
-                                                                   int32_t *__restrict__ rowc0, int32_t *__restrict__ rowsrc0,
-                                                                   int32_t *__restrict__ total0, BqScale2 second) {
-    const bool sc2 = !FUSED && blockIdx.y == 1;
-    const float radius = sc2 ? second.radius : radius0;
-    const int nsample = sc2 ? second.nsample : nsample0;
-    int32_t *__restrict__ idx_out = sc2 ? second.idx_out : idx_out0;
-    int32_t *__restrict__ rowc = sc2 ? second.rowc : rowc0;
-    int32_t *__restrict__ rowsrc = sc2 ? second.rowsrc : rowsrc0;
-    int32_t *__restrict__ total = sc2 ? second.total : total0;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
-    int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
-    uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
-    const int rstride = nsample + 1;
-    constexpr int CPW = 64 / NW;                                      // centres per wave
-    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // NW waves x BQC_HCAP
-    uint16_t *stage_all = hits_all + NW * BQC_HCAP;                    // NW waves x CPW centres x 64: the hits of each centre's first 64 candidates
-    const int tiles = (m + 63) / 64;
-    int b, tile;
-    if ((nb & 7) == 0) {
-        const int g = blockIdx.x, j = g >> 3;
-        b = (j / tiles) * 8 + (g & 7);
-        tile = j - (j / tiles) * tiles;
-    } else {
-        b = blockIdx.x / tiles;
-        tile = blockIdx.x - b * tiles;
+// The search of ONE tile of 64 centres by the NW waves of a workgroup (steps 1-4 of the comment above): fills rows[c][0 .. nsample) with the
+// padded lists, cnt_s[c] with the hit counts (0 for a centre beyond m) and cen[c] with the centres.  `base` = the scene's binned copy,
+// xyz / new_xyz = the scene's points / centres.  (A function of its own since round 6: a persistent search / emit pipeline was built on it and not kept, profiles/r06_bq_emit_anatomy.txt.)
+template <int NW>
+__device__ __forceinline__ void bqc_search_tile(const int lane, const int w, const int m0, const int n, const int m, const float radius, const int nsample,
+                                                const float *__restrict__ xyz, const char *__restrict__ base, const float *__restrict__ new_xyz,
+                                                float4 *cen, int *cnt_s, uint16_t *rows, const int rstride, uint16_t *hits_all, uint16_t *stage_all) {
+    constexpr int CPW = 64 / NW;
+#ifdef WS3D_BQC_NO_SEARCH2   // ablation (scripts/r06/bq_variants2.sh): NOTHING is searched -- every centre "finds" six neighbours
+    for (int ci = 0; ci < CPW; ++ci) {
+        const int c = CPW * w + ci;
+        uint16_t *row = rows + (size_t)c * rstride;
+        const uint16_t first = (uint16_t)(((m0 + c) * 7) % n);
+        for (int s2 = lane; s2 < nsample; s2 += 64) row[s2] = s2 < 6 ? (uint16_t)(((m0 + c) * 7 + s2 * 13) % n) : first;
+        if (lane == 0) {
+            cnt_s[c] = (m0 + c < m) ? 6 : 0;
+            cen[c] = (m0 + c < m) ? make_float4(new_xyz[(m0 + c) * 3], new_xyz[(m0 + c) * 3 + 1], new_xyz[(m0 + c) * 3 + 2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m0 = tile * 64;
-    xyz += (size_t)b * n * 3;
-    const char *base = ws + (size_t)b * bin_scene_stride(n);
+    return;
+#endif
     const float4 *sorted = reinterpret_cast<const float4 *>(base);
     const BinHeader hdr = *reinterpret_cast<const BinHeader *>(base + (size_t)n * 16);
     const uint16_t *start16 = reinterpret_cast<const uint16_t *>(base + (size_t)n * 16 + sizeof(BinHeader));
     const int *params = reinterpret_cast<const int *>(base + (size_t)n * 16 + sizeof(BinHeader) + GRID16_PARAMS);
-    new_xyz += (size_t)b * m * 3;
     uint16_t *hits = hits_all + w * BQC_HCAP;
     uint16_t *stage = stage_all + w * (CPW * 64);
     const float radius2 = radius * radius;
@@ -852,12 +935,63 @@ __global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, i
             if (lane == ci) l_h0 = __popcll(mask);
         }
     }
+    // ---- 2c. (round 6) a centre whose whole search was step 2a -- at most 64 candidates in at most four grid rows: most centres of a
+    // furthest-point-sampled scan -- is finished here TOGETHER with the wave's other such centres, four lanes per centre: rank of every hit among its
+    // centre's hits, the row stored in rank order, padded, counted.  One centre at a time (the loop below) each of these steps is an LDS round
+    // trip the wave waits for, CPW times over: the search of the c2 block ran at the speed of that chain (0.44 ms with 24 waves per CU, 1.0 ms
+    // with 8: time ~ 1 / occupancy).  Same hits, same order: bit-identical lists.
+    uint64_t simple_bits = 0;
+#ifndef WS3D_BQC_NO_BATCH
+    {
+        const int len_l = l_ke - l_k0;                                  // (0 beyond the centre's rows and for lanes without a centre)
+        int L_l = len_l + __shfl_xor(len_l, 1);
+        L_l += __shfl_xor(L_l, 2);
+        const int H_l = __shfl(l_h0, ci_l & (CPW - 1));
+        const bool simple_l = ci_l < CPW && !not_grid && l_nrows <= 4 && L_l <= 64;
+        simple_bits = __ballot(simple_l && q_l == 0);
+        if (simple_bits) {
+            const int c = CPW * w + (ci_l & (CPW - 1));
+            const uint16_t *hl = stage_all + w * (CPW * 64) + (ci_l & (CPW - 1)) * 64;
+            uint16_t *row = rows + (size_t)c * rstride;
+            const int Hs = simple_l ? H_l : 0;
+            int Hmax = Hs;
+            for (int o = 32; o > 0; o >>= 1) Hmax = max(Hmax, __shfl_xor(Hmax, o));
+            Hmax = __builtin_amdgcn_readfirstlane(Hmax);
+            for (int j0 = 0; j0 < Hmax; j0 += 4) {
+                const int j = j0 + q_l;
+                const bool act = j < Hs;
+                const int v = act ? (int)hl[j] : 0x7fffffff;
+                int rank = 0;
+                for (int i = 0; i < Hmax; i += 4) {                     // (a centre's stage row holds 64 entries: reads past its count are masked, never out of bounds)
+                    const int o0 = (int)hl[i], o1 = (int)hl[i + 1], o2 = (int)hl[i + 2], o3 = (int)hl[i + 3];
+                    rank += (int)(i < Hs && o0 < v) + (int)(i + 1 < Hs && o1 < v) + (int)(i + 2 < Hs && o2 < v) + (int)(i + 3 < Hs && o3 < v);
+                }
+                if (act && rank < nsample) row[rank] = (uint16_t)v;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (simple_l) {
+                const int cnt = min(Hs, nsample);
+                const uint16_t first = cnt > 0 ? row[0] : (uint16_t)0;
+                for (int s2 = cnt + q_l; s2 < nsample; s2 += 4) row[s2] = first;
+                if (q_l == 0) cnt_s[c] = (m0 + c < m) ? cnt : 0;
+            }
+        }
+    }
+#endif
     for (int ci = 0; ci < CPW; ++ci) {
+        if ((simple_bits >> (4 * ci)) & 1) continue;
         const int c = CPW * w + ci;                                    // centre slot of the workgroup
         uint16_t *row = rows + (size_t)c * rstride;
         const int src = 4 * ci;
+#ifdef WS3D_BQC_NO_SEARCH   // ablation (scripts/r06/bq_variants.sh): every centre "finds" six neighbours, nothing is searched
+        const int nrows = 0;
+        int cnt = 0;
+        if (m0 + c < m) { if (lane < 6) row[lane] = (uint16_t)(((m0 + c) * 7 + lane * 13) % n); cnt = 6; }
+#else
         const int nrows = __builtin_amdgcn_readlane(l_nrows, src);
         int cnt = 0;
+#endif
         if (nrows > 0) {
             int k0[4], len[4];
 #pragma unroll
@@ -967,6 +1101,46 @@ __global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, i
         for (int s2 = cnt + lane; s2 < nsample; s2 += 64) row[s2] = first;
         if (lane == 0) cnt_s[c] = (m0 + c < m) ? cnt : 0;
     }
+}
+
+struct BqScale2 { float radius; int nsample; int32_t *idx_out, *rowc, *rowsrc, *total; };
+template <bool FUSED, int NW>
+__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius0, int nsample0, int use_xyz,
+                                                                   const float *__restrict__ xyz, const char *__restrict__ ws,
+                                                                   const float *__restrict__ new_xyz, const float *__restrict__ features,
+                                                                   int32_t *__restrict__ idx_out0, float *__restrict__ out,
+                                                                   int32_t *__restrict__ rowc0, int32_t *__restrict__ rowsrc0,
+                                                                   int32_t *__restrict__ total0, BqScale2 second) {
+    const bool sc2 = !FUSED && blockIdx.y == 1;
+    const float radius = sc2 ? second.radius : radius0;
+    const int nsample = sc2 ? second.nsample : nsample0;
+    int32_t *__restrict__ idx_out = sc2 ? second.idx_out : idx_out0;
+    int32_t *__restrict__ rowc = sc2 ? second.rowc : rowc0;
+    int32_t *__restrict__ rowsrc = sc2 ? second.rowsrc : rowsrc0;
+    int32_t *__restrict__ total = sc2 ? second.total : total0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4 *cen = reinterpret_cast<float4 *>(smem);                    // 64
+    int *cnt_s = reinterpret_cast<int *>(cen + 64);                    // 64
+    uint16_t *rows = reinterpret_cast<uint16_t *>(cnt_s + 64);         // 64 * rstride
+    const int rstride = nsample + 1;
+    uint16_t *hits_all = rows + ((64 * rstride + 7) & ~7);            // NW waves x BQC_HCAP
+    uint16_t *stage_all = hits_all + NW * BQC_HCAP;                    // NW waves x CPW centres x 64: the hits of each centre's first 64 candidates
+    const int tiles = (m + 63) / 64;
+    int b, tile;
+    if ((nb & 7) == 0) {
+        const int g = blockIdx.x, j = g >> 3;
+        b = (j / tiles) * 8 + (g & 7);
+        tile = j - (j / tiles) * tiles;
+    } else {
+        b = blockIdx.x / tiles;
+        tile = blockIdx.x - b * tiles;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = tile * 64;
+    xyz += (size_t)b * n * 3;
+    const char *base = ws + (size_t)b * bin_scene_stride(n);
+    new_xyz += (size_t)b * m * 3;
+    bqc_search_tile<NW>(lane, w, m0, n, m, radius, nsample, xyz, base, new_xyz, cen, cnt_s, rows, rstride, hits_all, stage_all);
     __syncthreads();
     if (!FUSED && rowc) {
         // ---- the compact (centre, source) pairs of these 64 lists (gemm_pool.hip pair_compact_kernel, here without a launch of
@@ -994,8 +1168,17 @@ __global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, i
             }
         }
     }
-    bq_emit<uint16_t, FUSED, 64 * NW, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb);
+#ifdef WS3D_BQC_NO_EMIT      // ablation: one word per workgroup keeps the search alive
+    if (tid == 0 && idx_out) idx_out[((size_t)b * m + m0) * nsample] = (int)rows[0] + cnt_s[0];
+#else
+    // (the hit lists are dead behind the barrier: their first KB parks the centred first hit of every centre for the padding of the 3 + 1 channel emit.
+    // Fetched by the searching waves into a KB of its own instead -- no barrier inside the emit -- the workgroup's LDS crosses the allocation
+    // granule that leaves six workgroups per CU: 0.85 -> 0.92 ms.)
+    bq_emit<uint16_t, FUSED, 64 * NW, 64>(b, tid, m0, n, m, c_feat, nsample, use_xyz, xyz, features, idx_out, out, rows, rstride, cnt_s, cen, nb,
+                                          FUSED ? reinterpret_cast<float4 *>(hits_all) : nullptr);
+#endif
 }
+
 
 static size_t bq_smem(int nsample, size_t idx_bytes) {
     return sizeof(float4) * (BQ_NW * BQ_TILE + 64) + sizeof(int) * BQ_NW * 64 +
@@ -1033,7 +1216,10 @@ static int bq_launch(int b, int n, int m, int c, float radius, int nsample, int 
         // one wave per centre; 16 waves x 4 centres per tile when the tiles alone do not fill the chip, else 4 x 16
         const bool wide = (long)b * ((m + 63) / 64) * gz < BQC_WIDE_BELOW;
         const int nw = wide ? 16 : BQC_LARGE_NW;
-        const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
+        size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (nsample + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
+#ifdef WS3D_BQC_EXTRA_LDS     // occupancy probe (scripts/r06/bq_variants2.sh): unused LDS bytes per workgroup
+        smem_c += WS3D_BQC_EXTRA_LDS;
+#endif
         if (nsample <= 64 && smem_c <= 64 * 1024) {      // longer lists: one lane per centre (below)
             if (wide)
                 hipLaunchKernelGGL((ball_query_grid_coop_kernel<FUSED, 16>), dim3((unsigned)(b * ((m + 63) / 64)), 1, gz), dim3(1024), smem_c, st, b, n, m, c,
