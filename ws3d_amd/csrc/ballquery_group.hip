@@ -834,7 +834,12 @@ __global__ __launch_bounds__(256) void ball_query_grid_kernel(int nb, int n, int
 #ifndef BQC_LARGE_NW
 #define BQC_LARGE_NW 4      // waves per tile of the launches that fill the chip by themselves
 #endif
-constexpr int BQC_HCAP = 1024;        // hits kept per centre (uint16 in LDS, per wave)
+#ifndef BQC_HCAP
+#define BQC_HCAP 1024                 // hits kept per centre (uint16 in LDS, per wave)
+#endif
+#ifndef BQC_FUSED_WPE
+#define BQC_FUSED_WPE 1               // waves per SIMD the fused 4-wave kernel is compiled for (A/B: scripts/r06/bq_variants2.sh)
+#endif
 constexpr int BQC_MAX_CAND = 8192;    // candidates tested per centre before the ordered scan takes over
 
 // NW waves per workgroup share a tile of 64 centres, CPW = 64 / NW each: 4 x 16 when the launch fills the chip by itself (the c2 block: 32768
@@ -940,9 +945,11 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
     // centre's hits, the row stored in rank order, padded, counted.  One centre at a time (the loop below) each of these steps is an LDS round
     // trip the wave waits for, CPW times over: the search of the c2 block ran at the speed of that chain (0.44 ms with 24 waves per CU, 1.0 ms
     // with 8: time ~ 1 / occupancy).  Same hits, same order: bit-identical lists.
+    // (16 waves x 4 centres, the launches of a batch of 8: four centres per wave leave the step 16 of 64 lanes, and on the dense r = 0.5 m
+    // searches of level 1 few centres qualify -- measured 66 -> 73 us there, so those launches keep the loop alone)
     uint64_t simple_bits = 0;
 #ifndef WS3D_BQC_NO_BATCH
-    {
+    if constexpr (CPW >= 16) {
         const int len_l = l_ke - l_k0;                                  // (0 beyond the centre's rows and for lanes without a centre)
         int L_l = len_l + __shfl_xor(len_l, 1);
         L_l += __shfl_xor(L_l, 2);
@@ -1085,6 +1092,8 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
             }
             if (!ordered) {
                 // ---- 4. order: rank of each survivor = number of smaller survivors
+                // (round 6, measured and not kept: the select on two hits per lane in registers and the ranking through v_readlane instead of
+                // LDS broadcast reads -- no difference on the c2 block or the searches of a c3 batch, profiles/r06_bq_emit_anatomy.txt)
                 cnt = H;
                 if (lane < cnt) {
                     const int v = (int)hl[lane];
@@ -1105,7 +1114,7 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
 
 struct BqScale2 { float radius; int nsample; int32_t *idx_out, *rowc, *rowsrc, *total; };
 template <bool FUSED, int NW>
-__global__ __launch_bounds__(64 * NW) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius0, int nsample0, int use_xyz,
+__global__ __launch_bounds__(64 * NW, (FUSED && NW == 4) ? BQC_FUSED_WPE : 1) void ball_query_grid_coop_kernel(int nb, int n, int m, int c_feat, float radius0, int nsample0, int use_xyz,
                                                                    const float *__restrict__ xyz, const char *__restrict__ ws,
                                                                    const float *__restrict__ new_xyz, const float *__restrict__ features,
                                                                    int32_t *__restrict__ idx_out0, float *__restrict__ out,
