@@ -29,6 +29,8 @@ for b in 8 256; do
 done
 timeout 900 bash scripts/launches_per_step.sh > $OUT/launches_per_step.txt 2>&1
 timeout 1500 bash scripts/throughput_marginal.sh > $OUT/throughput_marginal_cost.txt 2>&1
+timeout 600 bash scripts/r06/cu_time_budget.sh > $OUT/cu_time_budget.log 2>&1; cp gpurun_out/cu/cu_time_budget.txt $OUT/cu_time_budget.txt 2>/dev/null
+timeout 300 python scripts/r06/bq_time.py default 2>&1 | grep -v amdgpu.ids > $OUT/bq_time.txt
 # ---- counters, LAST
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c /tmp/pmc_c5_$c /tmp/pmc_c3_$c /tmp/pmc_ops8_$c /tmp/pmc_ops256_$c

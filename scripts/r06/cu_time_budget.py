@@ -40,9 +40,10 @@ def report(path, step_ms=None):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # the traced process runs WARM + STEPS identical steps: keep the last STEPS / (WARM + STEPS) of the dispatches
-    n = len(rows)
-    per = n // (WARM + STEPS)
-    rows = rows[n - per * STEPS:]
+    # the traced process runs priming passes and WARM + STEPS identical eager steps; every step launches the level-1 sampling kernel once:
+    # keep the dispatches from the (STEPS)-th last of its launches on
+    fps = [i for i, r in enumerate(rows) if "fps_rounds2_kernel" in r["Kernel_Name"]]
+    rows = rows[fps[-STEPS]:] if len(fps) >= STEPS else rows
     fam = defaultdict(lambda: [0.0, 0.0, 0, 0.0])
     for r in rows:
         g = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
