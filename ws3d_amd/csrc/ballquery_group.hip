@@ -855,6 +855,16 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
                                                 const float *__restrict__ xyz, const char *__restrict__ base, const float *__restrict__ new_xyz,
                                                 float4 *cen, int *cnt_s, uint16_t *rows, const int rstride, uint16_t *hits_all, uint16_t *stage_all) {
     constexpr int CPW = 64 / NW;
+    // grid rows fetched per centre and batch.  A wave of <= 8 centres has the lanes for EIGHT, and the r >= 0.5 m searches of the network span
+    // 5-9 rows of the fine grid (with four per batch their centres take a second table fetch in the dense path).  Measured (round 6,
+    // -DBQC_ROWS_PER_BATCH=8, scripts/r06/bq_c3_ab.sh): the eight searches of an hdl64 batch 236 -> 229 us in all (level 2, r = 1.0: 32.6 -> 27.7;
+    // level 1, r = 0.5: 69.7 -> 69.1), of a lidar batch 163 -> 175 (the longer range cascade on every candidate): four stays the default.
+#ifdef BQC_ROWS_PER_BATCH
+    constexpr int R = BQC_ROWS_PER_BATCH;
+#else
+    constexpr int R = 4;
+#endif
+    static_assert(R * CPW <= 64 && (R == 4 || R == 8), "one lane per (centre, row) of a batch");
 #ifdef WS3D_BQC_NO_SEARCH2   // ablation (scripts/r06/bq_variants2.sh): NOTHING is searched -- every centre "finds" six neighbours
     for (int ci = 0; ci < CPW; ++ci) {
         const int c = CPW * w + ci;
@@ -884,8 +894,8 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
     const float zmin = __int_as_float(params[0]), inv_wz = __int_as_float(params[1]);
     const int id_bits = 32 - __builtin_clz(max(n - 1, 1));            // ids < n
 
-    // ---- 1. this lane's (centre, row) of the wave's CPW centres x first 4 grid rows (lanes 4 CPW .. 63 idle when CPW < 16)
-    const int ci_l = lane >> 2, q_l = lane & 3;
+    // ---- 1. this lane's (centre, row) of the wave's CPW centres x first R grid rows (lanes R CPW .. 63 idle)
+    const int ci_l = lane / R, q_l = lane % R;
     const int mi_l = ci_l < CPW ? m0 + CPW * w + ci_l : m;
     float lcx = 0.f, lcy = 0.f, lcz = 0.f;
     if (mi_l < m) { lcx = new_xyz[mi_l * 3 + 0]; lcy = new_xyz[mi_l * 3 + 1]; lcz = new_xyz[mi_l * 3 + 2]; }
@@ -905,9 +915,12 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
             l_ke = (int)start16[(l_iz0 + q_l) * gx + l_ix1 + 1];
         }
     }
-    // the four ranges of a centre laid end to end: position j -> index into `sorted`
-    auto locate = [&](const int j, const int (&k0)[4], const int p1, const int p2, const int p3) {
-        return j < p1 ? k0[0] + j : (j < p2 ? k0[1] + (j - p1) : (j < p3 ? k0[2] + (j - p2) : k0[3] + (j - p3)));
+    // the R ranges of a centre laid end to end (pe[q] = end of range q in that sequence): position j -> index into `sorted`
+    auto locate = [&](const int j, const int (&k0)[R], const int (&pe)[R]) {
+        int r = k0[0] + j;
+#pragma unroll
+        for (int q = 1; q < R; ++q) r = j >= pe[q - 1] ? k0[q] + (j - pe[q - 1]) : r;
+        return r;
     };
     // ---- 2a. the first 64 candidates of all CPW centres: CPW independent loads in flight, then the tests; the hits of centre i go
     //          to stage[i][..] (this is the whole search of a centre in a sparse neighbourhood -- no memory round trip per centre)
@@ -916,23 +929,22 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
         float4 pre[CPW];
 #pragma unroll
         for (int ci = 0; ci < CPW; ++ci) {
-            int k0[4], len[4];
+            int k0[R], pe[R];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                k0[q] = __builtin_amdgcn_readlane(l_k0, 4 * ci + q);
-                len[q] = __builtin_amdgcn_readlane(l_ke, 4 * ci + q) - k0[q];
+            for (int q = 0; q < R; ++q) {
+                k0[q] = __builtin_amdgcn_readlane(l_k0, R * ci + q);
+                pe[q] = (q ? pe[q - 1] : 0) + (__builtin_amdgcn_readlane(l_ke, R * ci + q) - k0[q]);
             }
-            const int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
+            const int L = pe[R - 1];
             pre[ci] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lane < L) pre[ci] = sorted[locate(lane, k0, p1, p2, p3)];
+            if (lane < L) pre[ci] = sorted[locate(lane, k0, pe)];
         }
 #pragma unroll
         for (int ci = 0; ci < CPW; ++ci) {
-            const int L4 = (__builtin_amdgcn_readlane(l_ke, 4 * ci) - __builtin_amdgcn_readlane(l_k0, 4 * ci)) +
-                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 1) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 1)) +
-                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 2) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 2)) +
-                           (__builtin_amdgcn_readlane(l_ke, 4 * ci + 3) - __builtin_amdgcn_readlane(l_k0, 4 * ci + 3));
-            const float cx = readlane_f(lcx, 4 * ci), cy = readlane_f(lcy, 4 * ci), cz = readlane_f(lcz, 4 * ci);
+            int L4 = 0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) L4 += __builtin_amdgcn_readlane(l_ke, R * ci + q) - __builtin_amdgcn_readlane(l_k0, R * ci + q);
+            const float cx = readlane_f(lcx, R * ci), cy = readlane_f(lcy, R * ci), cz = readlane_f(lcz, R * ci);
             const float dx = cx - pre[ci].x;
             const bool hit = lane < L4 && fabsf(dx) < rabs && sqdist3(dx, cy - pre[ci].y, cz - pre[ci].z) < radius2;
             const uint64_t mask = __ballot(hit);
@@ -949,7 +961,7 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
     // searches of level 1 few centres qualify -- measured 66 -> 73 us there, so those launches keep the loop alone)
     uint64_t simple_bits = 0;
 #ifndef WS3D_BQC_NO_BATCH
-    if constexpr (CPW >= 16) {
+    if constexpr (CPW >= 16 && R == 4) {
         const int len_l = l_ke - l_k0;                                  // (0 beyond the centre's rows and for lanes without a centre)
         int L_l = len_l + __shfl_xor(len_l, 1);
         L_l += __shfl_xor(L_l, 2);
@@ -987,10 +999,10 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
     }
 #endif
     for (int ci = 0; ci < CPW; ++ci) {
-        if ((simple_bits >> (4 * ci)) & 1) continue;
+        if ((simple_bits >> (R * ci)) & 1) continue;
         const int c = CPW * w + ci;                                    // centre slot of the workgroup
         uint16_t *row = rows + (size_t)c * rstride;
-        const int src = 4 * ci;
+        const int src = R * ci;
 #ifdef WS3D_BQC_NO_SEARCH   // ablation (scripts/r06/bq_variants.sh): every centre "finds" six neighbours, nothing is searched
         const int nrows = 0;
         int cnt = 0;
@@ -1000,17 +1012,17 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
         int cnt = 0;
 #endif
         if (nrows > 0) {
-            int k0[4], len[4];
+            int k0[R], pe[R];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < R; ++q) {
                 k0[q] = __builtin_amdgcn_readlane(l_k0, src + q);
-                len[q] = __builtin_amdgcn_readlane(l_ke, src + q) - k0[q];
+                pe[q] = (q ? pe[q - 1] : 0) + (__builtin_amdgcn_readlane(l_ke, src + q) - k0[q]);
             }
-            int p1 = len[0], p2 = p1 + len[1], p3 = p2 + len[2], L = p3 + len[3];
+            int L = pe[R - 1];
             int H = __builtin_amdgcn_readlane(l_h0, ci);
             const uint16_t *hl = stage + ci * 64;                       // this centre's hit list
             bool ordered = not_grid;
-            if (L > 64 || nrows > 4 || not_grid) {
+            if (L > 64 || nrows > R || not_grid) {
                 // ---- 2b. a dense neighbourhood: the rest of the candidates, 64 per step, appended to the wave's long list
                 const float cx = readlane_f(lcx, src), cy = readlane_f(lcy, src), cz = readlane_f(lcz, src);
                 const int ix0 = __builtin_amdgcn_readlane(l_ix0, src), ix1 = __builtin_amdgcn_readlane(l_ix1, src);
@@ -1018,25 +1030,25 @@ __device__ __forceinline__ void bqc_search_tile(const int lane, const int w, con
                 if (lane < H) hits[lane] = stage[ci * 64 + lane];
                 hl = hits;
                 int tested = 0;
-                for (int rb = 0; rb < nrows && !ordered; rb += 4) {
+                for (int rb = 0; rb < nrows && !ordered; rb += R) {
                     if (rb > 0) {
                         int a = 0, e = 0;
-                        if (lane < 4 && rb + lane < nrows) {
+                        if (lane < R && rb + lane < nrows) {
                             a = (int)start16[(iz0 + rb + lane) * gx + ix0];
                             e = (int)start16[(iz0 + rb + lane) * gx + ix1 + 1];
                         }
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                        for (int q = 0; q < R; ++q) {
                             k0[q] = __builtin_amdgcn_readlane(a, q);
-                            len[q] = __builtin_amdgcn_readlane(e, q) - k0[q];
+                            pe[q] = (q ? pe[q - 1] : 0) + (__builtin_amdgcn_readlane(e, q) - k0[q]);
                         }
-                        p1 = len[0]; p2 = p1 + len[1]; p3 = p2 + len[2]; L = p3 + len[3];
+                        L = pe[R - 1];
                     }
                     tested += L;
                     if (tested > BQC_MAX_CAND) { ordered = true; break; }
                     for (int j0 = rb == 0 ? 64 : 0; j0 < L; j0 += 64) {
                         const int j = j0 + lane;
-                        const float4 p = sorted[j < L ? locate(j, k0, p1, p2, p3) : k0[0]];
+                        const float4 p = sorted[j < L ? locate(j, k0, pe) : k0[0]];
                         const float dx = cx - p.x;
                         const bool hit = j < L && fabsf(dx) < rabs && sqdist3(dx, cy - p.y, cz - p.z) < radius2;
                         const uint64_t mask = __ballot(hit);
