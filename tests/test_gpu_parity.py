@@ -1128,6 +1128,37 @@ def test_three_interpolate_grad_deterministic_bit_exact(ops, oracle, B, C, n, m)
     np.testing.assert_array_equal(host(out), ref)
 
 
+def test_sa_module_avg_pool_equals_the_reference_composition(ops, oracle):
+    """pool_method='avg_pool' (pointnet2_modules.py:45-46; unused by the Stage-1 network): the module's output is the reference's own
+    composition -- ball_query -> grouping_operation -> subtract / cat -> SharedMLP -> F.avg_pool2d over the samples -- on the ORACLE's
+    lists and grouped tensors, with the module's own weights (the grouped inputs are bit-equal; the SharedMLP is the same torch /
+    library call on both sides)"""
+    import torch.nn.functional as F
+    from ws3d_amd import pn2_modules
+    torch.manual_seed(3)
+    sa = pn2_modules.PointnetSAModuleMSG(npoint=128, radii=[0.6, 1.2], nsamples=[8, 16], mlps=[[4, 8, 8], [4, 8, 16]], use_xyz=True, bn=True,
+                                         pool_method='avg_pool').cuda().eval()
+    pc = synth.make_batch("lidar", 2, 2048, 5)
+    xyz = pc[:, :, :3].copy()
+    feats = np.ascontiguousarray(np.repeat(pc[:, :, 3:], 4, axis=2).transpose(0, 2, 1))
+    with torch.no_grad():
+        nx, nf = sa(dev(xyz), dev(feats))
+    cidx = oracle.furthest_point_sample(xyz, 128)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(2)])
+    np.testing.assert_array_equal(host(nx), new_xyz)
+    xyz_t = np.ascontiguousarray(np.transpose(xyz, (0, 2, 1)))
+    parts = []
+    with torch.no_grad():
+        for (r, ns), mlp in zip(((0.6, 8), (1.2, 16)), sa.mlps):
+            idx = oracle.ball_query(r, ns, xyz, new_xyz)
+            g = np.concatenate([oracle.grouping_operation(xyz_t, idx) - np.transpose(new_xyz, (0, 2, 1))[..., None],
+                                oracle.grouping_operation(feats, idx)], 1)
+            y = mlp(dev(g))
+            parts.append(F.avg_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1))
+    np.testing.assert_allclose(host(nf), host(torch.cat(parts, 1)), rtol=1e-6, atol=1e-6)
+    assert nf.shape == (2, 24, 128)
+
+
 def test_autograd_backward_is_reproducible(ops):
     """a small SA + FP stack: two backward passes give bit-identical parameter gradients with the
     deterministic kernels"""
