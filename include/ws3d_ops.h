@@ -52,7 +52,7 @@ typedef void *ws3d_stream_t;
 #define WS3D_ABI_VERSION 6
 WS3D_API int ws3d_abi_version(void);
 /* Launch-geometry knobs of the persistent kernels (round 6): key 0 = workgroups of ws3d_chain_mlp3, 1 = of ws3d_mlp2_rows, 2 = of
- * ws3d_sa_mlp3_pool_compact, 3 = of ws3d_qinterp_gemm, 4 = of ws3d_compact_mlp_pair kinds 2 / 1 (along x); value 0 restores the built-in choice, a negative value only reads.  Returns the
+ * ws3d_sa_mlp3_pool_compact, 3 = of ws3d_qinterp_gemm, 4 = of ws3d_compact_mlp_pair kinds 2 / 1 (along x), 5 = waves per 64-centre tile of ws3d_ball_query_pairs2 launches that do not fill the chip (8; anything else: 16); value 0 restores the built-in choice, a negative value only reads.  Returns the
  * previous value (WS3D_E_INVALID for an unknown key).  Speed only: results do not depend on these. Process-wide, not thread-safe. */
 WS3D_API int ws3d_tune(int key, int value);
 /* Squared-distance convention this library was BUILT with (csrc/common.h WS3D_DIST_MODE; the reference spells

@@ -2735,6 +2735,39 @@ def test_query_and_group_one_feature_channel_with_lists(ops, oracle, B, N, M, r,
     np.testing.assert_array_equal(host(got), ref_idx)
 
 
+@pytest.mark.parametrize("N,M,radii,nss,kind", [(16384, 4096, (0.1, 0.5), (16, 32), "hdl64"), (4096, 1024, (0.5, 1.0), (16, 32), "hdl64"),
+                                                (4096, 1000, (1.0, 2.0), (16, 32), "lidar"), (2048, 64, (2.0, 4.0), (8, 64), "lidar")])
+def test_ball_query_pairs2_on_eight_waves_per_tile(ops, oracle, N, M, radii, nss, kind):
+    """ws3d_tune key 5 (round 6: Stage1Pipeline's throughput geometry): the two-scale search launch on 8 waves x 8 centres per tile instead of
+    16 x 4 -- the oracle's lists, and the same SET of compact (centre, source) pairs with the same totals as the default launch"""
+    B = 8
+    xyz = synth.make_batch(kind, B, N, 77)[:, :, :3].copy()
+    cidx = oracle.furthest_point_sample(xyz, M)
+    new_xyz = np.stack([xyz[b][cidx[b]] for b in range(B)])
+    x, c = dev(xyz), dev(new_xyz)
+    grid = ops.c.sort_points_x(x, grid=True)
+    res = {}
+    for nw in (0, 8):
+        prev = ops.c.tune("bq_wide_nw", nw)
+        try:
+            out = ops.c.ball_query_pairs2(radii, nss, x, c, grid)
+        finally:
+            ops.c.tune("bq_wide_nw", prev)
+        assert out is not None
+        res[nw] = []
+        for (idx, (rowc, rowsrc, total)) in out:
+            t = int(total.item())
+            pairs = np.stack([host(rowc[:t]), host(rowsrc[:t])], 1)
+            res[nw].append((host(idx), t, pairs[np.lexsort((pairs[:, 1], pairs[:, 0]))]))
+    for k in range(2):
+        ref = oracle.ball_query(radii[k], nss[k], xyz, new_xyz)
+        np.testing.assert_array_equal(res[8][k][0], ref)
+        np.testing.assert_array_equal(res[0][k][0], ref)
+        assert res[8][k][1] == res[0][k][1]
+        np.testing.assert_array_equal(res[8][k][2], res[0][k][2])
+    assert ops.c.tune("bq_wide_nw") == 0
+
+
 def test_ball_query_fill_equals_ball_query_on_a_cleared_tensor(ops):
     """ws3d_ball_query_fill into an UNCLEARED tensor == ws3d_ball_query into zeros, for every search kernel (grid, x slabs, brute
     force) and with centres that have no hit at all (NaN centres, a radius of 0)"""

@@ -784,7 +784,7 @@ def compact_mlp_pair(kind, scales, max_lds=160 * 1024, mids=None):
 
 
 CHAIN_WORKGROUPS = 0      # ws3d_chain_mlp3: workgroups per launch (0 = the library's choice, ws3d_tune key 0)
-TUNE_KEYS = {"chain_wgs": 0, "mlp2_wgs": 1, "sa1_wgs": 2, "fp_wgs": 3, "pair_wgs": 4}
+TUNE_KEYS = {"chain_wgs": 0, "mlp2_wgs": 1, "sa1_wgs": 2, "fp_wgs": 3, "pair_wgs": 4, "bq_wide_nw": 5}
 
 
 def tune(name: str, value: int = -1) -> int:

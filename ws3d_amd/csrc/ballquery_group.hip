@@ -1509,7 +1509,13 @@ extern "C" int ws3d_ball_query_pairs2(int b, int n, int m, const float *new_xyz,
     const int ns = nsample0 > nsample1 ? nsample0 : nsample1;
     const long tiles = (long)b * ((m + 63) / 64);
     const bool wide = tiles * 2 < BQC_WIDE_BELOW;
-    const int nw = wide ? 16 : BQC_LARGE_NW;
+    // ws3d_tune key 5 (round 6): 8 waves x 8 centres per tile instead of 16 x 4 in the launches that do not fill the chip -- a longer launch
+    // (level 2, r = 1.0: 26 -> 36 us alone) that holds half the waves: about +1 % on the 20-deep step (profiles/r06_bq_emit_anatomy.txt, section 10).
+    // Stage1Pipeline sets it while it captures at depth >= 4; a lone caller keeps 16.  Same lists, same pair sets.
+    constexpr int TUNE_BQ_WIDE_NW = 5;                         // (ws3d_tune key 5; the keys 0-4 are named in common.h)
+    static_assert(TUNE_BQ_WIDE_NW < TUNE_COUNT, "ws3d_tune key");
+    const bool wide8 = wide && g_tune[TUNE_BQ_WIDE_NW] == 8;
+    const int nw = wide ? (wide8 ? 8 : 16) : BQC_LARGE_NW;
     const size_t smem_c = sizeof(float4) * 64 + sizeof(int) * 64 + sizeof(uint16_t) * (size_t)(((64 * (ns + 1) + 7) & ~7) + nw * BQC_HCAP + 64 * 64);
     if (n > SORT_MAX_N || b > 65535 || tiles > 0x7fffffffL || ns > 64 || smem_c > 64 * 1024 || !grid_flavour(sorted_grid)) {
         set_error("ws3d_ball_query_pairs2: not covered (n=%d nsample=%d/%d, or the binned copy is not a fine-grid one): use ws3d_ball_query_pairs per scale", n, nsample0, nsample1);
@@ -1517,7 +1523,10 @@ extern "C" int ws3d_ball_query_pairs2(int b, int n, int m, const float *new_xyz,
     }
     const BqScale2 second{radius1, nsample1, idx1, rowc1, rowsrc1, total1};
     hipStream_t st = as_stream(stream);
-    if (wide)
+    if (wide8)
+        hipLaunchKernelGGL((ball_query_grid_coop_kernel<false, 8>), dim3((unsigned)tiles, 2, 1), dim3(512), smem_c, st, b, n, m, 0, radius0, nsample0, 4, xyz,
+                           reinterpret_cast<const char *>(sorted_grid), new_xyz, (const float *)nullptr, idx0, (float *)nullptr, rowc0, rowsrc0, total0, second);
+    else if (wide)
         hipLaunchKernelGGL((ball_query_grid_coop_kernel<false, 16>), dim3((unsigned)tiles, 2, 1), dim3(1024), smem_c, st, b, n, m, 0, radius0, nsample0, 4, xyz,
                            reinterpret_cast<const char *>(sorted_grid), new_xyz, (const float *)nullptr, idx0, (float *)nullptr, rowc0, rowsrc0, total0, second);
     else

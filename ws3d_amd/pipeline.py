@@ -59,7 +59,7 @@ def _slot_stream(device: torch.device, j: int) -> torch.cuda.Stream:
 # ~0.45 -- measured on the 20-deep c3 step: ws3d_chain_mlp3 64 workgroups +3-4 % against 256, ws3d_sa_mlp3_pool_compact 192 +2 % against 768,
 # ws3d_mlp2_rows 128 +0.7 % against 256 (profiles/r06_chain_mlp3_workgroups.txt, r06_tune_workgroups.txt, r06_tune_workgroups2.txt).  A lone batch (depth < 4, eager callers) keeps the full-chip grids,
 # which are 2.5 x faster in isolation.  The grids are baked into the graphs at capture; the library's knobs are restored behind it.
-THROUGHPUT_GEOMETRY = {"chain_wgs": 64, "sa1_wgs": 192, "mlp2_wgs": 128}
+THROUGHPUT_GEOMETRY = {"chain_wgs": 64, "sa1_wgs": 192, "mlp2_wgs": 128, "bq_wide_nw": 8}      # (bq_wide_nw: the search launches on 8 waves x 8 centres per tile, +1 %: profiles/r06_bq_emit_anatomy.txt section 10)
 THROUGHPUT_GEOMETRY_MIN_DEPTH = 4
 
 
